@@ -1,0 +1,11 @@
+"""harmonypy_amd -- MI355X-native Harmony iteration engine.
+
+Drop-in for the hot path of slowkow/harmonypy: ``run_harmony`` / ``Harmony`` keep the
+reference's signatures (harmonypy/__init__.py:1-4, harmony.py:49-67, 218-229); the
+``harmonize()`` loop runs as hand-written HIP kernels for gfx950 behind a C ABI
+(include/hmx.h, harmonypy_amd/libhmx.so).
+"""
+from .harmony import Harmony, run_harmony, BatchCodes  # noqa: F401
+
+__version__ = "0.1.0"
+__all__ = ["Harmony", "run_harmony", "BatchCodes", "__version__"]

@@ -1,0 +1,187 @@
+"""ctypes binding of libhmx.so (include/hmx.h).  Thin: argument marshalling and error text only.
+
+The library is the product's compute path; there is no fallback.  Importing this module
+without a built ``libhmx.so`` raises, and every entry point raises ``HmxError`` with the
+library's message when a call fails (for instance when no MI355X is visible).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhmx.so")
+
+# mirrors include/hmx.h
+HMX_TILE = 16
+HMX_Z_ORIG, HMX_Z_COS, HMX_Z_CORR, HMX_R, HMX_Y, HMX_O_GROUP, HMX_T_MASS, HMX_W = range(8)
+HMX_ROUND_CENTROIDS, HMX_ROUND_UPDATE_R, HMX_ROUND_OBJECTIVE = 1, 2, 4
+HMX_ROUND_ALL = 7
+
+EXPORTS = [
+    "hmx_last_error", "hmx_abi_version", "hmx_create", "hmx_destroy", "hmx_upload", "hmx_init_cluster",
+    "hmx_cluster_round", "hmx_moe_correct_ridge", "hmx_get", "hmx_set", "hmx_sync", "hmx_device_ptr",
+    "hmx_kernel_times", "hmx_enable_timing",
+]
+
+
+class HmxError(RuntimeError):
+    pass
+
+
+class HmxConfig(C.Structure):
+    _fields_ = [
+        ("n_cells", C.c_int64), ("n_pcs", C.c_int32), ("n_clusters", C.c_int32), ("n_batches", C.c_int32),
+        ("n_groups", C.c_int32), ("n_vars", C.c_int32), ("n_blocks", C.c_int32), ("device_id", C.c_int32),
+        ("lambda_estimation", C.c_int32), ("alpha", C.c_float), ("reserved", C.c_int32 * 6),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """dlopen libhmx.so and declare prototypes.  Raises if the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HmxError(f"{LIB_PATH} is missing: build it with `python -m harmonypy_amd._build` "
+                       "(hipcc --offload-arch=gfx950); harmonypy_amd has no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    lib.hmx_last_error.restype = C.c_char_p
+    lib.hmx_last_error.argtypes = []
+    lib.hmx_abi_version.restype = C.c_int
+    lib.hmx_create.argtypes = [C.POINTER(HmxConfig), C.POINTER(vp)]
+    lib.hmx_destroy.argtypes = [vp]
+    lib.hmx_destroy.restype = None
+    lib.hmx_upload.argtypes = [vp, vp, vp, i64, vp, i32, vp, vp, vp, vp, vp]
+    lib.hmx_init_cluster.argtypes = [vp, vp, vp]
+    lib.hmx_cluster_round.argtypes = [vp, C.c_int, vp, i64, vp, i32, vp, vp]
+    lib.hmx_moe_correct_ridge.argtypes = [vp]
+    lib.hmx_get.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    lib.hmx_set.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    lib.hmx_sync.argtypes = [vp]
+    lib.hmx_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.hmx_kernel_times.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_char_p)]
+    lib.hmx_enable_timing.argtypes = [vp, C.c_int]
+    for name in EXPORTS:
+        if name not in ("hmx_last_error", "hmx_destroy"):
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise HmxError(f"libhmx: {load().hmx_last_error().decode(errors='replace')} (code {rc})")
+    return rc
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+KERNEL_FAMILIES = ["assign_block", "assign_init", "rtz_round", "rtz_reduce", "block_table",
+                   "ridge_stats", "ridge_solve", "ridge_apply"]
+
+
+class Engine:
+    """One device-resident Harmony state (an ``hmx_engine``)."""
+
+    def __init__(self, n_cells, n_pcs, n_clusters, n_batches, n_groups, n_vars, n_blocks,
+                 lambda_estimation=False, alpha=0.2, device_id=0):
+        self._lib = load()
+        self._h = C.c_void_p()
+        cfg = HmxConfig(n_cells=n_cells, n_pcs=n_pcs, n_clusters=n_clusters, n_batches=n_batches,
+                        n_groups=n_groups, n_vars=n_vars, n_blocks=n_blocks, device_id=device_id,
+                        lambda_estimation=int(bool(lambda_estimation)), alpha=float(alpha))
+        _check(self._lib.hmx_create(C.byref(cfg), C.byref(self._h)))
+        self.N, self.d, self.K, self.B, self.G, self.V, self.nblk = (
+            n_cells, n_pcs, n_clusters, n_batches, n_groups, n_vars, n_blocks)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.hmx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, Z, static_cells, static_tile_group, group_cols, Pr_b, theta, sigma, lamb):
+        Z = _c(Z, np.float32)
+        sc = _c(static_cells, np.int32)
+        tg = _c(static_tile_group, np.int32)
+        gc = _c(group_cols, np.int32)
+        lamb = None if lamb is None else _c(lamb, np.float32)
+        assert Z.shape == (self.N, self.d)
+        _check(self._lib.hmx_upload(self._h, _ptr(Z), _ptr(sc), sc.size, _ptr(tg), tg.size, _ptr(gc),
+                                    _ptr(_c(Pr_b, np.float32)), _ptr(_c(theta, np.float32)),
+                                    _ptr(_c(sigma, np.float32)), _ptr(lamb)))
+
+    def init_cluster(self, Y0_rows):
+        Y0 = _c(Y0_rows, np.float32)
+        assert Y0.shape == (self.K, self.d)
+        out = np.zeros(4, np.float64)
+        _check(self._lib.hmx_init_cluster(self._h, _ptr(Y0), _ptr(out)))
+        return out
+
+    def cluster_round(self, cells, tile_group, block_tile_start, flags=HMX_ROUND_ALL):
+        cells = _c(cells, np.int32)
+        tg = _c(tile_group, np.int32)
+        bs = _c(block_tile_start, np.int32)
+        assert bs.size == self.nblk + 1
+        out = np.zeros(4, np.float64)
+        _check(self._lib.hmx_cluster_round(self._h, flags, _ptr(cells), cells.size, _ptr(tg), tg.size,
+                                           _ptr(bs), _ptr(out)))
+        return out
+
+    def moe_correct_ridge(self):
+        _check(self._lib.hmx_moe_correct_ridge(self._h))
+
+    _SHAPES = {
+        HMX_Z_ORIG: ("N", "d", np.float32), HMX_Z_COS: ("N", "d", np.float32), HMX_Z_CORR: ("N", "d", np.float32),
+        HMX_R: ("N", "K", np.float32), HMX_Y: ("K", "d", np.float32), HMX_O_GROUP: ("G", "K", np.float64),
+        HMX_T_MASS: (1, "K", np.float64),
+    }
+
+    def _shape(self, which):
+        if which == HMX_W:
+            return (self.G, self.K, self.d), np.float32
+        r, c, dt = self._SHAPES[which]
+        r = getattr(self, r) if isinstance(r, str) else r
+        return (r, getattr(self, c)), dt
+
+    def get(self, which):
+        shape, dt = self._shape(which)
+        out = np.empty(shape, dt)
+        _check(self._lib.hmx_get(self._h, which, _ptr(out), out.nbytes))
+        return out
+
+    def set(self, which, arr):
+        shape, dt = self._shape(which)
+        arr = _c(arr, dt)
+        assert arr.shape == tuple(shape), (arr.shape, shape)
+        _check(self._lib.hmx_set(self._h, which, _ptr(arr), arr.nbytes))
+
+    def sync(self):
+        _check(self._lib.hmx_sync(self._h))
+
+    def enable_timing(self, on=True):
+        _check(self._lib.hmx_enable_timing(self._h, int(on)))
+
+    def kernel_times(self):
+        """{family: (total_ms, launches)} since timing was enabled."""
+        buf = np.zeros(2 * len(KERNEL_FAMILIES), np.float64)
+        _check(self._lib.hmx_kernel_times(self._h, _ptr(buf), buf.size, None))
+        return {n: (float(buf[2 * i]), int(buf[2 * i + 1])) for i, n in enumerate(KERNEL_FAMILIES)}

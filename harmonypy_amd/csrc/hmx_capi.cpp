@@ -1,0 +1,537 @@
+// hmx_capi.cpp -- host side of libhmx.so: device state, kernel sequencing, the C ABI of
+// include/hmx.h.  Compiled with hipcc as HIP (-x hip).  No torch, no exceptions across the ABI.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "hmx.h"
+#include "hmx_internal.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(HMX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+enum Family { F_ASSIGN_BLOCK = 0, F_ASSIGN_INIT, F_RTZ_ROUND, F_RTZ_REDUCE, F_BLOCK_TABLE, F_RIDGE_STATS, F_RIDGE_SOLVE, F_RIDGE_APPLY, F_COUNT };
+const char* kFamilyNames = "assign_block\0assign_init\0rtz_round\0rtz_reduce\0block_table\0ridge_stats\0ridge_solve\0ridge_apply\0";
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int reserve(size_t count) {
+        if (count <= n) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
+        if (e != hipSuccess) return fail(HMX_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+        n = count;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+}  // namespace
+
+struct hmx_engine {
+    hmx_config cfg{};
+    int64_t N = 0;
+    int d = 0, dp = 0, K = 0, Kp = 0, K16 = 0, mt = 0, ntd = 0, ldy = 0, B = 0, G = 0, V = 0, nblk = 0;
+    int max_wgs = 1024;
+    hipStream_t stream = nullptr;
+    bool uploaded = false, clustered = false, timing = false;
+
+    DevBuf<float> Zorig, Zcos, Zcorr, R, Y, Yacc, sigma, theta, Pr_b, lamb, rp, lrp, slab, W;
+    DevBuf<int> group_cols, s_cells, s_tile_grp, r_cells, r_tile_grp, r_blk_start, task_t0, task_t1, task_grp;
+    DevBuf<double> Ogrp, Tmass, Sold, Snew, Ohist, objacc, Sr, Oxr, scratch;
+    double* obj_host = nullptr;  // pinned
+    int n_s_tiles = 0, ntasks = 0;
+    std::vector<int> h_task_grp;
+
+    struct Span { hipEvent_t a, b; int fam; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> pool;
+    double fam_ms[F_COUNT] = {0};
+    long fam_n[F_COUNT] = {0};
+};
+
+namespace {
+
+int use_device(hmx_engine* e) {
+    HIP_TRY(hipSetDevice(e->cfg.device_id));
+    return 0;
+}
+
+struct Timed {
+    hmx_engine* e;
+    hipEvent_t a = nullptr, b = nullptr;
+    int fam;
+    Timed(hmx_engine* e_, int fam_) : e(e_), fam(fam_) {
+        if (!e->timing) return;
+        auto get = [&]() {
+            hipEvent_t ev;
+            if (!e->pool.empty()) { ev = e->pool.back(); e->pool.pop_back(); }
+            else (void)hipEventCreate(&ev);
+            return ev;
+        };
+        a = get();
+        b = get();
+        (void)hipEventRecord(a, e->stream);
+    }
+    ~Timed() {
+        if (!a) return;
+        (void)hipEventRecord(b, e->stream);
+        e->spans.push_back({a, b, fam});
+    }
+};
+
+void drain_spans(hmx_engine* e) {
+    for (auto& s : e->spans) {
+        float ms = 0.f;
+        if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            e->fam_ms[s.fam] += ms;
+            e->fam_n[s.fam] += 1;
+        }
+        e->pool.push_back(s.a);
+        e->pool.push_back(s.b);
+    }
+    e->spans.clear();
+}
+
+int read_objective(hmx_engine* e, double out[4]) {
+    HIP_TRY(hipMemcpyAsync(e->obj_host, e->objacc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipGetLastError());
+    for (int i = 0; i < 4; ++i) out[i] = (double)(float)e->obj_host[i];  // `.item()` of an fp32 tensor
+    return 0;
+}
+
+AssignArgs assign_args(hmx_engine* e) {
+    AssignArgs a{};
+    a.Zcos = e->Zcos.p; a.Y = e->Y.p; a.sigma = e->sigma.p; a.rp = e->rp.p; a.lrp = e->lrp.p; a.R = e->R.p;
+    a.obj = e->objacc.p;
+    a.K = e->K; a.Kp = e->Kp; a.K16 = e->K16; a.mt = e->mt; a.dp = e->dp; a.ldy = e->ldy;
+    return a;
+}
+
+TableArgs table_args(hmx_engine* e) {
+    TableArgs t{};
+    t.group_cols = e->group_cols.p; t.Pr_b = e->Pr_b.p; t.theta = e->theta.p; t.sigma = e->sigma.p;
+    t.G = e->G; t.B = e->B; t.V = e->V; t.K16 = e->K16;
+    return t;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* hmx_last_error(void) { return g_err.c_str(); }
+int hmx_abi_version(void) { return HMX_ABI_VERSION; }
+
+int hmx_create(const hmx_config* cfg, hmx_engine** out) {
+    if (!cfg || !out) return fail(HMX_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->n_cells <= 0 || cfg->n_pcs <= 0 || cfg->n_clusters <= 0 || cfg->n_batches <= 0 || cfg->n_groups <= 0 ||
+        cfg->n_vars <= 0 || cfg->n_blocks <= 0)
+        return fail(HMX_ERR_ARG, "sizes must be positive");
+    if (cfg->n_clusters > 208) return fail(HMX_ERR_ARG, "n_clusters=%d > 208 not supported by this build", cfg->n_clusters);
+    if (cfg->n_pcs > 208) return fail(HMX_ERR_ARG, "n_pcs=%d > 208 not supported by this build", cfg->n_pcs);
+    if (cfg->n_cells > (int64_t)2000000000) return fail(HMX_ERR_ARG, "n_cells too large for 32-bit cell ids");
+    int ndev = 0;
+    hipError_t he = hipGetDeviceCount(&ndev);
+    if (he != hipSuccess || ndev <= 0) return fail(HMX_ERR_HIP, "no HIP device available (%s)", hipGetErrorString(he));
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(HMX_ERR_ARG, "device_id %d out of range (%d devices)", cfg->device_id, ndev);
+    hmx_engine* e = new (std::nothrow) hmx_engine();
+    if (!e) return fail(HMX_ERR_ARG, "out of host memory");
+    e->cfg = *cfg;
+    e->N = cfg->n_cells; e->d = cfg->n_pcs; e->K = cfg->n_clusters; e->B = cfg->n_batches; e->G = cfg->n_groups;
+    e->V = cfg->n_vars; e->nblk = cfg->n_blocks;
+    e->dp = (e->d + 3) & ~3;
+    e->Kp = (e->K + 3) & ~3;
+    e->mt = (e->K + 15) / 16;
+    e->K16 = 16 * e->mt;
+    e->ntd = (e->d + 15) / 16;
+    e->ldy = 16 * e->ntd;
+    int rc = 0;
+    do {
+        if ((rc = use_device(e))) break;
+        hipError_t se = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+        if (se != hipSuccess) { rc = fail(HMX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se)); break; }
+        const size_t N = (size_t)e->N, GK = (size_t)e->G * e->K16;
+        if ((rc = e->Zorig.reserve(N * e->dp)) || (rc = e->Zcos.reserve(N * e->dp)) || (rc = e->Zcorr.reserve(N * e->dp)) ||
+            (rc = e->R.reserve(N * e->Kp)) || (rc = e->Y.reserve((size_t)e->K16 * e->ldy)) ||
+            (rc = e->Yacc.reserve((size_t)e->K16 * e->ldy)) || (rc = e->sigma.reserve(e->K16)) ||
+            (rc = e->theta.reserve(e->B)) || (rc = e->Pr_b.reserve(e->B)) || (rc = e->lamb.reserve(e->B + 1)) ||
+            (rc = e->rp.reserve(GK)) || (rc = e->lrp.reserve(GK)) || (rc = e->group_cols.reserve((size_t)e->G * e->V)) ||
+            (rc = e->Ogrp.reserve(GK)) || (rc = e->Tmass.reserve(e->K16)) || (rc = e->Sold.reserve(GK * e->nblk)) ||
+            (rc = e->Snew.reserve(GK * e->nblk)) || (rc = e->Ohist.reserve(GK * e->nblk)) || (rc = e->objacc.reserve(4)) ||
+            (rc = e->Sr.reserve(GK * e->ldy)) || (rc = e->Oxr.reserve(GK)) ||
+            (rc = e->W.reserve(GK * e->ldy)) || (rc = e->r_blk_start.reserve(e->nblk + 1)))
+            break;
+        if (e->V > 1 && (rc = e->scratch.reserve((size_t)e->K16 * (e->B + 1) * (e->B + 1 + e->d)))) break;
+        hipError_t pe = hipHostMalloc(reinterpret_cast<void**>(&e->obj_host), 4 * sizeof(double), hipHostMallocDefault);
+        if (pe != hipSuccess) { rc = fail(HMX_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(pe)); break; }
+        (void)hipMemsetAsync(e->R.p, 0, N * e->Kp * sizeof(float), e->stream);
+        (void)hipMemsetAsync(e->Ogrp.p, 0, GK * sizeof(double), e->stream);
+        (void)hipMemsetAsync(e->Tmass.p, 0, e->K16 * sizeof(double), e->stream);
+        (void)hipMemsetAsync(e->W.p, 0, GK * e->ldy * sizeof(float), e->stream);
+        (void)hipMemsetAsync(e->Y.p, 0, (size_t)e->K16 * e->ldy * sizeof(float), e->stream);
+        (void)hipMemsetAsync(e->objacc.p, 0, 4 * sizeof(double), e->stream);
+    } while (0);
+    if (rc) {
+        std::string keep = g_err;
+        hmx_destroy(e);
+        g_err = keep;
+        return rc;
+    }
+    *out = e;
+    return HMX_OK;
+}
+
+void hmx_destroy(hmx_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device_id);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    drain_spans(e);
+    for (auto ev : e->pool) (void)hipEventDestroy(ev);
+    e->Zorig.release(); e->Zcos.release(); e->Zcorr.release(); e->R.release(); e->Y.release(); e->Yacc.release();
+    e->sigma.release(); e->theta.release(); e->Pr_b.release(); e->lamb.release(); e->rp.release(); e->lrp.release();
+    e->slab.release(); e->W.release(); e->group_cols.release(); e->s_cells.release(); e->s_tile_grp.release();
+    e->r_cells.release(); e->r_tile_grp.release(); e->r_blk_start.release(); e->task_t0.release(); e->task_t1.release();
+    e->task_grp.release(); e->Ogrp.release(); e->Tmass.release(); e->Sold.release(); e->Snew.release(); e->Ohist.release();
+    e->objacc.release(); e->Sr.release(); e->Oxr.release(); e->scratch.release();
+    if (e->obj_host) (void)hipHostFree(e->obj_host);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64_t n_static_pos,
+               const int32_t* static_tile_group, int32_t n_static_tiles, const int32_t* group_cols, const float* Pr_b,
+               const float* theta, const float* sigma, const float* lamb) {
+    if (!e || !Z || !static_cells || !static_tile_group || !group_cols || !Pr_b || !theta || !sigma)
+        return fail(HMX_ERR_ARG, "null argument");
+    if (!e->cfg.lambda_estimation && !lamb) return fail(HMX_ERR_ARG, "lamb is required unless lambda_estimation");
+    if (n_static_pos != (int64_t)n_static_tiles * HMX_TILE) return fail(HMX_ERR_ARG, "n_static_pos must be 16*n_static_tiles");
+    for (int64_t i = 0; i < n_static_pos; ++i)
+        if (static_cells[i] < -1 || static_cells[i] >= e->N) return fail(HMX_ERR_ARG, "static_cells[%lld] out of range", (long long)i);
+    for (int i = 0; i < n_static_tiles; ++i)
+        if (static_tile_group[i] < 0 || static_tile_group[i] >= e->G) return fail(HMX_ERR_ARG, "static_tile_group[%d] out of range", i);
+    for (int i = 0; i < e->G * e->V; ++i)
+        if (group_cols[i] < 0 || group_cols[i] >= e->B) return fail(HMX_ERR_ARG, "group_cols[%d] out of range", i);
+    int rc;
+    if ((rc = use_device(e))) return rc;
+    // Z rows padded to dp
+    {
+        std::vector<float> zp((size_t)e->N * e->dp, 0.f);
+        for (int64_t i = 0; i < e->N; ++i) std::memcpy(&zp[(size_t)i * e->dp], Z + (size_t)i * e->d, sizeof(float) * e->d);
+        HIP_TRY(hipMemcpyAsync(e->Zorig.p, zp.data(), zp.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->Zcorr.p, e->Zorig.p, zp.size() * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    launch_normalize_rows(e->Zorig.p, e->Zcos.p, e->N, e->dp, e->stream);  // harmony.py:238
+    std::vector<float> sg(e->K16, 0.f);
+    std::memcpy(sg.data(), sigma, sizeof(float) * e->K);
+    HIP_TRY(hipMemcpyAsync(e->sigma.p, sg.data(), sg.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->theta.p, theta, e->B * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->Pr_b.p, Pr_b, e->B * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    std::vector<float> lm(e->B + 1, 0.f);
+    if (lamb && !e->cfg.lambda_estimation) std::memcpy(lm.data(), lamb, sizeof(float) * (e->B + 1));
+    HIP_TRY(hipMemcpyAsync(e->lamb.p, lm.data(), lm.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->group_cols.p, group_cols, (size_t)e->G * e->V * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    if ((rc = e->s_cells.reserve(n_static_pos)) || (rc = e->s_tile_grp.reserve(n_static_tiles))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->s_cells.p, static_cells, n_static_pos * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->s_tile_grp.p, static_tile_group, n_static_tiles * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    e->n_s_tiles = n_static_tiles;
+    // ridge tasks: runs of <= 64 tiles of one group
+    std::vector<int> t0, t1, tg;
+    const int CH = 64;
+    for (int i = 0; i < n_static_tiles;) {
+        int j = i;
+        while (j < n_static_tiles && j - i < CH && static_tile_group[j] == static_tile_group[i]) ++j;
+        t0.push_back(i); t1.push_back(j); tg.push_back(static_tile_group[i]);
+        i = j;
+    }
+    for (size_t i = 1; i < tg.size(); ++i)
+        if (tg[i] < tg[i - 1]) return fail(HMX_ERR_ARG, "static tiles must be sorted by group");
+    e->ntasks = (int)t0.size();
+    e->h_task_grp = tg;
+    if ((rc = e->task_t0.reserve(t0.size())) || (rc = e->task_t1.reserve(t0.size())) || (rc = e->task_grp.reserve(t0.size()))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->task_t0.p, t0.data(), t0.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->task_t1.p, t1.data(), t1.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->task_grp.p, tg.data(), tg.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipGetLastError());
+    e->uploaded = true;
+    return HMX_OK;
+}
+
+int hmx_init_cluster(hmx_engine* e, const float* Y0, double obj_out[4]) {
+    if (!e || !Y0 || !obj_out) return fail(HMX_ERR_ARG, "null argument");
+    if (!e->uploaded) return fail(HMX_ERR_STATE, "hmx_upload must come first");
+    int rc;
+    if ((rc = use_device(e))) return rc;
+    std::vector<float> y((size_t)e->K16 * e->ldy, 0.f);
+    for (int k = 0; k < e->K; ++k) std::memcpy(&y[(size_t)k * e->ldy], Y0 + (size_t)k * e->d, sizeof(float) * e->d);
+    HIP_TRY(hipMemcpyAsync(e->Yacc.p, y.data(), y.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    launch_y_normalize(e->Yacc.p, e->Y.p, e->K, e->K16, e->d, e->ldy, e->stream);  // :377
+    const size_t GK = (size_t)e->G * e->K16;
+    HIP_TRY(hipMemsetAsync(e->Ogrp.p, 0, GK * sizeof(double), e->stream));
+    HIP_TRY(hipMemsetAsync(e->objacc.p, 0, 4 * sizeof(double), e->stream));
+    {
+        Timed t(e, F_ASSIGN_INIT);
+        AssignArgs a = assign_args(e);
+        a.cells = e->s_cells.p; a.tile_grp = e->s_tile_grp.p; a.S_out = e->Ogrp.p;  // O = R Phi^T exactly (:389)
+        a.tile_begin = 0; a.tile_end = e->n_s_tiles;
+        if (launch_assign(a, false, e->max_wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported cluster count");
+    }
+    {
+        Timed t(e, F_BLOCK_TABLE);
+        TableArgs ta = table_args(e);  // E = outer(R.sum(1), Pr_b) (:388) kept as T; cross-entropy term (:405-411)
+        ta.O_prev = e->Ogrp.p; ta.T_out = e->Tmass.p; ta.obj_cross = e->objacc.p + 2;
+        launch_block_table(ta, e->K16, e->stream);
+    }
+    e->clustered = true;
+    return read_objective(e, obj_out);
+}
+
+int hmx_cluster_round(hmx_engine* e, int flags, const int32_t* cells, int64_t n_pos, const int32_t* tile_group,
+                      int32_t n_tiles, const int32_t* block_tile_start, double obj_out[4]) {
+    if (!e || !obj_out) return fail(HMX_ERR_ARG, "null argument");
+    if (!e->clustered) return fail(HMX_ERR_STATE, "hmx_init_cluster (or hmx_set of R) must come first");
+    if ((flags & HMX_ROUND_OBJECTIVE) && !(flags & HMX_ROUND_UPDATE_R))
+        return fail(HMX_ERR_ARG, "HMX_ROUND_OBJECTIVE needs HMX_ROUND_UPDATE_R in this build");
+    if (!(flags & (HMX_ROUND_CENTROIDS | HMX_ROUND_UPDATE_R))) return fail(HMX_ERR_ARG, "nothing to do");
+    if (!cells || !tile_group || !block_tile_start) return fail(HMX_ERR_ARG, "null update-order list");
+    if (n_pos != (int64_t)n_tiles * HMX_TILE) return fail(HMX_ERR_ARG, "n_pos must be 16*n_tiles");
+    if (block_tile_start[0] != 0 || block_tile_start[e->nblk] != n_tiles) return fail(HMX_ERR_ARG, "block_tile_start must span [0, n_tiles]");
+    for (int b = 0; b < e->nblk; ++b)
+        if (block_tile_start[b + 1] < block_tile_start[b]) return fail(HMX_ERR_ARG, "block_tile_start must be non-decreasing");
+    int rc;
+    if ((rc = use_device(e))) return rc;
+    if ((rc = e->r_cells.reserve(n_pos)) || (rc = e->r_tile_grp.reserve(n_tiles))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->r_cells.p, cells, n_pos * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->r_tile_grp.p, tile_group, n_tiles * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->r_blk_start.p, block_tile_start, (e->nblk + 1) * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));  // host lists are borrowed for the call only
+    const size_t GK = (size_t)e->G * e->K16;
+    HIP_TRY(hipMemsetAsync(e->Sold.p, 0, GK * e->nblk * sizeof(double), e->stream));
+    HIP_TRY(hipMemsetAsync(e->Snew.p, 0, GK * e->nblk * sizeof(double), e->stream));
+    HIP_TRY(hipMemsetAsync(e->objacc.p, 0, 4 * sizeof(double), e->stream));
+
+    // ---- pass over the old R: centroid numerators (:443) and per-block removal sums (:491-492)
+    int nsub, spw;
+    rtz_geometry(e->mt, e->ntd, &nsub, &spw);
+    int wgs = std::min(256, std::max(1, (n_tiles + 31) / 32));
+    if ((rc = e->slab.reserve((size_t)wgs * 4 * spw))) return rc;
+    {
+        Timed t(e, F_RTZ_ROUND);
+        RtzArgs r{};
+        r.R = e->R.p; r.Z = e->Zcos.p; r.cells = e->r_cells.p; r.tile_grp = e->r_tile_grp.p; r.blk_start = e->r_blk_start.p;
+        r.S_out = e->Sold.p; r.slab = e->slab.p; r.n_tiles = n_tiles;
+        r.K = e->K; r.Kp = e->Kp; r.K16 = e->K16; r.G = e->G; r.mt = e->mt; r.dp = e->dp; r.ntd = e->ntd;
+        launch_rtz(r, wgs, e->stream);
+    }
+    if (flags & HMX_ROUND_CENTROIDS) {
+        Timed t(e, F_RTZ_REDUCE);
+        launch_rtz_reduce(e->slab.p, wgs * 4, e->mt, e->ntd, e->K16, e->ldy, e->Yacc.p, nullptr, nullptr, e->G, e->stream);
+        launch_y_normalize(e->Yacc.p, e->Y.p, e->K, e->K16, e->d, e->ldy, e->stream);  // :444
+    }
+    if (flags & HMX_ROUND_UPDATE_R) {
+        for (int b = 0; b < e->nblk; ++b) {
+            {
+                Timed t(e, F_BLOCK_TABLE);
+                TableArgs ta = table_args(e);
+                ta.O_prev = (b == 0) ? e->Ogrp.p : e->Ohist.p + GK * (b - 1);
+                ta.S_add = (b == 0) ? nullptr : e->Snew.p + GK * (b - 1);
+                ta.S_sub = e->Sold.p + GK * b;
+                ta.O_out = e->Ohist.p + GK * b;
+                ta.rp = e->rp.p; ta.lrp = e->lrp.p;
+                launch_block_table(ta, e->K16, e->stream);
+            }
+            if (block_tile_start[b + 1] > block_tile_start[b]) {
+                Timed t(e, F_ASSIGN_BLOCK);
+                AssignArgs a = assign_args(e);
+                a.cells = e->r_cells.p; a.tile_grp = e->r_tile_grp.p; a.S_out = e->Snew.p + GK * b;
+                a.tile_begin = block_tile_start[b]; a.tile_end = block_tile_start[b + 1];
+                if (launch_assign(a, true, e->max_wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported cluster count");
+            }
+        }
+        Timed t(e, F_BLOCK_TABLE);
+        TableArgs ta = table_args(e);  // close the round: O, T state and the cross-entropy term
+        ta.O_prev = e->Ohist.p + GK * (e->nblk - 1);
+        ta.S_add = e->Snew.p + GK * (e->nblk - 1);
+        ta.O_out = e->Ogrp.p; ta.T_out = e->Tmass.p;
+        if (flags & HMX_ROUND_OBJECTIVE) ta.obj_cross = e->objacc.p + 2;
+        launch_block_table(ta, e->K16, e->stream);
+    }
+    return read_objective(e, obj_out);
+}
+
+int hmx_moe_correct_ridge(hmx_engine* e) {
+    if (!e) return fail(HMX_ERR_ARG, "null argument");
+    if (!e->clustered) return fail(HMX_ERR_STATE, "no soft assignment yet");
+    int rc;
+    if ((rc = use_device(e))) return rc;
+    const size_t GK = (size_t)e->G * e->K16;
+    int nsub, spw;
+    rtz_geometry(e->mt, e->ntd, &nsub, &spw);
+    if ((rc = e->slab.reserve((size_t)std::max(e->ntasks, 1) * spw))) return rc;
+    HIP_TRY(hipMemsetAsync(e->Sr.p, 0, GK * e->ldy * sizeof(double), e->stream));
+    HIP_TRY(hipMemsetAsync(e->Oxr.p, 0, GK * sizeof(double), e->stream));
+    {
+        Timed t(e, F_RIDGE_STATS);
+        RtzArgs r{};
+        r.R = e->R.p; r.Z = e->Zorig.p; r.cells = e->s_cells.p; r.tile_grp = e->s_tile_grp.p;
+        r.task_tile0 = e->task_t0.p; r.task_tile1 = e->task_t1.p; r.task_grp = e->task_grp.p;
+        r.S_out = e->Oxr.p; r.slab = e->slab.p; r.n_tiles = e->n_s_tiles; r.ntasks = e->ntasks;
+        r.K = e->K; r.Kp = e->Kp; r.K16 = e->K16; r.G = e->G; r.mt = e->mt; r.dp = e->dp; r.ntd = e->ntd;
+        launch_rtz(r, (e->ntasks + 3) / 4, e->stream);
+        launch_rtz_reduce(e->slab.p, e->ntasks, e->mt, e->ntd, e->K16, e->ldy, nullptr, e->Sr.p, e->task_grp.p, e->G, e->stream);
+    }
+    {
+        Timed t(e, F_RIDGE_SOLVE);
+        RidgeSolveArgs s{};
+        s.S = e->Sr.p; s.Ox = e->Oxr.p; s.T = e->Tmass.p; s.lamb = e->lamb.p; s.Pr_b = e->Pr_b.p; s.group_cols = e->group_cols.p;
+        s.W = e->W.p; s.scratch = e->scratch.p; s.alpha = e->cfg.alpha; s.lambda_est = e->cfg.lambda_estimation;
+        s.K = e->K; s.K16 = e->K16; s.G = e->G; s.B = e->B; s.V = e->V; s.d = e->d; s.lds = e->ldy; s.ldw = e->ldy;
+        launch_ridge_solve(s, e->stream);
+    }
+    {
+        Timed t(e, F_RIDGE_APPLY);
+        ApplyArgs a{};
+        a.R = e->R.p; a.Zorig = e->Zorig.p; a.W = e->W.p; a.Zcorr = e->Zcorr.p; a.Zcos = e->Zcos.p;
+        a.cells = e->s_cells.p; a.tile_grp = e->s_tile_grp.p; a.n_tiles = e->n_s_tiles;
+        a.Kp = e->Kp; a.K16 = e->K16; a.dp = e->dp; a.ldw = e->ldy; a.mtd = e->ntd;
+        if (launch_ridge_apply(a, e->max_wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported n_pcs");
+    }
+    HIP_TRY(hipGetLastError());
+    return HMX_OK;
+}
+
+static int locate(hmx_engine* e, int which, void** p, size_t* bytes, int* rows, int* cols, int* ld, int* elem) {
+    const size_t N = (size_t)e->N;
+    switch (which) {
+        case HMX_Z_ORIG: *p = e->Zorig.p; *rows = (int)N; *cols = e->d; *ld = e->dp; *elem = 4; break;
+        case HMX_Z_COS: *p = e->Zcos.p; *rows = (int)N; *cols = e->d; *ld = e->dp; *elem = 4; break;
+        case HMX_Z_CORR: *p = e->Zcorr.p; *rows = (int)N; *cols = e->d; *ld = e->dp; *elem = 4; break;
+        case HMX_R: *p = e->R.p; *rows = (int)N; *cols = e->K; *ld = e->Kp; *elem = 4; break;
+        case HMX_Y: *p = e->Y.p; *rows = e->K; *cols = e->d; *ld = e->ldy; *elem = 4; break;
+        case HMX_O_GROUP: *p = e->Ogrp.p; *rows = e->G; *cols = e->K; *ld = e->K16; *elem = 8; break;
+        case HMX_T_MASS: *p = e->Tmass.p; *rows = 1; *cols = e->K; *ld = e->K16; *elem = 8; break;
+        case HMX_W: *p = e->W.p; *rows = e->G * e->K16; *cols = e->d; *ld = e->ldy; *elem = 4; break;
+        default: return fail(HMX_ERR_ARG, "unknown array selector %d", which);
+    }
+    *bytes = (size_t)(*rows) * (*cols) * (*elem);
+    return 0;
+}
+
+int hmx_get(hmx_engine* e, int which, void* host_out, size_t bytes) {
+    if (!e || !host_out) return fail(HMX_ERR_ARG, "null argument");
+    void* p; size_t need; int rows, cols, ld, elem, rc;
+    if ((rc = locate(e, which, &p, &need, &rows, &cols, &ld, &elem))) return rc;
+    if (which == HMX_W) need = (size_t)e->G * e->K * e->d * 4;
+    if (bytes != need) return fail(HMX_ERR_ARG, "array %d holds %zu bytes, caller passed %zu", which, need, bytes);
+    if ((rc = use_device(e))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (which == HMX_W) {  // G x K16 x ld -> G x K x d
+        for (int g = 0; g < e->G; ++g)
+            HIP_TRY(hipMemcpy2D((char*)host_out + (size_t)g * e->K * e->d * 4, (size_t)e->d * 4,
+                                (char*)p + (size_t)g * e->K16 * ld * 4, (size_t)ld * 4, (size_t)e->d * 4, e->K, hipMemcpyDeviceToHost));
+        return HMX_OK;
+    }
+    HIP_TRY(hipMemcpy2D(host_out, (size_t)cols * elem, p, (size_t)ld * elem, (size_t)cols * elem, rows, hipMemcpyDeviceToHost));
+    return HMX_OK;
+}
+
+int hmx_set(hmx_engine* e, int which, const void* host_in, size_t bytes) {
+    if (!e || !host_in) return fail(HMX_ERR_ARG, "null argument");
+    if (which == HMX_W) return fail(HMX_ERR_ARG, "W is an output");
+    void* p; size_t need; int rows, cols, ld, elem, rc;
+    if ((rc = locate(e, which, &p, &need, &rows, &cols, &ld, &elem))) return rc;
+    if (bytes != need) return fail(HMX_ERR_ARG, "array %d holds %zu bytes, caller passed %zu", which, need, bytes);
+    if (!e->uploaded) return fail(HMX_ERR_STATE, "hmx_upload must come first");
+    if ((rc = use_device(e))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemset(p, 0, (size_t)rows * ld * elem));
+    HIP_TRY(hipMemcpy2D(p, (size_t)ld * elem, host_in, (size_t)cols * elem, (size_t)cols * elem, rows, hipMemcpyHostToDevice));
+    if (which == HMX_R) {  // keep O and T consistent with the new assignment (exact sums)
+        const size_t GK = (size_t)e->G * e->K16;
+        HIP_TRY(hipMemsetAsync(e->Ogrp.p, 0, GK * sizeof(double), e->stream));
+        launch_group_sums(e->R.p, e->Kp, e->K, e->K16, e->s_cells.p, e->s_tile_grp.p, e->n_s_tiles, e->Ogrp.p, e->stream);
+        TableArgs ta = table_args(e);
+        ta.O_prev = e->Ogrp.p; ta.T_out = e->Tmass.p;
+        launch_block_table(ta, e->K16, e->stream);
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipGetLastError());
+        e->clustered = true;
+    }
+    return HMX_OK;
+}
+
+int hmx_sync(hmx_engine* e) {
+    if (!e) return fail(HMX_ERR_ARG, "null argument");
+    int rc;
+    if ((rc = use_device(e))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipGetLastError());
+    return HMX_OK;
+}
+
+int hmx_device_ptr(hmx_engine* e, int which, void** d_ptr, size_t* bytes) {
+    if (!e || !d_ptr || !bytes) return fail(HMX_ERR_ARG, "null argument");
+    size_t need; int rows, cols, ld, elem, rc;
+    if ((rc = locate(e, which, d_ptr, &need, &rows, &cols, &ld, &elem))) return rc;
+    *bytes = (size_t)rows * ld * elem;
+    return HMX_OK;
+}
+
+int hmx_enable_timing(hmx_engine* e, int on) {
+    if (!e) return fail(HMX_ERR_ARG, "null argument");
+    (void)hipSetDevice(e->cfg.device_id);
+    (void)hipStreamSynchronize(e->stream);
+    drain_spans(e);
+    e->timing = on != 0;
+    for (int i = 0; i < F_COUNT; ++i) { e->fam_ms[i] = 0; e->fam_n[i] = 0; }
+    return HMX_OK;
+}
+
+int hmx_kernel_times(hmx_engine* e, double* ms_out, int n, const char** names_out) {
+    if (!e || !ms_out) return fail(HMX_ERR_ARG, "null argument");
+    (void)hipSetDevice(e->cfg.device_id);
+    (void)hipStreamSynchronize(e->stream);
+    drain_spans(e);
+    // ms_out[2*i] = total ms of family i, ms_out[2*i+1] = number of launches
+    for (int i = 0; i < F_COUNT && 2 * i + 1 < n; ++i) { ms_out[2 * i] = e->fam_ms[i]; ms_out[2 * i + 1] = (double)e->fam_n[i]; }
+    if (names_out) *names_out = kFamilyNames;
+    return F_COUNT;
+}
+
+}  // extern "C"

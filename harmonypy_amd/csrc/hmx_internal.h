@@ -1,0 +1,94 @@
+// hmx_internal.h -- argument blocks shared by the kernels (hmx_kernels.hip) and the C ABI
+// host code (hmx_capi.cpp).  Not part of the public interface (include/hmx.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define HMX_RTZ_MTW 7 /* output tile block of k_rtz: 7 x 4 tiles of 16 x 16 = 112 accumulators */
+#define HMX_RTZ_NTW 4
+
+struct AssignArgs {
+    const float* Zcos;     // N x dp
+    const float* Y;        // K16 x ldy, unit rows, zero padded
+    const float* sigma;    // K16 (zero padded)
+    const float* rp;       // G x K16 powered diversity ratio summed over variables (PENALTY only)
+    const float* lrp;      // G x K16 log(rp)
+    float* R;              // N x Kp
+    const int* cells;      // list positions -> internal cell id, -1 = padding
+    const int* tile_grp;   // group of every tile
+    double* S_out;         // G x K16: sum of the new R per (group, cluster)
+    double* obj;           // [0] += sum R*dist, [1] += sum sigma R log R
+    int tile_begin, tile_end;
+    int K, Kp, K16, mt, dp, ldy;
+};
+
+struct RtzArgs {
+    const float* R;        // N x Kp
+    const float* Z;        // N x dp
+    const int* cells;
+    const int* tile_grp;
+    const int* blk_start;  // nblk+1 (block-major list) or null
+    const int* task_tile0; // per-wave task ranges (ridge) or null
+    const int* task_tile1;
+    const int* task_grp;
+    double* S_out;         // [blk][G][K16] column sums of R (or null)
+    float* slab;
+    int n_tiles, ntasks;
+    int K, Kp, K16, G, mt, dp, ntd;
+};
+
+struct TableArgs {
+    const double* O_prev;  // G x K16
+    const double* S_add;   // G x K16 or null
+    const double* S_sub;   // G x K16 or null
+    double* O_out;         // G x K16 or null
+    double* T_out;         // K16 or null
+    float* rp;             // G x K16 or null
+    float* lrp;
+    double* obj_cross;     // scalar accumulator or null
+    const int* group_cols; // G x V
+    const float* Pr_b;
+    const float* theta;
+    const float* sigma;
+    int G, B, V, K16;
+};
+
+struct RidgeSolveArgs {
+    const double* S;       // G x K16 x lds
+    const double* Ox;      // G x K16
+    const double* T;       // K16
+    const float* lamb;     // B+1
+    const float* Pr_b;
+    const int* group_cols;
+    float* W;              // G x K16 x ldw
+    double* scratch;       // general path: K16 x (B+1) x (B+1+d)
+    float alpha;
+    int lambda_est;
+    int K, K16, G, B, V, d, lds, ldw;
+};
+
+struct ApplyArgs {
+    const float* R;
+    const float* Zorig;
+    const float* W;        // G x K16 x ldw
+    float* Zcorr;
+    float* Zcos;
+    const int* cells;
+    const int* tile_grp;
+    int n_tiles;
+    int Kp, K16, dp, ldw, mtd;
+};
+
+void launch_normalize_rows(const float* Z, float* Zc, int64_t N, int dp, hipStream_t s);
+void launch_y_normalize(const float* src, float* dst, int K, int K16, int d, int ldy, hipStream_t s);
+int launch_assign(const AssignArgs& a, bool penalty, int max_wgs, hipStream_t s);
+void rtz_geometry(int mt, int ntd, int* nsub, int* slab_per_wave);
+void launch_rtz(const RtzArgs& a, int wgs, hipStream_t s);
+void launch_rtz_reduce(const float* slab, int nwaves, int mt, int ntd, int K16, int ld, float* out_f, double* out_d,
+                       const int* task_grp, int G, hipStream_t s);
+void launch_block_table(const TableArgs& a, int K16, hipStream_t s);
+void launch_group_sums(const float* R, int Kp, int K, int K16, const int* cells, const int* tile_grp, int n_tiles,
+                       double* Ogrp, hipStream_t s);
+void launch_ridge_solve(const RidgeSolveArgs& a, hipStream_t s);
+int launch_ridge_apply(const ApplyArgs& a, int max_wgs, hipStream_t s);

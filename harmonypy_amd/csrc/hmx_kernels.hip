@@ -1,0 +1,823 @@
+// hmx_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the Harmony iteration engine.
+//
+// Everything here is written for wave64 + v_mfma_f32_16x16x4_f32 (exact fp32 MFMA).
+// Data layout in HBM is cell-major: one row per cell (Z: dp floats, R: Kp floats), so a
+// cell's operands for the MFMA fragments are contiguous 16..64-byte pieces of its row.
+//
+// Fragment conventions (cdna_hip_programming.md §3):
+//   A operand: lane l holds A[i = l&15][k = l>>4]
+//   B operand: lane l holds B[k = l>>4][j = l&15]
+//   C/D      : lane l, reg r holds C[row = 4*(l>>4) + r][col = l&15]
+// Throughout: c16 = lane & 15, q = lane >> 4.
+//
+// A *tile* is 16 list positions that share one batch group; lists are padded with -1.
+//
+// Reference lines are harmonypy/harmony.py (v0.2.0).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hmx_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float wave_sum_q(float v) {
+    // sum over the 4 lanes that share c16 (q = 0..3)
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum_c16(float v) {
+    // sum over the 16 lanes that share q
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_all(double v) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// ------------------------------------------------------------------------------------------
+// Row normalisation: Z_cos = Z / ||Z||_2 per cell (harmony.py:238, 569)
+// one wave per 4 rows (16 lanes per row)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_normalize_rows(const float* __restrict__ Z, float* __restrict__ Zc,
+                                                        int64_t N, int dp) {
+    const int lane16 = threadIdx.x & 15;
+    int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (row >= N) return;  // whole 16-lane group leaves together
+    const float* z = Z + row * dp;
+    float ss = 0.f;
+    for (int j = lane16; j < dp; j += 16) ss += z[j] * z[j];
+    ss = wave_sum_c16(ss);
+    const float nrm = sqrtf(ss);
+    float* o = Zc + row * dp;
+    for (int j = lane16; j < dp; j += 16) o[j] = z[j] / nrm;
+}
+
+// ------------------------------------------------------------------------------------------
+// Centroid rows -> unit length (harmony.py:377, 444).  One 64-lane wave per cluster.
+// src: K16 x ldy raw sums (float), dst: K16 x ldy (rows >= K and cols >= d stay zero)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_y_normalize(const float* __restrict__ src, float* __restrict__ dst, int K,
+                                                    int d, int ldy) {
+    const int k = blockIdx.x;
+    const int lane = threadIdx.x;
+    float ss = 0.f;
+    if (k < K)
+        for (int j = lane; j < d; j += 64) ss += src[(size_t)k * ldy + j] * src[(size_t)k * ldy + j];
+    for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
+    const float nrm = sqrtf(ss);
+    for (int j = lane; j < ldy; j += 64) dst[(size_t)k * ldy + j] = (k < K && j < d) ? src[(size_t)k * ldy + j] / nrm : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------
+// Assignment kernel: distance GEMM + soft assignment (+ diversity penalty)
+//   harmony.py:380-385 (PENALTY = false, init_cluster)
+//   harmony.py:447, 466-468, 500-503 and the R-dependent sums of :399, :402 (PENALTY = true)
+//
+// C[cluster][cell] = Y (K16 x d) . Zcos^T: A = Y (rows from L1/L2, 16 B per lane),
+// B = Zcos rows gathered straight from HBM in fragment layout (16 B per lane: the four
+// q-lanes of a cell read 64 contiguous bytes of its row).  A lane ends up with the
+// clusters {16mt + 4q + r} of cell c16, so the softmax needs two xor-shuffles only.
+// ------------------------------------------------------------------------------------------
+template <int MT, int NT, bool PENALTY>
+__global__ __launch_bounds__(256) void k_assign(AssignArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int c16 = lane & 15, q = lane >> 4;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    const int mtn = a.mt;  // live cluster tiles (<= MT)
+
+    // contiguous tile range of this wave, in multiples of NT tiles
+    const int ntiles = a.tile_end - a.tile_begin;
+    int per = (ntiles + nwaves - 1) / nwaves;
+    per = ((per + NT - 1) / NT) * NT;
+    const int t0 = a.tile_begin + wave * per;
+    const int t1 = min(t0 + per, a.tile_end);
+    if (t0 >= t1) return;
+
+    float sg[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 16 * mt + 4 * q + r;
+            sg[mt][r] = (mt < mtn && k < a.K) ? a.sigma[k] : 0.f;  // 0 => exp(-2/0) = 0: padded cluster
+        }
+
+    float sacc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sacc[mt][r] = 0.f;
+    int cur_g = -1;
+    double km_acc = 0.0, ent_acc = 0.0;
+
+    const int kb_full = a.dp >> 4;           // full 16-column blocks of a Z row
+    const int tail = (a.dp - 16 * kb_full) >> 2;  // remaining 4-column steps
+
+    auto flush = [&](int g) {
+        if (g < 0) return;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (mt < mtn) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float s = wave_sum_c16(sacc[mt][r]);
+                    const int k = 16 * mt + 4 * q + r;
+                    if (c16 == 0 && k < a.K && s != 0.f) atomicAdd(&a.S_out[(size_t)g * a.K16 + k], (double)s);
+                    sacc[mt][r] = 0.f;
+                }
+            }
+        }
+    };
+
+    for (int t = t0; t < t1; t += NT) {
+        int cell[NT], grp[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int tt = t + nt;
+            cell[nt] = (tt < t1) ? a.cells[(size_t)tt * 16 + c16] : -1;
+            grp[nt] = (tt < t1) ? a.tile_grp[tt] : -1;
+        }
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        // ---- distance GEMM over the PC dimension --------------------------------------
+        for (int kb = 0; kb < kb_full; ++kb) {
+            f32x4 b[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                b[nt] = (cell[nt] >= 0) ? ld4(a.Zcos + (size_t)cell[nt] * a.dp + 16 * kb + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (mt < mtn) {
+                    const f32x4 ya = ld4(a.Y + (size_t)(16 * mt + c16) * a.ldy + 16 * kb + 4 * q);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA16(ya[i], b[nt][i], acc[mt][nt]);
+                }
+            }
+        }
+        for (int s = 0; s < tail; ++s) {
+            const int col = 16 * kb_full + 4 * s + q;
+            float b[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = (cell[nt] >= 0) ? a.Zcos[(size_t)cell[nt] * a.dp + col] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (mt < mtn) {
+                    const float ya = a.Y[(size_t)(16 * mt + c16) * a.ldy + col];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA16(ya, b[nt], acc[mt][nt]);
+                }
+            }
+        }
+
+        // ---- per tile: softmax, penalty, write-back, running sums ---------------------
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (grp[nt] < 0) continue;  // wave-uniform
+            if (grp[nt] != cur_g) {
+                flush(cur_g);
+                cur_g = grp[nt];
+            }
+            const bool live = cell[nt] >= 0;
+            float e[MT][4];
+            float e1 = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (mt < mtn) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float dist = 2.f * (1.f - acc[mt][nt][r]);  // :380 / :447
+                        const float arg = -dist / sg[mt][r];              // :383 / :466
+                        acc[mt][nt][r] = arg;
+                        e[mt][r] = expf(arg);                             // :384 / :467
+                        e1 += e[mt][r];
+                    }
+                }
+            }
+            e1 = wave_sum_q(e1);  // column sum of :385 / :468
+            float u1 = 1.f;
+            if (PENALTY) {
+                const float* rp = a.rp + (size_t)cur_g * a.K16;
+                float us = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (mt < mtn) {
+                        const f32x4 pw = ld4(rp + 16 * mt + 4 * q);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            e[mt][r] = (e[mt][r] / e1) * pw[r];  // :468 then :500
+                            us += e[mt][r];
+                        }
+                    }
+                }
+                us = wave_sum_q(us);
+                u1 = fmaxf(us, 1e-8f);  // :501-502
+            }
+            const float log_e1 = logf(e1);
+            const float log_u1 = PENALTY ? logf(u1) : 0.f;
+            float km = 0.f, ent = 0.f;
+            float* rrow = a.R + (size_t)(live ? cell[nt] : 0) * a.Kp;
+            const float* lrp = PENALTY ? (a.lrp + (size_t)cur_g * a.K16) : nullptr;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (mt < mtn) {
+                    f32x4 lp = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (PENALTY) lp = ld4(lrp + 16 * mt + 4 * q);
+                    f32x4 rv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float Rv = PENALTY ? (e[mt][r] / u1) : (e[mt][r] / e1);  // :503 / :385
+                        if (!live) Rv = 0.f;
+                        rv[r] = Rv;
+                        sacc[mt][r] += Rv;
+                        if (Rv > 0.f) {
+                            const float arg = acc[mt][nt][r];
+                            const float logR = arg - log_e1 + lp[r] - log_u1;
+                            km += Rv * (-arg * sg[mt][r]);   // R * dist           (:399)
+                            ent += sg[mt][r] * (Rv * logR);  // sigma * R log R    (:402)
+                        }
+                    }
+                    const int col = 16 * mt + 4 * q;
+                    if (live && col < a.Kp) st4(rrow + col, rv);
+                }
+            }
+            km_acc += (double)km;
+            ent_acc += (double)ent;
+        }
+    }
+    flush(cur_g);
+    km_acc = wave_sum_all(km_acc);
+    ent_acc = wave_sum_all(ent_acc);
+    if (lane == 0) {
+        atomicAdd(&a.obj[0], km_acc);
+        atomicAdd(&a.obj[1], ent_acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// R^T . Z over a list of cells:  out[cluster][pc] += sum_cells R[cell][cluster] * Z[cell][pc]
+//   - centroid numerator  Z_cos R^T        (harmony.py:443), whole round list, one output
+//   - block removal sums  R_blk Phi_blk^T  (harmony.py:491-492) as per-(block, group) column sums
+//   - ridge right-hand sides Phi_Rk Z_orig^T (harmony.py:556-563), one output per task
+// A = R^T: lane holds R[cell 4ks+q][16mt + c16]; B = Z: lane holds Z[cell 4ks+q][16nt + c16].
+// Each wave owns a contiguous tile range and a (MTW x NTW) block of output tiles selected
+// by blockIdx.y; its accumulators go to a per-wave slab in fragment order (reduced later).
+// ------------------------------------------------------------------------------------------
+template <int MTW, int NTW>
+__global__ __launch_bounds__(256, 2) void k_rtz(RtzArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int c16 = lane & 15, q = lane >> 4;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    const int sub = blockIdx.y;
+    const int nsub_n = (a.ntd + NTW - 1) / NTW;
+    const int mt0 = (sub / nsub_n) * MTW, nt0 = (sub % nsub_n) * NTW;
+    const bool first_col_block = (sub % nsub_n) == 0;
+
+    int t0, t1, task_grp = -1;
+    if (a.task_tile0) {  // one task per wave (ridge statistics)
+        if (wave >= a.ntasks) return;
+        t0 = a.task_tile0[wave];
+        t1 = a.task_tile1[wave];
+        task_grp = a.task_grp[wave];
+    } else {
+        const int per = (a.n_tiles + nwaves - 1) / nwaves;
+        t0 = wave * per;
+        t1 = min(t0 + per, a.n_tiles);
+    }
+
+    f32x4 acc[MTW][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float csum[MTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) csum[mt] = 0.f;
+    int cur_g = -1, cur_b = 0;
+
+    auto flush = [&]() {
+        if (cur_g < 0 || !first_col_block || a.S_out == nullptr) return;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+            const float s = wave_sum_q(csum[mt]);
+            const int k = 16 * (mt0 + mt) + c16;
+            if (q == 0 && k < a.K && s != 0.f)
+                atomicAdd(&a.S_out[((size_t)cur_b * a.G + cur_g) * a.K16 + k], (double)s);
+            csum[mt] = 0.f;
+        }
+    };
+
+    for (int t = t0; t < t1; ++t) {
+        const int g = a.tile_grp[t];
+        int b = cur_b;
+        if (a.blk_start) {
+            while (t >= a.blk_start[b + 1]) ++b;  // lists are block-major, so b only grows
+        }
+        if (g != cur_g || b != cur_b) {
+            flush();
+            cur_g = g;
+            cur_b = b;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int cell = a.cells[(size_t)t * 16 + 4 * ks + q];
+            float av[MTW], bv[NTW];
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                const int col = 16 * (mt0 + mt) + c16;
+                av[mt] = (cell >= 0 && col < a.Kp) ? a.R[(size_t)cell * a.Kp + col] : 0.f;
+                csum[mt] += av[mt];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int col = 16 * (nt0 + nt) + c16;
+                bv[nt] = (cell >= 0 && col < a.dp) ? a.Z[(size_t)cell * a.dp + col] : 0.f;
+            }
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MFMA16(av[mt], bv[nt], acc[mt][nt]);
+        }
+    }
+    flush();
+
+    // slab in fragment order: [wave][sub][mt][nt][r][lane]
+    float* slab = a.slab + ((size_t)wave * gridDim.y + sub) * (MTW * NTW * 256);
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[((mt * NTW + nt) * 4 + r) * 64 + lane] = acc[mt][nt][r];
+    (void)task_grp;
+}
+
+// Sum the per-wave slabs of k_rtz in fp64.  One thread per slab element.
+//   mode 0: out_f[k*ld + j]   = sum over all waves            (centroid numerator)
+//   mode 1: out_d[(g*K16 + k)*ld + j] += sum over the waves (= tasks) of group g (ridge)
+template <int MTW, int NTW>
+__global__ __launch_bounds__(256) void k_rtz_reduce(const float* __restrict__ slab, int nwaves, int nsub, int ntd,
+                                                    int K16, int ld, float* __restrict__ out_f,
+                                                    double* __restrict__ out_d, const int* __restrict__ task_grp,
+                                                    int G) {
+    const int per_sub = MTW * NTW * 256;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nsub * per_sub) return;
+    const int sub = idx / per_sub, e = idx % per_sub;
+    const int lane = e & 63, r = (e >> 6) & 3, tile = e >> 8;
+    const int mt = tile / NTW, nt = tile % NTW;
+    const int nsub_n = (ntd + NTW - 1) / NTW;
+    const int k = 16 * ((sub / nsub_n) * MTW + mt) + 4 * (lane >> 4) + r;
+    const int j = 16 * ((sub % nsub_n) * NTW + nt) + (lane & 15);
+    if (k >= K16 || j >= ld) return;
+    if (task_grp == nullptr) {
+        double s = 0.0;
+        for (int w = 0; w < nwaves; ++w) s += (double)slab[((size_t)w * nsub + sub) * per_sub + e];
+        out_f[(size_t)k * ld + j] = (float)s;
+    } else {
+        // tasks are sorted by group: run-length accumulate
+        int g = -1;
+        double s = 0.0;
+        for (int w = 0; w < nwaves; ++w) {
+            const int gw = task_grp[w];
+            if (gw != g) {
+                if (g >= 0) out_d[((size_t)g * K16 + k) * ld + j] = s;
+                g = gw;
+                s = 0.0;
+            }
+            s += (double)slab[((size_t)w * nsub + sub) * per_sub + e];
+        }
+        if (g >= 0) out_d[((size_t)g * K16 + k) * ld + j] = s;
+    }
+    (void)G;
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-block diversity table (harmony.py:491-499), one workgroup per cluster k.
+//   O_use[g] = O_prev[g] (+ S_new of the previous block) - S_old of this block
+//   E[k,b]   = T_use * Pr_b[b]              (harmony.py:491, kept as mass T instead of K x B)
+//   ratio    = clamp(E / clamp(O + E, 1e-8), 1e-8, 1) ** theta_b
+//   rp[g][k] = sum_v ratio[col(g, v)]        (= (ratio_powered @ Phi) for the cells of group g)
+// LDS: B doubles (column sums), B floats (powered ratio), reduction scratch.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_block_table(TableArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* ocol = reinterpret_cast<double*>(smem);           // B
+    double* red = ocol + a.B;                                  // 128
+    float* rpc = reinterpret_cast<float*>(red + 128);          // B
+    const int k = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int b = tid; b < a.B; b += blockDim.x) ocol[b] = 0.0;
+    __syncthreads();
+    double tpart = 0.0;
+    for (int g = tid; g < a.G; g += blockDim.x) {
+        const size_t i = (size_t)g * a.K16 + k;
+        double o = a.O_prev[i];
+        if (a.S_add) o += a.S_add[i];
+        if (a.S_sub) o -= a.S_sub[i];
+        if (a.O_out) a.O_out[i] = o;
+        tpart += o;
+        if (a.V == 1) {
+            ocol[a.group_cols[g]] = o;
+        } else {
+            for (int v = 0; v < a.V; ++v) atomicAdd(&ocol[a.group_cols[g * a.V + v]], o);
+        }
+    }
+    red[tid] = tpart;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const double T = red[0];
+    if (tid == 0 && a.T_out) a.T_out[k] = T;
+    if (a.rp) {
+        for (int b = tid; b < a.B; b += blockDim.x) {
+            const float O = (float)ocol[b];
+            const float E = (float)T * a.Pr_b[b];
+            const float oe = fmaxf(O + E, 1e-8f);                       // :495-496
+            const float ratio = fminf(fmaxf(E / oe, 1e-8f), 1.0f);      // :497-498
+            rpc[b] = powf(ratio, a.theta[b]);                           // :499
+        }
+        __syncthreads();
+        for (int g = tid; g < a.G; g += blockDim.x) {
+            float s = 0.f;
+            for (int v = 0; v < a.V; ++v) s += rpc[a.group_cols[g * a.V + v]];
+            a.rp[(size_t)g * a.K16 + k] = s;
+            a.lrp[(size_t)g * a.K16 + k] = logf(s);
+        }
+    }
+    if (a.obj_cross) {
+        // cross-entropy term of the objective (harmony.py:405-411) collapsed to K x B:
+        //   sum_b sigma_k theta_b log((O_c + E_c)/E_c) * (R Phi^T)[k,b]
+        double part = 0.0;
+        const float sig = a.sigma[k];
+        for (int b = tid; b < a.B; b += blockDim.x) {
+            const float O = (float)ocol[b];
+            const float Oc = fmaxf(O, 1e-8f);                           // :407
+            const float Ec = fmaxf((float)T * a.Pr_b[b], 1e-8f);        // :408
+            const float tl = a.theta[b] * logf((Oc + Ec) / Ec);         // :409-410
+            part += (double)(sig * O * tl);
+        }
+        __syncthreads();
+        red[tid] = part;
+        __syncthreads();
+        for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0) atomicAdd(a.obj_cross, red[0]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Group column sums of R over a static tile list (exact O after hmx_set(R)).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_group_sums(const float* __restrict__ R, int Kp, int K, int K16,
+                                                    const int* __restrict__ cells, const int* __restrict__ tile_grp,
+                                                    int n_tiles, double* __restrict__ Ogrp) {
+    const int t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const int g = tile_grp[t];
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        float s = 0.f;
+        for (int i = 0; i < 16; ++i) {
+            const int cell = cells[(size_t)t * 16 + i];
+            if (cell >= 0) s += R[(size_t)cell * Kp + k];
+        }
+        if (s != 0.f) atomicAdd(&Ogrp[(size_t)g * K16 + k], (double)s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Ridge solve, one workgroup per cluster k (harmony.py:541-565), single batch variable.
+// The system (Phi_moe diag(R_k) Phi_moe^T + diag(lambda)) W = Phi_moe diag(R_k) Z^T is an
+// arrowhead matrix; eliminating the batch rows gives, with O_b = sum_i R_ki [b(i)=b],
+// S_b = sum_{i in b} R_ki z_i  and c_b = lambda_b / (O_b + lambda_b):
+//     w_0 = (sum_b c_b S_b) / (lambda_0 + sum_b c_b O_b)
+//     w_b = (S_b - O_b w_0) / (O_b + lambda_b)
+// evaluated in fp64 (cancellation-free form).  Row 0 is dropped (harmony.py:565).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_ridge_solve_v1(RidgeSolveArgs a) {
+    const int k = blockIdx.x;
+    const int tid = threadIdx.x;
+    // lambda_b: fixed, or alpha * E[k,b] = alpha * T[k] * Pr_b[b] (harmony.py:587-591)
+    for (int j = tid; j < a.ldw; j += blockDim.x) {
+        double num = 0.0, den = a.lambda_est ? 0.0 : (double)a.lamb[0];
+        if (j < a.d) {
+            for (int b = 0; b < a.B; ++b) {
+                const double lam = a.lambda_est ? (double)(a.alpha * ((float)a.T[k] * a.Pr_b[b])) : (double)a.lamb[b + 1];
+                const double O = a.Ox[(size_t)b * a.K16 + k];
+                const double c = lam / (O + lam);
+                num += c * a.S[((size_t)b * a.K16 + k) * a.lds + j];
+                den += c * O;
+            }
+        }
+        const double w0 = (j < a.d && k < a.K) ? num / den : 0.0;
+        for (int b = 0; b < a.B; ++b) {
+            float w = 0.f;
+            if (j < a.d && k < a.K) {
+                const double lam = a.lambda_est ? (double)(a.alpha * ((float)a.T[k] * a.Pr_b[b])) : (double)a.lamb[b + 1];
+                const double O = a.Ox[(size_t)b * a.K16 + k];
+                w = (float)((a.S[((size_t)b * a.K16 + k) * a.lds + j] - O * w0) / (O + lam));
+            }
+            a.W[((size_t)b * a.K16 + k) * a.ldw + j] = w;
+        }
+    }
+}
+
+// General case (several batch variables): dense (B+1) x (B+1) system per cluster, Gauss-Jordan
+// with partial pivoting in fp64 on an augmented matrix [cov | rhs] held in global scratch.
+// One workgroup per cluster.  Group tables -> column tables:
+//   cov[0][0] = sum_g Ox[g] + lambda_0, cov[0][b+1] = Ocol[b], cov[b+1][c+1] = sum_{g has b,c} Ox[g]
+//   rhs[0] = sum_g S_g, rhs[b+1] = sum_{g has b} S_g;   W_eff[g] = sum_v w[col(g,v)+1]
+__global__ __launch_bounds__(256) void k_ridge_solve_general(RidgeSolveArgs a) {
+    const int k = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n = a.B + 1;
+    const int wcols = n + a.d;
+    double* M = a.scratch + (size_t)k * n * wcols;
+    __shared__ int piv_row;
+    __shared__ double piv_val;
+    for (int i = tid; i < n * wcols; i += blockDim.x) M[i] = 0.0;
+    __threadfence_block();
+    __syncthreads();
+    if (k >= a.K) {
+        for (int g = 0; g < a.G; ++g)
+            for (int j = tid; j < a.ldw; j += blockDim.x) a.W[((size_t)g * a.K16 + k) * a.ldw + j] = 0.f;
+        return;
+    }
+    // assemble (serial over groups, parallel over columns: no atomics)
+    for (int g = 0; g < a.G; ++g) {
+        const double O = a.Ox[(size_t)g * a.K16 + k];
+        const int* cols = a.group_cols + g * a.V;
+        if (tid == 0) {
+            M[0] += O;
+            for (int v = 0; v < a.V; ++v) {
+                const int b = cols[v] + 1;
+                M[b] += O;
+                M[(size_t)b * wcols] += O;
+                for (int u = 0; u < a.V; ++u) M[(size_t)b * wcols + cols[u] + 1] += O;
+            }
+        }
+        for (int j = tid; j < a.d; j += blockDim.x) {
+            const double s = a.S[((size_t)g * a.K16 + k) * a.lds + j];
+            M[n + j] += s;
+            for (int v = 0; v < a.V; ++v) M[(size_t)(cols[v] + 1) * wcols + n + j] += s;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    for (int b = tid; b < n; b += blockDim.x) {
+        double lam;
+        if (a.lambda_est) lam = (b == 0) ? 0.0 : (double)(a.alpha * ((float)a.T[k] * a.Pr_b[b - 1]));
+        else lam = (double)a.lamb[b];
+        M[(size_t)b * wcols + b] += lam;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // Gauss-Jordan
+    for (int c = 0; c < n; ++c) {
+        if (tid == 0) {
+            int best = c;
+            double bv = fabs(M[(size_t)c * wcols + c]);
+            for (int r = c + 1; r < n; ++r) {
+                const double v = fabs(M[(size_t)r * wcols + c]);
+                if (v > bv) { bv = v; best = r; }
+            }
+            piv_row = best;
+        }
+        __syncthreads();
+        const int pr = piv_row;
+        if (pr != c) {
+            for (int j = tid; j < wcols; j += blockDim.x) {
+                const double t = M[(size_t)c * wcols + j];
+                M[(size_t)c * wcols + j] = M[(size_t)pr * wcols + j];
+                M[(size_t)pr * wcols + j] = t;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (tid == 0) piv_val = M[(size_t)c * wcols + c];
+        __syncthreads();
+        const double inv = 1.0 / piv_val;
+        for (int j = tid; j < wcols; j += blockDim.x) M[(size_t)c * wcols + j] *= inv;
+        __threadfence_block();
+        __syncthreads();
+        // eliminate column c from every other row; thread owns (row, column-strip)
+        for (int r = 0; r < n; ++r) {
+            if (r == c) continue;
+            const double f = M[(size_t)r * wcols + c];
+            __syncthreads();
+            if (f != 0.0)
+                for (int j = tid; j < wcols; j += blockDim.x) M[(size_t)r * wcols + j] -= f * M[(size_t)c * wcols + j];
+            __threadfence_block();
+            __syncthreads();
+        }
+    }
+    for (int g = 0; g < a.G; ++g) {
+        const int* cols = a.group_cols + g * a.V;
+        for (int j = tid; j < a.ldw; j += blockDim.x) {
+            double w = 0.0;
+            if (j < a.d)
+                for (int v = 0; v < a.V; ++v) w += M[(size_t)(cols[v] + 1) * wcols + n + j];
+            a.W[((size_t)g * a.K16 + k) * a.ldw + j] = (float)w;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Ridge apply (harmony.py:566, 569):  Z_corr_i = Z_orig_i - sum_k R_ik W[g(i)][k][:],
+// then Z_cos_i = Z_corr_i / ||Z_corr_i||.
+// C[pc][cell] = W_g^T (d x K) . R^T (K x cells): A = W_g (4-byte loads, L1/L2), B = R rows
+// gathered 16 B per lane.  A lane ends with PCs {16mt + 4q + r} of cell c16.
+// ------------------------------------------------------------------------------------------
+template <int MTD, int NT>
+__global__ __launch_bounds__(256) void k_ridge_apply(ApplyArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int c16 = lane & 15, q = lane >> 4;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    int per = (a.n_tiles + nwaves - 1) / nwaves;
+    per = ((per + NT - 1) / NT) * NT;
+    const int t0 = wave * per, t1 = min(t0 + per, a.n_tiles);
+    const int kb_n = (a.Kp + 15) >> 4;
+    const int mtn = a.mtd;
+
+    for (int t = t0; t < t1; t += NT) {
+        // tiles of one step may belong to different groups: process same-group runs together
+        int cell[NT], grp[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int tt = t + nt;
+            cell[nt] = (tt < t1) ? a.cells[(size_t)tt * 16 + c16] : -1;
+            grp[nt] = (tt < t1) ? a.tile_grp[tt] : -1;
+        }
+        f32x4 acc[MTD][NT];
+#pragma unroll
+        for (int mt = 0; mt < MTD; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < kb_n; ++kb) {
+            const int col0 = 16 * kb + 4 * q;
+            f32x4 b[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                b[nt] = (cell[nt] >= 0 && col0 < a.Kp) ? ld4(a.R + (size_t)cell[nt] * a.Kp + col0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (grp[nt] < 0) continue;
+                const float* Wg = a.W + (size_t)grp[nt] * a.K16 * a.ldw;
+#pragma unroll
+                for (int mt = 0; mt < MTD; ++mt) {
+                    if (mt < mtn) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float wa = Wg[(size_t)(col0 + i) * a.ldw + 16 * mt + c16];
+                            acc[mt][nt] = MFMA16(wa, b[nt][i], acc[mt][nt]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (grp[nt] < 0) continue;
+            const bool live = cell[nt] >= 0;
+            const size_t row = (size_t)(live ? cell[nt] : 0) * a.dp;
+            float ss = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MTD; ++mt) {
+                if (mt < mtn) {
+                    const int col = 16 * mt + 4 * q;
+                    if (live && col < a.dp) {
+                        const f32x4 zo = ld4(a.Zorig + row + col);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            acc[mt][nt][r] = zo[r] - acc[mt][nt][r];
+                            ss += acc[mt][nt][r] * acc[mt][nt][r];
+                        }
+                        st4(a.Zcorr + row + col, acc[mt][nt]);
+                    }
+                }
+            }
+            ss = wave_sum_q(ss);
+            const float nrm = sqrtf(ss);
+#pragma unroll
+            for (int mt = 0; mt < MTD; ++mt) {
+                if (mt < mtn) {
+                    const int col = 16 * mt + 4 * q;
+                    if (live && col < a.dp) {
+                        f32x4 zc;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) zc[r] = acc[mt][nt][r] / nrm;
+                        st4(a.Zcos + row + col, zc);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side launchers (called from hmx_capi.cpp through hmx_internal.h)
+// ------------------------------------------------------------------------------------------
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+void launch_normalize_rows(const float* Z, float* Zc, int64_t N, int dp, hipStream_t s) {
+    if (N <= 0) return;
+    hipLaunchKernelGGL(k_normalize_rows, dim3(cdiv(N, 16)), dim3(256), 0, s, Z, Zc, N, dp);
+}
+
+void launch_y_normalize(const float* src, float* dst, int K, int K16, int d, int ldy, hipStream_t s) {
+    hipLaunchKernelGGL(k_y_normalize, dim3(K16), dim3(64), 0, s, src, dst, K, d, ldy);
+}
+
+int assign_grid(int ntiles, int nt_per_step, int max_wgs) {
+    const int steps = cdiv(ntiles, nt_per_step);
+    int wgs = cdiv(steps, 4);
+    if (wgs > max_wgs) wgs = max_wgs;
+    if (wgs < 1) wgs = 1;
+    return wgs;
+}
+
+int launch_assign(const AssignArgs& a, bool penalty, int max_wgs, hipStream_t s) {
+    const int ntiles = a.tile_end - a.tile_begin;
+    if (ntiles <= 0) return 0;
+    if (a.mt <= 7) {
+        constexpr int NT = 2;
+        const int wgs = assign_grid(ntiles, NT, max_wgs);
+        if (penalty) hipLaunchKernelGGL((k_assign<7, NT, true>), dim3(wgs), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_assign<7, NT, false>), dim3(wgs), dim3(256), 0, s, a);
+    } else if (a.mt <= 13) {
+        constexpr int NT = 1;
+        const int wgs = assign_grid(ntiles, NT, max_wgs);
+        if (penalty) hipLaunchKernelGGL((k_assign<13, NT, true>), dim3(wgs), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_assign<13, NT, false>), dim3(wgs), dim3(256), 0, s, a);
+    } else {
+        return -1;
+    }
+    return 0;
+}
+
+void rtz_geometry(int mt, int ntd, int* nsub, int* slab_per_wave) {
+    const int nsub_m = cdiv(mt, HMX_RTZ_MTW), nsub_n = cdiv(ntd, HMX_RTZ_NTW);
+    *nsub = nsub_m * nsub_n;
+    *slab_per_wave = (*nsub) * HMX_RTZ_MTW * HMX_RTZ_NTW * 256;
+}
+
+void launch_rtz(const RtzArgs& a, int wgs, hipStream_t s) {
+    int nsub, spw;
+    rtz_geometry(a.mt, a.ntd, &nsub, &spw);
+    hipLaunchKernelGGL((k_rtz<HMX_RTZ_MTW, HMX_RTZ_NTW>), dim3(wgs, nsub), dim3(256), 0, s, a);
+}
+
+void launch_rtz_reduce(const float* slab, int nwaves, int mt, int ntd, int K16, int ld, float* out_f, double* out_d,
+                       const int* task_grp, int G, hipStream_t s) {
+    int nsub, spw;
+    rtz_geometry(mt, ntd, &nsub, &spw);
+    hipLaunchKernelGGL((k_rtz_reduce<HMX_RTZ_MTW, HMX_RTZ_NTW>), dim3(cdiv(spw, 256)), dim3(256), 0, s, slab, nwaves,
+                       nsub, ntd, K16, ld, out_f, out_d, task_grp, G);
+}
+
+void launch_block_table(const TableArgs& a, int K16, hipStream_t s) {
+    const size_t sm = (size_t)a.B * 8 + 128 * 8 + (size_t)a.B * 4 + 16;
+    hipLaunchKernelGGL(k_block_table, dim3(K16), dim3(128), sm, s, a);
+}
+
+void launch_group_sums(const float* R, int Kp, int K, int K16, const int* cells, const int* tile_grp, int n_tiles,
+                       double* Ogrp, hipStream_t s) {
+    if (n_tiles <= 0) return;
+    hipLaunchKernelGGL(k_group_sums, dim3(n_tiles), dim3(128), 0, s, R, Kp, K, K16, cells, tile_grp, n_tiles, Ogrp);
+}
+
+void launch_ridge_solve(const RidgeSolveArgs& a, hipStream_t s) {
+    if (a.V == 1) hipLaunchKernelGGL(k_ridge_solve_v1, dim3(a.K16), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(k_ridge_solve_general, dim3(a.K16), dim3(256), 0, s, a);
+}
+
+int launch_ridge_apply(const ApplyArgs& a, int max_wgs, hipStream_t s) {
+    if (a.n_tiles <= 0) return 0;
+    constexpr int NT = 2;
+    const int wgs = assign_grid(a.n_tiles, NT, max_wgs);
+    if (a.mtd <= 4) hipLaunchKernelGGL((k_ridge_apply<4, NT>), dim3(wgs), dim3(256), 0, s, a);
+    else if (a.mtd <= 13) hipLaunchKernelGGL((k_ridge_apply<13, NT>), dim3(wgs), dim3(256), 0, s, a);
+    else return -1;
+    return 0;
+}

@@ -1,0 +1,537 @@
+"""Host side of the MI355X Harmony engine: the ``run_harmony`` / ``Harmony`` API.
+
+Mirrors the public interface of harmonypy v0.2.0 (``harmonypy/harmony.py:49-215`` for
+``run_harmony``, ``:218-569`` for ``Harmony``): same argument names and meaning, same
+attributes, history lists and NumPy-returning properties.  All arithmetic of the
+``harmonize()`` loop runs in ``libhmx.so`` (HIP kernels for gfx950) through ``_capi``;
+Python keeps what the reference keeps on the host: argument normalisation, the sklearn
+k-means++ initialisation call (``:369-373``), the convergence tests on the history lists
+(``:515-533``) and the random update order (``:471``), which is drawn from the same
+generator as the reference's ``device='cpu'`` run (``torch.manual_seed`` / ``torch.randperm``)
+so that both walk identical blocks.
+
+There is no CPU fallback: without ``libhmx.so`` and a visible MI355X this module raises.
+"""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+import pandas as pd
+
+from . import _capi
+
+logger = logging.getLogger("harmonypy_amd")
+if not logger.handlers:
+    _h = logging.StreamHandler()
+    _h.setFormatter(logging.Formatter("%(asctime)s - %(name)s - %(levelname)s - %(message)s"))
+    logger.addHandler(_h)
+    logger.setLevel(logging.INFO)
+
+# Test aids (never set by product code).  ``Y0``: d x K centroids used instead of the
+# sklearn call; ``forced_rounds``: list of k-means round counts replayed instead of the
+# objective thresholds (whose margins are a few fp32 ulps).
+_TEST_HOOKS = {"Y0": None, "forced_rounds": None}
+
+TILE = _capi.HMX_TILE
+
+
+class BatchCodes:
+    """Integer form of the batch design: ``codes[i, v]`` is the Phi row that cell ``i``
+    has set for variable ``v`` (what ``pd.get_dummies`` would one-hot, harmony.py:133)."""
+
+    def __init__(self, codes, n_batches):
+        codes = np.asarray(codes)
+        if codes.ndim == 1:
+            codes = codes[:, None]
+        self.codes = np.ascontiguousarray(codes, dtype=np.int32)
+        self.n_batches = int(n_batches)
+
+    @classmethod
+    def from_dense(cls, Phi):
+        """From the reference's dense B x N indicator matrix."""
+        Phi = np.asarray(Phi)
+        B, N = Phi.shape
+        per_cell = (Phi > 0).sum(axis=0)
+        V = int(per_cell[0]) if N else 1
+        if not np.all(per_cell == V) or V < 1:
+            raise ValueError("Phi must hold the same number of active batch rows for every cell")
+        rows, cols = np.nonzero(Phi.T > 0)          # row-major => sorted by cell, then Phi row
+        return cls(cols.reshape(N, V), B)
+
+    def dense(self):
+        N, V = self.codes.shape
+        Phi = np.zeros((self.n_batches, N), dtype=np.float32)
+        for v in range(V):
+            Phi[self.codes[:, v], np.arange(N)] = 1.0
+        return Phi
+
+
+def _device_index(device):
+    """Reference accepts 'cpu' | 'cuda' | 'mps' | None (harmony.py:35-46).  This engine is
+    MI355X only: None / 'cuda' / 'hip' [':n'] select a HIP device; anything else is an error."""
+    if device is None:
+        return 0
+    s = str(device)
+    base, _, idx = s.partition(":")
+    if base not in ("cuda", "hip", "gpu"):
+        raise ValueError(f"harmonypy_amd runs on AMD MI355X (HIP) devices only; device={device!r} is not available")
+    return int(idx) if idx else 0
+
+
+def run_harmony(
+    data_mat: np.ndarray,
+    meta_data: pd.DataFrame,
+    vars_use,
+    theta=None,
+    lamb=None,
+    sigma=0.1,
+    nclust=None,
+    tau=0,
+    block_size=0.05,
+    max_iter_harmony=10,
+    max_iter_kmeans=20,
+    epsilon_cluster=1e-5,
+    epsilon_harmony=1e-4,
+    alpha=0.2,
+    verbose=True,
+    random_state=0,
+    device=None,
+):
+    """Run Harmony batch-effect correction on an MI355X.
+
+    Same arguments, defaults and return type as ``harmonypy.run_harmony``
+    (harmony.py:49-115): ``data_mat`` cells x PCs or PCs x cells, ``meta_data`` cells x
+    variables, ``vars_use`` the batch column(s); ``lamb=-1`` estimates lambda per cluster.
+    Returns a finished ``Harmony`` object (``.Z_corr`` is cells x PCs).
+    """
+    p = _prepare_inputs(data_mat, meta_data, vars_use, theta, lamb, sigma, nclust, tau)
+    dev = _device_index(device)
+    if verbose:
+        logger.info(f"Running Harmony (HIP engine on MI355X device {dev})")
+        logger.info("  Parameters:")
+        logger.info(f"    max_iter_harmony: {max_iter_harmony}")
+        logger.info(f"    max_iter_kmeans: {max_iter_kmeans}")
+        logger.info(f"    epsilon_cluster: {epsilon_cluster}")
+        logger.info(f"    epsilon_harmony: {epsilon_harmony}")
+        logger.info(f"    nclust: {p['K']}")
+        logger.info(f"    block_size: {block_size}")
+        logger.info(f"    lamb: dynamic (alpha={alpha})" if p["lambda_estimation"] else f"    lamb: {p['lamb'][1:]}")
+        logger.info(f"    theta: {p['theta']}")
+        logger.info(f"    sigma: {p['sigma'][:5]}..." if len(p["sigma"]) > 5 else f"    sigma: {p['sigma']}")
+        logger.info(f"    random_state: {random_state}")
+        logger.info(f"  Data: {p['Z'].shape[0]} PCs x {p['Z'].shape[1]} cells")
+        logger.info(f"  Batch variables: {vars_use}")
+
+    # Seeds exactly as the reference sets them (harmony.py:199-200); the torch CPU
+    # generator is the source of the update order of every round (harmony.py:471).
+    import torch
+    np.random.seed(random_state)
+    torch.manual_seed(random_state)
+
+    return Harmony(
+        p["Z"], p["codes"], p["Pr_b"], p["sigma"],
+        p["theta"], p["lamb"], alpha, p["lambda_estimation"],
+        max_iter_harmony, max_iter_kmeans,
+        epsilon_cluster, epsilon_harmony, p["K"], block_size, verbose,
+        random_state, device,
+    )
+
+
+def _prepare_inputs(data_mat, meta_data, vars_use, theta=None, lamb=None, sigma=0.1, nclust=None, tau=0):
+    """Argument normalisation of ``run_harmony`` (harmony.py:116-173, 203-205) with the batch
+    design kept as integer codes instead of a dense one-hot matrix."""
+    N = meta_data.shape[0]
+    if hasattr(data_mat, "values"):
+        data_mat = data_mat.values
+    data_mat = np.asarray(data_mat)
+    if data_mat.shape[1] != N:                                  # harmony.py:117-118
+        data_mat = data_mat.T
+    assert data_mat.shape[1] == N, \
+        "data_mat and meta_data do not have the same number of cells"
+
+    if nclust is None:                                          # harmony.py:123-124
+        nclust = int(min(round(N / 30.0), 100))
+    if isinstance(sigma, (float, int)) and not isinstance(sigma, bool):   # harmony.py:126-127
+        sigma = np.repeat(float(sigma), nclust)
+    sigma = np.asarray(sigma, dtype=np.float32)
+    if isinstance(vars_use, str):
+        vars_use = [vars_use]
+
+    # Batch design as integer codes in pd.get_dummies' column order (harmony.py:133):
+    # variables in vars_use order, levels sorted within a variable.
+    codes = np.empty((N, len(vars_use)), dtype=np.int32)
+    phi_n = []
+    offset = 0
+    for v, name in enumerate(vars_use):
+        cat = pd.Categorical(meta_data[name])
+        if (cat.codes < 0).any():
+            raise ValueError(f"meta_data[{name!r}] has missing values")
+        codes[:, v] = cat.codes.astype(np.int32) + offset
+        phi_n.append(len(cat.categories))
+        offset += len(cat.categories)
+    phi_n = np.asarray(phi_n, dtype=int)                        # harmony.py:134
+    B = int(offset)
+
+    if theta is None:                                           # harmony.py:137-147
+        theta = np.repeat([2] * len(phi_n), phi_n).astype(np.float32)
+    elif isinstance(theta, (float, int)):
+        theta = np.repeat([theta] * len(phi_n), phi_n).astype(np.float32)
+    elif len(theta) == len(phi_n):
+        theta = np.repeat([theta], phi_n).astype(np.float32)
+    else:
+        theta = np.asarray(theta, dtype=np.float32)
+    assert len(theta) == np.sum(phi_n), "each batch variable must have a theta"
+
+    lambda_estimation = False                                   # harmony.py:150-166
+    if lamb is None:
+        lamb = np.insert(np.repeat([1] * len(phi_n), phi_n).astype(np.float32), 0, 0).astype(np.float32)
+    elif np.isscalar(lamb) and lamb == -1:
+        lambda_estimation = True
+        lamb = np.zeros(1, dtype=np.float32)
+    elif isinstance(lamb, (float, int)):
+        lamb = np.insert(np.repeat([lamb] * len(phi_n), phi_n).astype(np.float32), 0, 0).astype(np.float32)
+    elif len(lamb) == len(phi_n):
+        lamb = np.insert(np.repeat([lamb], phi_n).astype(np.float32), 0, 0).astype(np.float32)
+    else:
+        lamb = np.asarray(lamb, dtype=np.float32)
+        if len(lamb) == np.sum(phi_n):
+            lamb = np.insert(lamb, 0, 0).astype(np.float32)
+
+    N_b = np.bincount(codes.ravel(), minlength=B).astype(np.float32)   # harmony.py:169 (phi.sum(axis=1))
+    Pr_b = (N_b / N).astype(np.float32)                                # harmony.py:170
+    if tau > 0:                                                        # harmony.py:172-173
+        theta = theta * (1 - np.exp(-(N_b / (nclust * tau)) ** 2))
+
+    return dict(Z=np.asarray(data_mat, dtype=np.float32), codes=BatchCodes(codes, B), Pr_b=Pr_b,
+                sigma=sigma.astype(np.float32), theta=np.asarray(theta, dtype=np.float32), lamb=lamb,
+                lambda_estimation=lambda_estimation, K=int(nclust), vars_use=list(vars_use))
+
+
+def build_layout(codes):
+    """Group cells by their multi-hot batch pattern.
+
+    Returns (group_cols G x V, order internal->original, rank original->internal,
+    gid_int group of every internal cell, static_cells, static_tile_grp): the static list is
+    the identity over the group-sorted cells with every group padded to whole tiles.
+    """
+    N = codes.shape[0]
+    combos, gid = np.unique(codes, axis=0, return_inverse=True)
+    gid = gid.reshape(-1).astype(np.int32)
+    G = combos.shape[0]
+    order = np.argsort(gid, kind="stable").astype(np.int64)
+    rank = np.empty(N, dtype=np.int32)
+    rank[order] = np.arange(N, dtype=np.int32)
+    counts = np.bincount(gid, minlength=G)
+    cells, tile_grp = [], []
+    start = 0
+    for g, c in enumerate(counts):
+        nt = -(-int(c) // TILE)
+        seg = np.full(nt * TILE, -1, dtype=np.int32)
+        seg[:c] = np.arange(start, start + c, dtype=np.int32)
+        cells.append(seg)
+        tile_grp.append(np.full(nt, g, dtype=np.int32))
+        start += int(c)
+    return (np.ascontiguousarray(combos, dtype=np.int32), order, rank, gid[order],
+            np.concatenate(cells), np.concatenate(tile_grp))
+
+
+def build_block_lists(update_order, rank, gid_int, n_blocks, cells_per_block, G):
+    """Turn the reference's update order (harmony.py:471) into the engine's tile lists.
+
+    Block b holds positions [b*cpb, (b+1)*cpb) of the order, the last block the remainder
+    (harmony.py:482-484).  Only block membership matters to the update, so inside a block
+    cells are regrouped by batch group and every (block, group) run is padded with -1 to a
+    multiple of 16.  Returns (cells, tile_group, block_tile_start).
+    """
+    N, nb, cpb = len(update_order), int(n_blocks), int(cells_per_block)
+    pos = np.arange(N, dtype=np.int64)
+    blk = np.minimum(pos // cpb, nb - 1) if cpb > 0 else np.full(N, nb - 1, dtype=np.int64)
+    cell_int = rank[update_order]
+    key = blk * G + gid_int[cell_int]
+    srt = np.argsort(key, kind="stable")
+    key_s, cell_s = key[srt], cell_int[srt]
+    counts = np.bincount(key_s, minlength=nb * G)
+    tiles = -(-counts // TILE)
+    pad_start = np.concatenate([[0], np.cumsum(tiles * TILE)])
+    run_start = np.concatenate([[0], np.cumsum(counts)])
+    within = np.arange(N, dtype=np.int64) - run_start[key_s]
+    cells = np.full(int(pad_start[-1]), -1, dtype=np.int32)
+    cells[pad_start[key_s] + within] = cell_s
+    tile_grp = np.repeat(np.tile(np.arange(G, dtype=np.int32), nb), tiles)
+    blk_tiles = tiles.reshape(nb, G).sum(axis=1)
+    blk_start = np.concatenate([[0], np.cumsum(blk_tiles)]).astype(np.int32)
+    return cells, tile_grp, blk_start
+
+
+class Harmony:
+    """Device-resident Harmony state with the reference's object API (harmony.py:218-569).
+
+    ``Z`` is d x N (PCs x cells) like the reference's; ``Phi`` is the dense B x N indicator
+    matrix of the reference or a ``BatchCodes``.  The constructor runs the whole algorithm
+    (harmony.py:280-282); results are read through the same properties.
+    """
+
+    def __init__(
+            self, Z, Phi, Pr_b, sigma, theta, lamb, alpha, lambda_estimation,
+            max_iter_harmony, max_iter_kmeans,
+            epsilon_kmeans, epsilon_harmony, K, block_size, verbose,
+            random_state, device
+    ):
+        self.device = device
+        Z = np.asarray(Z, dtype=np.float32)
+        self.d, self.N = Z.shape
+        self._codes = Phi if isinstance(Phi, BatchCodes) else BatchCodes.from_dense(Phi)
+        if self._codes.codes.shape[0] != self.N:
+            raise ValueError("Phi and Z disagree on the number of cells")
+        self.B = self._codes.n_batches
+        self.K = int(K)
+        self.window_size = 3
+        self.epsilon_kmeans = epsilon_kmeans
+        self.epsilon_harmony = epsilon_harmony
+        self.alpha = alpha
+        self.lambda_estimation = bool(lambda_estimation)
+        self.block_size = block_size
+        self.max_iter_harmony = max_iter_harmony
+        self.max_iter_kmeans = max_iter_kmeans
+        self.verbose = verbose
+        self._Pr_b = np.asarray(Pr_b, dtype=np.float32)
+        self._sigma = np.asarray(sigma, dtype=np.float32)
+        self._theta = np.asarray(theta, dtype=np.float32)
+        self._lamb = np.asarray(lamb, dtype=np.float32)
+        if self._sigma.shape != (self.K,):
+            raise ValueError("sigma must have one entry per cluster")
+        if self._theta.shape != (self.B,) or self._Pr_b.shape != (self.B,):
+            raise ValueError("theta and Pr_b must have one entry per batch")
+        if not self.lambda_estimation and self._lamb.shape != (self.B + 1,):
+            raise ValueError("lamb must have B+1 entries (intercept first)")
+
+        self.objective_harmony = []
+        self.objective_kmeans = []
+        self.objective_kmeans_dist = []
+        self.objective_kmeans_entropy = []
+        self.objective_kmeans_cross = []
+        self.kmeans_rounds = []
+        self._pending_objective = None
+        self._forced_rounds = (list(_TEST_HOOKS["forced_rounds"])
+                               if _TEST_HOOKS["forced_rounds"] is not None else None)
+
+        self.allocate_buffers(Z)
+        self.init_cluster(random_state)
+        self.harmonize(self.max_iter_harmony, self.verbose)
+
+    # ------------------------------------------------------------------
+    # device state (replaces harmony.py:234-271 uploads and :357-364 buffers)
+    # ------------------------------------------------------------------
+    def allocate_buffers(self, Z=None):
+        codes = self._codes.codes
+        V = codes.shape[1]
+        # batch groups = distinct multi-hot rows of Phi; cells are stored group-sorted
+        (self._group_cols, self._order, self._rank, self._gid_int,
+         self._static_cells, self._static_tile_grp) = build_layout(codes)
+        self._G = self._group_cols.shape[0]
+        self._n_blocks = int(np.ceil(1.0 / self.block_size))                     # harmony.py:474
+        self._cells_per_block = int(self.N * self.block_size)                    # harmony.py:475
+
+        self._engine = _capi.Engine(self.N, self.d, self.K, self.B, self._G, V, self._n_blocks,
+                                    lambda_estimation=self.lambda_estimation, alpha=self.alpha,
+                                    device_id=_device_index(self.device))
+        if Z is not None:
+            Zi = np.ascontiguousarray(Z.T[self._order])                          # N x d, internal order
+            self._engine.upload(Zi, self._static_cells, self._static_tile_grp, self._group_cols,
+                                self._Pr_b, self._theta, self._sigma,
+                                None if self.lambda_estimation else self._lamb)
+
+    # ------------------------------------------------------------------
+    # read-back (harmony.py:288-355): fresh float32 NumPy arrays, cells x features
+    # ------------------------------------------------------------------
+    def _rows(self, which):
+        return self._engine.get(which)[self._rank]
+
+    @property
+    def Z_corr(self):
+        """Corrected embedding (N x d)."""
+        return self._rows(_capi.HMX_Z_CORR)
+
+    @property
+    def Z_orig(self):
+        """Input embedding (N x d)."""
+        return self._rows(_capi.HMX_Z_ORIG)
+
+    @property
+    def Z_cos(self):
+        """L2-normalised embedding used for clustering (N x d)."""
+        return self._rows(_capi.HMX_Z_COS)
+
+    @property
+    def R(self):
+        """Soft cluster assignment (N x K)."""
+        return self._rows(_capi.HMX_R)
+
+    @property
+    def Y(self):
+        """Unit-length cluster centroids (d x K)."""
+        return np.ascontiguousarray(self._engine.get(_capi.HMX_Y).T)
+
+    @property
+    def O(self):
+        """Observed batch-by-cluster mass (K x B)."""
+        og = self._engine.get(_capi.HMX_O_GROUP)                                 # G x K
+        O = np.zeros((self.K, self.B), dtype=np.float64)
+        for v in range(self._group_cols.shape[1]):
+            np.add.at(O.T, self._group_cols[:, v], og)
+        return O.astype(np.float32)
+
+    @property
+    def E(self):
+        """Expected batch-by-cluster mass (K x B) = cluster mass x batch proportion."""
+        T = self._engine.get(_capi.HMX_T_MASS).reshape(-1)
+        return np.outer(T.astype(np.float32), self._Pr_b).astype(np.float32)
+
+    @property
+    def Phi(self):
+        """One-hot batch indicators (N x B)."""
+        return np.ascontiguousarray(self._codes.dense().T)
+
+    @property
+    def Phi_moe(self):
+        """Batch indicators with a leading intercept column (N x (B+1))."""
+        return np.concatenate([np.ones((self.N, 1), np.float32), self.Phi], axis=1)
+
+    @property
+    def Pr_b(self):
+        return self._Pr_b.copy()
+
+    @property
+    def theta(self):
+        return self._theta.copy()
+
+    @property
+    def sigma(self):
+        return self._sigma.copy()
+
+    @property
+    def lamb(self):
+        return self._lamb.copy()
+
+    def result(self):
+        """Corrected data as a NumPy array (N x d), harmony.py:353-355."""
+        return self.Z_corr
+
+    # ------------------------------------------------------------------
+    # harmony.py:366-392
+    # ------------------------------------------------------------------
+    def init_cluster(self, random_state):
+        if _TEST_HOOKS["Y0"] is not None:
+            Y0 = np.asarray(_TEST_HOOKS["Y0"], dtype=np.float32)                 # d x K
+        else:
+            from sklearn.cluster import KMeans
+            if self.verbose:
+                logger.info("Computing initial centroids with sklearn.KMeans...")
+            Z_cos = self.Z_cos                                                   # N x d, original order
+            model = KMeans(n_clusters=self.K, init="k-means++", n_init=1, max_iter=25,
+                           random_state=random_state)                            # harmony.py:370-371
+            model.fit(Z_cos)
+            Y0 = np.asarray(model.cluster_centers_.T, dtype=np.float32)
+            if self.verbose:
+                logger.info("KMeans initialization complete.")
+        if Y0.shape != (self.d, self.K):
+            raise ValueError("initial centroids must be d x K")
+        self._Y0 = Y0
+        triple = self._engine.init_cluster(np.ascontiguousarray(Y0.T))           # :376-391 on device
+        self._pending_objective = triple
+        self.compute_objective()
+        self.objective_harmony.append(self.objective_kmeans[-1])                 # :392
+
+    # ------------------------------------------------------------------
+    # harmony.py:394-417: the three sums come back from the device with the round
+    # ------------------------------------------------------------------
+    def compute_objective(self):
+        if self._pending_objective is None:
+            raise RuntimeError("compute_objective() needs the sums produced by the preceding "
+                               "update_R()/init_cluster() call on the device")
+        kmeans_error, _entropy, _cross_entropy = (float(x) for x in self._pending_objective[:3])
+        self._pending_objective = None
+        norm_const = 2000.0 / self.N
+        self.objective_kmeans.append((kmeans_error + _entropy + _cross_entropy) * norm_const)
+        self.objective_kmeans_dist.append(kmeans_error * norm_const)
+        self.objective_kmeans_entropy.append(_entropy * norm_const)
+        self.objective_kmeans_cross.append(_cross_entropy * norm_const)
+
+    # ------------------------------------------------------------------
+    # harmony.py:419-435
+    # ------------------------------------------------------------------
+    def harmonize(self, iter_harmony=10, verbose=True):
+        converged = False
+        for i in range(1, iter_harmony + 1):
+            if verbose:
+                logger.info(f"Iteration {i} of {iter_harmony}")
+            self.cluster()
+            self.moe_correct_ridge()
+            converged = self.check_convergence(1)
+            if converged:
+                if verbose:
+                    logger.info(f"Converged after {i} iteration{'s' if i > 1 else ''}")
+                break
+        if verbose and not converged:
+            logger.info("Stopped before convergence")
+
+    # ------------------------------------------------------------------
+    # harmony.py:437-462
+    # ------------------------------------------------------------------
+    def cluster(self):
+        rounds = 0
+        forced = self._forced_rounds.pop(0) if self._forced_rounds else None
+        for i in range(self.max_iter_kmeans if forced is None else forced):
+            self._round(_capi.HMX_ROUND_ALL)                                     # :443-450
+            self.compute_objective()                                             # :453
+            if forced is None and i > self.window_size:
+                if self.check_convergence(0):                                    # :455-458
+                    rounds = i + 1
+                    break
+            rounds = i + 1
+        self.kmeans_rounds.append(rounds)
+        self.objective_harmony.append(self.objective_kmeans[-1])
+
+    def update_R(self):
+        """harmony.py:464-513 (one blocked sweep over a fresh random order)."""
+        self._round(_capi.HMX_ROUND_UPDATE_R | _capi.HMX_ROUND_OBJECTIVE)
+
+    def _update_order(self):
+        import torch
+        return torch.randperm(self.N).numpy()                                    # harmony.py:471
+
+    def _round(self, flags):
+        order = self._update_order()
+        cells, tile_grp, blk_start = self._block_lists(order)
+        self._pending_objective = self._engine.cluster_round(cells, tile_grp, blk_start, flags)
+
+    def _block_lists(self, update_order):
+        return build_block_lists(update_order, self._rank, self._gid_int, self._n_blocks,
+                                 self._cells_per_block, self._G)
+
+    # ------------------------------------------------------------------
+    # harmony.py:515-533
+    # ------------------------------------------------------------------
+    def check_convergence(self, i_type):
+        if i_type == 0:
+            if len(self.objective_kmeans) <= self.window_size + 1:
+                return False
+            w = self.window_size
+            obj_old = sum(self.objective_kmeans[-w - 1:-1])
+            obj_new = sum(self.objective_kmeans[-w:])
+            return abs(obj_old - obj_new) / abs(obj_old) < self.epsilon_kmeans
+        if i_type == 1:
+            if len(self.objective_harmony) < 2:
+                return False
+            obj_old = self.objective_harmony[-2]
+            obj_new = self.objective_harmony[-1]
+            return (obj_old - obj_new) / abs(obj_old) < self.epsilon_harmony
+        return True
+
+    # ------------------------------------------------------------------
+    # harmony.py:535-569
+    # ------------------------------------------------------------------
+    def moe_correct_ridge(self):
+        """Ridge regression correction for batch effects."""
+        self._engine.moe_correct_ridge()

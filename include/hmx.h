@@ -1,0 +1,128 @@
+/*
+ * hmx.h -- C ABI of the MI355X-native Harmony iteration engine (libhmx.so).
+ *
+ * The reference (slowkow/harmonypy v0.2.0) has no FFI boundary of its own: its
+ * hot path is the body of `class Harmony` (harmonypy/harmony.py:218-569), whose
+ * arithmetic is delegated to torch.  This header is the boundary a maintainer
+ * would bind instead of torch for that path (ctypes stub in INTEGRATION.md).
+ * Every entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all pointers are HOST pointers unless named d_*.
+ *   - return 0 on success, negative hmx_status on error; text via hmx_last_error()
+ *     (thread-local).  No exception crosses the boundary.
+ *   - caller owns every host buffer (borrowed for the duration of the call);
+ *     the engine owns all device memory until hmx_destroy().
+ *   - calls on one engine are not re-entrant; different engines are independent.
+ *   - "internal cell order": the caller sorts cells by batch group (the distinct
+ *     multi-hot rows of Phi) and hands rows in that order; the engine never sees
+ *     the original order.  A *tile* is 16 consecutive list positions that share
+ *     one group; position lists are padded with -1 up to tile boundaries.
+ */
+#ifndef HMX_H
+#define HMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HMX_ABI_VERSION 1
+#define HMX_TILE 16 /* cells per tile */
+
+typedef enum hmx_status {
+    HMX_OK = 0,
+    HMX_ERR_ARG = -1,     /* bad argument / unsupported shape */
+    HMX_ERR_HIP = -2,     /* a HIP runtime call failed */
+    HMX_ERR_STATE = -3,   /* call order violated (e.g. round before upload) */
+    HMX_ERR_COMM = -4     /* RCCL failure */
+} hmx_status;
+
+/* which = selector for hmx_get / hmx_set (sizes in elements of the listed type) */
+typedef enum hmx_array {
+    HMX_Z_ORIG = 0, /* float  N x d   internal order                (harmony.py:235)  */
+    HMX_Z_COS = 1,  /* float  N x d                                  (harmony.py:238)  */
+    HMX_Z_CORR = 2, /* float  N x d                                  (harmony.py:234)  */
+    HMX_R = 3,      /* float  N x K   soft assignments               (harmony.py:363)  */
+    HMX_Y = 4,      /* float  K x d   unit-length centroids as rows  (harmony.py:364)  */
+    HMX_O_GROUP = 5,/* double G x K   sum of R over the cells of a group; O[k,b] of
+                       harmony.py:360 is the sum over the groups containing column b   */
+    HMX_T_MASS = 6, /* double K       cluster mass; E[k,b] = T[k]*Pr_b[b] (harmony.py:361) */
+    HMX_W = 7       /* float  G x K x d  per-group correction vectors of the last ridge */
+} hmx_array;
+
+typedef struct hmx_config {
+    int64_t n_cells;          /* N  cells held by this engine (this rank's shard)      */
+    int32_t n_pcs;            /* d                                                      */
+    int32_t n_clusters;       /* K                                                      */
+    int32_t n_batches;        /* B  = number of Phi rows                                */
+    int32_t n_groups;         /* G  distinct multi-hot patterns (== B for one variable) */
+    int32_t n_vars;           /* V  active Phi rows per cell (len(vars_use))            */
+    int32_t n_blocks;         /* ceil(1/block_size)                 (harmony.py:474)    */
+    int32_t device_id;        /* HIP device ordinal                                     */
+    int32_t lambda_estimation;/* 0/1                                (harmony.py:541)    */
+    float alpha;              /*                                    (harmony.py:590)    */
+    int32_t reserved[6];
+} hmx_config;
+
+typedef struct hmx_engine hmx_engine;
+
+const char* hmx_last_error(void);
+int hmx_abi_version(void);
+
+/* Allocate the device state of one `Harmony` object (harmony.py:230-278, 357-364). */
+int hmx_create(const hmx_config* cfg, hmx_engine** out);
+void hmx_destroy(hmx_engine* e);
+
+/* Upload inputs (harmony.py:234-271).  Z: N x d row-major, internal order; the
+ * engine derives Z_cos (harmony.py:238).  static_cells/static_tile_group: the
+ * group-sorted identity list padded to tiles (n_static_pos = 16*n_static_tiles).
+ * group_cols: G x V Phi-row indices of every group.  lamb: B+1 floats, ignored
+ * when lambda_estimation. */
+int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64_t n_static_pos,
+               const int32_t* static_tile_group, int32_t n_static_tiles, const int32_t* group_cols,
+               const float* Pr_b, const float* theta, const float* sigma, const float* lamb);
+
+/* harmony.py:376-392 given the k-means centres of harmony.py:370-373.
+ * Y0: K x d row-major (centroids as rows, not yet normalised).
+ * obj_out = {sum R*dist, sum sigma*R*log R, cross-entropy term, 0}, each rounded to
+ * fp32 like the `.item()` calls of harmony.py:399-411. */
+int hmx_init_cluster(hmx_engine* e, const float* Y0, double obj_out[4]);
+
+/* One pass of the loop body harmony.py:443-453.
+ *   flags: HMX_ROUND_* bits; the reference's round is all three.
+ *   cells / tile_group / block_tile_start describe this round's update order
+ *   (harmony.py:471-484): positions are grouped by block, inside a block by group,
+ *   each (block, group) run padded with -1 to a multiple of 16.  block b owns tiles
+ *   [block_tile_start[b], block_tile_start[b+1]). */
+#define HMX_ROUND_CENTROIDS 1 /* harmony.py:443-447 */
+#define HMX_ROUND_UPDATE_R 2  /* harmony.py:450, 464-513 */
+#define HMX_ROUND_OBJECTIVE 4 /* harmony.py:453, 394-417 */
+int hmx_cluster_round(hmx_engine* e, int flags, const int32_t* cells, int64_t n_pos,
+                      const int32_t* tile_group, int32_t n_tiles, const int32_t* block_tile_start,
+                      double obj_out[4]);
+
+/* harmony.py:535-569. */
+int hmx_moe_correct_ridge(hmx_engine* e);
+
+/* Copy a state array to / from the host (property getters harmony.py:288-351). */
+int hmx_get(hmx_engine* e, int which, void* host_out, size_t bytes);
+int hmx_set(hmx_engine* e, int which, const void* host_in, size_t bytes);
+
+/* Block until all queued work of the engine finished. */
+int hmx_sync(hmx_engine* e);
+
+/* Device pointer of a state array (for callers that keep data resident). */
+int hmx_device_ptr(hmx_engine* e, int which, void** d_ptr, size_t* bytes);
+
+/* Average kernel time of the last call, per kernel family, measured with HIP events on
+ * the engine's stream.  names_out receives a static NUL-separated list. */
+int hmx_kernel_times(hmx_engine* e, double* ms_out, int n, const char** names_out);
+int hmx_enable_timing(hmx_engine* e, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HMX_H */
