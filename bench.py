@@ -1,7 +1,49 @@
 #!/usr/bin/env python3
-"""bench.py -- placeholder header, replaced below once the device-side update order lands."""
+"""bench.py -- throughput of the Harmony iteration engine on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W            (defaults finish in ~2-3 minutes)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): cells/sec/Harmony-iteration = cells x iterations / T_harmonize, inputs
+resident in HBM when the timed region starts.  A *step* is one Harmony iteration
+(harmony.py:421-432): `--rounds` k-means rounds of harmony.py:443-453 (fixed, default 10 = the
+mean of the reference's C3 schedule [20,10,5,5]; the objective is read back every round exactly
+as the reference's `.item()` calls do, the convergence test is evaluated but not acted on) plus
+one moe_correct_ridge (harmony.py:535-569).  The per-round update order is produced on the
+device inside the timed region.
+
+Workload at --gpus 1: BASELINE.json configs[2] (C3, the roofline point): synthetic 1M cells x
+50 PCs, 8 batches, K=100.  `--config c2` selects configs[1] (69k x 50, 4 batches, K=30).
+With N > 1 ranks every GPU holds one such shard (weak scaling).
+
+One JSON line on stdout (rank 0).  Besides the contract fields:
+  roofline     -- the dominant kernel (k_assign, one launch per update block): algorithmic bytes
+                  per launch (cells of a block x (4d + 4K + 4)) / average
+                  launch time from HIP events on the engine's stream, against 8 TB/s HBM.
+  cpu_baseline -- the NumPy oracle (a port of the reference's torch-CPU path) timed on this
+                  box's host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
 import numpy as np
 import pandas as pd
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (cells per GPU, PCs, batches, clusters)
+    "c2": (69_000, 50, 4, 30),
+    "c3": (1_000_000, 50, 8, 100),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def synthetic_dataset(N, d, B, K, seed=0):
@@ -24,3 +66,155 @@ def synthetic_dataset(N, d, B, K, seed=0):
     labels = np.array([f"b{i}" for i in range(B)])
     meta = pd.DataFrame({"batch": pd.Categorical.from_codes(batch, categories=labels)})
     return Z, meta
+
+
+def quick_centroids(Z, K, seed=0, sample=50_000):
+    """k-means++ / Lloyd on a subsample (untimed initialisation; harmony.py:370-372 on a sample)."""
+    from sklearn.cluster import KMeans
+    rng = np.random.default_rng(seed)
+    idx = rng.choice(Z.shape[0], size=min(sample, Z.shape[0]), replace=False)
+    Zs = Z[idx]
+    Zs = Zs / np.linalg.norm(Zs, axis=1, keepdims=True)
+    km = KMeans(n_clusters=K, init="k-means++", n_init=1, max_iter=25, random_state=seed).fit(Zs)
+    return np.asarray(km.cluster_centers_.T, dtype=np.float32)  # d x K
+
+
+def cpu_baseline(d, B, K, rounds, sample_cells, seed=1):
+    """Oracle (NumPy port of the reference's CPU path) on a bounded sample; one iteration."""
+    from oracle.harmony_oracle import OracleHarmony, prepare_inputs
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    Z, meta = synthetic_dataset(sample_cells, d, B, K, seed=seed)
+    Y0 = quick_centroids(Z, K, seed=seed)
+    p = prepare_inputs(Z, meta, ["batch"], nclust=K)
+    rng = np.random.default_rng(seed)
+    oo = OracleHarmony(p["Z"], p["phi"], p["Pr_b"], p["sigma"], p["theta"], p["lamb"], K=K, run=False,
+                       perm_source=lambda n: rng.permutation(n), forced_rounds=[rounds])
+    oo.init_cluster(0, Y0)
+    t0 = time.perf_counter()
+    oo.cluster()
+    oo.moe_correct_ridge()
+    oo.check_convergence(1)
+    dt = time.perf_counter() - t0
+    return {"value": sample_cells / dt, "unit": "cells/sec/Harmony-iteration", "cores": int(threads),
+            "kind": "port",
+            "sample": f"{sample_cells} cells x {d} PCs, {B} batches, K={K}: 1 iteration = {rounds} rounds + ridge "
+                      f"in {dt:.1f} s (NumPy oracle, BLAS threads={threads}, host has {os.cpu_count()} cpus)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--rounds", type=int, default=10, help="k-means rounds per Harmony iteration")
+    ap.add_argument("--cpu-sample", type=int, default=200_000, help="cells of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+
+    N, d, B, K = CONFIGS[args.config]
+    os.environ["HMX_UPDATE_ORDER"] = "device"
+    from harmonypy_amd import harmony as H
+
+    Z, meta = synthetic_dataset(N, d, B, K, seed=rank)
+    H._TEST_HOOKS["Y0"] = quick_centroids(Z, K, seed=0)
+    t_setup = time.perf_counter()
+    ho = H.run_harmony(Z, meta, ["batch"], nclust=K, max_iter_harmony=0, verbose=False, random_state=rank,
+                       device=f"cuda:{local_rank}")
+    H._TEST_HOOKS["Y0"] = None
+    t_setup = time.perf_counter() - t_setup
+
+    def step():
+        ho._forced_rounds = [args.rounds]
+        ho.cluster()
+        ho.moe_correct_ridge()
+        ho.check_convergence(1)
+
+    def fence():
+        ho._engine.sync()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timing = not args.no_roofline
+    if timing:
+        ho._engine.enable_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ktimes = ho._engine.kernel_times() if timing else {}
+    if timing:
+        ho._engine.enable_timing(False)
+
+    if rank != 0:
+        return
+    ms_per_step = 1e3 * dt / args.steps
+    value = N * world * args.steps / dt
+    out = {
+        "metric": "cells/sec/Harmony-iteration", "value": value, "unit": "cells/sec/Harmony-iteration",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE configs[{2 if args.config == 'c3' else 1}] ({args.config.upper()}): "
+                        f"{N} cells x {d} PCs, {B} batches, K={K} per GPU; step = 1 Harmony iteration = "
+                        f"{args.rounds} k-means rounds (block_size 0.05 -> 20 blocks) + 1 ridge correction",
+            "cells_per_gpu": N, "pcs": d, "batches": B, "clusters": K, "rounds_per_iteration": args.rounds,
+            "update_order": "device (keyed bijection, generated inside the timed region)",
+            "init": "k-means++ on a 50k-cell subsample, untimed", "parallelism": "cells sharded, 1 rank per GPU"
+                    if world > 1 else "single GPU",
+            "cell_rounds_per_sec": N * world * args.steps * args.rounds / dt,
+            "setup_s": t_setup,
+        },
+    }
+    if timing:
+        tot, cnt = ktimes.get("assign_block", (0.0, 0))
+        per_launch_ms = tot / max(cnt, 1)
+        cells_per_launch = N / 20.0
+        alg_bytes = cells_per_launch * (4 * d + 4 * K + 4)
+        achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        out["roofline"] = {"bound": "hbm", "kernel": "k_assign (per update block)", "achieved": achieved,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "avg_launch_us": per_launch_ms * 1e3, "launches": cnt,
+                           "algorithmic_bytes_per_launch": alg_bytes}
+        round_bytes = N * (4 * d + 8 * K + 8)
+        fam_ms = {k: round(v[0], 3) for k, v in ktimes.items()}
+        n_rounds = args.steps * args.rounds
+        t_round_kernels = sum(ktimes[k][0] for k in ("assign_block", "rtz_round", "rtz_reduce", "block_table")) / max(n_rounds, 1)
+        out["roofline"]["round"] = {
+            "algorithmic_bytes": round_bytes, "kernel_ms_per_round": t_round_kernels,
+            "frac_of_hbm_peak": (round_bytes / (t_round_kernels * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_round_kernels > 0 else 0.0,
+            "mfma_flops": N * 4 * d * K,
+            "frac_of_f32_mfma_peak": (N * 4 * d * K / (t_round_kernels * 1e-3) / 157.3e12) if t_round_kernels > 0 else 0.0}
+        out["kernel_ms_total"] = fam_ms
+    if args.cpu_sample > 0:
+        out["cpu_baseline"] = cpu_baseline(d, B, K, args.rounds, min(args.cpu_sample, N))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -17,12 +17,13 @@ LIB_PATH = os.path.join(_HERE, "libhmx.so")
 # mirrors include/hmx.h
 HMX_TILE = 16
 HMX_Z_ORIG, HMX_Z_COS, HMX_Z_CORR, HMX_R, HMX_Y, HMX_O_GROUP, HMX_T_MASS, HMX_W = range(8)
+HMX_ROUND_BLOCK_START, HMX_ROUND_CELLS, HMX_ROUND_TILE_GROUP = 8, 9, 10
 HMX_ROUND_CENTROIDS, HMX_ROUND_UPDATE_R, HMX_ROUND_OBJECTIVE = 1, 2, 4
 HMX_ROUND_ALL = 7
 
 EXPORTS = [
     "hmx_last_error", "hmx_abi_version", "hmx_create", "hmx_destroy", "hmx_upload", "hmx_init_cluster",
-    "hmx_cluster_round", "hmx_moe_correct_ridge", "hmx_get", "hmx_set", "hmx_sync", "hmx_device_ptr",
+    "hmx_cluster_round", "hmx_cluster_round_seeded", "hmx_moe_correct_ridge", "hmx_get", "hmx_set", "hmx_sync", "hmx_device_ptr",
     "hmx_kernel_times", "hmx_enable_timing",
 ]
 
@@ -61,6 +62,7 @@ def load():
     lib.hmx_upload.argtypes = [vp, vp, vp, i64, vp, i32, vp, vp, vp, vp, vp]
     lib.hmx_init_cluster.argtypes = [vp, vp, vp]
     lib.hmx_cluster_round.argtypes = [vp, C.c_int, vp, i64, vp, i32, vp, vp]
+    lib.hmx_cluster_round_seeded.argtypes = [vp, C.c_int, C.c_uint64, i64, vp]
     lib.hmx_moe_correct_ridge.argtypes = [vp]
     lib.hmx_get.argtypes = [vp, C.c_int, vp, C.c_size_t]
     lib.hmx_set.argtypes = [vp, C.c_int, vp, C.c_size_t]
@@ -146,6 +148,11 @@ class Engine:
                                            _ptr(bs), _ptr(out)))
         return out
 
+    def cluster_round_seeded(self, seed, cells_per_block, flags=HMX_ROUND_ALL):
+        out = np.zeros(4, np.float64)
+        _check(self._lib.hmx_cluster_round_seeded(self._h, flags, int(seed) & (2**64 - 1), int(cells_per_block), _ptr(out)))
+        return out
+
     def moe_correct_ridge(self):
         _check(self._lib.hmx_moe_correct_ridge(self._h))
 
@@ -173,6 +180,18 @@ class Engine:
         arr = _c(arr, dt)
         assert arr.shape == tuple(shape), (arr.shape, shape)
         _check(self._lib.hmx_set(self._h, which, _ptr(arr), arr.nbytes))
+
+    def round_lists(self):
+        """(cells, tile_group, block_tile_start) of the last round, as the device holds them."""
+        bs = np.empty(self.nblk + 1, np.int32)
+        _check(self._lib.hmx_get(self._h, HMX_ROUND_BLOCK_START, _ptr(bs), bs.nbytes))
+        nt = int(bs[-1])
+        cells = np.empty(nt * HMX_TILE, np.int32)
+        tg = np.empty(nt, np.int32)
+        if nt:
+            _check(self._lib.hmx_get(self._h, HMX_ROUND_CELLS, _ptr(cells), cells.nbytes))
+            _check(self._lib.hmx_get(self._h, HMX_ROUND_TILE_GROUP, _ptr(tg), tg.nbytes))
+        return cells, tg, bs
 
     def sync(self):
         _check(self._lib.hmx_sync(self._h))

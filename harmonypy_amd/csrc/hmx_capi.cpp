@@ -70,6 +70,8 @@ struct hmx_engine {
 
     DevBuf<float> Zorig, Zcos, Zcorr, R, Y, Yacc, sigma, theta, Pr_b, lamb, rp, lrp, slab, W;
     DevBuf<int> group_cols, s_cells, s_tile_grp, r_cells, r_tile_grp, r_blk_start, task_t0, task_t1, task_grp;
+    DevBuf<int> gstart, chunk_tab, run_count, run_start;
+    uint64_t seeded_rounds = 0;
     DevBuf<double> Ogrp, Tmass, Sold, Snew, Ohist, objacc, Sr, Oxr, scratch;
     double* obj_host = nullptr;  // pinned
     int n_s_tiles = 0, ntasks = 0;
@@ -225,7 +227,8 @@ void hmx_destroy(hmx_engine* e) {
     e->sigma.release(); e->theta.release(); e->Pr_b.release(); e->lamb.release(); e->rp.release(); e->lrp.release();
     e->slab.release(); e->W.release(); e->group_cols.release(); e->s_cells.release(); e->s_tile_grp.release();
     e->r_cells.release(); e->r_tile_grp.release(); e->r_blk_start.release(); e->task_t0.release(); e->task_t1.release();
-    e->task_grp.release(); e->Ogrp.release(); e->Tmass.release(); e->Sold.release(); e->Snew.release(); e->Ohist.release();
+    e->task_grp.release(); e->gstart.release(); e->chunk_tab.release(); e->run_count.release(); e->run_start.release();
+    e->Ogrp.release(); e->Tmass.release(); e->Sold.release(); e->Snew.release(); e->Ohist.release();
     e->objacc.release(); e->Sr.release(); e->Oxr.release(); e->scratch.release();
     if (e->obj_host) (void)hipHostFree(e->obj_host);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -269,6 +272,17 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
     HIP_TRY(hipMemcpyAsync(e->s_cells.p, static_cells, n_static_pos * sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(e->s_tile_grp.p, static_tile_group, n_static_tiles * sizeof(int), hipMemcpyHostToDevice, e->stream));
     e->n_s_tiles = n_static_tiles;
+    {   // first internal cell of every group (cells are stored group-sorted)
+        std::vector<int> gcount(e->G, 0), gs(e->G + 1, 0);
+        for (int t = 0; t < n_static_tiles; ++t)
+            for (int i = 0; i < HMX_TILE; ++i)
+                if (static_cells[(size_t)t * HMX_TILE + i] >= 0) gcount[static_tile_group[t]]++;
+        for (int g = 0; g < e->G; ++g) gs[g + 1] = gs[g] + gcount[g];
+        if (gs[e->G] != e->N) return fail(HMX_ERR_ARG, "static list must hold every cell exactly once");
+        if ((rc = e->gstart.reserve(e->G + 1))) return rc;
+        HIP_TRY(hipMemcpyAsync(e->gstart.p, gs.data(), gs.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
     // ridge tasks: runs of <= 64 tiles of one group
     std::vector<int> t0, t1, tg;
     const int CH = 64;
@@ -322,25 +336,10 @@ int hmx_init_cluster(hmx_engine* e, const float* Y0, double obj_out[4]) {
     return read_objective(e, obj_out);
 }
 
-int hmx_cluster_round(hmx_engine* e, int flags, const int32_t* cells, int64_t n_pos, const int32_t* tile_group,
-                      int32_t n_tiles, const int32_t* block_tile_start, double obj_out[4]) {
-    if (!e || !obj_out) return fail(HMX_ERR_ARG, "null argument");
-    if (!e->clustered) return fail(HMX_ERR_STATE, "hmx_init_cluster (or hmx_set of R) must come first");
-    if ((flags & HMX_ROUND_OBJECTIVE) && !(flags & HMX_ROUND_UPDATE_R))
-        return fail(HMX_ERR_ARG, "HMX_ROUND_OBJECTIVE needs HMX_ROUND_UPDATE_R in this build");
-    if (!(flags & (HMX_ROUND_CENTROIDS | HMX_ROUND_UPDATE_R))) return fail(HMX_ERR_ARG, "nothing to do");
-    if (!cells || !tile_group || !block_tile_start) return fail(HMX_ERR_ARG, "null update-order list");
-    if (n_pos != (int64_t)n_tiles * HMX_TILE) return fail(HMX_ERR_ARG, "n_pos must be 16*n_tiles");
-    if (block_tile_start[0] != 0 || block_tile_start[e->nblk] != n_tiles) return fail(HMX_ERR_ARG, "block_tile_start must span [0, n_tiles]");
-    for (int b = 0; b < e->nblk; ++b)
-        if (block_tile_start[b + 1] < block_tile_start[b]) return fail(HMX_ERR_ARG, "block_tile_start must be non-decreasing");
+// Kernel sequence of one round; the lists (cells, tile groups, block_tile_start) are already in
+// device memory.  tiles_upper[b] bounds the tile count of block b (grid sizing only).
+static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::vector<int>& tiles_upper, double obj_out[4]) {
     int rc;
-    if ((rc = use_device(e))) return rc;
-    if ((rc = e->r_cells.reserve(n_pos)) || (rc = e->r_tile_grp.reserve(n_tiles))) return rc;
-    HIP_TRY(hipMemcpyAsync(e->r_cells.p, cells, n_pos * sizeof(int), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->r_tile_grp.p, tile_group, n_tiles * sizeof(int), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->r_blk_start.p, block_tile_start, (e->nblk + 1) * sizeof(int), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));  // host lists are borrowed for the call only
     const size_t GK = (size_t)e->G * e->K16;
     HIP_TRY(hipMemsetAsync(e->Sold.p, 0, GK * e->nblk * sizeof(double), e->stream));
     HIP_TRY(hipMemsetAsync(e->Snew.p, 0, GK * e->nblk * sizeof(double), e->stream));
@@ -349,13 +348,13 @@ int hmx_cluster_round(hmx_engine* e, int flags, const int32_t* cells, int64_t n_
     // ---- pass over the old R: centroid numerators (:443) and per-block removal sums (:491-492)
     int nsub, spw;
     rtz_geometry(e->mt, e->ntd, &nsub, &spw);
-    int wgs = std::min(256, std::max(1, (n_tiles + 31) / 32));
+    int wgs = std::min(256, std::max(1, (n_tiles_upper + 31) / 32));
     if ((rc = e->slab.reserve((size_t)wgs * 4 * spw))) return rc;
     {
         Timed t(e, F_RTZ_ROUND);
         RtzArgs r{};
         r.R = e->R.p; r.Z = e->Zcos.p; r.cells = e->r_cells.p; r.tile_grp = e->r_tile_grp.p; r.blk_start = e->r_blk_start.p;
-        r.S_out = e->Sold.p; r.slab = e->slab.p; r.n_tiles = n_tiles;
+        r.S_out = e->Sold.p; r.slab = e->slab.p; r.n_tiles = n_tiles_upper; r.nblk = e->nblk;
         r.K = e->K; r.Kp = e->Kp; r.K16 = e->K16; r.G = e->G; r.mt = e->mt; r.dp = e->dp; r.ntd = e->ntd;
         launch_rtz(r, wgs, e->stream);
     }
@@ -376,11 +375,12 @@ int hmx_cluster_round(hmx_engine* e, int flags, const int32_t* cells, int64_t n_
                 ta.rp = e->rp.p; ta.lrp = e->lrp.p;
                 launch_block_table(ta, e->K16, e->stream);
             }
-            if (block_tile_start[b + 1] > block_tile_start[b]) {
+            if (tiles_upper[b] > 0) {
                 Timed t(e, F_ASSIGN_BLOCK);
                 AssignArgs a = assign_args(e);
                 a.cells = e->r_cells.p; a.tile_grp = e->r_tile_grp.p; a.S_out = e->Snew.p + GK * b;
-                a.tile_begin = block_tile_start[b]; a.tile_end = block_tile_start[b + 1];
+                a.blk_start = e->r_blk_start.p; a.blk = b;
+                a.tile_begin = 0; a.tile_end = tiles_upper[b];
                 if (launch_assign(a, true, e->max_wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported cluster count");
             }
         }
@@ -393,6 +393,73 @@ int hmx_cluster_round(hmx_engine* e, int flags, const int32_t* cells, int64_t n_
         launch_block_table(ta, e->K16, e->stream);
     }
     return read_objective(e, obj_out);
+}
+
+static int check_round_flags(hmx_engine* e, int flags, double* obj_out) {
+    if (!e || !obj_out) return fail(HMX_ERR_ARG, "null argument");
+    if (!e->clustered) return fail(HMX_ERR_STATE, "hmx_init_cluster (or hmx_set of R) must come first");
+    if ((flags & HMX_ROUND_OBJECTIVE) && !(flags & HMX_ROUND_UPDATE_R))
+        return fail(HMX_ERR_ARG, "HMX_ROUND_OBJECTIVE needs HMX_ROUND_UPDATE_R in this build");
+    if (!(flags & (HMX_ROUND_CENTROIDS | HMX_ROUND_UPDATE_R))) return fail(HMX_ERR_ARG, "nothing to do");
+    return 0;
+}
+
+int hmx_cluster_round(hmx_engine* e, int flags, const int32_t* cells, int64_t n_pos, const int32_t* tile_group,
+                      int32_t n_tiles, const int32_t* block_tile_start, double obj_out[4]) {
+    int rc;
+    if ((rc = check_round_flags(e, flags, obj_out))) return rc;
+    if (!cells || !tile_group || !block_tile_start) return fail(HMX_ERR_ARG, "null update-order list");
+    if (n_pos != (int64_t)n_tiles * HMX_TILE) return fail(HMX_ERR_ARG, "n_pos must be 16*n_tiles");
+    if (block_tile_start[0] != 0 || block_tile_start[e->nblk] != n_tiles) return fail(HMX_ERR_ARG, "block_tile_start must span [0, n_tiles]");
+    std::vector<int> upper(e->nblk);
+    for (int b = 0; b < e->nblk; ++b) {
+        if (block_tile_start[b + 1] < block_tile_start[b]) return fail(HMX_ERR_ARG, "block_tile_start must be non-decreasing");
+        upper[b] = block_tile_start[b + 1] - block_tile_start[b];
+    }
+    if ((rc = use_device(e))) return rc;
+    if ((rc = e->r_cells.reserve(n_pos)) || (rc = e->r_tile_grp.reserve(n_tiles))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->r_cells.p, cells, n_pos * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->r_tile_grp.p, tile_group, n_tiles * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->r_blk_start.p, block_tile_start, (e->nblk + 1) * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));  // host lists are borrowed for the call only
+    return round_body(e, flags, n_tiles, upper, obj_out);
+}
+
+int hmx_cluster_round_seeded(hmx_engine* e, int flags, uint64_t seed, int64_t cells_per_block, double obj_out[4]) {
+    int rc;
+    if ((rc = check_round_flags(e, flags, obj_out))) return rc;
+    if (cells_per_block < 0 || cells_per_block * (e->nblk - 1) > e->N) return fail(HMX_ERR_ARG, "cells_per_block out of range");
+    if ((rc = use_device(e))) return rc;
+    const int nkeys = e->nblk * e->G;
+    const int nchunks = order_chunks(e->N);
+    const size_t pos_cap = (size_t)e->N + (size_t)nkeys * (HMX_TILE - 1) + HMX_TILE;
+    if ((rc = e->r_cells.reserve(pos_cap)) || (rc = e->r_tile_grp.reserve(pos_cap / HMX_TILE + 1)) ||
+        (rc = e->chunk_tab.reserve((size_t)nchunks * nkeys)) || (rc = e->run_count.reserve(nkeys)) ||
+        (rc = e->run_start.reserve(nkeys)))
+        return rc;
+    OrderArgs o{};
+    o.N = e->N; o.cpb = cells_per_block; o.nblk = e->nblk; o.G = e->G;
+    int bits = 1;
+    while (((int64_t)1 << bits) < e->N) ++bits;
+    o.half_bits = (bits + 1) / 2;
+    // splitmix64 of (seed, round counter) -> two 32-bit round keys
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (e->seeded_rounds + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    o.key0 = (uint32_t)z; o.key1 = (uint32_t)(z >> 32) | 1u;
+    e->seeded_rounds++;
+    o.gstart = e->gstart.p; o.chunk_tab = e->chunk_tab.p; o.run_count = e->run_count.p; o.run_start = e->run_start.p;
+    o.blk_start = e->r_blk_start.p; o.cells = e->r_cells.p; o.tile_grp = e->r_tile_grp.p;
+    launch_order(o, e->stream);
+    std::vector<int> upper(e->nblk);
+    int total = 0;
+    for (int b = 0; b < e->nblk; ++b) {
+        const int64_t size_b = (b == e->nblk - 1) ? e->N - cells_per_block * (e->nblk - 1) : cells_per_block;
+        upper[b] = size_b > 0 ? (int)((size_b + HMX_TILE - 1) / HMX_TILE) + e->G : 0;
+        total += upper[b];
+    }
+    return round_body(e, flags, total, upper, obj_out);
 }
 
 int hmx_moe_correct_ridge(hmx_engine* e) {
@@ -456,6 +523,14 @@ static int locate(hmx_engine* e, int which, void** p, size_t* bytes, int* rows, 
 int hmx_get(hmx_engine* e, int which, void* host_out, size_t bytes) {
     if (!e || !host_out) return fail(HMX_ERR_ARG, "null argument");
     void* p; size_t need; int rows, cols, ld, elem, rc;
+    if (which == HMX_ROUND_BLOCK_START || which == HMX_ROUND_CELLS || which == HMX_ROUND_TILE_GROUP) {
+        DevBuf<int>& b = which == HMX_ROUND_BLOCK_START ? e->r_blk_start : which == HMX_ROUND_CELLS ? e->r_cells : e->r_tile_grp;
+        if (bytes > b.n * sizeof(int)) return fail(HMX_ERR_ARG, "round list holds %zu bytes, caller asked for %zu", b.n * sizeof(int), bytes);
+        if ((rc = use_device(e))) return rc;
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipMemcpy(host_out, b.p, bytes, hipMemcpyDeviceToHost));
+        return HMX_OK;
+    }
     if ((rc = locate(e, which, &p, &need, &rows, &cols, &ld, &elem))) return rc;
     if (which == HMX_W) need = (size_t)e->G * e->K * e->d * 4;
     if (bytes != need) return fail(HMX_ERR_ARG, "array %d holds %zu bytes, caller passed %zu", which, need, bytes);

@@ -19,7 +19,9 @@ struct AssignArgs {
     const int* tile_grp;   // group of every tile
     double* S_out;         // G x K16: sum of the new R per (group, cluster)
     double* obj;           // [0] += sum R*dist, [1] += sum sigma R log R
-    int tile_begin, tile_end;
+    const int* blk_start;  // device block_tile_start (nblk+1) or null => tile_begin/tile_end
+    int blk;
+    int tile_begin, tile_end;  // host-side range (or an upper bound of its length when blk_start)
     int K, Kp, K16, mt, dp, ldy;
 };
 
@@ -34,7 +36,7 @@ struct RtzArgs {
     const int* task_grp;
     double* S_out;         // [blk][G][K16] column sums of R (or null)
     float* slab;
-    int n_tiles, ntasks;
+    int n_tiles, ntasks, nblk;
     int K, Kp, K16, G, mt, dp, ntd;
 };
 
@@ -80,6 +82,21 @@ struct ApplyArgs {
     int Kp, K16, dp, ldw, mtd;
 };
 
+struct OrderArgs {
+    int64_t N, cpb;
+    int nblk, G, half_bits;
+    uint32_t key0, key1;
+    const int* gstart;     // G+1 first internal cell of every group
+    int* chunk_tab;        // nchunks x (nblk*G): histogram, then exclusive offsets
+    int* run_count;        // nblk*G
+    int* run_start;        // nblk*G (padded positions)
+    int* blk_start;        // nblk+1 (tiles)
+    int* cells;            // padded list
+    int* tile_grp;
+};
+
+void launch_order(const OrderArgs& a, hipStream_t s);
+int order_chunks(int64_t N);
 void launch_normalize_rows(const float* Z, float* Zc, int64_t N, int dp, hipStream_t s);
 void launch_y_normalize(const float* src, float* dst, int K, int K16, int d, int ldy, hipStream_t s);
 int launch_assign(const AssignArgs& a, bool penalty, int max_wgs, hipStream_t s);

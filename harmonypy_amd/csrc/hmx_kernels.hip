@@ -95,12 +95,15 @@ __global__ __launch_bounds__(256) void k_assign(AssignArgs a) {
     const int nwaves = gridDim.x * 4;
     const int mtn = a.mt;  // live cluster tiles (<= MT)
 
-    // contiguous tile range of this wave, in multiples of NT tiles
-    const int ntiles = a.tile_end - a.tile_begin;
+    // contiguous tile range of this wave, in multiples of NT tiles; the block's tile range
+    // lives in device memory (it is produced on the device when the update order is)
+    const int tile_begin = a.blk_start ? a.blk_start[a.blk] : a.tile_begin;
+    const int tile_end = a.blk_start ? a.blk_start[a.blk + 1] : a.tile_end;
+    const int ntiles = tile_end - tile_begin;
     int per = (ntiles + nwaves - 1) / nwaves;
     per = ((per + NT - 1) / NT) * NT;
-    const int t0 = a.tile_begin + wave * per;
-    const int t1 = min(t0 + per, a.tile_end);
+    const int t0 = tile_begin + wave * per;
+    const int t1 = min(t0 + per, tile_end);
     if (t0 >= t1) return;
 
     float sg[MT][4];
@@ -296,9 +299,10 @@ __global__ __launch_bounds__(256, 2) void k_rtz(RtzArgs a) {
         t1 = a.task_tile1[wave];
         task_grp = a.task_grp[wave];
     } else {
-        const int per = (a.n_tiles + nwaves - 1) / nwaves;
-        t0 = wave * per;
-        t1 = min(t0 + per, a.n_tiles);
+        const int n_tiles = a.blk_start ? a.blk_start[a.nblk] : a.n_tiles;
+        const int per = (n_tiles + nwaves - 1) / nwaves;
+        t0 = min(wave * per, n_tiles);
+        t1 = min(t0 + per, n_tiles);
     }
 
     f32x4 acc[MTW][NTW];
@@ -735,6 +739,128 @@ __global__ __launch_bounds__(256) void k_ridge_apply(ApplyArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Device-side update order (replaces torch.randperm + the gather/argsort of harmony.py:471-480,
+// 512-513 when the caller does not supply an order).
+//
+// A keyed bijection pi on [0, N) (cycle-walking Feistel network) plays the role of the random
+// permutation: position p of the order holds cell pi(p); block b = positions [b*cpb, (b+1)*cpb),
+// the last block takes the remainder (harmony.py:482-484).  Three passes turn that into the
+// engine's lists -- cells of a block regrouped by batch group, every (block, group) run padded
+// to 16 -- without atomics whose order could change the result:
+//   count   : one wave per chunk of positions, per-chunk histogram over key = block*G + group
+//   offsets : exclusive scan over chunks per key, run/tile starts, block_tile_start, tile groups
+//   scatter : every position writes its cell at run_start + (#earlier positions with its key)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ uint32_t feistel_perm(uint32_t x, uint32_t n, int half_bits, uint32_t k0, uint32_t k1) {
+    const uint32_t mask = (1u << half_bits) - 1u;
+    do {
+        uint32_t l = x >> half_bits, r = x & mask;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const uint32_t f = mix32(r * 0x9E3779B1u + k0 + (uint32_t)i * k1) & mask;
+            const uint32_t nl = r;
+            r = l ^ f;
+            l = nl;
+        }
+        x = (l << half_bits) | r;
+    } while (x >= n);
+    return x;
+}
+__device__ __forceinline__ int group_of_cell(const int* __restrict__ gstart, int G, int cell) {
+    int lo = 0, hi = G;  // gstart[g] <= cell < gstart[g+1]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (gstart[mid] <= cell) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+#define ORDER_CHUNK 1024  /* positions per wave */
+
+// mode 0: write per-chunk histograms; mode 1: scatter cells using chunk offsets
+template <int MODE>
+__global__ __launch_bounds__(64) void k_order_pass(OrderArgs a) {
+    extern __shared__ int cnt[];  // nkeys running counters of this chunk
+    const int lane = threadIdx.x;
+    const int chunk = blockIdx.x;
+    const int nkeys = a.nblk * a.G;
+    for (int i = lane; i < nkeys; i += 64) cnt[i] = (MODE == 1) ? a.chunk_tab[(size_t)chunk * nkeys + i] : 0;
+    __syncthreads();
+    const int64_t base = (int64_t)chunk * ORDER_CHUNK;
+    for (int s = 0; s < ORDER_CHUNK / 64; ++s) {
+        const int64_t p = base + s * 64 + lane;
+        const bool live = p < a.N;
+        int cell = 0, key = -1;
+        if (live) {
+            cell = (int)feistel_perm((uint32_t)p, (uint32_t)a.N, a.half_bits, a.key0, a.key1);
+            const int b = (a.cpb > 0) ? (int)min((int64_t)(p / a.cpb), (int64_t)(a.nblk - 1)) : a.nblk - 1;
+            key = b * a.G + group_of_cell(a.gstart, a.G, cell);
+        }
+        // rank among the lanes of this step that share the key, in position order
+        unsigned long long todo = __ballot(live);
+        int rank = 0, cnt_before = 0;
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int k0 = __shfl(key, leader, 64);
+            const unsigned long long same = __ballot(live && key == k0);
+            if (live && key == k0) {
+                rank = __popcll(same & ((1ull << lane) - 1ull));
+                cnt_before = cnt[k0];
+            }
+            __syncthreads();
+            if (lane == leader) cnt[k0] += __popcll(same);
+            __syncthreads();
+            todo &= ~same;
+        }
+        if (MODE == 1 && live) a.cells[a.run_start[key] + cnt_before + rank] = cell;
+    }
+    if (MODE == 0) {
+        __syncthreads();
+        for (int i = lane; i < nkeys; i += 64) a.chunk_tab[(size_t)chunk * nkeys + i] = cnt[i];
+    }
+}
+
+// One workgroup: per-key exclusive scan over chunks (in place), run/tile tables, block starts.
+__global__ __launch_bounds__(256) void k_order_offsets(OrderArgs a, int nchunks) {
+    const int nkeys = a.nblk * a.G;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < nkeys; k += blockDim.x) {
+        int run = 0;
+        for (int c = 0; c < nchunks; ++c) {
+            const int v = a.chunk_tab[(size_t)c * nkeys + k];
+            a.chunk_tab[(size_t)c * nkeys + k] = run;
+            run += v;
+        }
+        a.run_count[k] = run;
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        int pos = 0;
+        for (int k = 0; k < nkeys; ++k) {
+            if (k % a.G == 0) a.blk_start[k / a.G] = pos / 16;
+            a.run_start[k] = pos;
+            pos += ((a.run_count[k] + 15) / 16) * 16;
+        }
+        a.blk_start[a.nblk] = pos / 16;
+    }
+}
+
+// Fill padding and tile groups: one workgroup per key.
+__global__ __launch_bounds__(64) void k_order_finish(OrderArgs a) {
+    const int key = blockIdx.x;
+    const int start = a.run_start[key], n = a.run_count[key];
+    const int padded = ((n + 15) / 16) * 16;
+    for (int i = n + threadIdx.x; i < padded; i += 64) a.cells[start + i] = -1;
+    for (int t = threadIdx.x; t < padded / 16; t += 64) a.tile_grp[start / 16 + t] = key % a.G;
+}
+
 // ------------------------------------------------------------------------------------------
 // host-side launchers (called from hmx_capi.cpp through hmx_internal.h)
 // ------------------------------------------------------------------------------------------
@@ -811,6 +937,17 @@ void launch_ridge_solve(const RidgeSolveArgs& a, hipStream_t s) {
     if (a.V == 1) hipLaunchKernelGGL(k_ridge_solve_v1, dim3(a.K16), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(k_ridge_solve_general, dim3(a.K16), dim3(256), 0, s, a);
 }
+
+void launch_order(const OrderArgs& a, hipStream_t s) {
+    const int nchunks = cdiv(a.N, ORDER_CHUNK);
+    const size_t sm = (size_t)a.nblk * a.G * sizeof(int);
+    hipLaunchKernelGGL(k_order_pass<0>, dim3(nchunks), dim3(64), sm, s, a);
+    hipLaunchKernelGGL(k_order_offsets, dim3(1), dim3(256), 0, s, a, nchunks);
+    hipLaunchKernelGGL(k_order_finish, dim3(a.nblk * a.G), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_order_pass<1>, dim3(nchunks), dim3(64), sm, s, a);
+}
+
+int order_chunks(int64_t N) { return cdiv(N, ORDER_CHUNK); }
 
 int launch_ridge_apply(const ApplyArgs& a, int max_wgs, hipStream_t s) {
     if (a.n_tiles <= 0) return 0;

@@ -28,6 +28,17 @@ if not logger.handlers:
     logger.addHandler(_h)
     logger.setLevel(logging.INFO)
 
+# Source of the per-round update order (harmony.py:471):
+#   "torch"  -- torch.randperm on the CPU generator seeded by run_harmony, i.e. the very stream
+#               of the reference's device='cpu' run; the order is regrouped on the host.
+#   "device" -- keyed bijection evaluated on the GPU (hmx_cluster_round_seeded); no host work,
+#               a different (statistically equivalent) stream.
+#   "auto"   -- "torch" up to AUTO_DEVICE_ORDER_CELLS cells, "device" above: the host path
+#               costs ~0.2 s per round per million cells and would dominate the loop.
+# Override with the environment variable HMX_UPDATE_ORDER.
+UPDATE_ORDER = "auto"
+AUTO_DEVICE_ORDER_CELLS = 200_000
+
 # Test aids (never set by product code).  ``Y0``: d x K centroids used instead of the
 # sklearn call; ``forced_rounds``: list of k-means round counts replayed instead of the
 # objective thresholds (whose margins are a few fp32 ulps).
@@ -315,6 +326,14 @@ class Harmony:
         self._pending_objective = None
         self._forced_rounds = (list(_TEST_HOOKS["forced_rounds"])
                                if _TEST_HOOKS["forced_rounds"] is not None else None)
+        import os
+        mode = os.environ.get("HMX_UPDATE_ORDER", UPDATE_ORDER)
+        if mode not in ("auto", "torch", "device"):
+            raise ValueError(f"HMX_UPDATE_ORDER={mode!r}: expected auto, torch or device")
+        if mode == "auto":
+            mode = "torch" if self.N <= AUTO_DEVICE_ORDER_CELLS else "device"
+        self.update_order = mode
+        self._seed = int(random_state) if random_state is not None else 0
 
         self.allocate_buffers(Z)
         self.init_cluster(random_state)
@@ -502,6 +521,9 @@ class Harmony:
         return torch.randperm(self.N).numpy()                                    # harmony.py:471
 
     def _round(self, flags):
+        if self.update_order == "device":
+            self._pending_objective = self._engine.cluster_round_seeded(self._seed, self._cells_per_block, flags)
+            return
         order = self._update_order()
         cells, tile_grp, blk_start = self._block_lists(order)
         self._pending_objective = self._engine.cluster_round(cells, tile_grp, blk_start, flags)

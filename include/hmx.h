@@ -50,7 +50,11 @@ typedef enum hmx_array {
     HMX_O_GROUP = 5,/* double G x K   sum of R over the cells of a group; O[k,b] of
                        harmony.py:360 is the sum over the groups containing column b   */
     HMX_T_MASS = 6, /* double K       cluster mass; E[k,b] = T[k]*Pr_b[b] (harmony.py:361) */
-    HMX_W = 7       /* float  G x K x d  per-group correction vectors of the last ridge */
+    HMX_W = 7,      /* float  G x K x d  per-group correction vectors of the last ridge */
+    /* the update-order lists of the last round (read-only; int32) */
+    HMX_ROUND_BLOCK_START = 8, /* n_blocks+1 tile offsets                                  */
+    HMX_ROUND_CELLS = 9,       /* 16 * block_start[n_blocks] list positions, -1 = padding  */
+    HMX_ROUND_TILE_GROUP = 10  /* block_start[n_blocks] groups                              */
 } hmx_array;
 
 typedef struct hmx_config {
@@ -103,6 +107,14 @@ int hmx_init_cluster(hmx_engine* e, const float* Y0, double obj_out[4]);
 int hmx_cluster_round(hmx_engine* e, int flags, const int32_t* cells, int64_t n_pos,
                       const int32_t* tile_group, int32_t n_tiles, const int32_t* block_tile_start,
                       double obj_out[4]);
+
+/* Same round, update order drawn on the device: a keyed bijection of [0, N) (round key from
+ * `seed` and the engine's round counter) stands in for torch.randperm (harmony.py:471); blocks
+ * are cells_per_block positions each, the last one takes the remainder (harmony.py:475-484).
+ * Statistically equivalent to, not bitwise the same stream as, the reference's generator
+ * (the reference itself changes stream between its 'cpu' and 'cuda' devices). */
+int hmx_cluster_round_seeded(hmx_engine* e, int flags, uint64_t seed, int64_t cells_per_block,
+                             double obj_out[4]);
 
 /* harmony.py:535-569. */
 int hmx_moe_correct_ridge(hmx_engine* e);

@@ -144,7 +144,13 @@ class OracleHarmony:
                  lambda_estimation=False, max_iter_harmony=10, max_iter_kmeans=20,
                  epsilon_kmeans=1e-5, epsilon_harmony=1e-4, K=None, block_size=0.05,
                  random_state=0, Y0=None, perm_source=None, run=True, hooks=None,
-                 forced_rounds=None):
+                 forced_rounds=None, ridge_dtype=np.float32):
+        # ridge_dtype=float64 is NOT the reference's arithmetic: it evaluates the same ridge
+        # equations (harmony.py:547-566) in double.  The reference's fp32 inverse amplifies
+        # rounding by cond(cov) ~ cluster mass / lambda: measured with the reference itself at
+        # 69k cells, K=30: 9e-4 relative change of Z_corr between 1 and 8 host threads.  Tests
+        # at that scale therefore check the engine against this better-conditioned evaluation.
+        self.ridge_dtype = np.dtype(ridge_dtype)
         self.Z_orig = np.array(Z, dtype=F32)                     # d x N  (:235)
         self.Z_corr = self.Z_orig.copy()                         # (:234)
         self.Z_cos = _col_unit(self.Z_orig)                      # (:238)
@@ -312,7 +318,10 @@ class OracleHarmony:
 
     # ---- harmony.py:535-569 ---------------------------------------------
     def moe_correct_ridge(self):
-        self.Z_corr = self.Z_orig.copy()                                 # :537
+        T = self.ridge_dtype.type
+        Z_orig = self.Z_orig.astype(T)
+        Phi_moe = self.Phi_moe.astype(T)
+        Z_corr = Z_orig.copy()                                           # :537
         self.W_all = np.zeros((self.K, self.B + 1, self.d), F32)
         for k in range(self.K):
             if self.lambda_estimation:                                   # :541-544, 587-591
@@ -320,19 +329,21 @@ class OracleHarmony:
                 lam[1:] = self.E[k, :] * F32(self.alpha)
             else:
                 lam = self.lamb
-            Phi_Rk = self.Phi_moe * self.R[k, :]                         # :547
-            cov = (Phi_Rk @ self.Phi_moe.T + np.diag(lam)).astype(F32)   # :550
-            inv_cov = np.linalg.inv(cov).astype(F32)                     # :553
-            Z_tmp = self.Z_orig * self.R[k, :]                           # :556
-            W = inv_cov[:, 0:1] @ Z_tmp.sum(axis=1, dtype=F32, keepdims=True).T   # :559
+            Rk = self.R[k, :].astype(T)
+            Phi_Rk = Phi_moe * Rk                                        # :547
+            cov = (Phi_Rk @ Phi_moe.T + np.diag(lam.astype(T))).astype(T)   # :550
+            inv_cov = np.linalg.inv(cov).astype(T)                       # :553
+            Z_tmp = Z_orig * Rk                                          # :556
+            W = inv_cov[:, 0:1] @ Z_tmp.sum(axis=1, dtype=T, keepdims=True).T   # :559
             for b in range(self.B):                                      # :561-563
                 # C-contiguous gather so the row sums are pairwise like torch's
                 cols = np.ascontiguousarray(Z_tmp[:, self.batch_index[b]])
-                part = cols.sum(axis=1, dtype=F32, keepdims=True)
+                part = cols.sum(axis=1, dtype=T, keepdims=True)
                 W = W + inv_cov[:, b + 1:b + 2] @ part.T
             W[0, :] = 0                                                  # :565
             self.W_all[k] = W
-            self.Z_corr = (self.Z_corr - W.T @ Phi_Rk).astype(F32)       # :566
+            Z_corr = (Z_corr - W.T @ Phi_Rk).astype(T)                   # :566
+        self.Z_corr = Z_corr.astype(F32)
         self.Z_cos = _col_unit(self.Z_corr)                              # :569
         self._emit("ridge")
 
@@ -344,7 +355,8 @@ class OracleHarmony:
 def oracle_run_harmony(data_mat, meta_data, vars_use, theta=None, lamb=None, sigma=0.1,
                        nclust=None, tau=0, block_size=0.05, max_iter_harmony=10,
                        max_iter_kmeans=20, epsilon_cluster=1e-5, epsilon_harmony=1e-4,
-                       alpha=0.2, random_state=0, Y0=None, hooks=None, forced_rounds=None):
+                       alpha=0.2, random_state=0, Y0=None, hooks=None, forced_rounds=None,
+                       ridge_dtype=np.float32):
     """``run_harmony`` (harmony.py:49-215) on the oracle; seeds like :199-200."""
     import torch
     p = prepare_inputs(data_mat, meta_data, vars_use, theta, lamb, sigma, nclust, tau)
@@ -353,4 +365,5 @@ def oracle_run_harmony(data_mat, meta_data, vars_use, theta=None, lamb=None, sig
     return OracleHarmony(p["Z"], p["phi"], p["Pr_b"], p["sigma"], p["theta"], p["lamb"],
                          alpha, p["lambda_estimation"], max_iter_harmony, max_iter_kmeans,
                          epsilon_cluster, epsilon_harmony, p["K"], block_size,
-                         random_state, Y0=Y0, hooks=hooks, forced_rounds=forced_rounds)
+                         random_state, Y0=Y0, hooks=hooks, forced_rounds=forced_rounds,
+                         ridge_dtype=ridge_dtype)

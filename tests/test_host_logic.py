@@ -1,0 +1,184 @@
+"""CPU tests of the host side: argument normalisation, batch groups, tile lists, the C ABI
+surface.  No compute call is made (there is no GPU here); the product has no CPU fallback."""
+import os
+import re
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import ROOT, load_case
+
+
+def test_library_exports_every_declared_symbol():
+    """libhmx.so loads and exports exactly what include/hmx.h declares."""
+    from harmonypy_amd import _capi
+    header = open(os.path.join(ROOT, "include", "hmx.h")).read()
+    declared = sorted(set(re.findall(r"\b(hmx_[a-z_0-9]+)\s*\(", header)))
+    assert declared, "no declarations found"
+    lib = _capi.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in hmx.h but not exported"
+    assert sorted(_capi.EXPORTS) == declared
+    assert lib.hmx_abi_version() == 1
+
+
+def test_engine_fails_loudly_without_gpu():
+    """No silent fallback: without a HIP device the constructor raises with the library's text."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from harmonypy_amd import _capi
+    with pytest.raises(_capi.HmxError) as ei:
+        _capi.Engine(100, 5, 3, 2, 2, 1, 20)
+    assert "HIP" in str(ei.value) or "device" in str(ei.value)
+
+
+def test_bad_arguments_are_rejected_by_the_abi():
+    import ctypes as C
+    from harmonypy_amd import _capi
+    lib = _capi.load()
+    h = C.c_void_p()
+    cfg = _capi.HmxConfig(n_cells=0, n_pcs=5, n_clusters=3, n_batches=2, n_groups=2, n_vars=1, n_blocks=20)
+    assert lib.hmx_create(C.byref(cfg), C.byref(h)) == -1
+    assert b"positive" in lib.hmx_last_error()
+    cfg = _capi.HmxConfig(n_cells=10, n_pcs=5, n_clusters=999, n_batches=2, n_groups=2, n_vars=1, n_blocks=20)
+    assert lib.hmx_create(C.byref(cfg), C.byref(h)) == -1
+    assert lib.hmx_create(None, C.byref(h)) == -1
+    assert lib.hmx_moe_correct_ridge(None) == -1
+    assert lib.hmx_sync(None) == -1
+
+
+def test_device_argument():
+    from harmonypy_amd.harmony import _device_index
+    assert _device_index(None) == 0
+    assert _device_index("cuda") == 0
+    assert _device_index("cuda:3") == 3
+    assert _device_index("hip:1") == 1
+    for bad in ("cpu", "mps", "xla"):
+        with pytest.raises(ValueError):
+            _device_index(bad)
+
+
+CASES = [
+    dict(),
+    dict(theta=1.0, tau=5, sigma=0.2, nclust=20),
+    dict(lamb=-1),
+    dict(theta=[2.0, 1.0], lamb=[1.0, 0.5]),
+    dict(theta=[2.0, 1.0, 0.5, 3.0, 1.0, 1.0, 2.0], lamb=[1, 2, 3, 4, 5, 6, 7]),
+    dict(lamb=0.5, theta=3),
+]
+
+
+@pytest.mark.parametrize("kw", CASES)
+def test_prepare_inputs_matches_oracle_front_end(kw):
+    """harmony.py:116-173: same Z orientation, K, sigma, theta, lamb, Pr_b; codes == one-hot."""
+    from harmonypy_amd.harmony import _prepare_inputs
+    from oracle import prepare_inputs
+    data, meta, _, _, _ = load_case("pbmc_two_vars")
+    two = any(isinstance(v, list) and len(v) in (2, 7) for v in kw.values())
+    vars_use = ["donor", "tech"] if two else "donor"
+    a = _prepare_inputs(data, meta, vars_use, **kw)
+    b = prepare_inputs(data, meta, vars_use, **kw)
+    assert a["K"] == b["K"] and a["lambda_estimation"] == b["lambda_estimation"]
+    np.testing.assert_array_equal(a["Z"], b["Z"])
+    np.testing.assert_array_equal(a["codes"].dense(), b["phi"])
+    for key in ("sigma", "theta", "lamb", "Pr_b"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+        assert a[key].dtype == np.float32
+    # either orientation of data_mat is accepted (harmony.py:117-118)
+    a2 = _prepare_inputs(data.T, meta, vars_use, **kw)
+    np.testing.assert_array_equal(a2["Z"], a["Z"])
+    a3 = _prepare_inputs(pd.DataFrame(data), meta, vars_use, **kw)
+    np.testing.assert_array_equal(a3["Z"], a["Z"])
+
+
+def test_prepare_inputs_errors():
+    from harmonypy_amd.harmony import _prepare_inputs
+    data, meta, _, _, _ = load_case("pbmc_short")
+    with pytest.raises(AssertionError):
+        _prepare_inputs(data[:100], meta, "donor")
+    with pytest.raises(AssertionError):
+        _prepare_inputs(data, meta, "donor", theta=[1.0, 2.0])
+
+
+def test_batch_codes_dense_roundtrip():
+    from harmonypy_amd.harmony import BatchCodes
+    rng = np.random.default_rng(0)
+    codes = np.stack([rng.integers(0, 3, 50), 3 + rng.integers(0, 4, 50)], axis=1)
+    bc = BatchCodes(codes, 7)
+    back = BatchCodes.from_dense(bc.dense())
+    np.testing.assert_array_equal(back.codes, codes)
+    bad = bc.dense()
+    bad[:, 0] = 0
+    with pytest.raises(ValueError):
+        BatchCodes.from_dense(bad)
+
+
+def test_layout_groups_and_static_tiles():
+    from harmonypy_amd.harmony import TILE, build_layout
+    rng = np.random.default_rng(1)
+    codes = np.stack([rng.integers(0, 3, 1000), 3 + rng.integers(0, 2, 1000)], axis=1).astype(np.int32)
+    group_cols, order, rank, gid_int, cells, tile_grp = build_layout(codes)
+    G = group_cols.shape[0]
+    assert G == len(np.unique(codes, axis=0))
+    np.testing.assert_array_equal(rank[order], np.arange(1000))
+    np.testing.assert_array_equal(codes[order], group_cols[gid_int])       # internal cell -> its columns
+    assert np.all(np.diff(gid_int) >= 0)                                   # group-sorted
+    assert cells.size == TILE * tile_grp.size
+    live = cells[cells >= 0]
+    np.testing.assert_array_equal(live, np.arange(1000))                   # identity list
+    for t, g in enumerate(tile_grp):                                       # one group per tile
+        c = cells[t * TILE:(t + 1) * TILE]
+        assert np.all(gid_int[c[c >= 0]] == g)
+
+
+@pytest.mark.parametrize("N,block_size", [(3500, 0.05), (1237, 0.07), (37, 0.05), (16, 0.3), (1000, 0.13)])
+def test_block_lists_reproduce_reference_blocks(N, block_size):
+    """Blocks of harmony.py:474-484 as sets; (block, group) runs padded to tiles."""
+    from harmonypy_amd.harmony import TILE, build_block_lists, build_layout
+    rng = np.random.default_rng(N)
+    codes = rng.integers(0, 4, N).astype(np.int32)[:, None]
+    group_cols, order, rank, gid_int, _, _ = build_layout(codes)
+    G = group_cols.shape[0]
+    upd = rng.permutation(N)
+    nb = int(np.ceil(1.0 / block_size))
+    cpb = int(N * block_size)
+    cells, tile_grp, blk_start = build_block_lists(upd, rank, gid_int, nb, cpb, G)
+    assert blk_start[0] == 0 and blk_start[-1] == tile_grp.size and cells.size == TILE * tile_grp.size
+    seen = []
+    for b in range(nb):
+        lo = b * cpb
+        hi = N if b == nb - 1 else (b + 1) * cpb
+        ref_members = set(upd[lo:hi].tolist())                              # original cell ids
+        mine = cells[blk_start[b] * TILE: blk_start[b + 1] * TILE]
+        mine = mine[mine >= 0]
+        assert set(order[mine].tolist()) == ref_members
+        seen.append(mine)
+        for t in range(blk_start[b], blk_start[b + 1]):
+            c = cells[t * TILE:(t + 1) * TILE]
+            assert np.all(gid_int[c[c >= 0]] == tile_grp[t]) and (c >= 0).any()
+    allc = np.concatenate(seen)
+    assert allc.size == N and len(set(allc.tolist())) == N                  # every cell exactly once
+
+
+def test_check_convergence_semantics():
+    """harmony.py:515-533 on hand-made histories."""
+    from harmonypy_amd.harmony import Harmony
+    ho = object.__new__(Harmony)
+    ho.window_size, ho.epsilon_kmeans, ho.epsilon_harmony = 3, 1e-5, 1e-4
+    ho.objective_kmeans = [10.0, 9.0, 8.0, 7.0]
+    assert ho.check_convergence(0) is False                                 # needs > window+1 entries
+    ho.objective_kmeans = [10.0, 9.0, 9.0, 9.0, 9.0]
+    assert ho.check_convergence(0) == (abs(27.0 - 27.0) / 27.0 < 1e-5)
+    ho.objective_kmeans = [10.0, 9.0, 8.0, 7.0, 6.0]
+    assert not ho.check_convergence(0)
+    ho.objective_harmony = [5.0]
+    assert ho.check_convergence(1) is False
+    ho.objective_harmony = [5.0, 5.0 - 1e-6]
+    assert ho.check_convergence(1)
+    ho.objective_harmony = [5.0, 6.0]                                       # signed test: an increase converges
+    assert ho.check_convergence(1)
+    ho.objective_harmony = [5.0, 4.0]
+    assert not ho.check_convergence(1)
+    assert ho.check_convergence(2) is True

@@ -238,7 +238,12 @@ def test_edge_shapes_against_oracle(N, d, K, B, bs):
 
 def test_config2_shape_properties_and_oracle():
     """BASELINE.json configs[1] shape (69k x 50, 4 batches, K=30): engine vs oracle on the same
-    schedule plus size-independent invariants."""
+    schedule plus size-independent invariants.
+
+    At ~2300 cells per cluster and lambda=1 the ridge system has cond ~ 7e3 and the reference's
+    fp32 inverse (harmony.py:553) no longer pins Z_corr: the reference differs from itself by
+    9e-4 between 1 and 8 host threads (measured).  The oracle is therefore asked to
+    evaluate the same ridge equations in float64 here."""
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import synthetic_dataset
@@ -246,12 +251,79 @@ def test_config2_shape_properties_and_oracle():
     Z, meta = synthetic_dataset(69000, 50, 4, 30, seed=0)
     kw = dict(nclust=30, max_iter_harmony=2, max_iter_kmeans=5, epsilon_cluster=0.0, epsilon_harmony=-1e30,
               random_state=0)
-    oo = oracle_run_harmony(Z, meta, ["batch"], **kw)
+    oo = oracle_run_harmony(Z, meta, ["batch"], ridge_dtype=np.float64, **kw)
     ho = _run_engine(Z, meta, ["batch"], Y0=oo.Y0, **kw)
-    assert_z_close(ho.Z_corr, oo.result())
+    rel_f, max_rel = assert_z_close(ho.Z_corr, oo.result())
+    print(f"config2: relF={rel_f:.2e} max={max_rel:.2e}")
+    np.testing.assert_allclose(ho.objective_kmeans, oo.objective_kmeans, rtol=2e-5)
     R = ho.R
     np.testing.assert_allclose(R.sum(axis=1), 1.0, atol=3e-6)
     np.testing.assert_allclose(ho.O.sum(axis=0), np.bincount(meta["batch"].cat.codes if hasattr(meta["batch"], "cat")
                                                               else pd.Categorical(meta["batch"]).codes), rtol=1e-5)
     np.testing.assert_allclose(np.linalg.norm(ho.Z_cos, axis=1), 1.0, atol=3e-6)
     np.testing.assert_allclose(np.linalg.norm(ho.Y, axis=0), 1.0, atol=3e-6)
+
+
+# ------------------------------------------------------------------------------------------
+# device-side update order (hmx_cluster_round_seeded)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,B,bs", [(3500, 3, 0.05), (1237, 4, 0.07), (37, 2, 0.05), (100003, 5, 0.05)])
+def test_device_order_is_a_valid_partition(N, B, bs, monkeypatch):
+    """Every cell exactly once, block sizes of harmony.py:475-484, one group per tile, fresh order
+    every round, and (statistically) batch-balanced blocks."""
+    from harmonypy_amd import harmony as H
+    monkeypatch.setenv("HMX_UPDATE_ORDER", "device")
+    rng = np.random.default_rng(N)
+    batch = rng.integers(0, B, size=N)
+    batch[:B] = np.arange(B)
+    Z = (rng.normal(size=(N, 6)) + batch[:, None]).astype(np.float32)
+    meta = pd.DataFrame({"b": [f"b{i}" for i in batch]})
+    ho = H.run_harmony(Z, meta, ["b"], nclust=4, block_size=bs, max_iter_harmony=0, verbose=False, random_state=3)
+    assert ho.update_order == "device"
+    nb, cpb = ho._n_blocks, ho._cells_per_block
+    prev = None
+    for rnd in range(2):
+        ho._round(7)
+        ho.compute_objective()
+        cells, tg, bstart = ho._engine.round_lists()
+        assert bstart[0] == 0 and np.all(np.diff(bstart) >= 0)
+        live = cells[cells >= 0]
+        assert live.size == N and np.array_equal(np.sort(live), np.arange(N))
+        for b in range(nb):
+            blk = cells[bstart[b] * 16: bstart[b + 1] * 16]
+            blk = blk[blk >= 0]
+            want = (N - cpb * (nb - 1)) if b == nb - 1 else cpb
+            assert blk.size == want, (b, blk.size, want)
+        tile_of = np.repeat(tg, 16)
+        assert np.array_equal(ho._gid_int[live], tile_of[cells >= 0])
+        first_block = np.sort(cells[:bstart[1] * 16][cells[:bstart[1] * 16] >= 0])
+        if prev is not None and cpb >= 8:
+            assert not np.array_equal(first_block, prev)          # a fresh order every round
+        prev = first_block
+    if N >= 3500:
+        # block 0 of a uniform random partition holds each batch in proportion (4 sigma)
+        blk = cells[:bstart[1] * 16]
+        blk = blk[blk >= 0]
+        counts = np.bincount(ho._gid_int[blk], minlength=B)
+        p = np.bincount(batch, minlength=B) / N
+        sd = np.sqrt(blk.size * p * (1 - p))
+        assert np.all(np.abs(counts - blk.size * p) < 4 * sd + 1)
+    np.testing.assert_allclose(ho.R.sum(axis=1), 1.0, atol=3e-6)
+
+
+def test_device_order_gives_equivalent_correction(monkeypatch):
+    """A different random stream moves Z_corr like a different seed does in the reference
+    (4e-3 relative), nothing more: per-PC correlation with the reference's
+    output stays > 0.999 and the objective lands within 0.5 %."""
+    from scipy.stats import pearsonr
+    from harmonypy_amd import harmony as H
+    data, meta, vars_use, kw, g = load_case("pbmc_default")
+    monkeypatch.setenv("HMX_UPDATE_ORDER", "device")
+    ho = _run_engine(data, meta, vars_use, Y0=g["Y0"], **kw)
+    assert ho.update_order == "device"
+    Z = ho.Z_corr
+    cors = [pearsonr(Z[:, j], g["Z_corr"][:, j])[0] for j in range(Z.shape[1])]
+    assert min(cors) > 0.999, min(cors)
+    rel_f, _ = z_errors(Z, g["Z_corr"])
+    assert rel_f < 3e-2
+    assert abs(ho.objective_harmony[-1] / g["objective_harmony"][-1] - 1) < 5e-3
