@@ -144,7 +144,10 @@ def main():
         ho._forced_rounds = [args.rounds]
         ho.cluster()
         ho.moe_correct_ridge()
-        ho.check_convergence(1)
+        try:
+            ho.check_convergence(1)
+        except ZeroDivisionError:   # only with the timing-experiment builds (HMX_LIB), whose sums are void
+            pass
 
     def fence():
         ho._engine.sync()

@@ -33,9 +33,16 @@ def needs_build() -> bool:
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
+def build(force: bool = False, verbose: bool = True, extra_flags=(), out: str | None = None) -> str:
+    """``out`` builds a variant library (timing experiments: e.g. -DHMX_ABL=..) next to libhmx.so."""
+    if out is not None:
+        return _compile(out, verbose, extra_flags)
     if not force and not needs_build():
         return LIB
+    return _compile(LIB, verbose, extra_flags)
+
+
+def _compile(LIB, verbose, extra_flags):
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-x", "hip"]
@@ -50,6 +57,10 @@ def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv,
-          extra_flags=[a for a in sys.argv[1:] if a != "--force"])
-    print(LIB)
+    args = [a for a in sys.argv[1:] if a != "--force"]
+    out = None
+    if "-o" in args:
+        i = args.index("-o")
+        out = os.path.abspath(args[i + 1])
+        del args[i:i + 2]
+    print(build(force="--force" in sys.argv, extra_flags=args, out=out))

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhmx.so")
+LIB_PATH = os.environ.get("HMX_LIB") or os.path.join(_HERE, "libhmx.so")   # HMX_LIB: variant builds for timing experiments
 
 # mirrors include/hmx.h
 HMX_TILE = 16

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -65,6 +66,8 @@ struct hmx_engine {
     int64_t N = 0;
     int d = 0, dp = 0, K = 0, Kp = 0, K16 = 0, mt = 0, ntd = 0, ldy = 0, B = 0, G = 0, V = 0, nblk = 0;
     int max_wgs = 1024;
+    int ablate = 0;          // HMX_ABLATE: timing experiments only (results become wrong)
+    int tiles_per_wave = 2;  // k_assign_lds grid sizing (HMX_TILES_PER_WAVE)
     hipStream_t stream = nullptr;
     bool uploaded = false, clustered = false, timing = false;
 
@@ -128,10 +131,16 @@ void drain_spans(hmx_engine* e) {
 }
 
 int read_objective(hmx_engine* e, double out[4]) {
-    HIP_TRY(hipMemcpyAsync(e->obj_host, e->objacc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    const int n = 2 * HMX_OBJ_SLOTS + 2;
+    HIP_TRY(hipMemcpyAsync(e->obj_host, e->objacc.p, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipGetLastError());
-    for (int i = 0; i < 4; ++i) out[i] = (double)(float)e->obj_host[i];  // `.item()` of an fp32 tensor
+    double km = 0.0, ent = 0.0;
+    for (int i = 0; i < HMX_OBJ_SLOTS; ++i) { km += e->obj_host[2 * i]; ent += e->obj_host[2 * i + 1]; }
+    out[0] = (double)(float)km;  // `.item()` of an fp32 tensor
+    out[1] = (double)(float)ent;
+    out[2] = (double)(float)e->obj_host[2 * HMX_OBJ_SLOTS];
+    out[3] = 0.0;
     return 0;
 }
 
@@ -140,6 +149,7 @@ AssignArgs assign_args(hmx_engine* e) {
     a.Zcos = e->Zcos.p; a.Y = e->Y.p; a.sigma = e->sigma.p; a.rp = e->rp.p; a.lrp = e->lrp.p; a.R = e->R.p;
     a.obj = e->objacc.p;
     a.K = e->K; a.Kp = e->Kp; a.K16 = e->K16; a.mt = e->mt; a.dp = e->dp; a.ldy = e->ldy;
+    a.G = e->G; a.tiles_per_wave = e->tiles_per_wave; a.ablate = e->ablate;
     return a;
 }
 
@@ -181,6 +191,8 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
     e->K16 = 16 * e->mt;
     e->ntd = (e->d + 15) / 16;
     e->ldy = 16 * e->ntd;
+    if (const char* ab = getenv("HMX_ABLATE")) e->ablate = atoi(ab);
+    if (const char* tpw = getenv("HMX_TILES_PER_WAVE")) e->tiles_per_wave = std::max(1, atoi(tpw));
     int rc = 0;
     do {
         if ((rc = use_device(e))) break;
@@ -193,19 +205,19 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
             (rc = e->theta.reserve(e->B)) || (rc = e->Pr_b.reserve(e->B)) || (rc = e->lamb.reserve(e->B + 1)) ||
             (rc = e->rp.reserve(GK)) || (rc = e->lrp.reserve(GK)) || (rc = e->group_cols.reserve((size_t)e->G * e->V)) ||
             (rc = e->Ogrp.reserve(GK)) || (rc = e->Tmass.reserve(e->K16)) || (rc = e->Sold.reserve(GK * e->nblk)) ||
-            (rc = e->Snew.reserve(GK * e->nblk)) || (rc = e->Ohist.reserve(GK * e->nblk)) || (rc = e->objacc.reserve(4)) ||
+            (rc = e->Snew.reserve(GK * e->nblk)) || (rc = e->Ohist.reserve(GK * e->nblk)) || (rc = e->objacc.reserve(2 * HMX_OBJ_SLOTS + 2)) ||
             (rc = e->Sr.reserve(GK * e->ldy)) || (rc = e->Oxr.reserve(GK)) ||
             (rc = e->W.reserve(GK * e->ldy)) || (rc = e->r_blk_start.reserve(e->nblk + 1)))
             break;
         if (e->V > 1 && (rc = e->scratch.reserve((size_t)e->K16 * (e->B + 1) * (e->B + 1 + e->d)))) break;
-        hipError_t pe = hipHostMalloc(reinterpret_cast<void**>(&e->obj_host), 4 * sizeof(double), hipHostMallocDefault);
+        hipError_t pe = hipHostMalloc(reinterpret_cast<void**>(&e->obj_host), (2 * HMX_OBJ_SLOTS + 2) * sizeof(double), hipHostMallocDefault);
         if (pe != hipSuccess) { rc = fail(HMX_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(pe)); break; }
         (void)hipMemsetAsync(e->R.p, 0, N * e->Kp * sizeof(float), e->stream);
         (void)hipMemsetAsync(e->Ogrp.p, 0, GK * sizeof(double), e->stream);
         (void)hipMemsetAsync(e->Tmass.p, 0, e->K16 * sizeof(double), e->stream);
         (void)hipMemsetAsync(e->W.p, 0, GK * e->ldy * sizeof(float), e->stream);
         (void)hipMemsetAsync(e->Y.p, 0, (size_t)e->K16 * e->ldy * sizeof(float), e->stream);
-        (void)hipMemsetAsync(e->objacc.p, 0, 4 * sizeof(double), e->stream);
+        (void)hipMemsetAsync(e->objacc.p, 0, (2 * HMX_OBJ_SLOTS + 2) * sizeof(double), e->stream);
     } while (0);
     if (rc) {
         std::string keep = g_err;
@@ -318,7 +330,7 @@ int hmx_init_cluster(hmx_engine* e, const float* Y0, double obj_out[4]) {
     launch_y_normalize(e->Yacc.p, e->Y.p, e->K, e->K16, e->d, e->ldy, e->stream);  // :377
     const size_t GK = (size_t)e->G * e->K16;
     HIP_TRY(hipMemsetAsync(e->Ogrp.p, 0, GK * sizeof(double), e->stream));
-    HIP_TRY(hipMemsetAsync(e->objacc.p, 0, 4 * sizeof(double), e->stream));
+    HIP_TRY(hipMemsetAsync(e->objacc.p, 0, (2 * HMX_OBJ_SLOTS + 2) * sizeof(double), e->stream));
     {
         Timed t(e, F_ASSIGN_INIT);
         AssignArgs a = assign_args(e);
@@ -329,7 +341,7 @@ int hmx_init_cluster(hmx_engine* e, const float* Y0, double obj_out[4]) {
     {
         Timed t(e, F_BLOCK_TABLE);
         TableArgs ta = table_args(e);  // E = outer(R.sum(1), Pr_b) (:388) kept as T; cross-entropy term (:405-411)
-        ta.O_prev = e->Ogrp.p; ta.T_out = e->Tmass.p; ta.obj_cross = e->objacc.p + 2;
+        ta.O_prev = e->Ogrp.p; ta.T_out = e->Tmass.p; ta.obj_cross = e->objacc.p + 2 * HMX_OBJ_SLOTS;
         launch_block_table(ta, e->K16, e->stream);
     }
     e->clustered = true;
@@ -343,7 +355,7 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
     const size_t GK = (size_t)e->G * e->K16;
     HIP_TRY(hipMemsetAsync(e->Sold.p, 0, GK * e->nblk * sizeof(double), e->stream));
     HIP_TRY(hipMemsetAsync(e->Snew.p, 0, GK * e->nblk * sizeof(double), e->stream));
-    HIP_TRY(hipMemsetAsync(e->objacc.p, 0, 4 * sizeof(double), e->stream));
+    HIP_TRY(hipMemsetAsync(e->objacc.p, 0, (2 * HMX_OBJ_SLOTS + 2) * sizeof(double), e->stream));
 
     // ---- pass over the old R: centroid numerators (:443) and per-block removal sums (:491-492)
     int nsub, spw;
@@ -389,7 +401,7 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         ta.O_prev = e->Ohist.p + GK * (e->nblk - 1);
         ta.S_add = e->Snew.p + GK * (e->nblk - 1);
         ta.O_out = e->Ogrp.p; ta.T_out = e->Tmass.p;
-        if (flags & HMX_ROUND_OBJECTIVE) ta.obj_cross = e->objacc.p + 2;
+        if (flags & HMX_ROUND_OBJECTIVE) ta.obj_cross = e->objacc.p + 2 * HMX_OBJ_SLOTS;
         launch_block_table(ta, e->K16, e->stream);
     }
     return read_objective(e, obj_out);

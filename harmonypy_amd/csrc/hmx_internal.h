@@ -7,6 +7,7 @@
 
 #define HMX_RTZ_MTW 7 /* output tile block of k_rtz: 7 x 4 tiles of 16 x 16 = 112 accumulators */
 #define HMX_RTZ_NTW 4
+#define HMX_OBJ_SLOTS 64 /* objective partials are spread over this many fp64 slot pairs */
 
 struct AssignArgs {
     const float* Zcos;     // N x dp
@@ -18,11 +19,12 @@ struct AssignArgs {
     const int* cells;      // list positions -> internal cell id, -1 = padding
     const int* tile_grp;   // group of every tile
     double* S_out;         // G x K16: sum of the new R per (group, cluster)
-    double* obj;           // [0] += sum R*dist, [1] += sum sigma R log R
+    double* obj;           // HMX_OBJ_SLOTS x {sum R*dist, sum sigma R log R} partial sums
     const int* blk_start;  // device block_tile_start (nblk+1) or null => tile_begin/tile_end
     int blk;
     int tile_begin, tile_end;  // host-side range (or an upper bound of its length when blk_start)
     int K, Kp, K16, mt, dp, ldy;
+    int G, ldy_lds, tables_in_lds, tiles_per_wave, ablate;
 };
 
 struct RtzArgs {

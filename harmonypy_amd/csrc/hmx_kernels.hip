@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "hmx_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -269,6 +271,256 @@ __global__ __launch_bounds__(256) void k_assign(AssignArgs a) {
     if (lane == 0) {
         atomicAdd(&a.obj[0], km_acc);
         atomicAdd(&a.obj[1], ent_acc);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// k_assign_lds: the assignment kernel for shapes whose centroid table fits the LDS
+// (K <= 112, d <= 64: every BASELINE config except C5).  Same arithmetic as k_assign; the
+// structure is what makes it fast:
+//   * 512-thread workgroups; Y, sigma and the penalty tables rp / log rp are staged once per
+//     workgroup into LDS, A fragments come from ds_read_b128;
+//   * each wave owns a 16-cell tile at a time: it gathers the tile's Z_cos rows (16 B per lane,
+//     four lanes cover 64 contiguous bytes of a row) into a private LDS tile, so the k-loop is
+//     a short runtime loop without per-lane operand arrays -- ~100 VGPRs, 4-5 waves per SIMD,
+//     and one wave's gather hides under the other waves' MFMA / VALU work;
+//   * block sums: 16-lane DPP reduction -> fp64 ds_add -> one global fp64 atomic per table
+//     entry and workgroup; objective partials: one fp64 atomic per workgroup into 64 slots.
+// MT is the exact number of 16-cluster tiles (no guards inside the unrolled loops).
+// ------------------------------------------------------------------------------------------
+#define DPP_F(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xF, 0xF, true))
+__device__ __forceinline__ float row16_sum(float v) {
+    v += DPP_F(v, 0xB1);   // quad_perm [1,0,3,2]
+    v += DPP_F(v, 0x4E);   // quad_perm [2,3,0,1]
+    v += DPP_F(v, 0x141);  // row_half_mirror
+    v += DPP_F(v, 0x140);  // row_mirror
+    return v;
+}
+
+// exp(x) for x <= 0 as 2^(x log2 e): the product is split into a rounded head and an fma tail so
+// that the relative error stays ~1 ulp over the whole range of arguments (|x| up to ~100 would
+// otherwise lose 2^-24 * |x| log2 e).  v_exp_f32 is the hardware exp2.
+__device__ __forceinline__ float fast_exp(float x) {
+    const float L2E_HI = 1.44269502162933349609375f;        // float(log2 e)
+    const float L2E_LO = 1.925963033500011e-08f;             // log2 e - L2E_HI
+    x = fmaxf(x, -120.f);                                    // exp underflows to 0 long before; keeps -inf (padded clusters) finite
+    const float th = x * L2E_HI;
+    const float tl = fmaf(x, L2E_HI, -th) + x * L2E_LO;      // exact product tail + low part
+    const float p = __builtin_amdgcn_exp2f(th);
+    return fmaf(p, tl * 0.693147182464599609375f, p);        // 2^(th+tl) ~= 2^th (1 + tl ln 2)
+}
+
+#define ASSIGN_WAVES 8
+#ifndef HMX_ABL
+#define HMX_ABL 0   /* timing experiments only: 1 no block sums, 2 no R store, 4 cheap math, 8 no GEMM, 16 no tile loop, 32 no gather */
+#endif
+
+template <int MT, bool PENALTY>
+__global__ __launch_bounds__(64 * ASSIGN_WAVES, 3) void k_assign_lds(AssignArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int LDY = a.ldy_lds;  // row stride of Ys and of the Z tiles (floats, multiple of 4)
+    const int K16 = 16 * MT;
+    float* Ys = reinterpret_cast<float*>(smem);                         // K16 x LDY
+    float* sig = Ys + (size_t)K16 * LDY;                                // K16 sigma
+    float* nis = sig + K16;                                             // K16 -1/sigma (0 for pads)
+    float* rpT = nis + K16;                                             // G x K16
+    float* lrpT = rpT + (PENALTY ? (size_t)a.G * K16 : 0);              // G x K16
+    double* Sd = reinterpret_cast<double*>(lrpT + (PENALTY ? (size_t)a.G * K16 : 0));  // G x K16
+    float* Zt_all = reinterpret_cast<float*>(Sd + (size_t)a.G * K16);   // waves x 16 x LDY
+    double* objw = reinterpret_cast<double*>(Zt_all + (size_t)ASSIGN_WAVES * 16 * LDY);  // waves x 2
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int c16 = lane & 15, q = lane >> 4;
+    const int wave = blockIdx.x * ASSIGN_WAVES + wv;
+    const int nwaves = gridDim.x * ASSIGN_WAVES;
+    const int c4n = a.dp >> 2;
+    const int kb_full = a.dp >> 4;
+    const int tail = c4n - 4 * kb_full;
+    float* Zt = Zt_all + (size_t)wv * 16 * LDY;
+
+    const int tile_begin = a.blk_start ? a.blk_start[a.blk] : a.tile_begin;
+    const int tile_end = a.blk_start ? a.blk_start[a.blk + 1] : a.tile_end;
+    const int ntiles = tile_end - tile_begin;
+    const int per = (ntiles + nwaves - 1) / nwaves;
+    const int t0 = min(tile_begin + wave * per, tile_end);
+    const int t1 = min(t0 + per, tile_end);
+
+    // first tile: cell ids and Z_cos rows are requested before the table fill so that their
+    // latency overlaps it (a wave usually owns one or two tiles of a block)
+    int cell = (t0 < t1) ? a.cells[(size_t)t0 * 16 + c16] : -1;
+    f32x4 zrow[4];   // d <= 64: at most 4 pieces of 16 B per lane
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c4 = q + 4 * j;
+        zrow[j] = (cell >= 0 && c4 < c4n && !(HMX_ABL & 32)) ? ld4(a.Zcos + (size_t)cell * a.dp + 4 * c4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ---- stage the tables -------------------------------------------------------------------
+    for (int i = tid; i < K16 * c4n; i += 64 * ASSIGN_WAVES) {
+        const int row = i / c4n, c4 = i - row * c4n;
+        st4(Ys + (size_t)row * LDY + 4 * c4, ld4(a.Y + (size_t)row * a.ldy + 4 * c4));
+    }
+    for (int i = tid; i < K16; i += 64 * ASSIGN_WAVES) {
+        const float sgm = (i < a.K) ? a.sigma[i] : 0.f;
+        sig[i] = sgm;
+        nis[i] = (i < a.K) ? -1.0f / sgm : -INFINITY;   // pads: exp(2 * -inf) = 0
+    }
+    {
+        const int gk = a.G * K16;
+        if (PENALTY && a.tables_in_lds)
+            for (int i = tid; i < gk; i += 64 * ASSIGN_WAVES) {
+                rpT[i] = a.rp[i];
+                lrpT[i] = a.lrp[i];
+            }
+        if (a.tables_in_lds)
+            for (int i = tid; i < gk; i += 64 * ASSIGN_WAVES) Sd[i] = 0.0;
+    }
+    __syncthreads();
+
+    double km_acc = 0.0, ent_acc = 0.0;
+    for (int t = t0; t < ((HMX_ABL & 16) ? t0 : t1); ++t) {
+        const int grp = __builtin_amdgcn_readfirstlane(a.tile_grp[t]);
+        const bool live = cell >= 0;
+        // ---- the tile's Z_cos rows go to the wave's LDS tile --------------------------------
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c4 = q + 4 * j;
+            if (c4 < c4n) st4(Zt + (size_t)c16 * LDY + 4 * c4, zrow[j]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // request the next tile's rows now; they land while this tile computes
+        const int cell_cur = cell;
+        if (t + 1 < t1) {
+            cell = a.cells[(size_t)(t + 1) * 16 + c16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c4 = q + 4 * j;
+                zrow[j] = (cell >= 0 && c4 < c4n && !(HMX_ABL & 32)) ? ld4(a.Zcos + (size_t)cell * a.dp + 4 * c4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+
+        // ---- distance GEMM: C[cluster][cell] = Y . Zcos^T over the PC dimension ------------
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < ((HMX_ABL & 8) ? 0 : kb_full); ++kb) {
+            const f32x4 zb = ld4(Zt + (size_t)c16 * LDY + 16 * kb + 4 * q);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f32x4 ya = ld4(Ys + (size_t)(16 * mt + c16) * LDY + 16 * kb + 4 * q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[mt] = MFMA16(ya[i], zb[i], acc[mt]);
+            }
+        }
+        for (int s = 0; s < ((HMX_ABL & 8) ? 0 : tail); ++s) {
+            const int col = 16 * kb_full + 4 * s + q;
+            const float zb = Zt[(size_t)c16 * LDY + col];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = MFMA16(Ys[(size_t)(16 * mt + c16) * LDY + col], zb, acc[mt]);
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- softmax over clusters (a lane holds clusters 16mt + 4q + r of cell c16) --------
+        // Divisions of the reference (:383, :385, :468, :503) are evaluated as products with
+        // correctly rounded reciprocals (<= 1 ulp apart; tests/test_parity_gpu.py pins the effect).
+        float e[MT][4];
+        float e1 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 ni = ld4(nis + 16 * mt + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dist = 2.f * (1.f - acc[mt][r]);   // :380 / :447
+                const float arg = dist * ni[r];                // :383 / :466   -dist / sigma
+                acc[mt][r] = arg;
+#if HMX_ABL & 4
+                e[mt][r] = arg * 0.001f + 1.0f;
+#else
+                e[mt][r] = fast_exp(arg);                      // :384 / :467
+#endif
+                e1 += e[mt][r];
+            }
+        }
+        e1 = wave_sum_q(e1);                                   // column sum of :385 / :468
+        const float inv_e1 = 1.0f / e1;
+        float u1 = 1.f;
+        if (PENALTY) {
+            const float* rp = a.tables_in_lds ? (rpT + (size_t)grp * K16) : (a.rp + (size_t)grp * K16);
+            float us = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f32x4 pw = ld4(rp + 16 * mt + 4 * q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e[mt][r] = (e[mt][r] * inv_e1) * pw[r];    // :468 then :500
+                    us += e[mt][r];
+                }
+            }
+            us = wave_sum_q(us);
+            u1 = fmaxf(us, 1e-8f);                             // :501-502
+        }
+        const float log_e1 = logf(e1);
+        const float log_u1 = PENALTY ? logf(u1) : 0.f;
+        const float inv_den = PENALTY ? 1.0f / u1 : inv_e1;
+        const float log_den = log_e1 + log_u1;
+        float km = 0.f, ent = 0.f;
+        float* rrow = a.R + (size_t)(live ? cell_cur : 0) * a.Kp;
+        const float* lrp = PENALTY ? (a.tables_in_lds ? (lrpT + (size_t)grp * K16) : (a.lrp + (size_t)grp * K16)) : nullptr;
+        double* sdst = a.tables_in_lds ? (Sd + (size_t)grp * K16) : (a.S_out + (size_t)grp * K16);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 sg = ld4(sig + 16 * mt + 4 * q);
+            f32x4 lp = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (PENALTY) lp = ld4(lrp + 16 * mt + 4 * q);
+            f32x4 rv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float Rv = e[mt][r] * inv_den;                 // :503 / :385
+                Rv = live ? Rv : 0.f;
+                rv[r] = Rv;
+                const float arg = acc[mt][r];
+                const float logR = arg - log_den + lp[r];
+                const bool pos = Rv > 0.f;
+                km += pos ? Rv * (-arg * sg[r]) : 0.f;         // R * dist         (:399)
+                ent += pos ? sg[r] * (Rv * logR) : 0.f;        // sigma R log R    (:402)
+            }
+            const int col = 16 * mt + 4 * q;
+            if (live && col < a.Kp && !(HMX_ABL & 2)) st4(rrow + col, rv);
+            // block sums of the new R (:506-507): 16-cell DPP reduction, one fp64 add per (group, cluster)
+            if (HMX_ABL & 1) continue;
+            f32x4 ss;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ss[r] = row16_sum(rv[r]);
+            if (c16 == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(sdst + col + r, (double)ss[r]);
+            }
+        }
+        km_acc += (double)km;
+        ent_acc += (double)ent;
+    }
+
+    km_acc = wave_sum_all(km_acc);
+    ent_acc = wave_sum_all(ent_acc);
+    if (lane == 0) {
+        objw[2 * wv] = km_acc;
+        objw[2 * wv + 1] = ent_acc;
+    }
+    __syncthreads();
+    if (tid < 2) {
+        double v = 0.0;
+        for (int w = 0; w < ASSIGN_WAVES; ++w) v += objw[2 * w + tid];
+        if (v != 0.0) atomicAdd(&a.obj[2 * (blockIdx.x & (HMX_OBJ_SLOTS - 1)) + tid], v);
+    }
+    if (a.tables_in_lds) {
+        const int gk = a.G * K16;
+        for (int i = tid; i < gk; i += 64 * ASSIGN_WAVES) {
+            const double v = Sd[i];
+            if (v != 0.0) atomicAdd(&a.S_out[i], v);
+        }
     }
 }
 
@@ -883,9 +1135,41 @@ int assign_grid(int ntiles, int nt_per_step, int max_wgs) {
     return wgs;
 }
 
-int launch_assign(const AssignArgs& a, bool penalty, int max_wgs, hipStream_t s) {
+static int lds_ldy(int dp) { return ((dp >> 2) & 1) ? dp : dp + 4; }  // (LDY/4) odd: spreads ds_read_b128 rows over banks
+
+template <int MT>
+static void launch_assign_lds(const AssignArgs& a, bool penalty, int wgs, size_t sm, hipStream_t s) {
+    if (penalty) hipLaunchKernelGGL((k_assign_lds<MT, true>), dim3(wgs), dim3(64 * ASSIGN_WAVES), sm, s, a);
+    else hipLaunchKernelGGL((k_assign_lds<MT, false>), dim3(wgs), dim3(64 * ASSIGN_WAVES), sm, s, a);
+}
+
+int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t s) {
+    AssignArgs a = a_in;
     const int ntiles = a.tile_end - a.tile_begin;
     if (ntiles <= 0) return 0;
+    // LDS-resident path: Y, sigma, wave tiles (+ rp, lrp, fp64 block sums when they fit)
+    const int LDY = lds_ldy(a.dp);
+    const size_t base_bytes = ((size_t)a.K16 * LDY + 2 * a.K16 + (size_t)ASSIGN_WAVES * 16 * LDY) * 4 + ASSIGN_WAVES * 16;
+    const size_t tab_bytes = (size_t)a.G * a.K16 * (penalty ? 16 : 8);
+    if (a.mt <= 7 && a.dp <= 64 && base_bytes <= 100 * 1024) {
+        a.ldy_lds = LDY;
+        a.tables_in_lds = (base_bytes + tab_bytes <= 150 * 1024) ? 1 : 0;
+        const size_t sm = base_bytes + tab_bytes;   // layout keeps the table slots even when unused
+        if (sm <= 160 * 1024) {
+            int wgs = cdiv(ntiles, ASSIGN_WAVES * a.tiles_per_wave);
+            wgs = std::max(1, std::min(wgs, max_wgs));
+            switch (a.mt) {
+                case 1: launch_assign_lds<1>(a, penalty, wgs, sm, s); break;
+                case 2: launch_assign_lds<2>(a, penalty, wgs, sm, s); break;
+                case 3: launch_assign_lds<3>(a, penalty, wgs, sm, s); break;
+                case 4: launch_assign_lds<4>(a, penalty, wgs, sm, s); break;
+                case 5: launch_assign_lds<5>(a, penalty, wgs, sm, s); break;
+                case 6: launch_assign_lds<6>(a, penalty, wgs, sm, s); break;
+                default: launch_assign_lds<7>(a, penalty, wgs, sm, s); break;
+            }
+            return 0;
+        }
+    }
     if (a.mt <= 7) {
         constexpr int NT = 2;
         const int wgs = assign_grid(ntiles, NT, max_wgs);
