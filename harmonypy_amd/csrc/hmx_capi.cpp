@@ -67,7 +67,7 @@ struct hmx_engine {
     int d = 0, dp = 0, K = 0, Kp = 0, K16 = 0, mt = 0, ntd = 0, ldy = 0, B = 0, G = 0, V = 0, nblk = 0;
     int max_wgs = 1024;
     int ablate = 0;          // HMX_ABLATE: timing experiments only (results become wrong)
-    int tiles_per_wave = 2;  // k_assign_lds grid sizing (HMX_TILES_PER_WAVE)
+    int tiles_per_wave = 1;  // k_assign_lds grid sizing (HMX_TILES_PER_WAVE)
     hipStream_t stream = nullptr;
     bool uploaded = false, clustered = false, timing = false;
 
@@ -75,7 +75,7 @@ struct hmx_engine {
     DevBuf<int> group_cols, s_cells, s_tile_grp, r_cells, r_tile_grp, r_blk_start, task_t0, task_t1, task_grp;
     DevBuf<int> gstart, chunk_tab, run_count, run_start;
     uint64_t seeded_rounds = 0;
-    DevBuf<double> Ogrp, Tmass, Sold, Snew, Ohist, objacc, Sr, Oxr, scratch;
+    DevBuf<double> Ogrp, Tmass, Sold, Snew, Ohist, objacc, Sr, Oxr, scratch, Yacc64;
     double* obj_host = nullptr;  // pinned
     int n_s_tiles = 0, ntasks = 0;
     std::vector<int> h_task_grp;
@@ -201,7 +201,7 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
         const size_t N = (size_t)e->N, GK = (size_t)e->G * e->K16;
         if ((rc = e->Zorig.reserve(N * e->dp)) || (rc = e->Zcos.reserve(N * e->dp)) || (rc = e->Zcorr.reserve(N * e->dp)) ||
             (rc = e->R.reserve(N * e->Kp)) || (rc = e->Y.reserve((size_t)e->K16 * e->ldy)) ||
-            (rc = e->Yacc.reserve((size_t)e->K16 * e->ldy)) || (rc = e->sigma.reserve(e->K16)) ||
+            (rc = e->Yacc.reserve((size_t)e->K16 * e->ldy)) || (rc = e->Yacc64.reserve((size_t)e->K16 * e->ldy)) || (rc = e->sigma.reserve(e->K16)) ||
             (rc = e->theta.reserve(e->B)) || (rc = e->Pr_b.reserve(e->B)) || (rc = e->lamb.reserve(e->B + 1)) ||
             (rc = e->rp.reserve(GK)) || (rc = e->lrp.reserve(GK)) || (rc = e->group_cols.reserve((size_t)e->G * e->V)) ||
             (rc = e->Ogrp.reserve(GK)) || (rc = e->Tmass.reserve(e->K16)) || (rc = e->Sold.reserve(GK * e->nblk)) ||
@@ -241,7 +241,7 @@ void hmx_destroy(hmx_engine* e) {
     e->r_cells.release(); e->r_tile_grp.release(); e->r_blk_start.release(); e->task_t0.release(); e->task_t1.release();
     e->task_grp.release(); e->gstart.release(); e->chunk_tab.release(); e->run_count.release(); e->run_start.release();
     e->Ogrp.release(); e->Tmass.release(); e->Sold.release(); e->Snew.release(); e->Ohist.release();
-    e->objacc.release(); e->Sr.release(); e->Oxr.release(); e->scratch.release();
+    e->objacc.release(); e->Yacc64.release(); e->Sr.release(); e->Oxr.release(); e->scratch.release();
     if (e->obj_host) (void)hipHostFree(e->obj_host);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -372,8 +372,9 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
     }
     if (flags & HMX_ROUND_CENTROIDS) {
         Timed t(e, F_RTZ_REDUCE);
-        launch_rtz_reduce(e->slab.p, wgs * 4, e->mt, e->ntd, e->K16, e->ldy, e->Yacc.p, nullptr, nullptr, e->G, e->stream);
-        launch_y_normalize(e->Yacc.p, e->Y.p, e->K, e->K16, e->d, e->ldy, e->stream);  // :444
+        HIP_TRY(hipMemsetAsync(e->Yacc64.p, 0, (size_t)e->K16 * e->ldy * sizeof(double), e->stream));
+        launch_rtz_reduce(e->slab.p, wgs * 4, e->mt, e->ntd, e->K16, e->ldy, e->Yacc64.p, nullptr, e->stream);
+        launch_y_normalize_d(e->Yacc64.p, e->Y.p, e->K, e->K16, e->d, e->ldy, e->stream);  // :444
     }
     if (flags & HMX_ROUND_UPDATE_R) {
         for (int b = 0; b < e->nblk; ++b) {
@@ -493,7 +494,7 @@ int hmx_moe_correct_ridge(hmx_engine* e) {
         r.S_out = e->Oxr.p; r.slab = e->slab.p; r.n_tiles = e->n_s_tiles; r.ntasks = e->ntasks;
         r.K = e->K; r.Kp = e->Kp; r.K16 = e->K16; r.G = e->G; r.mt = e->mt; r.dp = e->dp; r.ntd = e->ntd;
         launch_rtz(r, (e->ntasks + 3) / 4, e->stream);
-        launch_rtz_reduce(e->slab.p, e->ntasks, e->mt, e->ntd, e->K16, e->ldy, nullptr, e->Sr.p, e->task_grp.p, e->G, e->stream);
+        launch_rtz_reduce(e->slab.p, e->ntasks, e->mt, e->ntd, e->K16, e->ldy, e->Sr.p, e->task_grp.p, e->stream);
     }
     {
         Timed t(e, F_RIDGE_SOLVE);

@@ -104,8 +104,9 @@ void launch_y_normalize(const float* src, float* dst, int K, int K16, int d, int
 int launch_assign(const AssignArgs& a, bool penalty, int max_wgs, hipStream_t s);
 void rtz_geometry(int mt, int ntd, int* nsub, int* slab_per_wave);
 void launch_rtz(const RtzArgs& a, int wgs, hipStream_t s);
-void launch_rtz_reduce(const float* slab, int nwaves, int mt, int ntd, int K16, int ld, float* out_f, double* out_d,
-                       const int* task_grp, int G, hipStream_t s);
+void launch_y_normalize_d(const double* src, float* dst, int K, int K16, int d, int ldy, hipStream_t s);
+void launch_rtz_reduce(const float* slab, int nwaves, int mt, int ntd, int K16, int ld, double* out,
+                       const int* task_grp, hipStream_t s);
 void launch_block_table(const TableArgs& a, int K16, hipStream_t s);
 void launch_group_sums(const float* R, int Kp, int K, int K16, const int* cells, const int* tile_grp, int n_tiles,
                        double* Ogrp, hipStream_t s);

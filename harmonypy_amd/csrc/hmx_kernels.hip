@@ -67,16 +67,20 @@ __global__ __launch_bounds__(256) void k_normalize_rows(const float* __restrict_
 // Centroid rows -> unit length (harmony.py:377, 444).  One 64-lane wave per cluster.
 // src: K16 x ldy raw sums (float), dst: K16 x ldy (rows >= K and cols >= d stay zero)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_y_normalize(const float* __restrict__ src, float* __restrict__ dst, int K,
+template <typename T>
+__global__ __launch_bounds__(64) void k_y_normalize(const T* __restrict__ src, float* __restrict__ dst, int K,
                                                     int d, int ldy) {
     const int k = blockIdx.x;
     const int lane = threadIdx.x;
     float ss = 0.f;
     if (k < K)
-        for (int j = lane; j < d; j += 64) ss += src[(size_t)k * ldy + j] * src[(size_t)k * ldy + j];
+        for (int j = lane; j < d; j += 64) {
+            const float v = (float)src[(size_t)k * ldy + j];   // fp64 sums are rounded to fp32 first (:443)
+            ss += v * v;
+        }
     for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
     const float nrm = sqrtf(ss);
-    for (int j = lane; j < ldy; j += 64) dst[(size_t)k * ldy + j] = (k < K && j < d) ? src[(size_t)k * ldy + j] / nrm : 0.f;
+    for (int j = lane; j < ldy; j += 64) dst[(size_t)k * ldy + j] = (k < K && j < d) ? (float)src[(size_t)k * ldy + j] / nrm : 0.f;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -317,13 +321,13 @@ __device__ __forceinline__ float fast_exp(float x) {
 #endif
 
 template <int MT, bool PENALTY>
-__global__ __launch_bounds__(64 * ASSIGN_WAVES, 3) void k_assign_lds(AssignArgs a) {
+__global__ __launch_bounds__(64 * ASSIGN_WAVES, 4) void k_assign_lds(AssignArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int LDY = a.ldy_lds;  // row stride of Ys and of the Z tiles (floats, multiple of 4)
-    const int K16 = 16 * MT;
+    constexpr int K16 = 16 * MT;
     float* Ys = reinterpret_cast<float*>(smem);                         // K16 x LDY
     float* sig = Ys + (size_t)K16 * LDY;                                // K16 sigma
-    float* nis = sig + K16;                                             // K16 -1/sigma (0 for pads)
+    float* nis = sig + K16;                                             // K16 -1/sigma (-inf for pads)
     float* rpT = nis + K16;                                             // G x K16
     float* lrpT = rpT + (PENALTY ? (size_t)a.G * K16 : 0);              // G x K16
     double* Sd = reinterpret_cast<double*>(lrpT + (PENALTY ? (size_t)a.G * K16 : 0));  // G x K16
@@ -334,29 +338,27 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES, 3) void k_assign_lds(AssignArgs 
     const int lane = tid & 63;
     const int wv = tid >> 6;
     const int c16 = lane & 15, q = lane >> 4;
-    const int wave = blockIdx.x * ASSIGN_WAVES + wv;
-    const int nwaves = gridDim.x * ASSIGN_WAVES;
     const int c4n = a.dp >> 2;
     const int kb_full = a.dp >> 4;
     const int tail = c4n - 4 * kb_full;
     float* Zt = Zt_all + (size_t)wv * 16 * LDY;
 
+    // one tile per wave: the grid covers (an upper bound of) the block's tiles
     const int tile_begin = a.blk_start ? a.blk_start[a.blk] : a.tile_begin;
     const int tile_end = a.blk_start ? a.blk_start[a.blk + 1] : a.tile_end;
-    const int ntiles = tile_end - tile_begin;
-    const int per = (ntiles + nwaves - 1) / nwaves;
-    const int t0 = min(tile_begin + wave * per, tile_end);
-    const int t1 = min(t0 + per, tile_end);
+    const int t = tile_begin + blockIdx.x * ASSIGN_WAVES + wv;
+    const bool has_tile = t < tile_end;                                 // wave-uniform
 
-    // first tile: cell ids and Z_cos rows are requested before the table fill so that their
-    // latency overlaps it (a wave usually owns one or two tiles of a block)
-    int cell = (t0 < t1) ? a.cells[(size_t)t0 * 16 + c16] : -1;
+    // the tile's cell ids and Z_cos rows are requested first: their latency overlaps the table fill
+    const int cell = has_tile ? a.cells[(size_t)t * 16 + c16] : -1;
+    const bool live = cell >= 0;
     f32x4 zrow[4];   // d <= 64: at most 4 pieces of 16 B per lane
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int c4 = q + 4 * j;
-        zrow[j] = (cell >= 0 && c4 < c4n && !(HMX_ABL & 32)) ? ld4(a.Zcos + (size_t)cell * a.dp + 4 * c4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int c4 = min(q + 4 * j, c4n - 1);
+        zrow[j] = ld4(a.Zcos + (size_t)(live ? cell : 0) * a.dp + 4 * c4);
     }
+    const int grp = has_tile ? __builtin_amdgcn_readfirstlane(a.tile_grp[t]) : 0;
 
     // ---- stage the tables -------------------------------------------------------------------
     for (int i = tid; i < K16 * c4n; i += 64 * ASSIGN_WAVES) {
@@ -378,30 +380,16 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES, 3) void k_assign_lds(AssignArgs 
         if (a.tables_in_lds)
             for (int i = tid; i < gk; i += 64 * ASSIGN_WAVES) Sd[i] = 0.0;
     }
+    // the wave's Z tile (dead lanes hold zeros)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c4 = q + 4 * j;
+        if (c4 < c4n) st4(Zt + (size_t)c16 * LDY + 4 * c4, live ? zrow[j] : (f32x4){0.f, 0.f, 0.f, 0.f});
+    }
     __syncthreads();
 
-    double km_acc = 0.0, ent_acc = 0.0;
-    for (int t = t0; t < ((HMX_ABL & 16) ? t0 : t1); ++t) {
-        const int grp = __builtin_amdgcn_readfirstlane(a.tile_grp[t]);
-        const bool live = cell >= 0;
-        // ---- the tile's Z_cos rows go to the wave's LDS tile --------------------------------
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c4 = q + 4 * j;
-            if (c4 < c4n) st4(Zt + (size_t)c16 * LDY + 4 * c4, zrow[j]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        // request the next tile's rows now; they land while this tile computes
-        const int cell_cur = cell;
-        if (t + 1 < t1) {
-            cell = a.cells[(size_t)(t + 1) * 16 + c16];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c4 = q + 4 * j;
-                zrow[j] = (cell >= 0 && c4 < c4n && !(HMX_ABL & 32)) ? ld4(a.Zcos + (size_t)cell * a.dp + 4 * c4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-        }
-
+    double km_d = 0.0, ent_d = 0.0;
+    if (has_tile && !(HMX_ABL & 16)) {
         // ---- distance GEMM: C[cluster][cell] = Y . Zcos^T over the PC dimension ------------
         f32x4 acc[MT];
 #pragma unroll
@@ -421,12 +409,12 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES, 3) void k_assign_lds(AssignArgs 
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = MFMA16(Ys[(size_t)(16 * mt + c16) * LDY + col], zb, acc[mt]);
         }
-        __builtin_amdgcn_wave_barrier();
 
         // ---- softmax over clusters (a lane holds clusters 16mt + 4q + r of cell c16) --------
         // Divisions of the reference (:383, :385, :468, :503) are evaluated as products with
         // correctly rounded reciprocals (<= 1 ulp apart; tests/test_parity_gpu.py pins the effect).
-        float e[MT][4];
+        // Only the exponent arguments stay in registers; exp() is re-evaluated per pass (5 VALU
+        // ops) instead of holding a second K-sized array per lane: 4 waves per SIMD.
         float e1 = 0.f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -436,52 +424,51 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES, 3) void k_assign_lds(AssignArgs 
                 const float dist = 2.f * (1.f - acc[mt][r]);   // :380 / :447
                 const float arg = dist * ni[r];                // :383 / :466   -dist / sigma
                 acc[mt][r] = arg;
-#if HMX_ABL & 4
-                e[mt][r] = arg * 0.001f + 1.0f;
-#else
-                e[mt][r] = fast_exp(arg);                      // :384 / :467
-#endif
-                e1 += e[mt][r];
+                e1 += (HMX_ABL & 4) ? arg * 0.001f + 1.0f : fast_exp(arg);   // :384 / :467
             }
         }
         e1 = wave_sum_q(e1);                                   // column sum of :385 / :468
         const float inv_e1 = 1.0f / e1;
+        const float* rp = nullptr;
         float u1 = 1.f;
         if (PENALTY) {
-            const float* rp = a.tables_in_lds ? (rpT + (size_t)grp * K16) : (a.rp + (size_t)grp * K16);
+            rp = a.tables_in_lds ? (rpT + (size_t)grp * K16) : (a.rp + (size_t)grp * K16);
             float us = 0.f;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const f32x4 pw = ld4(rp + 16 * mt + 4 * q);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    e[mt][r] = (e[mt][r] * inv_e1) * pw[r];    // :468 then :500
-                    us += e[mt][r];
+                    const float ex = (HMX_ABL & 4) ? acc[mt][r] * 0.001f + 1.0f : fast_exp(acc[mt][r]);
+                    us += (ex * inv_e1) * pw[r];               // :468 then :500
                 }
             }
             us = wave_sum_q(us);
             u1 = fmaxf(us, 1e-8f);                             // :501-502
         }
-        const float log_e1 = logf(e1);
-        const float log_u1 = PENALTY ? logf(u1) : 0.f;
-        const float inv_den = PENALTY ? 1.0f / u1 : inv_e1;
-        const float log_den = log_e1 + log_u1;
+        const float log_den = logf(e1) + (PENALTY ? logf(u1) : 0.f);
+        const float inv_u1 = PENALTY ? 1.0f / u1 : 1.0f;
         float km = 0.f, ent = 0.f;
-        float* rrow = a.R + (size_t)(live ? cell_cur : 0) * a.Kp;
+        float* rrow = a.R + (size_t)(live ? cell : 0) * a.Kp;
         const float* lrp = PENALTY ? (a.tables_in_lds ? (lrpT + (size_t)grp * K16) : (a.lrp + (size_t)grp * K16)) : nullptr;
         double* sdst = a.tables_in_lds ? (Sd + (size_t)grp * K16) : (a.S_out + (size_t)grp * K16);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const f32x4 sg = ld4(sig + 16 * mt + 4 * q);
             f32x4 lp = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (PENALTY) lp = ld4(lrp + 16 * mt + 4 * q);
+            f32x4 pw = (f32x4){1.f, 1.f, 1.f, 1.f};
+            if (PENALTY) {
+                lp = ld4(lrp + 16 * mt + 4 * q);
+                pw = ld4(rp + 16 * mt + 4 * q);
+            }
             f32x4 rv;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float Rv = e[mt][r] * inv_den;                 // :503 / :385
+                const float arg = acc[mt][r];
+                const float ex = (HMX_ABL & 4) ? arg * 0.001f + 1.0f : fast_exp(arg);
+                float Rv = PENALTY ? ((ex * inv_e1) * pw[r]) * inv_u1 : ex * inv_e1;   // :503 / :385
                 Rv = live ? Rv : 0.f;
                 rv[r] = Rv;
-                const float arg = acc[mt][r];
                 const float logR = arg - log_den + lp[r];
                 const bool pos = Rv > 0.f;
                 km += pos ? Rv * (-arg * sg[r]) : 0.f;         // R * dist         (:399)
@@ -490,24 +477,22 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES, 3) void k_assign_lds(AssignArgs 
             const int col = 16 * mt + 4 * q;
             if (live && col < a.Kp && !(HMX_ABL & 2)) st4(rrow + col, rv);
             // block sums of the new R (:506-507): 16-cell DPP reduction, one fp64 add per (group, cluster)
-            if (HMX_ABL & 1) continue;
-            f32x4 ss;
+            if (!(HMX_ABL & 1)) {
+                f32x4 ss;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ss[r] = row16_sum(rv[r]);
-            if (c16 == 0) {
+                for (int r = 0; r < 4; ++r) ss[r] = row16_sum(rv[r]);
+                if (c16 == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(sdst + col + r, (double)ss[r]);
+                    for (int r = 0; r < 4; ++r) atomicAdd(sdst + col + r, (double)ss[r]);
+                }
             }
         }
-        km_acc += (double)km;
-        ent_acc += (double)ent;
+        km_d = wave_sum_all((double)km);
+        ent_d = wave_sum_all((double)ent);
     }
-
-    km_acc = wave_sum_all(km_acc);
-    ent_acc = wave_sum_all(ent_acc);
     if (lane == 0) {
-        objw[2 * wv] = km_acc;
-        objw[2 * wv + 1] = ent_acc;
+        objw[2 * wv] = km_d;
+        objw[2 * wv + 1] = ent_d;
     }
     __syncthreads();
     if (tid < 2) {
@@ -624,14 +609,15 @@ __global__ __launch_bounds__(256, 2) void k_rtz(RtzArgs a) {
     (void)task_grp;
 }
 
-// Sum the per-wave slabs of k_rtz in fp64.  One thread per slab element.
-//   mode 0: out_f[k*ld + j]   = sum over all waves            (centroid numerator)
-//   mode 1: out_d[(g*K16 + k)*ld + j] += sum over the waves (= tasks) of group g (ridge)
+// Sum the per-wave slabs of k_rtz in fp64.  blockIdx.x covers the slab elements, blockIdx.y a
+// segment of the slabs (waves / tasks); partial sums meet in fp64 atomics, whose order does not
+// change an fp32-rounded result.  `out` must be zeroed by the caller.
+//   task_grp == null: out[k*ld + j]              += sum over the segment's waves  (centroid numerator)
+//   task_grp != null: out[(g*K16 + k)*ld + j]    += sum over the segment's tasks of group g (ridge)
 template <int MTW, int NTW>
 __global__ __launch_bounds__(256) void k_rtz_reduce(const float* __restrict__ slab, int nwaves, int nsub, int ntd,
-                                                    int K16, int ld, float* __restrict__ out_f,
-                                                    double* __restrict__ out_d, const int* __restrict__ task_grp,
-                                                    int G) {
+                                                    int K16, int ld, double* __restrict__ out,
+                                                    const int* __restrict__ task_grp, int seg_len) {
     const int per_sub = MTW * NTW * 256;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= nsub * per_sub) return;
@@ -642,26 +628,19 @@ __global__ __launch_bounds__(256) void k_rtz_reduce(const float* __restrict__ sl
     const int k = 16 * ((sub / nsub_n) * MTW + mt) + 4 * (lane >> 4) + r;
     const int j = 16 * ((sub % nsub_n) * NTW + nt) + (lane & 15);
     if (k >= K16 || j >= ld) return;
-    if (task_grp == nullptr) {
-        double s = 0.0;
-        for (int w = 0; w < nwaves; ++w) s += (double)slab[((size_t)w * nsub + sub) * per_sub + e];
-        out_f[(size_t)k * ld + j] = (float)s;
-    } else {
-        // tasks are sorted by group: run-length accumulate
-        int g = -1;
-        double s = 0.0;
-        for (int w = 0; w < nwaves; ++w) {
-            const int gw = task_grp[w];
-            if (gw != g) {
-                if (g >= 0) out_d[((size_t)g * K16 + k) * ld + j] = s;
-                g = gw;
-                s = 0.0;
-            }
-            s += (double)slab[((size_t)w * nsub + sub) * per_sub + e];
+    const int w0 = blockIdx.y * seg_len, w1 = min(w0 + seg_len, nwaves);
+    int g = -1;
+    double acc = 0.0;
+    for (int w = w0; w < w1; ++w) {
+        const int gw = task_grp ? task_grp[w] : 0;
+        if (gw != g) {
+            if (g >= 0 && acc != 0.0) atomicAdd(&out[((size_t)g * K16 + k) * ld + j], acc);
+            g = gw;
+            acc = 0.0;
         }
-        if (g >= 0) out_d[((size_t)g * K16 + k) * ld + j] = s;
+        acc += (double)slab[((size_t)w * nsub + sub) * per_sub + e];
     }
-    (void)G;
+    if (g >= 0 && acc != 0.0) atomicAdd(&out[((size_t)g * K16 + k) * ld + j], acc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1002,7 +981,8 @@ __global__ __launch_bounds__(256) void k_ridge_apply(ApplyArgs a) {
 // engine's lists -- cells of a block regrouped by batch group, every (block, group) run padded
 // to 16 -- without atomics whose order could change the result:
 //   count   : one wave per chunk of positions, per-chunk histogram over key = block*G + group
-//   offsets : exclusive scan over chunks per key, run/tile starts, block_tile_start, tile groups
+//   scan    : exclusive scan over chunks per key (one workgroup per key)
+//   runs    : run/tile starts, block_tile_start, padding, tile groups
 //   scatter : every position writes its cell at run_start + (#earlier positions with its key)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t mix32(uint32_t h) {
@@ -1078,21 +1058,36 @@ __global__ __launch_bounds__(64) void k_order_pass(OrderArgs a) {
     }
 }
 
-// One workgroup: per-key exclusive scan over chunks (in place), run/tile tables, block starts.
-__global__ __launch_bounds__(256) void k_order_offsets(OrderArgs a, int nchunks) {
+// One workgroup per key: exclusive scan of the per-chunk counts (in place) and the run length.
+__global__ __launch_bounds__(256) void k_order_scan(OrderArgs a, int nchunks) {
+    __shared__ int part[256];
+    const int nkeys = a.nblk * a.G;
+    const int key = blockIdx.x, tid = threadIdx.x;
+    const int per = (nchunks + 255) / 256;
+    const int c0 = min(tid * per, nchunks), c1 = min(c0 + per, nchunks);
+    int sum = 0;
+    for (int c = c0; c < c1; ++c) sum += a.chunk_tab[(size_t)c * nkeys + key];
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {   // inclusive Hillis-Steele scan of the 256 partial sums
+        const int v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - sum;                   // exclusive prefix of this thread's chunk range
+    for (int c = c0; c < c1; ++c) {
+        const int v = a.chunk_tab[(size_t)c * nkeys + key];
+        a.chunk_tab[(size_t)c * nkeys + key] = run;
+        run += v;
+    }
+    if (tid == 255) a.run_count[key] = part[255];
+}
+
+// One workgroup: run starts (padded), block_tile_start, then padding and tile groups of every run.
+__global__ __launch_bounds__(1024) void k_order_runs(OrderArgs a) {
     const int nkeys = a.nblk * a.G;
     const int tid = threadIdx.x;
-    for (int k = tid; k < nkeys; k += blockDim.x) {
-        int run = 0;
-        for (int c = 0; c < nchunks; ++c) {
-            const int v = a.chunk_tab[(size_t)c * nkeys + k];
-            a.chunk_tab[(size_t)c * nkeys + k] = run;
-            run += v;
-        }
-        a.run_count[k] = run;
-    }
-    __threadfence();
-    __syncthreads();
     if (tid == 0) {
         int pos = 0;
         for (int k = 0; k < nkeys; ++k) {
@@ -1102,15 +1097,14 @@ __global__ __launch_bounds__(256) void k_order_offsets(OrderArgs a, int nchunks)
         }
         a.blk_start[a.nblk] = pos / 16;
     }
-}
-
-// Fill padding and tile groups: one workgroup per key.
-__global__ __launch_bounds__(64) void k_order_finish(OrderArgs a) {
-    const int key = blockIdx.x;
-    const int start = a.run_start[key], n = a.run_count[key];
-    const int padded = ((n + 15) / 16) * 16;
-    for (int i = n + threadIdx.x; i < padded; i += 64) a.cells[start + i] = -1;
-    for (int t = threadIdx.x; t < padded / 16; t += 64) a.tile_grp[start / 16 + t] = key % a.G;
+    __threadfence();
+    __syncthreads();
+    for (int key = 0; key < nkeys; ++key) {
+        const int start = a.run_start[key], n = a.run_count[key];
+        const int padded = ((n + 15) / 16) * 16;
+        for (int i = n + tid; i < padded; i += 1024) a.cells[start + i] = -1;
+        for (int t = tid; t < padded / 16; t += 1024) a.tile_grp[start / 16 + t] = key % a.G;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1124,7 +1118,10 @@ void launch_normalize_rows(const float* Z, float* Zc, int64_t N, int dp, hipStre
 }
 
 void launch_y_normalize(const float* src, float* dst, int K, int K16, int d, int ldy, hipStream_t s) {
-    hipLaunchKernelGGL(k_y_normalize, dim3(K16), dim3(64), 0, s, src, dst, K, d, ldy);
+    hipLaunchKernelGGL(k_y_normalize<float>, dim3(K16), dim3(64), 0, s, src, dst, K, d, ldy);
+}
+void launch_y_normalize_d(const double* src, float* dst, int K, int K16, int d, int ldy, hipStream_t s) {
+    hipLaunchKernelGGL(k_y_normalize<double>, dim3(K16), dim3(64), 0, s, src, dst, K, d, ldy);
 }
 
 int assign_grid(int ntiles, int nt_per_step, int max_wgs) {
@@ -1156,8 +1153,7 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
         a.tables_in_lds = (base_bytes + tab_bytes <= 150 * 1024) ? 1 : 0;
         const size_t sm = base_bytes + tab_bytes;   // layout keeps the table slots even when unused
         if (sm <= 160 * 1024) {
-            int wgs = cdiv(ntiles, ASSIGN_WAVES * a.tiles_per_wave);
-            wgs = std::max(1, std::min(wgs, max_wgs));
+            const int wgs = cdiv(ntiles, ASSIGN_WAVES);   // one tile per wave
             switch (a.mt) {
                 case 1: launch_assign_lds<1>(a, penalty, wgs, sm, s); break;
                 case 2: launch_assign_lds<2>(a, penalty, wgs, sm, s); break;
@@ -1198,12 +1194,13 @@ void launch_rtz(const RtzArgs& a, int wgs, hipStream_t s) {
     hipLaunchKernelGGL((k_rtz<HMX_RTZ_MTW, HMX_RTZ_NTW>), dim3(wgs, nsub), dim3(256), 0, s, a);
 }
 
-void launch_rtz_reduce(const float* slab, int nwaves, int mt, int ntd, int K16, int ld, float* out_f, double* out_d,
-                       const int* task_grp, int G, hipStream_t s) {
+void launch_rtz_reduce(const float* slab, int nwaves, int mt, int ntd, int K16, int ld, double* out,
+                       const int* task_grp, hipStream_t s) {
     int nsub, spw;
     rtz_geometry(mt, ntd, &nsub, &spw);
-    hipLaunchKernelGGL((k_rtz_reduce<HMX_RTZ_MTW, HMX_RTZ_NTW>), dim3(cdiv(spw, 256)), dim3(256), 0, s, slab, nwaves,
-                       nsub, ntd, K16, ld, out_f, out_d, task_grp, G);
+    const int seg_len = 32;   // slabs summed by one thread before its fp64 atomic
+    hipLaunchKernelGGL((k_rtz_reduce<HMX_RTZ_MTW, HMX_RTZ_NTW>), dim3(cdiv(spw, 256), cdiv(nwaves, seg_len)), dim3(256), 0, s,
+                       slab, nwaves, nsub, ntd, K16, ld, out, task_grp, seg_len);
 }
 
 void launch_block_table(const TableArgs& a, int K16, hipStream_t s) {
@@ -1226,8 +1223,8 @@ void launch_order(const OrderArgs& a, hipStream_t s) {
     const int nchunks = cdiv(a.N, ORDER_CHUNK);
     const size_t sm = (size_t)a.nblk * a.G * sizeof(int);
     hipLaunchKernelGGL(k_order_pass<0>, dim3(nchunks), dim3(64), sm, s, a);
-    hipLaunchKernelGGL(k_order_offsets, dim3(1), dim3(256), 0, s, a, nchunks);
-    hipLaunchKernelGGL(k_order_finish, dim3(a.nblk * a.G), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_order_scan, dim3(a.nblk * a.G), dim3(256), 0, s, a, nchunks);
+    hipLaunchKernelGGL(k_order_runs, dim3(1), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(k_order_pass<1>, dim3(nchunks), dim3(64), sm, s, a);
 }
 
