@@ -6,6 +6,7 @@ reference's signatures (harmonypy/__init__.py:1-4, harmony.py:49-67, 218-229); t
 (include/hmx.h, harmonypy_amd/libhmx.so).
 """
 from .harmony import Harmony, run_harmony, BatchCodes  # noqa: F401
+from .dist import Shard  # noqa: F401
 
 __version__ = "0.1.0"
-__all__ = ["Harmony", "run_harmony", "BatchCodes", "__version__"]
+__all__ = ["Harmony", "run_harmony", "BatchCodes", "Shard", "__version__"]

@@ -24,8 +24,11 @@ HMX_ROUND_ALL = 7
 EXPORTS = [
     "hmx_last_error", "hmx_abi_version", "hmx_create", "hmx_destroy", "hmx_upload", "hmx_init_cluster",
     "hmx_cluster_round", "hmx_cluster_round_seeded", "hmx_moe_correct_ridge", "hmx_get", "hmx_set", "hmx_sync", "hmx_device_ptr",
-    "hmx_kernel_times", "hmx_enable_timing",
+    "hmx_kernel_times", "hmx_enable_timing", "hmx_comm_unique_id", "hmx_comm_init", "hmx_set_host_allreduce",
 ]
+HMX_ABI_VERSION = 2
+HMX_UNIQUE_ID_BYTES = 128
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
 
 
 class HmxError(RuntimeError):
@@ -34,9 +37,9 @@ class HmxError(RuntimeError):
 
 class HmxConfig(C.Structure):
     _fields_ = [
-        ("n_cells", C.c_int64), ("n_pcs", C.c_int32), ("n_clusters", C.c_int32), ("n_batches", C.c_int32),
-        ("n_groups", C.c_int32), ("n_vars", C.c_int32), ("n_blocks", C.c_int32), ("device_id", C.c_int32),
-        ("lambda_estimation", C.c_int32), ("alpha", C.c_float), ("reserved", C.c_int32 * 6),
+        ("n_cells", C.c_int64), ("n_cells_global", C.c_int64), ("n_pcs", C.c_int32), ("n_clusters", C.c_int32),
+        ("n_batches", C.c_int32), ("n_groups", C.c_int32), ("n_vars", C.c_int32), ("n_blocks", C.c_int32),
+        ("device_id", C.c_int32), ("lambda_estimation", C.c_int32), ("alpha", C.c_float), ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -59,7 +62,10 @@ def load():
     lib.hmx_create.argtypes = [C.POINTER(HmxConfig), C.POINTER(vp)]
     lib.hmx_destroy.argtypes = [vp]
     lib.hmx_destroy.restype = None
-    lib.hmx_upload.argtypes = [vp, vp, vp, i64, vp, i32, vp, vp, vp, vp, vp]
+    lib.hmx_upload.argtypes = [vp, vp, vp, i64, vp, i32, vp, vp, vp, vp, vp, vp]
+    lib.hmx_comm_unique_id.argtypes = [vp]
+    lib.hmx_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    lib.hmx_set_host_allreduce.argtypes = [vp, HOST_ALLREDUCE_FN, vp]
     lib.hmx_init_cluster.argtypes = [vp, vp, vp]
     lib.hmx_cluster_round.argtypes = [vp, C.c_int, vp, i64, vp, i32, vp, vp]
     lib.hmx_cluster_round_seeded.argtypes = [vp, C.c_int, C.c_uint64, i64, vp]
@@ -99,10 +105,11 @@ class Engine:
     """One device-resident Harmony state (an ``hmx_engine``)."""
 
     def __init__(self, n_cells, n_pcs, n_clusters, n_batches, n_groups, n_vars, n_blocks,
-                 lambda_estimation=False, alpha=0.2, device_id=0):
+                 lambda_estimation=False, alpha=0.2, device_id=0, n_cells_global=0):
         self._lib = load()
         self._h = C.c_void_p()
-        cfg = HmxConfig(n_cells=n_cells, n_pcs=n_pcs, n_clusters=n_clusters, n_batches=n_batches,
+        self._host_cb = None
+        cfg = HmxConfig(n_cells=n_cells, n_cells_global=n_cells_global, n_pcs=n_pcs, n_clusters=n_clusters, n_batches=n_batches,
                         n_groups=n_groups, n_vars=n_vars, n_blocks=n_blocks, device_id=device_id,
                         lambda_estimation=int(bool(lambda_estimation)), alpha=float(alpha))
         _check(self._lib.hmx_create(C.byref(cfg), C.byref(self._h)))
@@ -120,8 +127,9 @@ class Engine:
         except Exception:
             pass
 
-    def upload(self, Z, static_cells, static_tile_group, group_cols, Pr_b, theta, sigma, lamb):
+    def upload(self, Z, static_cells, static_tile_group, group_cols, Pr_b, theta, sigma, lamb, global_id=None):
         Z = _c(Z, np.float32)
+        global_id = None if global_id is None else _c(global_id, np.int32)
         sc = _c(static_cells, np.int32)
         tg = _c(static_tile_group, np.int32)
         gc = _c(group_cols, np.int32)
@@ -129,7 +137,32 @@ class Engine:
         assert Z.shape == (self.N, self.d)
         _check(self._lib.hmx_upload(self._h, _ptr(Z), _ptr(sc), sc.size, _ptr(tg), tg.size, _ptr(gc),
                                     _ptr(_c(Pr_b, np.float32)), _ptr(_c(theta, np.float32)),
-                                    _ptr(_c(sigma, np.float32)), _ptr(lamb)))
+                                    _ptr(_c(sigma, np.float32)), _ptr(lamb), _ptr(global_id)))
+
+    # ---- transports of a sharded job (include/hmx.h) ------------------------------------------
+    def comm_init(self, unique_id: bytes, n_ranks: int, rank: int):
+        """RCCL communicator bound to the engine's stream."""
+        assert len(unique_id) == HMX_UNIQUE_ID_BYTES
+        buf = C.create_string_buffer(unique_id, HMX_UNIQUE_ID_BYTES)
+        _check(self._lib.hmx_comm_init(self._h, buf, int(n_ranks), int(rank)))
+
+    def set_host_allreduce(self, fn):
+        """``fn(np.ndarray[float64])`` must sum the array over all ranks in place."""
+        if fn is None:
+            _check(self._lib.hmx_set_host_allreduce(self._h, C.cast(None, HOST_ALLREDUCE_FN), None))
+            self._host_cb = None
+            return
+
+        def _cb(_ctx, buf, count):
+            try:
+                fn(np.ctypeslib.as_array(buf, shape=(count,)))
+                return 0
+            except Exception:                                   # never let an exception cross the C ABI
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._host_cb = HOST_ALLREDUCE_FN(_cb)                  # keep the thunk alive
+        _check(self._lib.hmx_set_host_allreduce(self._h, self._host_cb, None))
 
     def init_cluster(self, Y0_rows):
         Y0 = _c(Y0_rows, np.float32)
@@ -195,6 +228,12 @@ class Engine:
 
     def sync(self):
         _check(self._lib.hmx_sync(self._h))
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(HMX_UNIQUE_ID_BYTES)
+        _check(load().hmx_comm_unique_id(buf))
+        return buf.raw
 
     def enable_timing(self, on=True):
         _check(self._lib.hmx_enable_timing(self._h, int(on)))

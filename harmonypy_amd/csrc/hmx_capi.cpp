@@ -1,6 +1,7 @@
 // hmx_capi.cpp -- host side of libhmx.so: device state, kernel sequencing, the C ABI of
 // include/hmx.h.  Compiled with hipcc as HIP (-x hip).  No torch, no exceptions across the ABI.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -13,6 +14,8 @@
 
 #include "hmx.h"
 #include "hmx_internal.h"
+
+struct hmx_nccl_id { char internal[HMX_UNIQUE_ID_BYTES]; };   // layout of ncclUniqueId (rccl.h)
 
 namespace {
 
@@ -73,10 +76,24 @@ struct hmx_engine {
 
     DevBuf<float> Zorig, Zcos, Zcorr, R, Y, Yacc, sigma, theta, Pr_b, lamb, rp, lrp, slab, W;
     DevBuf<int> group_cols, s_cells, s_tile_grp, r_cells, r_tile_grp, r_blk_start, task_t0, task_t1, task_grp;
-    DevBuf<int> gstart, chunk_tab, run_count, run_start;
+    DevBuf<int> gstart, chunk_tab, run_count, run_start, global_id;
     uint64_t seeded_rounds = 0;
-    DevBuf<double> Ogrp, Tmass, Sold, Snew, Ohist, objacc, Sr, Oxr, scratch, Yacc64;
+    int64_t Ng = 0;              // cells of the whole job (all ranks)
+    DevBuf<double> Ogrp, Tmass, Ohist, scratch;
+    // Tables that are summed over ranks live in one allocation, laid out so that tables summed at the
+    // same point of the algorithm are neighbours (one collective each):
+    //   Sold [nblk][G][K16] | Yacc64 [K16][ldy] | Snew [nblk][G][K16] | objacc [2*SLOTS+2] | Sr [G][K16][ldy] | Oxr [G][K16]
+    DevBuf<double> xch;
+    double *Sold = nullptr, *Yacc64 = nullptr, *Snew = nullptr, *objacc = nullptr, *Sr = nullptr, *Oxr = nullptr;
     double* obj_host = nullptr;  // pinned
+    // transport for sharded jobs (null / 1 = single engine)
+    void* nccl_comm = nullptr;
+    int n_ranks = 1, rank = 0;
+    hmx_host_allreduce_fn host_fn = nullptr;
+    void* host_ctx = nullptr;
+    double* stage_host = nullptr;  // pinned staging buffer of the host transport
+    size_t stage_n = 0;
+    long n_collectives = 0;
     int n_s_tiles = 0, ntasks = 0;
     std::vector<int> h_task_grp;
 
@@ -93,6 +110,81 @@ int use_device(hmx_engine* e) {
     HIP_TRY(hipSetDevice(e->cfg.device_id));
     return 0;
 }
+
+
+// ---- transport of sharded jobs -------------------------------------------------------------
+// RCCL is bound at run time (dlopen) so that a single-GPU user never needs it: the entry points
+// below are the only ones used.  The library must share this process's HIP runtime with the
+// engine (stream handles are runtime objects): the ROCm installation's librccl.so.1 does.
+struct RcclApi {
+    void* handle = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, hmx_nccl_id, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+
+int rccl_load() {
+    if (g_rccl.handle) return 0;
+    const char* names[] = {getenv("HMX_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    void* h = nullptr;
+    std::string tried;
+    for (const char* n : names) {
+        if (!n || !*n) continue;
+        h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+        tried += std::string(" ") + n + " (" + dlerror() + ")";
+    }
+    if (!h) return fail(HMX_ERR_COMM, "RCCL not found:%s", tried.c_str());
+    RcclApi a;
+    a.handle = h;
+    a.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<int (*)(void**, int, hmx_nccl_id, int)>(dlsym(h, "ncclCommInitRank"));
+    a.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(h, "ncclAllReduce"));
+    a.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommDestroy"));
+    a.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(h, "ncclGetErrorString"));
+    if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy || !a.GetErrorString)
+        return fail(HMX_ERR_COMM, "RCCL library lacks an expected entry point");
+    g_rccl = a;
+    return 0;
+}
+
+void comm_release(hmx_engine* e) {
+    if (e->nccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(e->nccl_comm);
+    e->nccl_comm = nullptr;
+}
+
+// Sum `count` doubles at device pointer `p` over all ranks, in place, ordered on the engine's stream.
+int sum_over_ranks(hmx_engine* e, double* p, size_t count) {
+    if (count == 0) return 0;
+    if (e->nccl_comm) {
+        const int r = g_rccl.AllReduce(p, p, count, /*ncclFloat64*/ 8, /*ncclSum*/ 0, e->nccl_comm, e->stream);
+        if (r != 0) return fail(HMX_ERR_COMM, "ncclAllReduce(%zu doubles) failed: %s", count, g_rccl.GetErrorString(r));
+        e->n_collectives++;
+        return 0;
+    }
+    if (e->host_fn) {
+        if (count > e->stage_n) {
+            if (e->stage_host) (void)hipHostFree(e->stage_host);
+            e->stage_host = nullptr;
+            e->stage_n = 0;
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->stage_host), count * sizeof(double), hipHostMallocDefault));
+            e->stage_n = count;
+        }
+        HIP_TRY(hipMemcpyAsync(e->stage_host, p, count * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        const int r = e->host_fn(e->host_ctx, e->stage_host, count);
+        if (r != 0) return fail(HMX_ERR_COMM, "host all-reduce callback returned %d", r);
+        HIP_TRY(hipMemcpyAsync(p, e->stage_host, count * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        e->n_collectives++;
+        return 0;
+    }
+    return 0;
+}
+
+bool sharded(const hmx_engine* e) { return e->nccl_comm != nullptr || e->host_fn != nullptr; }
 
 struct Timed {
     hmx_engine* e;
@@ -132,7 +224,7 @@ void drain_spans(hmx_engine* e) {
 
 int read_objective(hmx_engine* e, double out[4]) {
     const int n = 2 * HMX_OBJ_SLOTS + 2;
-    HIP_TRY(hipMemcpyAsync(e->obj_host, e->objacc.p, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->obj_host, e->objacc, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipGetLastError());
     double km = 0.0, ent = 0.0;
@@ -147,7 +239,7 @@ int read_objective(hmx_engine* e, double out[4]) {
 AssignArgs assign_args(hmx_engine* e) {
     AssignArgs a{};
     a.Zcos = e->Zcos.p; a.Y = e->Y.p; a.sigma = e->sigma.p; a.rp = e->rp.p; a.lrp = e->lrp.p; a.R = e->R.p;
-    a.obj = e->objacc.p;
+    a.obj = e->objacc;
     a.K = e->K; a.Kp = e->Kp; a.K16 = e->K16; a.mt = e->mt; a.dp = e->dp; a.ldy = e->ldy;
     a.G = e->G; a.tiles_per_wave = e->tiles_per_wave; a.ablate = e->ablate;
     return a;
@@ -176,6 +268,8 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
     if (cfg->n_clusters > 208) return fail(HMX_ERR_ARG, "n_clusters=%d > 208 not supported by this build", cfg->n_clusters);
     if (cfg->n_pcs > 208) return fail(HMX_ERR_ARG, "n_pcs=%d > 208 not supported by this build", cfg->n_pcs);
     if (cfg->n_cells > (int64_t)2000000000) return fail(HMX_ERR_ARG, "n_cells too large for 32-bit cell ids");
+    if (cfg->n_cells_global != 0 && (cfg->n_cells_global < cfg->n_cells || cfg->n_cells_global > (int64_t)2000000000))
+        return fail(HMX_ERR_ARG, "n_cells_global must lie in [n_cells, 2e9]");
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
     if (he != hipSuccess || ndev <= 0) return fail(HMX_ERR_HIP, "no HIP device available (%s)", hipGetErrorString(he));
@@ -185,6 +279,7 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
     e->cfg = *cfg;
     e->N = cfg->n_cells; e->d = cfg->n_pcs; e->K = cfg->n_clusters; e->B = cfg->n_batches; e->G = cfg->n_groups;
     e->V = cfg->n_vars; e->nblk = cfg->n_blocks;
+    e->Ng = cfg->n_cells_global > 0 ? cfg->n_cells_global : cfg->n_cells;
     e->dp = (e->d + 3) & ~3;
     e->Kp = (e->K + 3) & ~3;
     e->mt = (e->K + 15) / 16;
@@ -201,14 +296,22 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
         const size_t N = (size_t)e->N, GK = (size_t)e->G * e->K16;
         if ((rc = e->Zorig.reserve(N * e->dp)) || (rc = e->Zcos.reserve(N * e->dp)) || (rc = e->Zcorr.reserve(N * e->dp)) ||
             (rc = e->R.reserve(N * e->Kp)) || (rc = e->Y.reserve((size_t)e->K16 * e->ldy)) ||
-            (rc = e->Yacc.reserve((size_t)e->K16 * e->ldy)) || (rc = e->Yacc64.reserve((size_t)e->K16 * e->ldy)) || (rc = e->sigma.reserve(e->K16)) ||
+            (rc = e->Yacc.reserve((size_t)e->K16 * e->ldy)) || (rc = e->sigma.reserve(e->K16)) ||
             (rc = e->theta.reserve(e->B)) || (rc = e->Pr_b.reserve(e->B)) || (rc = e->lamb.reserve(e->B + 1)) ||
             (rc = e->rp.reserve(GK)) || (rc = e->lrp.reserve(GK)) || (rc = e->group_cols.reserve((size_t)e->G * e->V)) ||
-            (rc = e->Ogrp.reserve(GK)) || (rc = e->Tmass.reserve(e->K16)) || (rc = e->Sold.reserve(GK * e->nblk)) ||
-            (rc = e->Snew.reserve(GK * e->nblk)) || (rc = e->Ohist.reserve(GK * e->nblk)) || (rc = e->objacc.reserve(2 * HMX_OBJ_SLOTS + 2)) ||
-            (rc = e->Sr.reserve(GK * e->ldy)) || (rc = e->Oxr.reserve(GK)) ||
+            (rc = e->Ogrp.reserve(GK)) || (rc = e->Tmass.reserve(e->K16)) || (rc = e->Ohist.reserve(GK * e->nblk)) ||
             (rc = e->W.reserve(GK * e->ldy)) || (rc = e->r_blk_start.reserve(e->nblk + 1)))
             break;
+        {
+            const size_t n_sold = GK * e->nblk, n_y = (size_t)e->K16 * e->ldy, n_obj = 2 * HMX_OBJ_SLOTS + 2;
+            if ((rc = e->xch.reserve(2 * n_sold + n_y + n_obj + GK * e->ldy + GK))) break;
+            e->Sold = e->xch.p;
+            e->Yacc64 = e->Sold + n_sold;
+            e->Snew = e->Yacc64 + n_y;
+            e->objacc = e->Snew + n_sold;
+            e->Sr = e->objacc + n_obj;
+            e->Oxr = e->Sr + GK * e->ldy;
+        }
         if (e->V > 1 && (rc = e->scratch.reserve((size_t)e->K16 * (e->B + 1) * (e->B + 1 + e->d)))) break;
         hipError_t pe = hipHostMalloc(reinterpret_cast<void**>(&e->obj_host), (2 * HMX_OBJ_SLOTS + 2) * sizeof(double), hipHostMallocDefault);
         if (pe != hipSuccess) { rc = fail(HMX_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(pe)); break; }
@@ -217,7 +320,7 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
         (void)hipMemsetAsync(e->Tmass.p, 0, e->K16 * sizeof(double), e->stream);
         (void)hipMemsetAsync(e->W.p, 0, GK * e->ldy * sizeof(float), e->stream);
         (void)hipMemsetAsync(e->Y.p, 0, (size_t)e->K16 * e->ldy * sizeof(float), e->stream);
-        (void)hipMemsetAsync(e->objacc.p, 0, (2 * HMX_OBJ_SLOTS + 2) * sizeof(double), e->stream);
+        (void)hipMemsetAsync(e->objacc, 0, (2 * HMX_OBJ_SLOTS + 2) * sizeof(double), e->stream);
     } while (0);
     if (rc) {
         std::string keep = g_err;
@@ -240,8 +343,10 @@ void hmx_destroy(hmx_engine* e) {
     e->slab.release(); e->W.release(); e->group_cols.release(); e->s_cells.release(); e->s_tile_grp.release();
     e->r_cells.release(); e->r_tile_grp.release(); e->r_blk_start.release(); e->task_t0.release(); e->task_t1.release();
     e->task_grp.release(); e->gstart.release(); e->chunk_tab.release(); e->run_count.release(); e->run_start.release();
-    e->Ogrp.release(); e->Tmass.release(); e->Sold.release(); e->Snew.release(); e->Ohist.release();
-    e->objacc.release(); e->Yacc64.release(); e->Sr.release(); e->Oxr.release(); e->scratch.release();
+    e->Ogrp.release(); e->Tmass.release(); e->Ohist.release(); e->xch.release(); e->scratch.release();
+    e->global_id.release();
+    comm_release(e);
+    if (e->stage_host) (void)hipHostFree(e->stage_host);
     if (e->obj_host) (void)hipHostFree(e->obj_host);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -249,7 +354,7 @@ void hmx_destroy(hmx_engine* e) {
 
 int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64_t n_static_pos,
                const int32_t* static_tile_group, int32_t n_static_tiles, const int32_t* group_cols, const float* Pr_b,
-               const float* theta, const float* sigma, const float* lamb) {
+               const float* theta, const float* sigma, const float* lamb, const int32_t* global_id) {
     if (!e || !Z || !static_cells || !static_tile_group || !group_cols || !Pr_b || !theta || !sigma)
         return fail(HMX_ERR_ARG, "null argument");
     if (!e->cfg.lambda_estimation && !lamb) return fail(HMX_ERR_ARG, "lamb is required unless lambda_estimation");
@@ -260,8 +365,19 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
         if (static_tile_group[i] < 0 || static_tile_group[i] >= e->G) return fail(HMX_ERR_ARG, "static_tile_group[%d] out of range", i);
     for (int i = 0; i < e->G * e->V; ++i)
         if (group_cols[i] < 0 || group_cols[i] >= e->B) return fail(HMX_ERR_ARG, "group_cols[%d] out of range", i);
+    if (!global_id && e->Ng != e->N) return fail(HMX_ERR_ARG, "global_id is required when n_cells_global != n_cells");
+    if (global_id)
+        for (int64_t i = 0; i < e->N; ++i)
+            if (global_id[i] < 0 || global_id[i] >= e->Ng) return fail(HMX_ERR_ARG, "global_id[%lld] out of range", (long long)i);
     int rc;
     if ((rc = use_device(e))) return rc;
+    if (global_id) {
+        if ((rc = e->global_id.reserve(e->N))) return rc;
+        HIP_TRY(hipMemcpyAsync(e->global_id.p, global_id, e->N * sizeof(int), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    } else {
+        e->global_id.release();
+    }
     // Z rows padded to dp
     {
         std::vector<float> zp((size_t)e->N * e->dp, 0.f);
@@ -330,7 +446,7 @@ int hmx_init_cluster(hmx_engine* e, const float* Y0, double obj_out[4]) {
     launch_y_normalize(e->Yacc.p, e->Y.p, e->K, e->K16, e->d, e->ldy, e->stream);  // :377
     const size_t GK = (size_t)e->G * e->K16;
     HIP_TRY(hipMemsetAsync(e->Ogrp.p, 0, GK * sizeof(double), e->stream));
-    HIP_TRY(hipMemsetAsync(e->objacc.p, 0, (2 * HMX_OBJ_SLOTS + 2) * sizeof(double), e->stream));
+    HIP_TRY(hipMemsetAsync(e->objacc, 0, (2 * HMX_OBJ_SLOTS + 2) * sizeof(double), e->stream));
     {
         Timed t(e, F_ASSIGN_INIT);
         AssignArgs a = assign_args(e);
@@ -338,10 +454,11 @@ int hmx_init_cluster(hmx_engine* e, const float* Y0, double obj_out[4]) {
         a.tile_begin = 0; a.tile_end = e->n_s_tiles;
         if (launch_assign(a, false, e->max_wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported cluster count");
     }
+    if ((rc = sum_over_ranks(e, e->Ogrp.p, GK)) || (rc = sum_over_ranks(e, e->objacc, 2 * HMX_OBJ_SLOTS))) return rc;
     {
         Timed t(e, F_BLOCK_TABLE);
         TableArgs ta = table_args(e);  // E = outer(R.sum(1), Pr_b) (:388) kept as T; cross-entropy term (:405-411)
-        ta.O_prev = e->Ogrp.p; ta.T_out = e->Tmass.p; ta.obj_cross = e->objacc.p + 2 * HMX_OBJ_SLOTS;
+        ta.O_prev = e->Ogrp.p; ta.T_out = e->Tmass.p; ta.obj_cross = e->objacc + 2 * HMX_OBJ_SLOTS;
         launch_block_table(ta, e->K16, e->stream);
     }
     e->clustered = true;
@@ -353,9 +470,9 @@ int hmx_init_cluster(hmx_engine* e, const float* Y0, double obj_out[4]) {
 static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::vector<int>& tiles_upper, double obj_out[4]) {
     int rc;
     const size_t GK = (size_t)e->G * e->K16;
-    HIP_TRY(hipMemsetAsync(e->Sold.p, 0, GK * e->nblk * sizeof(double), e->stream));
-    HIP_TRY(hipMemsetAsync(e->Snew.p, 0, GK * e->nblk * sizeof(double), e->stream));
-    HIP_TRY(hipMemsetAsync(e->objacc.p, 0, (2 * HMX_OBJ_SLOTS + 2) * sizeof(double), e->stream));
+    HIP_TRY(hipMemsetAsync(e->Sold, 0, GK * e->nblk * sizeof(double), e->stream));
+    HIP_TRY(hipMemsetAsync(e->Snew, 0, GK * e->nblk * sizeof(double), e->stream));
+    HIP_TRY(hipMemsetAsync(e->objacc, 0, (2 * HMX_OBJ_SLOTS + 2) * sizeof(double), e->stream));
 
     // ---- pass over the old R: centroid numerators (:443) and per-block removal sums (:491-492)
     int nsub, spw;
@@ -366,15 +483,20 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         Timed t(e, F_RTZ_ROUND);
         RtzArgs r{};
         r.R = e->R.p; r.Z = e->Zcos.p; r.cells = e->r_cells.p; r.tile_grp = e->r_tile_grp.p; r.blk_start = e->r_blk_start.p;
-        r.S_out = e->Sold.p; r.slab = e->slab.p; r.n_tiles = n_tiles_upper; r.nblk = e->nblk;
+        r.S_out = e->Sold; r.slab = e->slab.p; r.n_tiles = n_tiles_upper; r.nblk = e->nblk;
         r.K = e->K; r.Kp = e->Kp; r.K16 = e->K16; r.G = e->G; r.mt = e->mt; r.dp = e->dp; r.ntd = e->ntd;
         launch_rtz(r, wgs, e->stream);
     }
     if (flags & HMX_ROUND_CENTROIDS) {
         Timed t(e, F_RTZ_REDUCE);
-        HIP_TRY(hipMemsetAsync(e->Yacc64.p, 0, (size_t)e->K16 * e->ldy * sizeof(double), e->stream));
-        launch_rtz_reduce(e->slab.p, wgs * 4, e->mt, e->ntd, e->K16, e->ldy, e->Yacc64.p, nullptr, e->stream);
-        launch_y_normalize_d(e->Yacc64.p, e->Y.p, e->K, e->K16, e->d, e->ldy, e->stream);  // :444
+        HIP_TRY(hipMemsetAsync(e->Yacc64, 0, (size_t)e->K16 * e->ldy * sizeof(double), e->stream));
+        launch_rtz_reduce(e->slab.p, wgs * 4, e->mt, e->ntd, e->K16, e->ldy, e->Yacc64, nullptr, e->stream);
+    }
+    // removal sums of every block and the centroid numerators: one collective (neighbours in xch)
+    if ((rc = sum_over_ranks(e, e->Sold, GK * e->nblk + ((flags & HMX_ROUND_CENTROIDS) ? (size_t)e->K16 * e->ldy : 0)))) return rc;
+    if (flags & HMX_ROUND_CENTROIDS) {
+        Timed t(e, F_RTZ_REDUCE);
+        launch_y_normalize_d(e->Yacc64, e->Y.p, e->K, e->K16, e->d, e->ldy, e->stream);  // :444
     }
     if (flags & HMX_ROUND_UPDATE_R) {
         for (int b = 0; b < e->nblk; ++b) {
@@ -382,8 +504,8 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
                 Timed t(e, F_BLOCK_TABLE);
                 TableArgs ta = table_args(e);
                 ta.O_prev = (b == 0) ? e->Ogrp.p : e->Ohist.p + GK * (b - 1);
-                ta.S_add = (b == 0) ? nullptr : e->Snew.p + GK * (b - 1);
-                ta.S_sub = e->Sold.p + GK * b;
+                ta.S_add = (b == 0) ? nullptr : e->Snew + GK * (b - 1);
+                ta.S_sub = e->Sold + GK * b;
                 ta.O_out = e->Ohist.p + GK * b;
                 ta.rp = e->rp.p; ta.lrp = e->lrp.p;
                 launch_block_table(ta, e->K16, e->stream);
@@ -391,18 +513,22 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
             if (tiles_upper[b] > 0) {
                 Timed t(e, F_ASSIGN_BLOCK);
                 AssignArgs a = assign_args(e);
-                a.cells = e->r_cells.p; a.tile_grp = e->r_tile_grp.p; a.S_out = e->Snew.p + GK * b;
+                a.cells = e->r_cells.p; a.tile_grp = e->r_tile_grp.p; a.S_out = e->Snew + GK * b;
                 a.blk_start = e->r_blk_start.p; a.blk = b;
                 a.tile_begin = 0; a.tile_end = tiles_upper[b];
                 if (launch_assign(a, true, e->max_wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported cluster count");
             }
+            // the block's new sums (:506-507) over all ranks; the last block takes the two objective
+            // sums (:399, :402) along: objacc follows Snew in xch
+            const bool last = b == e->nblk - 1;
+            if ((rc = sum_over_ranks(e, e->Snew + GK * b, GK + (last ? 2 * HMX_OBJ_SLOTS : 0)))) return rc;
         }
         Timed t(e, F_BLOCK_TABLE);
         TableArgs ta = table_args(e);  // close the round: O, T state and the cross-entropy term
         ta.O_prev = e->Ohist.p + GK * (e->nblk - 1);
-        ta.S_add = e->Snew.p + GK * (e->nblk - 1);
+        ta.S_add = e->Snew + GK * (e->nblk - 1);
         ta.O_out = e->Ogrp.p; ta.T_out = e->Tmass.p;
-        if (flags & HMX_ROUND_OBJECTIVE) ta.obj_cross = e->objacc.p + 2 * HMX_OBJ_SLOTS;
+        if (flags & HMX_ROUND_OBJECTIVE) ta.obj_cross = e->objacc + 2 * HMX_OBJ_SLOTS;
         launch_block_table(ta, e->K16, e->stream);
     }
     return read_objective(e, obj_out);
@@ -441,7 +567,7 @@ int hmx_cluster_round(hmx_engine* e, int flags, const int32_t* cells, int64_t n_
 int hmx_cluster_round_seeded(hmx_engine* e, int flags, uint64_t seed, int64_t cells_per_block, double obj_out[4]) {
     int rc;
     if ((rc = check_round_flags(e, flags, obj_out))) return rc;
-    if (cells_per_block < 0 || cells_per_block * (e->nblk - 1) > e->N) return fail(HMX_ERR_ARG, "cells_per_block out of range");
+    if (cells_per_block < 0 || cells_per_block * (e->nblk - 1) > e->Ng) return fail(HMX_ERR_ARG, "cells_per_block out of range");
     if ((rc = use_device(e))) return rc;
     const int nkeys = e->nblk * e->G;
     const int nchunks = order_chunks(e->N);
@@ -451,9 +577,10 @@ int hmx_cluster_round_seeded(hmx_engine* e, int flags, uint64_t seed, int64_t ce
         (rc = e->run_start.reserve(nkeys)))
         return rc;
     OrderArgs o{};
-    o.N = e->N; o.cpb = cells_per_block; o.nblk = e->nblk; o.G = e->G;
+    o.N = e->N; o.Ng = e->Ng; o.cpb = cells_per_block; o.nblk = e->nblk; o.G = e->G;
+    o.global_id = e->global_id.p;
     int bits = 1;
-    while (((int64_t)1 << bits) < e->N) ++bits;
+    while (((int64_t)1 << bits) < e->Ng) ++bits;
     o.half_bits = (bits + 1) / 2;
     // splitmix64 of (seed, round counter) -> two 32-bit round keys
     uint64_t z = seed + 0x9E3779B97F4A7C15ull * (e->seeded_rounds + 1);
@@ -467,12 +594,60 @@ int hmx_cluster_round_seeded(hmx_engine* e, int flags, uint64_t seed, int64_t ce
     launch_order(o, e->stream);
     std::vector<int> upper(e->nblk);
     int total = 0;
-    for (int b = 0; b < e->nblk; ++b) {
-        const int64_t size_b = (b == e->nblk - 1) ? e->N - cells_per_block * (e->nblk - 1) : cells_per_block;
-        upper[b] = size_b > 0 ? (int)((size_b + HMX_TILE - 1) / HMX_TILE) + e->G : 0;
-        total += upper[b];
+    if (e->Ng == e->N) {
+        // every block's size is known: cells_per_block, the last one takes the remainder (:482-484)
+        for (int b = 0; b < e->nblk; ++b) {
+            const int64_t size_b = (b == e->nblk - 1) ? e->N - cells_per_block * (e->nblk - 1) : cells_per_block;
+            upper[b] = size_b > 0 ? (int)((size_b + HMX_TILE - 1) / HMX_TILE) + e->G : 0;
+            total += upper[b];
+        }
+    } else {
+        // a shard holds a random share of every block: read the tile offsets back (84 bytes)
+        std::vector<int> bs(e->nblk + 1);
+        HIP_TRY(hipMemcpyAsync(bs.data(), e->r_blk_start.p, bs.size() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (int b = 0; b < e->nblk; ++b) upper[b] = bs[b + 1] - bs[b];
+        total = bs[e->nblk];
     }
     return round_body(e, flags, total, upper, obj_out);
+}
+
+int hmx_comm_unique_id(void* out_id) {
+    if (!out_id) return fail(HMX_ERR_ARG, "null argument");
+    int rc;
+    if ((rc = rccl_load())) return rc;
+    hmx_nccl_id id;
+    std::memset(&id, 0, sizeof id);
+    const int r = g_rccl.GetUniqueId(&id);
+    if (r != 0) return fail(HMX_ERR_COMM, "ncclGetUniqueId failed: %s", g_rccl.GetErrorString(r));
+    std::memcpy(out_id, &id, sizeof id);
+    return HMX_OK;
+}
+
+int hmx_comm_init(hmx_engine* e, const void* unique_id, int n_ranks, int rank) {
+    if (!e || !unique_id) return fail(HMX_ERR_ARG, "null argument");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(HMX_ERR_ARG, "rank %d of %d", rank, n_ranks);
+    if (e->host_fn) return fail(HMX_ERR_STATE, "a host transport is already attached");
+    int rc;
+    if ((rc = use_device(e)) || (rc = rccl_load())) return rc;
+    comm_release(e);
+    hmx_nccl_id id;
+    std::memcpy(&id, unique_id, sizeof id);
+    void* comm = nullptr;
+    const int r = g_rccl.CommInitRank(&comm, n_ranks, id, rank);
+    if (r != 0 || !comm) return fail(HMX_ERR_COMM, "ncclCommInitRank(rank %d of %d) failed: %s", rank, n_ranks, g_rccl.GetErrorString(r));
+    e->nccl_comm = comm;
+    e->n_ranks = n_ranks;
+    e->rank = rank;
+    return HMX_OK;
+}
+
+int hmx_set_host_allreduce(hmx_engine* e, hmx_host_allreduce_fn fn, void* ctx) {
+    if (!e) return fail(HMX_ERR_ARG, "null argument");
+    if (fn) comm_release(e);   // the host transport replaces an RCCL communicator
+    e->host_fn = fn;
+    e->host_ctx = ctx;
+    return HMX_OK;
 }
 
 int hmx_moe_correct_ridge(hmx_engine* e) {
@@ -484,22 +659,23 @@ int hmx_moe_correct_ridge(hmx_engine* e) {
     int nsub, spw;
     rtz_geometry(e->mt, e->ntd, &nsub, &spw);
     if ((rc = e->slab.reserve((size_t)std::max(e->ntasks, 1) * spw))) return rc;
-    HIP_TRY(hipMemsetAsync(e->Sr.p, 0, GK * e->ldy * sizeof(double), e->stream));
-    HIP_TRY(hipMemsetAsync(e->Oxr.p, 0, GK * sizeof(double), e->stream));
+    HIP_TRY(hipMemsetAsync(e->Sr, 0, GK * e->ldy * sizeof(double), e->stream));
+    HIP_TRY(hipMemsetAsync(e->Oxr, 0, GK * sizeof(double), e->stream));
     {
         Timed t(e, F_RIDGE_STATS);
         RtzArgs r{};
         r.R = e->R.p; r.Z = e->Zorig.p; r.cells = e->s_cells.p; r.tile_grp = e->s_tile_grp.p;
         r.task_tile0 = e->task_t0.p; r.task_tile1 = e->task_t1.p; r.task_grp = e->task_grp.p;
-        r.S_out = e->Oxr.p; r.slab = e->slab.p; r.n_tiles = e->n_s_tiles; r.ntasks = e->ntasks;
+        r.S_out = e->Oxr; r.slab = e->slab.p; r.n_tiles = e->n_s_tiles; r.ntasks = e->ntasks;
         r.K = e->K; r.Kp = e->Kp; r.K16 = e->K16; r.G = e->G; r.mt = e->mt; r.dp = e->dp; r.ntd = e->ntd;
         launch_rtz(r, (e->ntasks + 3) / 4, e->stream);
-        launch_rtz_reduce(e->slab.p, e->ntasks, e->mt, e->ntd, e->K16, e->ldy, e->Sr.p, e->task_grp.p, e->stream);
+        launch_rtz_reduce(e->slab.p, e->ntasks, e->mt, e->ntd, e->K16, e->ldy, e->Sr, e->task_grp.p, e->stream);
     }
+    if ((rc = sum_over_ranks(e, e->Sr, GK * e->ldy + GK))) return rc;   // Sr and Oxr are neighbours
     {
         Timed t(e, F_RIDGE_SOLVE);
         RidgeSolveArgs s{};
-        s.S = e->Sr.p; s.Ox = e->Oxr.p; s.T = e->Tmass.p; s.lamb = e->lamb.p; s.Pr_b = e->Pr_b.p; s.group_cols = e->group_cols.p;
+        s.S = e->Sr; s.Ox = e->Oxr; s.T = e->Tmass.p; s.lamb = e->lamb.p; s.Pr_b = e->Pr_b.p; s.group_cols = e->group_cols.p;
         s.W = e->W.p; s.scratch = e->scratch.p; s.alpha = e->cfg.alpha; s.lambda_est = e->cfg.lambda_estimation;
         s.K = e->K; s.K16 = e->K16; s.G = e->G; s.B = e->B; s.V = e->V; s.d = e->d; s.lds = e->ldy; s.ldw = e->ldy;
         launch_ridge_solve(s, e->stream);
@@ -574,6 +750,7 @@ int hmx_set(hmx_engine* e, int which, const void* host_in, size_t bytes) {
         const size_t GK = (size_t)e->G * e->K16;
         HIP_TRY(hipMemsetAsync(e->Ogrp.p, 0, GK * sizeof(double), e->stream));
         launch_group_sums(e->R.p, e->Kp, e->K, e->K16, e->s_cells.p, e->s_tile_grp.p, e->n_s_tiles, e->Ogrp.p, e->stream);
+        if ((rc = sum_over_ranks(e, e->Ogrp.p, GK))) return rc;
         TableArgs ta = table_args(e);
         ta.O_prev = e->Ogrp.p; ta.T_out = e->Tmass.p;
         launch_block_table(ta, e->K16, e->stream);

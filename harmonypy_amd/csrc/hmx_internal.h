@@ -85,7 +85,8 @@ struct ApplyArgs {
 };
 
 struct OrderArgs {
-    int64_t N, cpb;
+    int64_t N, Ng, cpb;    // local cells, cells of the whole job, positions per block (global)
+    const int* global_id;  // N (null = the internal index)
     int nblk, G, half_bits;
     uint32_t key0, key1;
     const int* gstart;     // G+1 first internal cell of every group

@@ -975,30 +975,33 @@ __global__ __launch_bounds__(256) void k_ridge_apply(ApplyArgs a) {
 // Device-side update order (replaces torch.randperm + the gather/argsort of harmony.py:471-480,
 // 512-513 when the caller does not supply an order).
 //
-// A keyed bijection pi on [0, N) (cycle-walking Feistel network) plays the role of the random
-// permutation: position p of the order holds cell pi(p); block b = positions [b*cpb, (b+1)*cpb),
-// the last block takes the remainder (harmony.py:482-484).  Three passes turn that into the
+// A keyed bijection pi on [0, Ng) (cycle-walking Feistel network; Ng = cells of the whole job)
+// plays the role of the random permutation: position p of the order holds global cell pi(p);
+// block b = positions [b*cpb, (b+1)*cpb), the last block takes the remainder (harmony.py:482-484).
+// Every cell finds its own position as p = pi^-1(global id): no rank of a sharded job needs the
+// others' cells, and the blocks do not depend on the sharding.  Three passes turn that into the
 // engine's lists -- cells of a block regrouped by batch group, every (block, group) run padded
 // to 16 -- without atomics whose order could change the result:
-//   count   : one wave per chunk of positions, per-chunk histogram over key = block*G + group
+//   count   : one wave per chunk of cells, per-chunk histogram over key = block*G + group
 //   scan    : exclusive scan over chunks per key (one workgroup per key)
 //   runs    : run/tile starts, block_tile_start, padding, tile groups
-//   scatter : every position writes its cell at run_start + (#earlier positions with its key)
+//   scatter : every cell goes to run_start + (#earlier cells with its key)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t mix32(uint32_t h) {
     h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
     return h;
 }
-__device__ __forceinline__ uint32_t feistel_perm(uint32_t x, uint32_t n, int half_bits, uint32_t k0, uint32_t k1) {
+// inverse of the 6-round Feistel network  (l, r) -> (r, l ^ F_i(r)), i = 0..5, with cycle walking
+__device__ __forceinline__ uint32_t feistel_position(uint32_t x, uint32_t n, int half_bits, uint32_t k0, uint32_t k1) {
     const uint32_t mask = (1u << half_bits) - 1u;
     do {
         uint32_t l = x >> half_bits, r = x & mask;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const uint32_t f = mix32(r * 0x9E3779B1u + k0 + (uint32_t)i * k1) & mask;
-            const uint32_t nl = r;
-            r = l ^ f;
-            l = nl;
+        for (int i = 5; i >= 0; --i) {
+            const uint32_t f = mix32(l * 0x9E3779B1u + k0 + (uint32_t)i * k1) & mask;
+            const uint32_t pl = r ^ f;
+            r = l;
+            l = pl;
         }
         x = (l << half_bits) | r;
     } while (x >= n);
@@ -1013,7 +1016,7 @@ __device__ __forceinline__ int group_of_cell(const int* __restrict__ gstart, int
     return lo;
 }
 
-#define ORDER_CHUNK 1024  /* positions per wave */
+#define ORDER_CHUNK 1024  /* cells per wave */
 
 // mode 0: write per-chunk histograms; mode 1: scatter cells using chunk offsets
 template <int MODE>
@@ -1026,15 +1029,17 @@ __global__ __launch_bounds__(64) void k_order_pass(OrderArgs a) {
     __syncthreads();
     const int64_t base = (int64_t)chunk * ORDER_CHUNK;
     for (int s = 0; s < ORDER_CHUNK / 64; ++s) {
-        const int64_t p = base + s * 64 + lane;
-        const bool live = p < a.N;
-        int cell = 0, key = -1;
+        const int64_t ci = base + s * 64 + lane;
+        const bool live = ci < a.N;
+        const int cell = (int)ci;
+        int key = -1;
         if (live) {
-            cell = (int)feistel_perm((uint32_t)p, (uint32_t)a.N, a.half_bits, a.key0, a.key1);
+            const uint32_t gid = a.global_id ? (uint32_t)a.global_id[cell] : (uint32_t)cell;
+            const int64_t p = feistel_position(gid, (uint32_t)a.Ng, a.half_bits, a.key0, a.key1);
             const int b = (a.cpb > 0) ? (int)min((int64_t)(p / a.cpb), (int64_t)(a.nblk - 1)) : a.nblk - 1;
             key = b * a.G + group_of_cell(a.gstart, a.G, cell);
         }
-        // rank among the lanes of this step that share the key, in position order
+        // rank among the lanes of this step that share the key, in cell order
         unsigned long long todo = __ballot(live);
         int rank = 0, cnt_before = 0;
         while (todo) {

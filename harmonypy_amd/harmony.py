@@ -38,6 +38,8 @@ if not logger.handlers:
 # Override with the environment variable HMX_UPDATE_ORDER.
 UPDATE_ORDER = "auto"
 AUTO_DEVICE_ORDER_CELLS = 200_000
+# sharded jobs: rank 0 fits the initial k-means on all cells up to this many, else on a subsample
+KMEANS_GATHER_CELLS = 2_000_000
 
 # Test aids (never set by product code).  ``Y0``: d x K centroids used instead of the
 # sklearn call; ``forced_rounds``: list of k-means round counts replayed instead of the
@@ -108,6 +110,8 @@ def run_harmony(
     verbose=True,
     random_state=0,
     device=None,
+    *,
+    shard=None,
 ):
     """Run Harmony batch-effect correction on an MI355X.
 
@@ -115,8 +119,13 @@ def run_harmony(
     (harmony.py:49-115): ``data_mat`` cells x PCs or PCs x cells, ``meta_data`` cells x
     variables, ``vars_use`` the batch column(s); ``lamb=-1`` estimates lambda per cluster.
     Returns a finished ``Harmony`` object (``.Z_corr`` is cells x PCs).
+
+    ``shard`` (keyword only, not in the reference): a ``harmonypy_amd.Shard``.  Every rank of
+    the process group then passes ITS slice of the cells (rank r holds the r-th contiguous
+    slice) and gets back an object over those cells; batch proportions, cluster count, blocks,
+    centroids and corrections are those of the whole job (``dist.py``).
     """
-    p = _prepare_inputs(data_mat, meta_data, vars_use, theta, lamb, sigma, nclust, tau)
+    p = _prepare_inputs(data_mat, meta_data, vars_use, theta, lamb, sigma, nclust, tau, shard=shard)
     dev = _device_index(device)
     if verbose:
         logger.info(f"Running Harmony (HIP engine on MI355X device {dev})")
@@ -145,13 +154,14 @@ def run_harmony(
         p["theta"], p["lamb"], alpha, p["lambda_estimation"],
         max_iter_harmony, max_iter_kmeans,
         epsilon_cluster, epsilon_harmony, p["K"], block_size, verbose,
-        random_state, device,
+        random_state, device, shard=shard,
     )
 
 
-def _prepare_inputs(data_mat, meta_data, vars_use, theta=None, lamb=None, sigma=0.1, nclust=None, tau=0):
+def _prepare_inputs(data_mat, meta_data, vars_use, theta=None, lamb=None, sigma=0.1, nclust=None, tau=0, shard=None):
     """Argument normalisation of ``run_harmony`` (harmony.py:116-173, 203-205) with the batch
-    design kept as integer codes instead of a dense one-hot matrix."""
+    design kept as integer codes instead of a dense one-hot matrix.  With ``shard`` the inputs
+    are this rank's slice; cell counts, batch levels and batch sizes are those of the whole job."""
     N = meta_data.shape[0]
     if hasattr(data_mat, "values"):
         data_mat = data_mat.values
@@ -161,8 +171,11 @@ def _prepare_inputs(data_mat, meta_data, vars_use, theta=None, lamb=None, sigma=
     assert data_mat.shape[1] == N, \
         "data_mat and meta_data do not have the same number of cells"
 
+    N_all = N
+    if shard is not None:
+        _, N_all = shard.layout(N)
     if nclust is None:                                          # harmony.py:123-124
-        nclust = int(min(round(N / 30.0), 100))
+        nclust = int(min(round(N_all / 30.0), 100))
     if isinstance(sigma, (float, int)) and not isinstance(sigma, bool):   # harmony.py:126-127
         sigma = np.repeat(float(sigma), nclust)
     sigma = np.asarray(sigma, dtype=np.float32)
@@ -176,6 +189,13 @@ def _prepare_inputs(data_mat, meta_data, vars_use, theta=None, lamb=None, sigma=
     offset = 0
     for v, name in enumerate(vars_use):
         cat = pd.Categorical(meta_data[name])
+        if shard is not None:
+            # the levels of the whole job: identical declared categories are kept as they are,
+            # otherwise the sorted union (what pd.Categorical would find on the unsharded column)
+            levels = shard.allgather_object(list(cat.categories))
+            if any(lv != levels[0] for lv in levels):
+                merged = sorted(set().union(*levels))
+                cat = pd.Categorical(meta_data[name], categories=merged)
         if (cat.codes < 0).any():
             raise ValueError(f"meta_data[{name!r}] has missing values")
         codes[:, v] = cat.codes.astype(np.int32) + offset
@@ -209,8 +229,11 @@ def _prepare_inputs(data_mat, meta_data, vars_use, theta=None, lamb=None, sigma=
         if len(lamb) == np.sum(phi_n):
             lamb = np.insert(lamb, 0, 0).astype(np.float32)
 
-    N_b = np.bincount(codes.ravel(), minlength=B).astype(np.float32)   # harmony.py:169 (phi.sum(axis=1))
-    Pr_b = (N_b / N).astype(np.float32)                                # harmony.py:170
+    counts = np.bincount(codes.ravel(), minlength=B).astype(np.int64)
+    if shard is not None:
+        shard.allreduce_(counts)
+    N_b = counts.astype(np.float32)                                    # harmony.py:169 (phi.sum(axis=1))
+    Pr_b = (N_b / N_all).astype(np.float32)                            # harmony.py:170
     if tau > 0:                                                        # harmony.py:172-173
         theta = theta * (1 - np.exp(-(N_b / (nclust * tau)) ** 2))
 
@@ -219,15 +242,25 @@ def _prepare_inputs(data_mat, meta_data, vars_use, theta=None, lamb=None, sigma=
                 lambda_estimation=lambda_estimation, K=int(nclust), vars_use=list(vars_use))
 
 
-def build_layout(codes):
+def build_layout(codes, combos=None):
     """Group cells by their multi-hot batch pattern.
 
     Returns (group_cols G x V, order internal->original, rank original->internal,
     gid_int group of every internal cell, static_cells, static_tile_grp): the static list is
     the identity over the group-sorted cells with every group padded to whole tiles.
+    ``combos`` (sorted unique rows) fixes the groups of the whole job for a shard that may not
+    hold cells of every group.
     """
     N = codes.shape[0]
-    combos, gid = np.unique(codes, axis=0, return_inverse=True)
+    if combos is None:
+        combos, gid = np.unique(codes, axis=0, return_inverse=True)
+    else:
+        combos = np.asarray(combos, dtype=codes.dtype)
+        both, inv = np.unique(np.vstack([combos, codes]), axis=0, return_inverse=True)
+        if both.shape[0] != combos.shape[0]:
+            raise ValueError("a cell's batch pattern is missing from the job-wide group table")
+        inv = inv.reshape(-1)
+        gid = inv[combos.shape[0]:]
     gid = gid.reshape(-1).astype(np.int32)
     G = combos.shape[0]
     order = np.argsort(gid, kind="stable").astype(np.int64)
@@ -247,17 +280,25 @@ def build_layout(codes):
             np.concatenate(cells), np.concatenate(tile_grp))
 
 
-def build_block_lists(update_order, rank, gid_int, n_blocks, cells_per_block, G):
+def build_block_lists(update_order, rank, gid_int, n_blocks, cells_per_block, G, offset=0):
     """Turn the reference's update order (harmony.py:471) into the engine's tile lists.
 
     Block b holds positions [b*cpb, (b+1)*cpb) of the order, the last block the remainder
     (harmony.py:482-484).  Only block membership matters to the update, so inside a block
     cells are regrouped by batch group and every (block, group) run is padded with -1 to a
     multiple of 16.  Returns (cells, tile_group, block_tile_start).
+
+    ``update_order`` is a permutation of ALL cells of the job; a shard (``len(rank)`` cells,
+    global ids ``offset ..``) keeps its own cells of every block.
     """
-    N, nb, cpb = len(update_order), int(n_blocks), int(cells_per_block)
-    pos = np.arange(N, dtype=np.int64)
-    blk = np.minimum(pos // cpb, nb - 1) if cpb > 0 else np.full(N, nb - 1, dtype=np.int64)
+    Ng, nb, cpb = len(update_order), int(n_blocks), int(cells_per_block)
+    update_order = np.asarray(update_order, dtype=np.int64)
+    pos = np.arange(Ng, dtype=np.int64)
+    blk = np.minimum(pos // cpb, nb - 1) if cpb > 0 else np.full(Ng, nb - 1, dtype=np.int64)
+    if len(rank) != Ng or offset:
+        mine = (update_order >= offset) & (update_order < offset + len(rank))
+        update_order, blk = update_order[mine] - offset, blk[mine]
+    N = len(update_order)
     cell_int = rank[update_order]
     key = blk * G + gid_int[cell_int]
     srt = np.argsort(key, kind="stable")
@@ -287,11 +328,14 @@ class Harmony:
             self, Z, Phi, Pr_b, sigma, theta, lamb, alpha, lambda_estimation,
             max_iter_harmony, max_iter_kmeans,
             epsilon_kmeans, epsilon_harmony, K, block_size, verbose,
-            random_state, device
+            random_state, device, shard=None
     ):
         self.device = device
+        self.shard = shard
         Z = np.asarray(Z, dtype=np.float32)
         self.d, self.N = Z.shape
+        # cells of the whole job and this rank's first global cell id (N_global == N unsharded)
+        self._offset, self.N_global = (0, self.N) if shard is None else shard.layout(self.N)
         self._codes = Phi if isinstance(Phi, BatchCodes) else BatchCodes.from_dense(Phi)
         if self._codes.codes.shape[0] != self.N:
             raise ValueError("Phi and Z disagree on the number of cells")
@@ -331,7 +375,7 @@ class Harmony:
         if mode not in ("auto", "torch", "device"):
             raise ValueError(f"HMX_UPDATE_ORDER={mode!r}: expected auto, torch or device")
         if mode == "auto":
-            mode = "torch" if self.N <= AUTO_DEVICE_ORDER_CELLS else "device"
+            mode = "torch" if self.N_global <= AUTO_DEVICE_ORDER_CELLS else "device"
         self.update_order = mode
         self._seed = int(random_state) if random_state is not None else 0
 
@@ -346,20 +390,27 @@ class Harmony:
         codes = self._codes.codes
         V = codes.shape[1]
         # batch groups = distinct multi-hot rows of Phi; cells are stored group-sorted
+        combos = None
+        if self.shard is not None:   # the groups of the whole job
+            parts = self.shard.allgather_object(np.unique(codes, axis=0))
+            combos = np.unique(np.vstack(parts), axis=0)
         (self._group_cols, self._order, self._rank, self._gid_int,
-         self._static_cells, self._static_tile_grp) = build_layout(codes)
+         self._static_cells, self._static_tile_grp) = build_layout(codes, combos)
         self._G = self._group_cols.shape[0]
         self._n_blocks = int(np.ceil(1.0 / self.block_size))                     # harmony.py:474
-        self._cells_per_block = int(self.N * self.block_size)                    # harmony.py:475
+        self._cells_per_block = int(self.N_global * self.block_size)             # harmony.py:475
 
         self._engine = _capi.Engine(self.N, self.d, self.K, self.B, self._G, V, self._n_blocks,
                                     lambda_estimation=self.lambda_estimation, alpha=self.alpha,
-                                    device_id=_device_index(self.device))
+                                    device_id=_device_index(self.device), n_cells_global=self.N_global)
+        self.transport = None if self.shard is None else self.shard.attach(self._engine)
         if Z is not None:
             Zi = np.ascontiguousarray(Z.T[self._order])                          # N x d, internal order
+            # a cell's id in the whole job = its row in the unsharded input
+            gid = (self._offset + self._order).astype(np.int32)
             self._engine.upload(Zi, self._static_cells, self._static_tile_grp, self._group_cols,
                                 self._Pr_b, self._theta, self._sigma,
-                                None if self.lambda_estimation else self._lamb)
+                                None if self.lambda_estimation else self._lamb, global_id=gid)
 
     # ------------------------------------------------------------------
     # read-back (harmony.py:288-355): fresh float32 NumPy arrays, cells x features
@@ -444,14 +495,27 @@ class Harmony:
         if _TEST_HOOKS["Y0"] is not None:
             Y0 = np.asarray(_TEST_HOOKS["Y0"], dtype=np.float32)                 # d x K
         else:
-            from sklearn.cluster import KMeans
             if self.verbose:
                 logger.info("Computing initial centroids with sklearn.KMeans...")
             Z_cos = self.Z_cos                                                   # N x d, original order
-            model = KMeans(n_clusters=self.K, init="k-means++", n_init=1, max_iter=25,
-                           random_state=random_state)                            # harmony.py:370-371
-            model.fit(Z_cos)
-            Y0 = np.asarray(model.cluster_centers_.T, dtype=np.float32)
+            if self.shard is not None:
+                # the reference fits on every cell (harmony.py:369-372); rank 0 does so on the
+                # gathered cells up to KMEANS_GATHER_CELLS, above that on an even subsample
+                take = np.arange(self.N)
+                if self.N_global > KMEANS_GATHER_CELLS:
+                    n = max(1, int(round(KMEANS_GATHER_CELLS * self.N / self.N_global)))
+                    take = np.linspace(0, self.N - 1, n).astype(np.int64)
+                parts = self.shard.allgather_object(Z_cos[take])
+                Z_cos = np.concatenate(parts, axis=0) if self.shard.rank == 0 else None
+            Y0 = None
+            if Z_cos is not None:
+                from sklearn.cluster import KMeans
+                model = KMeans(n_clusters=self.K, init="k-means++", n_init=1, max_iter=25,
+                               random_state=random_state)                        # harmony.py:370-371
+                model.fit(Z_cos)
+                Y0 = np.asarray(model.cluster_centers_.T, dtype=np.float32)
+            if self.shard is not None:
+                Y0 = self.shard.broadcast_object(Y0)
             if self.verbose:
                 logger.info("KMeans initialization complete.")
         if Y0.shape != (self.d, self.K):
@@ -471,7 +535,7 @@ class Harmony:
                                "update_R()/init_cluster() call on the device")
         kmeans_error, _entropy, _cross_entropy = (float(x) for x in self._pending_objective[:3])
         self._pending_objective = None
-        norm_const = 2000.0 / self.N
+        norm_const = 2000.0 / self.N_global
         self.objective_kmeans.append((kmeans_error + _entropy + _cross_entropy) * norm_const)
         self.objective_kmeans_dist.append(kmeans_error * norm_const)
         self.objective_kmeans_entropy.append(_entropy * norm_const)
@@ -518,7 +582,7 @@ class Harmony:
 
     def _update_order(self):
         import torch
-        return torch.randperm(self.N).numpy()                                    # harmony.py:471
+        return torch.randperm(self.N_global).numpy()                             # harmony.py:471 (same stream on every rank)
 
     def _round(self, flags):
         if self.update_order == "device":
@@ -530,7 +594,7 @@ class Harmony:
 
     def _block_lists(self, update_order):
         return build_block_lists(update_order, self._rank, self._gid_int, self._n_blocks,
-                                 self._cells_per_block, self._G)
+                                 self._cells_per_block, self._G, offset=self._offset)
 
     # ------------------------------------------------------------------
     # harmony.py:515-533

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HMX_ABI_VERSION 1
+#define HMX_ABI_VERSION 2
 #define HMX_TILE 16 /* cells per tile */
 
 typedef enum hmx_status {
@@ -59,6 +59,9 @@ typedef enum hmx_array {
 
 typedef struct hmx_config {
     int64_t n_cells;          /* N  cells held by this engine (this rank's shard)      */
+    int64_t n_cells_global;   /* cells of the whole job over all ranks (0 = n_cells);
+                                 the update order (harmony.py:471-484) is a permutation of
+                                 this many cells and blocks are cut from it              */
     int32_t n_pcs;            /* d                                                      */
     int32_t n_clusters;       /* K                                                      */
     int32_t n_batches;        /* B  = number of Phi rows                                */
@@ -68,7 +71,7 @@ typedef struct hmx_config {
     int32_t device_id;        /* HIP device ordinal                                     */
     int32_t lambda_estimation;/* 0/1                                (harmony.py:541)    */
     float alpha;              /*                                    (harmony.py:590)    */
-    int32_t reserved[6];
+    int32_t reserved[4];
 } hmx_config;
 
 typedef struct hmx_engine hmx_engine;
@@ -84,10 +87,33 @@ void hmx_destroy(hmx_engine* e);
  * engine derives Z_cos (harmony.py:238).  static_cells/static_tile_group: the
  * group-sorted identity list padded to tiles (n_static_pos = 16*n_static_tiles).
  * group_cols: G x V Phi-row indices of every group.  lamb: B+1 floats, ignored
- * when lambda_estimation. */
+ * when lambda_estimation.  Pr_b (harmony.py:170) is the batch proportion over the
+ * whole job.  global_id: for every internal cell its index in [0, n_cells_global)
+ * (the cell's row in the unsharded input); NULL = the internal index itself. */
 int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64_t n_static_pos,
                const int32_t* static_tile_group, int32_t n_static_tiles, const int32_t* group_cols,
-               const float* Pr_b, const float* theta, const float* sigma, const float* lamb);
+               const float* Pr_b, const float* theta, const float* sigma, const float* lamb,
+               const int32_t* global_id);
+
+/* ---- cells sharded over several engines (one process per GPU) -------------------------
+ * Every cross-cell quantity of the path is a small fp64 table -- centroid numerators K x d
+ * (harmony.py:443), batch-by-cluster sums K x B of a block (harmony.py:491-492, 506-507),
+ * the three objective sums (harmony.py:399-411), the ridge statistics (harmony.py:550,
+ * 559-563).  With a transport attached the engine sums each of them over all ranks at the
+ * point where the reference forms it, so every rank walks the same O/E/Y/W.  All ranks must
+ * make the same calls in the same order.
+ *
+ * hmx_comm_init: RCCL communicator over xGMI bound to the engine's stream (stream-ordered
+ * ncclAllReduce, no host round trip).  unique_id: NCCL_UNIQUE_ID_BYTES (128) bytes obtained
+ * from hmx_comm_unique_id on one rank and broadcast by the caller.
+ * hmx_set_host_allreduce: any other transport (the tests use gloo): the engine stages the
+ * table to host memory, calls fn(ctx, buf, count) which must sum buf over the ranks in
+ * place, and copies it back. */
+#define HMX_UNIQUE_ID_BYTES 128
+int hmx_comm_unique_id(void* out_id);
+int hmx_comm_init(hmx_engine* e, const void* unique_id, int n_ranks, int rank);
+typedef int (*hmx_host_allreduce_fn)(void* ctx, double* buf, size_t count);
+int hmx_set_host_allreduce(hmx_engine* e, hmx_host_allreduce_fn fn, void* ctx);
 
 /* harmony.py:376-392 given the k-means centres of harmony.py:370-373.
  * Y0: K x d row-major (centroids as rows, not yet normalised).
@@ -108,9 +134,12 @@ int hmx_cluster_round(hmx_engine* e, int flags, const int32_t* cells, int64_t n_
                       const int32_t* tile_group, int32_t n_tiles, const int32_t* block_tile_start,
                       double obj_out[4]);
 
-/* Same round, update order drawn on the device: a keyed bijection of [0, N) (round key from
- * `seed` and the engine's round counter) stands in for torch.randperm (harmony.py:471); blocks
- * are cells_per_block positions each, the last one takes the remainder (harmony.py:475-484).
+/* Same round, update order drawn on the device: a keyed bijection of [0, n_cells_global)
+ * (round key from `seed` and the engine's round counter) stands in for torch.randperm
+ * (harmony.py:471): a cell's position in the order is the inverse bijection of its global id,
+ * so every rank of a sharded job finds the blocks of its own cells without communication and
+ * the blocks do not depend on how the cells are sharded.  Blocks are cells_per_block positions
+ * of the global order each, the last one takes the remainder (harmony.py:475-484).
  * Statistically equivalent to, not bitwise the same stream as, the reference's generator
  * (the reference itself changes stream between its 'cpu' and 'cuda' devices). */
 int hmx_cluster_round_seeded(hmx_engine* e, int flags, uint64_t seed, int64_t cells_per_block,
