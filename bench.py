@@ -46,17 +46,20 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def synthetic_dataset(N, d, B, K, seed=0):
+def synthetic_dataset(N, d, B, K, seed=0, cell_seed=None):
     """Seeded PC-like matrix with batch offsets (SURVEY.md §8d / BASELINE.md §3):
     PC scale 1/sqrt(1+j); T = max(K//2, 5) cell-type centres N(0, 3^2)*scale; batch offsets
     N(0,1)*scale; batch proportions Dirichlet(5); unit noise*scale; float32; one categorical
-    column ``batch`` with labels b0..b{B-1}."""
+    column ``batch`` with labels b0..b{B-1}.  ``cell_seed`` (default: none) draws different cells
+    from the same population: the shards of one sharded job."""
     rng = np.random.default_rng(seed)
     T = max(K // 2, 5)
     scale = (1.0 / np.sqrt(1.0 + np.arange(d))).astype(np.float32)
     centres = (rng.normal(0, 3.0, (T, d)) * scale).astype(np.float32)
     offsets = (rng.normal(0, 1.0, (B, d)) * scale).astype(np.float32)
     p = rng.dirichlet(5.0 * np.ones(B))
+    if cell_seed is not None:
+        rng = np.random.default_rng([seed, 1 + int(cell_seed)])
     batch = rng.choice(B, size=N, p=p).astype(np.int32)
     typ = rng.integers(0, T, size=N)
     Z = rng.standard_normal((N, d), dtype=np.float32)
@@ -123,20 +126,33 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     import torch
     dist = None
-    if world > 1:
+    shard = None
+    if world > 1 or os.environ.get("HMX_BENCH_FORCE_SHARD"):
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29512")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl")
 
     N, d, B, K = CONFIGS[args.config]
     os.environ["HMX_UPDATE_ORDER"] = "device"
+    import harmonypy_amd
     from harmonypy_amd import harmony as H
 
-    Z, meta = synthetic_dataset(N, d, B, K, seed=rank)
-    H._TEST_HOOKS["Y0"] = quick_centroids(Z, K, seed=0)
+    # every rank holds one shard of N cells of ONE job of world*N cells (weak scaling): the same
+    # cell types and batch effects on every rank (seed 0), different cells (cell_seed = rank)
+    Z, meta = synthetic_dataset(N, d, B, K, seed=0, cell_seed=rank)
+    Y0 = quick_centroids(Z, K, seed=0) if rank == 0 else None
+    if dist is not None:
+        shard = harmonypy_amd.Shard()            # nccl group -> the engine's own RCCL communicator
+        Y0 = shard.broadcast_object(Y0)
+    H._TEST_HOOKS["Y0"] = Y0
     t_setup = time.perf_counter()
-    ho = H.run_harmony(Z, meta, ["batch"], nclust=K, max_iter_harmony=0, verbose=False, random_state=rank,
-                       device=f"cuda:{local_rank}")
+    ho = H.run_harmony(Z, meta, ["batch"], nclust=K, max_iter_harmony=0, verbose=False, random_state=0,
+                       device=f"cuda:{local_rank}", shard=shard)
     H._TEST_HOOKS["Y0"] = None
     t_setup = time.perf_counter() - t_setup
 
@@ -188,8 +204,10 @@ def main():
                         f"{args.rounds} k-means rounds (block_size 0.05 -> 20 blocks) + 1 ridge correction",
             "cells_per_gpu": N, "pcs": d, "batches": B, "clusters": K, "rounds_per_iteration": args.rounds,
             "update_order": "device (keyed bijection, generated inside the timed region)",
-            "init": "k-means++ on a 50k-cell subsample, untimed", "parallelism": "cells sharded, 1 rank per GPU"
-                    if world > 1 else "single GPU",
+            "init": "k-means++ on a 50k-cell subsample, untimed",
+            "parallelism": (f"cells sharded over {world} ranks (1 per GPU), tables summed by {ho.transport} "
+                            f"all-reduce: 1 + 20 per round, 1 per ridge") if shard is not None else "single GPU",
+            "cells_total": N * world,
             "cell_rounds_per_sec": N * world * args.steps * args.rounds / dt,
             "setup_s": t_setup,
         },
@@ -214,7 +232,7 @@ def main():
             "mfma_flops": N * 4 * d * K,
             "frac_of_f32_mfma_peak": (N * 4 * d * K / (t_round_kernels * 1e-3) / 157.3e12) if t_round_kernels > 0 else 0.0}
         out["kernel_ms_total"] = fam_ms
-    if args.cpu_sample > 0:
+    if args.cpu_sample > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(d, B, K, args.rounds, min(args.cpu_sample, N))
     print(json.dumps(out))
 

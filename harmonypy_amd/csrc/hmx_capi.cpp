@@ -83,6 +83,11 @@ struct hmx_engine {
     // Tables that are summed over ranks live in one allocation, laid out so that tables summed at the
     // same point of the algorithm are neighbours (one collective each):
     //   Sold [nblk][G][K16] | Yacc64 [K16][ldy] | Snew [nblk][G][K16] | objacc [2*SLOTS+2] | Sr [G][K16][ldy] | Oxr [G][K16]
+    DevBuf<double> Sslots;       // k_round: nblk x HMX_ROUND_SLOTS x G x K16
+    DevBuf<unsigned> sync_words; // k_round: {arrival counter, error flag}
+    unsigned* sync_host = nullptr;  // pinned copy of sync_words
+    int n_cus = 0;
+    int round_mode = 1;          // 1: persistent k_round when the shape allows it, 0: one launch per block (HMX_ROUND_MODE=blocks)
     DevBuf<double> xch;
     double *Sold = nullptr, *Yacc64 = nullptr, *Snew = nullptr, *objacc = nullptr, *Sr = nullptr, *Oxr = nullptr;
     double* obj_host = nullptr;  // pinned
@@ -268,6 +273,8 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
     if (cfg->n_clusters > 208) return fail(HMX_ERR_ARG, "n_clusters=%d > 208 not supported by this build", cfg->n_clusters);
     if (cfg->n_pcs > 208) return fail(HMX_ERR_ARG, "n_pcs=%d > 208 not supported by this build", cfg->n_pcs);
     if (cfg->n_cells > (int64_t)2000000000) return fail(HMX_ERR_ARG, "n_cells too large for 32-bit cell ids");
+    if (cfg->n_blocks > 60) return fail(HMX_ERR_ARG, "n_blocks=%d > 60 not supported by this build", cfg->n_blocks);
+    if (cfg->n_vars > 8) return fail(HMX_ERR_ARG, "n_vars=%d > 8 not supported by this build", cfg->n_vars);
     if (cfg->n_cells_global != 0 && (cfg->n_cells_global < cfg->n_cells || cfg->n_cells_global > (int64_t)2000000000))
         return fail(HMX_ERR_ARG, "n_cells_global must lie in [n_cells, 2e9]");
     int ndev = 0;
@@ -280,7 +287,7 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
     e->N = cfg->n_cells; e->d = cfg->n_pcs; e->K = cfg->n_clusters; e->B = cfg->n_batches; e->G = cfg->n_groups;
     e->V = cfg->n_vars; e->nblk = cfg->n_blocks;
     e->Ng = cfg->n_cells_global > 0 ? cfg->n_cells_global : cfg->n_cells;
-    e->dp = (e->d + 3) & ~3;
+    e->dp = round_row_floats(e->d) ? round_row_floats(e->d) : ((e->d + 3) & ~3);   // rows of 32 / 52 / 64 floats feed k_round
     e->Kp = (e->K + 3) & ~3;
     e->mt = (e->K + 15) / 16;
     e->K16 = 16 * e->mt;
@@ -288,9 +295,12 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
     e->ldy = 16 * e->ntd;
     if (const char* ab = getenv("HMX_ABLATE")) e->ablate = atoi(ab);
     if (const char* tpw = getenv("HMX_TILES_PER_WAVE")) e->tiles_per_wave = std::max(1, atoi(tpw));
+    if (const char* rm = getenv("HMX_ROUND_MODE")) e->round_mode = (std::string(rm) == "blocks") ? 0 : 1;
     int rc = 0;
     do {
         if ((rc = use_device(e))) break;
+        (void)hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, cfg->device_id);
+        if (e->n_cus <= 0) e->n_cus = 64;
         hipError_t se = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
         if (se != hipSuccess) { rc = fail(HMX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se)); break; }
         const size_t N = (size_t)e->N, GK = (size_t)e->G * e->K16;
@@ -312,6 +322,12 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
             e->Sr = e->objacc + n_obj;
             e->Oxr = e->Sr + GK * e->ldy;
         }
+        if ((rc = e->Sslots.reserve(GK * e->nblk * HMX_ROUND_SLOTS)) || (rc = e->sync_words.reserve(2))) break;
+        if (hipHostMalloc(reinterpret_cast<void**>(&e->sync_host), 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
+            rc = fail(HMX_ERR_HIP, "hipHostMalloc failed");
+            break;
+        }
+        e->sync_host[0] = e->sync_host[1] = 0;
         if (e->V > 1 && (rc = e->scratch.reserve((size_t)e->K16 * (e->B + 1) * (e->B + 1 + e->d)))) break;
         hipError_t pe = hipHostMalloc(reinterpret_cast<void**>(&e->obj_host), (2 * HMX_OBJ_SLOTS + 2) * sizeof(double), hipHostMallocDefault);
         if (pe != hipSuccess) { rc = fail(HMX_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(pe)); break; }
@@ -344,7 +360,8 @@ void hmx_destroy(hmx_engine* e) {
     e->r_cells.release(); e->r_tile_grp.release(); e->r_blk_start.release(); e->task_t0.release(); e->task_t1.release();
     e->task_grp.release(); e->gstart.release(); e->chunk_tab.release(); e->run_count.release(); e->run_start.release();
     e->Ogrp.release(); e->Tmass.release(); e->Ohist.release(); e->xch.release(); e->scratch.release();
-    e->global_id.release();
+    e->global_id.release(); e->Sslots.release(); e->sync_words.release();
+    if (e->sync_host) (void)hipHostFree(e->sync_host);
     comm_release(e);
     if (e->stage_host) (void)hipHostFree(e->stage_host);
     if (e->obj_host) (void)hipHostFree(e->obj_host);
@@ -498,7 +515,72 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         Timed t(e, F_RTZ_REDUCE);
         launch_y_normalize_d(e->Yacc64, e->Y.p, e->K, e->K16, e->d, e->ldy, e->stream);  // :444
     }
-    if (flags & HMX_ROUND_UPDATE_R) {
+    const bool mega = (flags & HMX_ROUND_UPDATE_R) && e->round_mode == 1 && !sharded(e) && e->mt <= 7 && round_row_floats(e->d) == e->dp &&
+                      round_lds_bytes(e->K16, e->dp, e->G, e->B) <= 150 * 1024;
+    if (mega) {
+        // the whole sweep in one persistent launch (k_round); closes O, T and the objective itself
+        HIP_TRY(hipMemsetAsync(e->Sslots.p, 0, GK * e->nblk * HMX_ROUND_SLOTS * sizeof(double), e->stream));
+        HIP_TRY(hipMemsetAsync(e->sync_words.p, 0, 2 * sizeof(unsigned), e->stream));
+        int max_upper = 0;
+        for (int b = 0; b < e->nblk; ++b) max_upper = std::max(max_upper, tiles_upper[b]);
+        const int wgs = std::min(e->n_cus, std::max(1, (max_upper + 13) / 14));   // ~14 of a workgroup's 16 tile slots
+        Timed t(e, F_ASSIGN_BLOCK);
+        RoundArgs ra{};
+        ra.Zcos = e->Zcos.p; ra.Y = e->Y.p; ra.sigma = e->sigma.p; ra.R = e->R.p;
+        ra.cells = e->r_cells.p; ra.tile_grp = e->r_tile_grp.p; ra.blk_start = e->r_blk_start.p;
+        ra.O_start = e->Ogrp.p; ra.S_old = e->Sold; ra.S_new = e->Sslots.p; ra.O_out = e->Ogrp.p; ra.T_out = e->Tmass.p;
+        ra.obj = e->objacc; ra.group_cols = e->group_cols.p; ra.Pr_b = e->Pr_b.p; ra.theta = e->theta.p;
+        ra.counter = e->sync_words.p; ra.error = e->sync_words.p + 1;
+        ra.K = e->K; ra.Kp = e->Kp; ra.K16 = e->K16; ra.dp = e->dp; ra.ldy = e->ldy; ra.G = e->G; ra.B = e->B; ra.V = e->V;
+        ra.nblk = e->nblk;
+#ifdef HMX_ROUND_PROF
+        static DevBuf<unsigned long long> prof;
+        static int prof_rounds = 0;
+        if (prof.reserve((size_t)wgs * e->nblk * 16)) return -1;
+        ra.prof = prof.p;
+#endif
+        if (launch_round(ra, e->mt, wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported shape for k_round");
+#ifdef HMX_ROUND_PROF
+        if (++prof_rounds == 25) {   // one round in steady state: phase durations over workgroups and blocks
+            std::vector<unsigned long long> h((size_t)wgs * e->nblk * 16);
+            (void)hipStreamSynchronize(e->stream);
+            (void)hipMemcpy(h.data(), prof.p, h.size() * 8, hipMemcpyDeviceToHost);
+            const char* names[5] = {"wait", "table", "post", "flush+arrive", "pre(next)"};
+            for (int ph = 0; ph < 5; ++ph) {
+                double sum = 0, mx = 0;
+                for (int w = 0; w < wgs; ++w)
+                    for (int b = 0; b < e->nblk; ++b) {
+                        const double dtk = (double)(h[((size_t)w * e->nblk + b) * 16 + ph + 1] - h[((size_t)w * e->nblk + b) * 16 + ph]);
+                        sum += dtk; mx = std::max(mx, dtk);
+                    }
+                fprintf(stderr, "[k_round prof] %-14s mean %.0f ticks  max %.0f\n", names[ph], sum / (wgs * e->nblk), mx);
+            }
+            double tot = 0;
+            for (int w = 0; w < wgs; ++w) tot += (double)(h[((size_t)w * e->nblk + e->nblk - 1) * 16 + 5] - h[(size_t)w * e->nblk * 16]);
+            {
+                double s1 = 0, s2 = 0, s3 = 0;
+                for (int w = 0; w < wgs; ++w)
+                    for (int b = 0; b < e->nblk; ++b) {
+                        const unsigned long long* r = &h[((size_t)w * e->nblk + b) * 16];
+                        s1 += (double)(r[6] - r[1]); s2 += (double)(r[7] - r[6]); s3 += (double)(r[2] - r[7]);
+                    }
+                fprintf(stderr, "[k_round prof] table split: O update %.0f, pow %.0f, rp/log %.0f\n", s1 / (wgs * e->nblk), s2 / (wgs * e->nblk), s3 / (wgs * e->nblk));
+            }
+            {
+                double s1 = 0, s2 = 0, s3 = 0, sp = 0;
+                for (int w = 0; w < wgs; ++w)
+                    for (int b = 1; b < e->nblk; ++b) {
+                        const unsigned long long* r = &h[((size_t)w * e->nblk + b) * 16];
+                        s1 += (double)(r[8] - r[0]); s2 += (double)(r[9] - r[8]); s3 += (double)(r[1] - r[9]); sp += (double)r[10];
+                    }
+                const double n = (double)wgs * (e->nblk - 1);
+                fprintf(stderr, "[k_round prof] wait split: gather issue %.0f, poll %.0f (%.1f spins), syncthreads %.0f\n", s1 / n, s2 / n, sp / n, s3 / n);
+            }
+            fprintf(stderr, "[k_round prof] whole sweep mean %.0f ticks over %d workgroups\n", tot / wgs, wgs);
+        }
+#endif
+        HIP_TRY(hipMemcpyAsync(e->sync_host, e->sync_words.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+    } else if (flags & HMX_ROUND_UPDATE_R) {
         for (int b = 0; b < e->nblk; ++b) {
             {
                 Timed t(e, F_BLOCK_TABLE);
@@ -531,7 +613,12 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         if (flags & HMX_ROUND_OBJECTIVE) ta.obj_cross = e->objacc + 2 * HMX_OBJ_SLOTS;
         launch_block_table(ta, e->K16, e->stream);
     }
-    return read_objective(e, obj_out);
+    rc = read_objective(e, obj_out);
+    if (rc == 0 && mega && e->sync_host[1] != 0) {
+        e->sync_host[1] = 0;
+        return fail(HMX_ERR_STATE, "k_round: a grid-wide wait timed out (workgroups not co-resident?); set HMX_ROUND_MODE=blocks");
+    }
+    return rc;
 }
 
 static int check_round_flags(hmx_engine* e, int flags, double* obj_out) {

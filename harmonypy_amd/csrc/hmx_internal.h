@@ -27,6 +27,32 @@ struct AssignArgs {
     int G, ldy_lds, tables_in_lds, tiles_per_wave, ablate;
 };
 
+#define HMX_ROUND_SLOTS 4 /* k_round: a block's new sums are spread over this many fp64 tables */
+
+// One whole update_R sweep (all blocks) in one persistent launch (k_round).
+struct RoundArgs {
+    const float* Zcos;       // N x dp
+    const float* Y;          // K16 x ldy
+    const float* sigma;      // K16
+    float* R;                // N x Kp
+    const int* cells;        // block-major padded list
+    const int* tile_grp;
+    const int* blk_start;    // nblk+1 tile offsets (device)
+    const double* O_start;   // G x K16: O at the start of the round
+    const double* S_old;     // nblk x G x K16: removal sums of every block (from the old R)
+    double* S_new;           // nblk x HMX_ROUND_SLOTS x G x K16, zeroed by the caller
+    double* O_out;           // G x K16: O after the round
+    double* T_out;           // K16: cluster mass after the round
+    double* obj;             // HMX_OBJ_SLOTS x 2 partial sums + cross-entropy term at [2*HMX_OBJ_SLOTS]
+    const int* group_cols;   // G x V
+    const float* Pr_b;
+    const float* theta;
+    unsigned* counter;       // arrivals (zeroed by the caller)
+    unsigned* error;         // set to 1 when a wait gave up (zeroed by the caller)
+    unsigned long long* prof;  // HMX_ROUND_PROF builds: wgs x nblk x 8 time stamps (or null)
+    int K, Kp, K16, dp, ldy, ldy_lds, G, B, V, nblk;
+};
+
 struct RtzArgs {
     const float* R;        // N x Kp
     const float* Z;        // N x dp
@@ -98,6 +124,9 @@ struct OrderArgs {
     int* tile_grp;
 };
 
+size_t round_lds_bytes(int K16, int dp, int G, int B);
+int round_row_floats(int d);
+int launch_round(const RoundArgs& a, int mt, int wgs, hipStream_t s);
 void launch_order(const OrderArgs& a, hipStream_t s);
 int order_chunks(int64_t N);
 void launch_normalize_rows(const float* Z, float* Zc, int64_t N, int dp, hipStream_t s);

@@ -510,6 +510,563 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES, 4) void k_assign_lds(AssignArgs 
 }
 
 // ------------------------------------------------------------------------------------------
+// k_round: one whole update_R sweep (harmony.py:464-513, all blocks) in ONE persistent launch.
+//
+// The blocks of a sweep are strictly sequential -- block b needs O and E with the new sums of
+// block b-1 put back (harmony.py:491-507) -- but only through a K x B table; everything else a
+// cell needs (its Z_cos row, the distance GEMM against Y, exp and the first normalisation,
+// harmony.py:447, 466-468) does not depend on that table.  So:
+//   * one workgroup of 8 waves per CU stays resident for the whole sweep; Y, sigma live in LDS;
+//   * block b's tiles are dealt round-robin over the workgroups, two tiles per wave; the
+//     table-independent half of a tile ("pre": gather, MFMA, exp-sum; the exponent arguments
+//     stay in 4*MT registers per tile) runs BEFORE the wave waits for block b-1 to complete,
+//     i.e. it overlaps the grid-wide hand-off;
+//   * hand-off: every workgroup adds its block sums to one of HMX_ROUND_SLOTS fp64 tables with
+//     agent-scope atomics, drains them (s_waitcnt vmcnt(0)), and one lane bumps an arrival
+//     counter; consumers poll the counter with relaxed agent-scope loads and read the tables
+//     with agent-scope atomic loads -- 8-byte agent atomics on both sides, so no cache
+//     write-back / invalidate is needed (cdna_hip_programming.md, Guideline 16);
+//   * every workgroup then rebuilds the block's diversity table itself (k_block_table's
+//     arithmetic: O, E = T Pr_b, clamp, pow, log) in LDS and finishes its tiles ("post":
+//     penalty, renormalisation, R row store, new block sums, objective terms).
+// Waits are bounded: a workgroup that is not resident would otherwise hang the grid; on timeout
+// a.error is set and the host reports it.
+// ------------------------------------------------------------------------------------------
+#ifndef HMX_RABL
+#define HMX_RABL 0   /* timing experiments only: 1 no block sums, 2 no R store, 4 no exp in round_post */
+#endif
+#ifdef HMX_ROUND_PROF   /* timing experiments only: per-workgroup phase stamps (s_memtime) */
+#define RSTAMP(slot) do { if (tid == 0 && a.prof) a.prof[((size_t)wg * a.nblk + b) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RSTAMP(slot) do { } while (0)
+#endif
+#define ROUND_WAVES 8   /* 2 waves per SIMD: 256 registers per lane, two tiles in flight per wave */
+#define ROUND_TPW 2     /* tiles a wave carries across the hand-off */
+#define ROUND_THREADS (64 * ROUND_WAVES)
+
+__device__ __forceinline__ double ld_agent(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// KS = row length of Z_cos in 4-float k-steps (dp = 4 KS).  Lane (c16, q) takes the 16-byte pieces
+// q, q+4, .. of its cell's row -- piece j is exactly the B operand of the four k-steps of column
+// block j -- plus one float per tail k-step.  The matching A operands come from the centroid
+// table in LDS.
+template <int KS>
+struct RoundZ {
+    static constexpr int NF = KS / 4, NT = KS % 4;
+    f32x4 zp[NF > 0 ? NF : 1];
+    float zt[NT > 0 ? NT : 1];
+};
+template <int MT>
+struct RoundTile {
+    f32x4 arg[MT];   // -dist / sigma (:447, :466); round_post_pass1 turns it into exp(arg) * ratio^theta in place
+    int cell, grp;
+};
+
+__device__ __forceinline__ void wg_barrier_lds() {
+    // workgroup barrier that orders LDS traffic only: global loads already in flight (the next
+    // block's operands) keep travelling instead of being drained as __syncthreads() would
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// issue the loads of a tile's Z_cos rows.  Dead lanes (cell < 0: list padding, or no tile at
+// all) read cell 0's row: their results are finite and are multiplied by zero later.
+template <int KS>
+__device__ __forceinline__ void round_issue_z(const float* __restrict__ Zcos, int cell, int q, RoundZ<KS>& Z) {
+    constexpr int NF = KS / 4, NT = KS % 4;
+    const float* zr = Zcos + (size_t)(cell >= 0 ? cell : 0) * (4 * KS);
+#pragma unroll
+    for (int j = 0; j < NF; ++j) Z.zp[j] = ld4(zr + 16 * j + 4 * q);
+#pragma unroll
+    for (int s = 0; s < NT; ++s) Z.zt[s] = zr[16 * NF + 4 * s + q];
+}
+
+// table-independent half of a tile: distance GEMM against the LDS-resident centroids -> exponent arguments
+template <int MT, int KS>
+__device__ __forceinline__ void round_compute(const float* Ys, const float* nis, int LDY, int c16, int q,
+                                              const RoundZ<KS>& Z, RoundTile<MT>& T) {
+    constexpr int NF = KS / 4, NT = KS % 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) T.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 ya = ld4(Ys + (size_t)(16 * mt + c16) * LDY + 16 * j + 4 * q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) T.arg[mt] = MFMA16(ya[i], Z.zp[j][i], T.arg[mt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the centroid fragments of one column block live at a time
+    }
+#pragma unroll
+    for (int s = 0; s < NT; ++s) {
+        const int col = 16 * NF + 4 * s + q;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) T.arg[mt] = MFMA16(Ys[(size_t)(16 * mt + c16) * LDY + col], Z.zt[s], T.arg[mt]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const f32x4 ni = ld4(nis + 16 * mt + 4 * q);
+        const f32x4 one = (f32x4){1.f, 1.f, 1.f, 1.f};
+        T.arg[mt] = (2.f * (one - T.arg[mt])) * ni;          // dist = 2 (1 - Y.Z) (:447), arg = -dist / sigma (:466)
+    }
+}
+
+// table-dependent half: exp, penalty, renormalisation, R row, block sums, objective terms.
+// With ex = exp(arg), e1 = sum ex (:467-468), t = ex * ratio^theta (:500) and U = sum t:
+//   R = (t / e1) / max(U / e1, 1e-8) = t / max(U, 1e-8 e1)                         (:501-503)
+//   sum R dist          = -scl sum t sigma arg,                  scl = 1 / max(U, 1e-8 e1)   (:399, dist = -arg sigma)
+//   sum sigma R log R   =  scl [sum t sigma arg + sum t sigma log(ratio^theta) - log(max(U, 1e-8 e1)) sum t sigma]   (:402)
+// so ONE exp per entry and one pass over the exponent arguments yields everything; t replaces
+// arg in place.  The arithmetic is written on pairs so that it maps to v_pk_* instructions.
+// Padded clusters carry arg = -120 (exp underflows to an exact 0) and sigma 0.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float fast_exp_finite(float x) {   // fast_exp without the clamp: finite arguments only
+    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f;
+    const float th = x * L2E_HI;
+    const float tl = fmaf(x, L2E_LO, fmaf(x, L2E_HI, -th));
+    const float p = __builtin_amdgcn_exp2f(th);
+    return fmaf(p, tl * 0.693147182464599609375f, p);
+}
+#ifndef HMX_PACKED
+#define HMX_PACKED 0
+#endif
+__device__ __forceinline__ f32x2 fast_exp2(f32x2 x) {   // fast_exp on a pair, finite arguments only
+    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f;
+    const f32x2 th = x * L2E_HI;
+    f32x2 tl = __builtin_elementwise_fma(x, (f32x2){L2E_HI, L2E_HI}, -th);
+    tl = __builtin_elementwise_fma(x, (f32x2){L2E_LO, L2E_LO}, tl);
+    f32x2 p;
+    p.x = __builtin_amdgcn_exp2f(th.x);
+    p.y = __builtin_amdgcn_exp2f(th.y);
+    return __builtin_elementwise_fma(p, tl * 0.693147182464599609375f, p);
+}
+
+template <int MT>
+__device__ __forceinline__ void round_post_pass1(const float* sig, const float* rpT, const float* lrpT, int q,
+                                                 RoundTile<MT>& T, float& scl, double& km_acc, double& ent_acc) {
+    constexpr int K16 = 16 * MT;
+    const float* rp = rpT + (size_t)T.grp * K16;
+    const float* lrp = lrpT + (size_t)T.grp * K16;
+#if HMX_PACKED
+    f32x2 e1v = {0.f, 0.f}, uv = {0.f, 0.f}, a1v = {0.f, 0.f}, a2v = {0.f, 0.f}, a3v = {0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const f32x4 pw = ld4(rp + 16 * mt + 4 * q);
+        const f32x4 lp = ld4(lrp + 16 * mt + 4 * q);
+        const f32x4 sg = ld4(sig + 16 * mt + 4 * q);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x2 arg = h ? T.arg[mt].zw : T.arg[mt].xy;
+            const f32x2 pwh = h ? pw.zw : pw.xy, lph = h ? lp.zw : lp.xy, sgh = h ? sg.zw : sg.xy;
+            const f32x2 ex = fast_exp2(arg);                 // :467
+            e1v += ex;
+            const f32x2 t = ex * pwh;                        // :500 (the 1/e1 of :468 cancels, see above)
+            const f32x2 ts = t * sgh;
+            uv += t;
+            a1v = __builtin_elementwise_fma(ts, arg, a1v);
+            a2v = __builtin_elementwise_fma(ts, lph, a2v);
+            a3v += ts;
+            if (h) T.arg[mt].zw = t; else T.arg[mt].xy = t;
+        }
+    }
+    const float e1 = wave_sum_q(e1v.x + e1v.y);            // column sum of :468
+    const float us = wave_sum_q(uv.x + uv.y);
+    const float a1 = a1v.x + a1v.y, a2 = a2v.x + a2v.y, a3 = a3v.x + a3v.y;
+#else
+    float e1 = 0.f, us = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const f32x4 pw = ld4(rp + 16 * mt + 4 * q);
+        const f32x4 lp = ld4(lrp + 16 * mt + 4 * q);
+        const f32x4 sg = ld4(sig + 16 * mt + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float arg = T.arg[mt][r];
+#if HMX_RABL & 4
+            const float ex = arg * 0.001f + 1.0f;
+#else
+            const float ex = fast_exp_finite(arg);           // :467
+#endif
+            e1 += ex;
+            const float t = ex * pw[r];                      // :500 (the 1/e1 of :468 cancels, see above)
+            const float ts = t * sg[r];
+            us += t;
+            a1 = fmaf(ts, arg, a1);
+            a2 = fmaf(ts, lp[r], a2);
+            a3 += ts;
+            T.arg[mt][r] = t;
+        }
+    }
+    e1 = wave_sum_q(e1);                                   // column sum of :468
+    us = wave_sum_q(us);
+#endif
+    const float den = fmaxf(us, 1e-8f * e1);               // e1 * max(sum R_new, 1e-8)   (:501-502)
+    scl = (T.cell >= 0) ? 1.0f / den : 0.f;                // dead lanes (list padding) contribute exact zeros
+    km_acc -= (double)(scl * a1);
+    ent_acc += (double)(scl * (a1 + a2 - logf(den) * a3));
+}
+
+// second pass for the two tiles a wave carries: R rows out, sums over the 16 cells of a tile into
+// the block's (group, cluster) table.  Tiles of one group (the usual case: a wave's tiles are
+// neighbours in the block's group-sorted list) share one cross-lane reduction.
+template <int MT>
+__device__ __forceinline__ void round_post_pass2(const RoundArgs& a, double* Sd, int c16, int q, const RoundTile<MT>& T0,
+                                                 float scl0, bool has1, const RoundTile<MT>& T1, float scl1) {
+    constexpr int K16 = 16 * MT;
+    const bool live0 = T0.cell >= 0, live1 = has1 && T1.cell >= 0;
+    float* row0 = a.R + (size_t)(live0 ? T0.cell : 0) * a.Kp;
+    float* row1 = a.R + (size_t)(live1 ? T1.cell : 0) * a.Kp;
+    const bool joint = has1 && T1.grp == T0.grp;           // wave-uniform
+    double* sd0 = Sd + (size_t)T0.grp * K16;
+    double* sd1 = Sd + (size_t)T1.grp * K16;
+    if (!has1) scl1 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int col = 16 * mt + 4 * q;
+        const f32x4 rv0 = T0.arg[mt] * scl0;               // :503
+        const f32x4 rv1 = T1.arg[mt] * scl1;
+#if !(HMX_RABL & 2)
+        if (live0 && col < a.Kp) st4(row0 + col, rv0);
+        if (live1 && col < a.Kp) st4(row1 + col, rv1);
+#endif
+#if !(HMX_RABL & 1)
+        if (joint) {
+            const f32x4 sm = rv0 + rv1;
+            f32x4 ss;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ss[r] = row16_sum(sm[r]);      // (:506-507)
+            if (c16 == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(sd0 + col + r, (double)ss[r]);
+            }
+        } else {
+            f32x4 s0, s1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s0[r] = row16_sum(rv0[r]);
+                s1[r] = row16_sum(rv1[r]);
+            }
+            if (c16 == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    atomicAdd(sd0 + col + r, (double)s0[r]);
+                    if (has1) atomicAdd(sd1 + col + r, (double)s1[r]);
+                }
+            }
+        }
+#endif
+    }
+}
+
+template <int MT, int KS>
+__global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int K16 = 16 * MT;
+    constexpr int NF = KS / 4, NT = KS % 4;
+    const int GK = a.G * K16;
+    const int LDY = a.ldy_lds;
+    float* Ys0 = reinterpret_cast<float*>(smem);                         // K16 x LDY
+    float* sig0 = Ys0 + (size_t)K16 * LDY;                               // K16
+    float* nis0 = sig0 + K16;                                            // K16  -1/sigma (-1e30 for pads)
+    float* sig = sig0;
+    float* nis = nis0;
+    float* rpT = nis + K16;                                              // G x K16
+    float* lrpT = rpT + GK;                                              // G x K16
+    float* rpc = lrpT + GK;                                              // B x K16 powered ratios
+    double* Ocur = reinterpret_cast<double*>(rpc + (size_t)K16 * a.B);   // G x K16 (all offsets so far are even)
+    double* Sd = Ocur + GK;                                              // G x K16 this block's new sums
+    double* Tm = Sd + GK;                                                // K16 cluster mass
+    double* objw = Tm + K16;                                             // waves x 2
+    float* prb = reinterpret_cast<float*>(objw + 2 * ROUND_WAVES);       // B
+    float* tht = prb + a.B;                                              // B
+    int* gcol = reinterpret_cast<int*>(tht + a.B);                       // G x V
+    int* bgrp = gcol + a.G * a.V;                                        // B: the group holding batch b (V == 1)
+    int* bs = bgrp + a.B;                                                // nblk + 3 tile offsets (two sentinels)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int c16 = lane & 15, q = lane >> 4;
+    const int wg = blockIdx.x, nwg = gridDim.x;
+
+    for (int i = tid; i < a.B; i += ROUND_THREADS) {
+        prb[i] = a.Pr_b[i];
+        tht[i] = a.theta[i];
+    }
+    for (int i = tid; i < a.G * a.V; i += ROUND_THREADS) {
+        gcol[i] = a.group_cols[i];
+        if (a.V == 1) bgrp[a.group_cols[i]] = i;
+    }
+    for (int i = tid; i < a.nblk + 3; i += ROUND_THREADS) bs[i] = a.blk_start[min(i, a.nblk)];
+    for (int i = tid; i < K16; i += ROUND_THREADS) {
+        const float sgm = (i < a.K) ? a.sigma[i] : 0.f;
+        sig[i] = sgm;
+        nis[i] = (i < a.K) ? -1.0f / sgm : -60.f;   // pads: Y row 0 -> dist 2 -> arg -120 -> exp == 0
+    }
+    for (int i = tid; i < GK; i += ROUND_THREADS) Ocur[i] = a.O_start[i];
+    for (int i = tid; i < K16 * KS; i += ROUND_THREADS) {
+        const int row = i / KS, c4 = i - row * KS;
+        st4(Ys0 + (size_t)row * LDY + 4 * c4, ld4(a.Y + (size_t)row * a.ldy + 4 * c4));
+    }
+    __syncthreads();
+    (void)NF; (void)NT;
+
+    RoundTile<MT> T[ROUND_TPW];
+    RoundZ<KS> Z[ROUND_TPW];
+    int cell1[ROUND_TPW], grp1[ROUND_TPW];   // ids of block b+1's tiles (landed)
+    int cell2[ROUND_TPW], grp2[ROUND_TPW];   // ids of block b+2's tiles (travelling)
+    double km_acc = 0.0, ent_acc = 0.0;
+    bool failed = false;
+    // tiles 2p, 2p+1 of a block go to workgroup p % nwg, wave (p / nwg) % WAVES (pass p / nwg / WAVES)
+    const int j_first = ROUND_TPW * (wg + nwg * wv);
+    const int j_slot = ROUND_TPW * nwg * ROUND_WAVES;
+    auto load_ids = [&](int blk, int u, int& cell, int& grp) {   // blk may run past the last block: bs[] has sentinels
+        const int j = j_first + u;
+        const int t0 = bs[blk], t1 = bs[blk + 1];
+        const bool valid = j < t1 - t0;
+        cell = valid ? a.cells[(size_t)(t0 + j) * 16 + c16] : -1;
+        grp = valid ? a.tile_grp[t0 + j] : 0;
+    };
+
+    const float* Ys = Ys0;
+    // ---- prologue: block 0 computed, block 1's ids landed ---------------------------------------
+#pragma unroll
+    for (int u = 0; u < ROUND_TPW; ++u) {
+        load_ids(0, u, T[u].cell, T[u].grp);
+        load_ids(1, u, cell1[u], grp1[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < ROUND_TPW; ++u) round_issue_z<KS>(a.Zcos, T[u].cell, q, Z[u]);
+#pragma unroll
+    for (int u = 0; u < ROUND_TPW; ++u) {
+        round_compute<MT, KS>(Ys, nis, LDY, c16, q, Z[u], T[u]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    for (int b = 0; b < a.nblk; ++b) {
+        const int tb = bs[b], ntl = bs[b + 1] - tb;
+        {   // the tables do not change, but re-reading them every block is cheaper than the ~150
+            // registers the compiler would spend keeping their fragments live across the sweep
+            int zero = 0;
+            asm volatile("" : "+v"(zero));
+            Ys = Ys0 + zero;
+            sig = sig0 + zero;
+            nis = nis0 + zero;
+        }
+        RSTAMP(0);
+        // ---- operands of the following blocks start travelling: Z_cos rows of block b+1 (ids known),
+        //      ids of block b+2.  Nothing below waits for them before round_compute.
+#pragma unroll
+        for (int u = 0; u < ROUND_TPW; ++u) {
+            round_issue_z<KS>(a.Zcos, cell1[u], q, Z[u]);
+            load_ids(b + 2, u, cell2[u], grp2[u]);
+        }
+        RSTAMP(8);
+        // ---- wait until every workgroup has added its sums of block b-1 ---------------------
+        if (b > 0 && wv == 0) {
+            const unsigned want = (unsigned)b * (unsigned)nwg;
+            unsigned spins = 0;
+            while (ld_agent(a.counter) < want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 24)) { failed = true; break; }
+            }
+#ifdef HMX_ROUND_PROF
+            if (tid == 0 && a.prof) a.prof[((size_t)wg * a.nblk + b) * 16 + 10] = spins;
+#endif
+        }
+        RSTAMP(9);
+        wg_barrier_lds();
+        RSTAMP(1);
+        // ---- O without this block, with the previous block's new sums (:491-492, 506-507) ---
+        for (int i = tid; i < GK; i += ROUND_THREADS) {
+            double add[HMX_ROUND_SLOTS];
+            if (b > 0 && !(HMX_RABL & 8)) {
+                const double* sn = a.S_new + (size_t)(b - 1) * HMX_ROUND_SLOTS * GK + i;
+#pragma unroll
+                for (int s = 0; s < HMX_ROUND_SLOTS; ++s) add[s] = ld_agent(sn + (size_t)s * GK);   // independent loads
+            } else {
+#pragma unroll
+                for (int s = 0; s < HMX_ROUND_SLOTS; ++s) add[s] = 0.0;
+            }
+            double o = Ocur[i] - a.S_old[(size_t)b * GK + i];
+#pragma unroll
+            for (int s = 0; s < HMX_ROUND_SLOTS; ++s) o += add[s];
+            Ocur[i] = o;
+            Sd[i] = 0.0;
+        }
+        wg_barrier_lds();
+        RSTAMP(6);
+        // ---- cluster mass, then ratio ** theta per (batch, cluster)  (:491, 495-499) ----------
+        for (int k = tid; k < K16; k += ROUND_THREADS) {
+            double t = 0.0;
+            for (int g = 0; g < a.G; ++g) t += Ocur[(size_t)g * K16 + k];
+            Tm[k] = t;
+        }
+        wg_barrier_lds();
+        for (int i = tid; i < K16 * a.B; i += ROUND_THREADS) {
+            const int bb = i / K16, k = i - bb * K16;
+            double Ob;
+            if (a.V == 1) {
+                Ob = Ocur[(size_t)bgrp[bb] * K16 + k];
+            } else {
+                Ob = 0.0;
+                for (int g = 0; g < a.G; ++g) {
+                    bool has = false;
+                    for (int v = 0; v < a.V; ++v) has |= gcol[g * a.V + v] == bb;
+                    if (has) Ob += Ocur[(size_t)g * K16 + k];
+                }
+            }
+            const float O = (float)Ob;
+            const float E = (float)Tm[k] * prb[bb];                     // :491 (E kept as mass T)
+            const float oe = fmaxf(O + E, 1e-8f);                       // :495-496
+            const float ratio = fminf(fmaxf(E / oe, 1e-8f), 1.0f);      // :497-498
+#if HMX_RABL & 16
+            rpc[i] = ratio * tht[bb];
+#else
+            rpc[i] = powf(ratio, tht[bb]);                              // :499
+#endif
+        }
+        wg_barrier_lds();
+        RSTAMP(7);
+        for (int i = tid; i < GK; i += ROUND_THREADS) {
+            const int g = i / K16, k = i - g * K16;
+            float s = 0.f;
+            for (int v = 0; v < a.V; ++v) s += rpc[(size_t)gcol[g * a.V + v] * K16 + k];
+            rpT[i] = s;                                                 // (ratio_pow @ Phi) for the cells of group g
+#if HMX_RABL & 16
+            lrpT[i] = s - 1.0f;
+#else
+            lrpT[i] = logf(s);
+#endif
+        }
+        wg_barrier_lds();
+        RSTAMP(2);
+        // ---- finish this block's tiles --------------------------------------------------------
+        if (j_first < ntl) {
+            float scl0, scl1 = 0.f;
+            const bool has1 = j_first + 1 < ntl;
+            round_post_pass1<MT>(sig, rpT, lrpT, q, T[0], scl0, km_acc, ent_acc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has1) round_post_pass1<MT>(sig, rpT, lrpT, q, T[1], scl1, km_acc, ent_acc);
+            __builtin_amdgcn_sched_barrier(0);
+            round_post_pass2<MT>(a, Sd, c16, q, T[0], scl0, has1, T[1], scl1);
+        }
+        for (int j = j_first + j_slot; j < ntl; j += j_slot) {   // blocks larger than the grid carries
+#pragma unroll 1
+            for (int u = 0; u < ROUND_TPW; ++u) {
+                if (j + u >= ntl) break;
+                RoundTile<MT> X;
+                RoundZ<KS> XZ;
+                X.cell = a.cells[(size_t)(tb + j + u) * 16 + c16];
+                X.grp = a.tile_grp[tb + j + u];
+                round_issue_z<KS>(a.Zcos, X.cell, q, XZ);
+                round_compute<MT, KS>(Ys, nis, LDY, c16, q, XZ, X);
+                float sclx;
+                round_post_pass1<MT>(sig, rpT, lrpT, q, X, sclx, km_acc, ent_acc);
+                round_post_pass2<MT>(a, Sd, c16, q, X, sclx, false, X, 0.f);
+            }
+        }
+        wg_barrier_lds();
+        RSTAMP(3);
+        // ---- publish the block's new sums, then arrive ---------------------------------------
+        {
+            double* dst = a.S_new + ((size_t)b * HMX_ROUND_SLOTS + (wg % HMX_ROUND_SLOTS)) * GK;
+            for (int i = tid; i < GK; i += ROUND_THREADS) {
+                const double v = Sd[i];
+                if (v != 0.0) atomicAdd(dst + i, v);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the sums are performed (and the next operands landed)
+        wg_barrier_lds();
+        if (tid == 0) __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        RSTAMP(4);
+        // ---- table-independent half of the next block's tiles: overlaps the hand-off ----------
+#pragma unroll
+        for (int u = 0; u < ROUND_TPW; ++u) {
+            T[u].cell = cell1[u];
+            T[u].grp = grp1[u];
+            cell1[u] = cell2[u];
+            grp1[u] = grp2[u];
+        }
+        if (b + 1 < a.nblk) {
+#pragma unroll
+            for (int u = 0; u < ROUND_TPW; ++u) {
+                round_compute<MT, KS>(Ys, nis, LDY, c16, q, Z[u], T[u]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        RSTAMP(5);
+    }
+
+    // ---- objective partial sums (:399, :402) ----------------------------------------------------
+    km_acc = wave_sum_all(km_acc);
+    ent_acc = wave_sum_all(ent_acc);
+    if (lane == 0) {
+        objw[2 * wv] = km_acc;
+        objw[2 * wv + 1] = ent_acc;
+    }
+    __syncthreads();
+    if (tid < 2) {
+        double v = 0.0;
+        for (int w = 0; w < ROUND_WAVES; ++w) v += objw[2 * w + tid];
+        if (v != 0.0) atomicAdd(&a.obj[2 * (wg & (HMX_OBJ_SLOTS - 1)) + tid], v);
+    }
+    if (failed && tid == 0) atomicExch(a.error, 1u);
+    if (wg != 0) return;
+
+    // ---- workgroup 0 closes the sweep: O, cluster mass, cross-entropy term (:405-411) -----------
+    if (wv == 0) {
+        const unsigned want = (unsigned)a.nblk * (unsigned)nwg;
+        unsigned spins = 0;
+        while (ld_agent(a.counter) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 24)) { if (lane == 0) atomicExch(a.error, 1u); break; }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < GK; i += ROUND_THREADS) {
+        double o = Ocur[i];
+        const double* sn = a.S_new + (size_t)(a.nblk - 1) * HMX_ROUND_SLOTS * GK + i;
+#pragma unroll
+        for (int s = 0; s < HMX_ROUND_SLOTS; ++s) o += ld_agent(sn + (size_t)s * GK);
+        Ocur[i] = o;
+        a.O_out[i] = o;
+    }
+    __syncthreads();
+    double part = 0.0;
+    for (int i = tid; i < K16 * a.B; i += ROUND_THREADS) {
+        const int bb = i / K16, k = i - bb * K16;
+        double Tk = 0.0, Ob = 0.0;
+        for (int g = 0; g < a.G; ++g) {
+            const double o = Ocur[(size_t)g * K16 + k];
+            Tk += o;
+            bool has = false;
+            for (int v = 0; v < a.V; ++v) has |= gcol[g * a.V + v] == bb;
+            if (has) Ob += o;
+        }
+        if (bb == 0) a.T_out[k] = Tk;
+        const float O = (float)Ob;
+        const float Oc = fmaxf(O, 1e-8f);                               // :407
+        const float Ec = fmaxf((float)Tk * prb[bb], 1e-8f);             // :408
+        const float tl = tht[bb] * logf((Oc + Ec) / Ec);                // :409-410
+        part += (double)(sig[k] * O * tl);
+    }
+    part = wave_sum_all(part);
+    if (lane == 0) objw[wv] = part;
+    __syncthreads();
+    if (tid == 0) {
+        double v = 0.0;
+        for (int w = 0; w < ROUND_WAVES; ++w) v += objw[w];
+        atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS], v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // R^T . Z over a list of cells:  out[cluster][pc] += sum_cells R[cell][cluster] * Z[cell][pc]
 //   - centroid numerator  Z_cos R^T        (harmony.py:443), whole round list, one output
 //   - block removal sums  R_blk Phi_blk^T  (harmony.py:491-492) as per-(block, group) column sums
@@ -1183,6 +1740,53 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
         else hipLaunchKernelGGL((k_assign<13, NT, false>), dim3(wgs), dim3(256), 0, s, a);
     } else {
         return -1;
+    }
+    return 0;
+}
+
+size_t round_lds_bytes(int K16, int dp, int G, int B) {
+    const size_t GK = (size_t)G * K16;
+    // sigma, -1/sigma, rp, lrp, rpc | O, S, T, objective scratch (fp64) | Pr_b, theta, group_cols (V <= 8), bgrp, block offsets
+    return ((size_t)K16 * lds_ldy(dp) + 2 * (size_t)K16 + 2 * GK + (size_t)K16 * B) * 4 + (2 * GK + K16 + 2 * ROUND_WAVES) * 8 +
+           (3 * (size_t)B + (size_t)G * 8 + 64) * 4;
+}
+
+// k_round is compiled for Z_cos rows of 32, 52 and 64 floats (d <= 32, <= 52, <= 64: the engine pads
+// its rows to the next of these) and 1..7 cluster tiles.
+int round_row_floats(int d) { return d <= 32 ? 32 : d <= 52 ? 52 : d <= 64 ? 64 : 0; }
+
+template <int MT, int KS>
+static void launch_round_t(const RoundArgs& a, int wgs, size_t sm, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_round<MT, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_round<MT, KS>), dim3(wgs), dim3(ROUND_THREADS), sm, s, a);
+}
+template <int KS>
+static void launch_round_ks(const RoundArgs& a, int mt, int wgs, size_t sm, hipStream_t s) {
+    switch (mt) {
+        case 1: launch_round_t<1, KS>(a, wgs, sm, s); break;
+        case 2: launch_round_t<2, KS>(a, wgs, sm, s); break;
+        case 3: launch_round_t<3, KS>(a, wgs, sm, s); break;
+        case 4: launch_round_t<4, KS>(a, wgs, sm, s); break;
+        case 5: launch_round_t<5, KS>(a, wgs, sm, s); break;
+        case 6: launch_round_t<6, KS>(a, wgs, sm, s); break;
+        default: launch_round_t<7, KS>(a, wgs, sm, s); break;
+    }
+}
+
+int launch_round(const RoundArgs& a_in, int mt, int wgs, hipStream_t s) {
+    RoundArgs a = a_in;
+    a.ldy_lds = lds_ldy(a.dp);
+    const size_t sm = round_lds_bytes(a.K16, a.dp, a.G, a.B);
+    if (mt < 1 || mt > 7 || sm > 150 * 1024) return -1;
+    switch (a.dp) {
+        case 32: launch_round_ks<8>(a, mt, wgs, sm, s); break;
+        case 52: launch_round_ks<13>(a, mt, wgs, sm, s); break;
+        case 64: launch_round_ks<16>(a, mt, wgs, sm, s); break;
+        default: return -1;
     }
     return 0;
 }
