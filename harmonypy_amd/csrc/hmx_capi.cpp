@@ -87,6 +87,7 @@ struct hmx_engine {
     DevBuf<unsigned> sync_words; // k_round: {arrival counter, error flag}
     unsigned* sync_host = nullptr;  // pinned copy of sync_words
     int n_cus = 0;
+    int rtz_wgs_per_cu = 4;      // k_rtz2 grid (HMX_RTZ_WGS_PER_CU)
     int round_mode = 1;          // 1: persistent k_round when the shape allows it, 0: one launch per block (HMX_ROUND_MODE=blocks)
     DevBuf<double> xch;
     double *Sold = nullptr, *Yacc64 = nullptr, *Snew = nullptr, *objacc = nullptr, *Sr = nullptr, *Oxr = nullptr;
@@ -295,6 +296,7 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
     e->ldy = 16 * e->ntd;
     if (const char* ab = getenv("HMX_ABLATE")) e->ablate = atoi(ab);
     if (const char* tpw = getenv("HMX_TILES_PER_WAVE")) e->tiles_per_wave = std::max(1, atoi(tpw));
+    if (const char* rw = getenv("HMX_RTZ_WGS_PER_CU")) e->rtz_wgs_per_cu = std::max(1, std::min(8, atoi(rw)));
     if (const char* rm = getenv("HMX_ROUND_MODE")) e->round_mode = (std::string(rm) == "blocks") ? 0 : 1;
     int rc = 0;
     do {
@@ -428,9 +430,10 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
         HIP_TRY(hipMemcpyAsync(e->gstart.p, gs.data(), gs.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
     }
-    // ridge tasks: runs of <= 64 tiles of one group
+    // ridge tasks: runs of tiles of one group; with k_rtz2 a task is one workgroup's share, sized
+    // for about four tasks per CU (k_rtz: one task per wave, <= 64 tiles)
     std::vector<int> t0, t1, tg;
-    const int CH = 64;
+    const int CH = rtz2_ok(e->mt, e->dp) ? std::max(16, (n_static_tiles + 2 * e->rtz_wgs_per_cu * e->n_cus - 1) / (2 * e->rtz_wgs_per_cu * e->n_cus)) : 64;
     for (int i = 0; i < n_static_tiles;) {
         int j = i;
         while (j < n_static_tiles && j - i < CH && static_tile_group[j] == static_tile_group[i]) ++j;
@@ -494,20 +497,24 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
     // ---- pass over the old R: centroid numerators (:443) and per-block removal sums (:491-492)
     int nsub, spw;
     rtz_geometry(e->mt, e->ntd, &nsub, &spw);
-    int wgs = std::min(256, std::max(1, (n_tiles_upper + 31) / 32));
-    if ((rc = e->slab.reserve((size_t)wgs * 4 * spw))) return rc;
+    const bool rtz2 = rtz2_ok(e->mt, e->dp) && e->round_mode == 1;
+    int wgs = rtz2 ? std::min(e->rtz_wgs_per_cu * e->n_cus, std::max(1, (n_tiles_upper + 7) / 8))
+                   : std::min(256, std::max(1, (n_tiles_upper + 31) / 32));
+    if ((rc = e->slab.reserve(rtz2 ? (size_t)wgs * rtz2_slab_floats(e->mt, e->dp) : (size_t)wgs * 4 * spw))) return rc;
     {
         Timed t(e, F_RTZ_ROUND);
         RtzArgs r{};
         r.R = e->R.p; r.Z = e->Zcos.p; r.cells = e->r_cells.p; r.tile_grp = e->r_tile_grp.p; r.blk_start = e->r_blk_start.p;
         r.S_out = e->Sold; r.slab = e->slab.p; r.n_tiles = n_tiles_upper; r.nblk = e->nblk;
         r.K = e->K; r.Kp = e->Kp; r.K16 = e->K16; r.G = e->G; r.mt = e->mt; r.dp = e->dp; r.ntd = e->ntd;
-        launch_rtz(r, wgs, e->stream);
+        if (rtz2) launch_rtz2(r, wgs, e->stream);
+        else launch_rtz(r, wgs, e->stream);
     }
     if (flags & HMX_ROUND_CENTROIDS) {
         Timed t(e, F_RTZ_REDUCE);
         HIP_TRY(hipMemsetAsync(e->Yacc64, 0, (size_t)e->K16 * e->ldy * sizeof(double), e->stream));
-        launch_rtz_reduce(e->slab.p, wgs * 4, e->mt, e->ntd, e->K16, e->ldy, e->Yacc64, nullptr, e->stream);
+        if (rtz2) launch_rtz2_reduce(e->slab.p, wgs, e->mt, e->dp, e->K16, e->ldy, e->Yacc64, nullptr, e->stream);
+        else launch_rtz_reduce(e->slab.p, wgs * 4, e->mt, e->ntd, e->K16, e->ldy, e->Yacc64, nullptr, e->stream);
     }
     // removal sums of every block and the centroid numerators: one collective (neighbours in xch)
     if ((rc = sum_over_ranks(e, e->Sold, GK * e->nblk + ((flags & HMX_ROUND_CENTROIDS) ? (size_t)e->K16 * e->ldy : 0)))) return rc;
@@ -745,7 +752,8 @@ int hmx_moe_correct_ridge(hmx_engine* e) {
     const size_t GK = (size_t)e->G * e->K16;
     int nsub, spw;
     rtz_geometry(e->mt, e->ntd, &nsub, &spw);
-    if ((rc = e->slab.reserve((size_t)std::max(e->ntasks, 1) * spw))) return rc;
+    const bool rtz2 = rtz2_ok(e->mt, e->dp);   // tasks were cut for it in hmx_upload
+    if ((rc = e->slab.reserve((size_t)std::max(e->ntasks, 1) * (rtz2 ? rtz2_slab_floats(e->mt, e->dp) : spw)))) return rc;
     HIP_TRY(hipMemsetAsync(e->Sr, 0, GK * e->ldy * sizeof(double), e->stream));
     HIP_TRY(hipMemsetAsync(e->Oxr, 0, GK * sizeof(double), e->stream));
     {
@@ -755,8 +763,13 @@ int hmx_moe_correct_ridge(hmx_engine* e) {
         r.task_tile0 = e->task_t0.p; r.task_tile1 = e->task_t1.p; r.task_grp = e->task_grp.p;
         r.S_out = e->Oxr; r.slab = e->slab.p; r.n_tiles = e->n_s_tiles; r.ntasks = e->ntasks;
         r.K = e->K; r.Kp = e->Kp; r.K16 = e->K16; r.G = e->G; r.mt = e->mt; r.dp = e->dp; r.ntd = e->ntd;
-        launch_rtz(r, (e->ntasks + 3) / 4, e->stream);
-        launch_rtz_reduce(e->slab.p, e->ntasks, e->mt, e->ntd, e->K16, e->ldy, e->Sr, e->task_grp.p, e->stream);
+        if (rtz2) {
+            launch_rtz2(r, e->ntasks, e->stream);
+            launch_rtz2_reduce(e->slab.p, e->ntasks, e->mt, e->dp, e->K16, e->ldy, e->Sr, e->task_grp.p, e->stream);
+        } else {
+            launch_rtz(r, (e->ntasks + 3) / 4, e->stream);
+            launch_rtz_reduce(e->slab.p, e->ntasks, e->mt, e->ntd, e->K16, e->ldy, e->Sr, e->task_grp.p, e->stream);
+        }
     }
     if ((rc = sum_over_ranks(e, e->Sr, GK * e->ldy + GK))) return rc;   // Sr and Oxr are neighbours
     {

@@ -66,6 +66,7 @@ struct RtzArgs {
     float* slab;
     int n_tiles, ntasks, nblk;
     int K, Kp, K16, G, mt, dp, ntd;
+    int ldr, ldz;          // k_rtz2: LDS row strides (set by the launcher)
 };
 
 struct TableArgs {
@@ -133,6 +134,10 @@ void launch_normalize_rows(const float* Z, float* Zc, int64_t N, int dp, hipStre
 void launch_y_normalize(const float* src, float* dst, int K, int K16, int d, int ldy, hipStream_t s);
 int launch_assign(const AssignArgs& a, bool penalty, int max_wgs, hipStream_t s);
 void rtz_geometry(int mt, int ntd, int* nsub, int* slab_per_wave);
+bool rtz2_ok(int mt, int dp);
+int rtz2_slab_floats(int mt, int dp);
+void launch_rtz2(const RtzArgs& a, int wgs, hipStream_t s);
+void launch_rtz2_reduce(const float* slab, int nslabs, int mt, int dp, int K16, int ld, double* out, const int* task_grp, hipStream_t s);
 void launch_rtz(const RtzArgs& a, int wgs, hipStream_t s);
 void launch_y_normalize_d(const double* src, float* dst, int K, int K16, int d, int ldy, hipStream_t s);
 void launch_rtz_reduce(const float* slab, int nwaves, int mt, int ntd, int K16, int ld, double* out,

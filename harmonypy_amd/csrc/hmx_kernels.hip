@@ -1166,6 +1166,216 @@ __global__ __launch_bounds__(256, 2) void k_rtz(RtzArgs a) {
     (void)task_grp;
 }
 
+// ------------------------------------------------------------------------------------------
+// k_rtz2: the same product for shapes whose rows fit the LDS comfortably (K <= 112, d <= 64),
+// built for HBM streaming instead of latency:
+//   * a workgroup of 4 waves owns ALL output tiles (wave w: PC column block w % NTD, cluster tiles
+//     w / NTD, + 4/NTD, ..) and walks a contiguous range of tiles (or one task);
+//   * a tile's 16 R rows and 16 Z rows are fetched with 16-byte loads (row-contiguous, so every
+//     cache line is used whole), staged through a double-buffered LDS tile whose row strides
+//     (= 16 mod 32 floats) make the fragment reads conflict-free, one workgroup barrier per tile;
+//   * the loads of tile t+2 and the cell ids of tile t+3 are in flight while tile t is multiplied;
+//   * two workgroups per CU (512 in all) so that one's MFMA phase covers the other's memory phase.
+// Per-workgroup accumulators go to a slab in fragment order [tile][r][lane] (reduced by k_rtz2_reduce).
+// ------------------------------------------------------------------------------------------
+template <int MT, int NTD>
+__global__ __launch_bounds__(256, 2) void k_rtz2(RtzArgs a) {
+    constexpr int SPLIT = 4 / NTD;                  // waves sharing one PC column block
+    constexpr int MTW = (MT + SPLIT - 1) / SPLIT;   // cluster tiles per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* lds = reinterpret_cast<float*>(smem);
+    const int LDR = a.ldr, LDZ = a.ldz;
+    const int tile_floats = 16 * (LDR + LDZ);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c16 = lane & 15, q = lane >> 4;
+    const int nt = wv % NTD, ms = wv / NTD;
+    const int wg = blockIdx.x;
+
+    int t0, t1;
+    if (a.task_tile0) {
+        if (wg >= a.ntasks) return;
+        t0 = a.task_tile0[wg];
+        t1 = a.task_tile1[wg];
+    } else {
+        const int n_tiles = a.blk_start ? a.blk_start[a.nblk] : a.n_tiles;
+        const int per = (n_tiles + gridDim.x - 1) / gridDim.x;
+        t0 = min(wg * per, n_tiles);
+        t1 = min(t0 + per, n_tiles);
+    }
+
+    // this thread's (up to 3) 16-byte pieces of a tile: fixed (array, row, column), only the cell changes
+    const int kp4 = a.Kp >> 2, dp4 = a.dp >> 2;
+    const int nR = 16 * kp4, nZ = 16 * dp4;
+    int it_row[3], it_src[3], it_dst[3];   // row in the tile; float offset inside the source row (-1: none; bit 30: Z); LDS float offset
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int i = tid + 256 * s;
+        if (i < nR) {
+            it_row[s] = i / kp4;
+            it_src[s] = 4 * (i - it_row[s] * kp4);
+            it_dst[s] = it_row[s] * LDR + it_src[s];
+        } else if (i < nR + nZ) {
+            const int j = i - nR;
+            it_row[s] = j / dp4;
+            const int c = 4 * (j - it_row[s] * dp4);
+            it_src[s] = c | (1 << 30);
+            it_dst[s] = 16 * LDR + it_row[s] * LDZ + c;
+        } else {
+            it_row[s] = 0;
+            it_src[s] = -1;
+            it_dst[s] = 0;
+        }
+    }
+    for (int i = tid; i < 2 * tile_floats; i += 256) lds[i] = 0.f;   // the padding columns stay zero
+    // per-tile bookkeeping (group, block) comes from LDS copies: a dependent global load per tile
+    // would cost a full memory round trip on the critical path
+    int* grp_l = reinterpret_cast<int*>(lds + 2 * tile_floats);      // 256 tile groups
+    int* bs_l = grp_l + 256;                                          // nblk + 1 tile offsets
+    const int task_g = a.task_tile0 ? a.task_grp[wg] : -1;
+    if (a.blk_start)
+        for (int i = tid; i <= a.nblk; i += 256) bs_l[i] = a.blk_start[i];
+
+    f32x4 acc[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float csum[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) csum[i] = 0.f;
+    int cur_g = -1, cur_b = 0;
+    const bool sums = nt == 0 && a.S_out != nullptr;
+    auto flush = [&]() {
+        if (cur_g < 0 || !sums) return;
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            const int mt = ms + i * SPLIT;
+            const float sv = wave_sum_q(csum[i]);
+            const int k = 16 * mt + c16;
+            if (q == 0 && mt < MT && k < a.K && sv != 0.f) atomicAdd(&a.S_out[((size_t)cur_b * a.G + cur_g) * a.K16 + k], (double)sv);
+            csum[i] = 0.f;
+        }
+    };
+    auto ids_of = [&](int t, int (&id)[3]) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) id[s] = (t < t1 && it_src[s] != -1) ? a.cells[(size_t)t * 16 + it_row[s]] : -1;
+    };
+    auto fetch = [&](const int (&id)[3], f32x4 (&v)[3]) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            v[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (id[s] >= 0) {
+                const bool isz = (it_src[s] >> 30) & 1;
+                const int off = it_src[s] & 0xFFFFFF;
+                v[s] = isz ? ld4(a.Z + (size_t)id[s] * a.dp + off) : ld4(a.R + (size_t)id[s] * a.Kp + off);
+            }
+        }
+    };
+    auto stash = [&](int buf, const f32x4 (&v)[3]) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            if (it_src[s] != -1) st4(lds + (size_t)buf * tile_floats + it_dst[s], v[s]);
+    };
+
+    // software pipeline: tile t multiplies from LDS while tile t+1 is written to the other LDS buffer,
+    // the loads of tiles t+2 .. t+RTZ_DEPTH travel in registers and the cell ids of tile
+    // t+RTZ_DEPTH+1 are on their way
+    constexpr int RTZ_DEPTH = 2;
+    int id_n[3];
+    f32x4 v[RTZ_DEPTH][3];
+    __syncthreads();
+    if (t0 < t1) {
+        ids_of(t0, id_n);
+        fetch(id_n, v[0]);
+        stash(0, v[0]);
+#pragma unroll
+        for (int dpt = 0; dpt < RTZ_DEPTH; ++dpt) {
+            ids_of(t0 + 1 + dpt, id_n);
+            fetch(id_n, v[dpt]);          // tiles t0+1 .. t0+RTZ_DEPTH travelling
+        }
+        ids_of(t0 + 1 + RTZ_DEPTH, id_n);
+    }
+    for (int t = t0; t < t1; ++t) {
+        const int buf = (t - t0) & 1;
+        __syncthreads();          // tile t is complete in lds[buf]; nobody reads lds[buf ^ 1] any more
+        stash(buf ^ 1, v[0]);     // tile t+1 (its loads were issued RTZ_DEPTH iterations ago)
+#pragma unroll
+        for (int dpt = 0; dpt + 1 < RTZ_DEPTH; ++dpt)
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) v[dpt][s3] = v[dpt + 1][s3];
+        fetch(id_n, v[RTZ_DEPTH - 1]);        // tile t+1+RTZ_DEPTH
+        ids_of(t + 2 + RTZ_DEPTH, id_n);      // ids for the fetch of the next iteration
+        int g = task_g;
+        if (task_g < 0) {
+            if (((t - t0) & 255) == 0) {          // refill the group window (workgroup-uniform)
+                __syncthreads();
+                if (t + tid < t1) grp_l[tid] = a.tile_grp[t + tid];
+                __syncthreads();
+            }
+            g = grp_l[(t - t0) & 255];
+        }
+        int b = cur_b;
+        if (a.blk_start) {
+            while (t >= bs_l[b + 1]) ++b;         // lists are block-major, so b only grows
+        }
+        if (g != cur_g || b != cur_b) {
+            flush();
+            cur_g = g;
+            cur_b = b;
+        }
+        const float* Rt = lds + (size_t)buf * tile_floats;
+        const float* Zt = Rt + 16 * LDR;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float bv = Zt[(4 * ks + q) * LDZ + 16 * nt + c16];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+                const int mt = ms + i * SPLIT;
+                if (mt < MT) {
+                    const float av = Rt[(4 * ks + q) * LDR + 16 * mt + c16];
+                    csum[i] += av;
+                    acc[i] = MFMA16(av, bv, acc[i]);
+                }
+            }
+        }
+    }
+    flush();
+    float* slab = a.slab + (size_t)wg * (MT * NTD * 256);
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int mt = ms + i * SPLIT;
+        if (mt < MT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[((mt * NTD + nt) * 4 + r) * 64 + lane] = acc[i][r];
+        }
+    }
+}
+
+// Sum the per-workgroup slabs of k_rtz2 in fp64 (same contract as k_rtz_reduce).
+__global__ __launch_bounds__(256) void k_rtz2_reduce(const float* __restrict__ slab, int nslabs, int MT, int NTD, int K16,
+                                                     int ld, double* __restrict__ out, const int* __restrict__ task_grp,
+                                                     int seg_len) {
+    const int per = MT * NTD * 256;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= per) return;
+    const int lane = e & 63, r = (e >> 6) & 3, tile = e >> 8;
+    const int mt = tile / NTD, nt = tile % NTD;
+    const int k = 16 * mt + 4 * (lane >> 4) + r;
+    const int j = 16 * nt + (lane & 15);
+    if (k >= K16 || j >= ld) return;
+    const int w0 = blockIdx.y * seg_len, w1 = min(w0 + seg_len, nslabs);
+    int g = -1;
+    double acc = 0.0;
+    for (int w = w0; w < w1; ++w) {
+        const int gw = task_grp ? task_grp[w] : 0;
+        if (gw != g) {
+            if (g >= 0 && acc != 0.0) atomicAdd(&out[((size_t)g * K16 + k) * ld + j], acc);
+            g = gw;
+            acc = 0.0;
+        }
+        acc += (double)slab[(size_t)w * per + e];
+    }
+    if (g >= 0 && acc != 0.0) atomicAdd(&out[((size_t)g * K16 + k) * ld + j], acc);
+}
+
 // Sum the per-wave slabs of k_rtz in fp64.  blockIdx.x covers the slab elements, blockIdx.y a
 // segment of the slabs (waves / tasks); partial sums meet in fp64 atomics, whose order does not
 // change an fp32-rounded result.  `out` must be zeroed by the caller.
@@ -1573,7 +1783,7 @@ __device__ __forceinline__ int group_of_cell(const int* __restrict__ gstart, int
     return lo;
 }
 
-#define ORDER_CHUNK 1024  /* cells per wave */
+#define ORDER_CHUNK 256  /* cells per wave: short chunks = many waves to hide the serial LDS chain */
 
 // mode 0: write per-chunk histograms; mode 1: scatter cells using chunk offsets
 template <int MODE>
@@ -1595,6 +1805,10 @@ __global__ __launch_bounds__(64) void k_order_pass(OrderArgs a) {
             const int64_t p = feistel_position(gid, (uint32_t)a.Ng, a.half_bits, a.key0, a.key1);
             const int b = (a.cpb > 0) ? (int)min((int64_t)(p / a.cpb), (int64_t)(a.nblk - 1)) : a.nblk - 1;
             key = b * a.G + group_of_cell(a.gstart, a.G, cell);
+        }
+        if (MODE == 0) {                      // a histogram needs no order
+            if (live) atomicAdd(&cnt[key], 1);
+            continue;
         }
         // rank among the lanes of this step that share the key, in cell order
         unsigned long long todo = __ballot(live);
@@ -1646,27 +1860,30 @@ __global__ __launch_bounds__(256) void k_order_scan(OrderArgs a, int nchunks) {
     if (tid == 255) a.run_count[key] = part[255];
 }
 
-// One workgroup: run starts (padded), block_tile_start, then padding and tile groups of every run.
-__global__ __launch_bounds__(1024) void k_order_runs(OrderArgs a) {
+// One workgroup per key (block, group): its run start (every workgroup sums the padded lengths of the
+// keys before its own -- a few hundred integers), block_tile_start, the run's padding and tile groups.
+__global__ __launch_bounds__(256) void k_order_runs(OrderArgs a) {
+    __shared__ int part[256];
     const int nkeys = a.nblk * a.G;
-    const int tid = threadIdx.x;
-    if (tid == 0) {
-        int pos = 0;
-        for (int k = 0; k < nkeys; ++k) {
-            if (k % a.G == 0) a.blk_start[k / a.G] = pos / 16;
-            a.run_start[k] = pos;
-            pos += ((a.run_count[k] + 15) / 16) * 16;
-        }
-        a.blk_start[a.nblk] = pos / 16;
-    }
-    __threadfence();
+    const int key = blockIdx.x, tid = threadIdx.x;
+    int sum = 0;
+    for (int k = tid; k < key; k += 256) sum += ((a.run_count[k] + 15) / 16) * 16;
+    part[tid] = sum;
     __syncthreads();
-    for (int key = 0; key < nkeys; ++key) {
-        const int start = a.run_start[key], n = a.run_count[key];
-        const int padded = ((n + 15) / 16) * 16;
-        for (int i = n + tid; i < padded; i += 1024) a.cells[start + i] = -1;
-        for (int t = tid; t < padded / 16; t += 1024) a.tile_grp[start / 16 + t] = key % a.G;
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) part[tid] += part[tid + s];
+        __syncthreads();
     }
+    const int start = part[0];
+    const int n = a.run_count[key];
+    const int padded = ((n + 15) / 16) * 16;
+    if (tid == 0) {
+        a.run_start[key] = start;
+        if (key % a.G == 0) a.blk_start[key / a.G] = start / 16;
+        if (key == nkeys - 1) a.blk_start[a.nblk] = (start + padded) / 16;
+    }
+    for (int i = n + tid; i < padded; i += 256) a.cells[start + i] = -1;
+    for (int t = tid; t < padded / 16; t += 256) a.tile_grp[start / 16 + t] = key % a.G;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1791,6 +2008,41 @@ int launch_round(const RoundArgs& a_in, int mt, int wgs, hipStream_t s) {
     return 0;
 }
 
+// k_rtz2 applies when a tile's rows fit its LDS layout: K <= 112 (7 cluster tiles), d <= 64
+bool rtz2_ok(int mt, int dp) { return mt >= 1 && mt <= 7 && (dp == 32 || dp == 52 || dp == 64); }
+int rtz2_slab_floats(int mt, int dp) { return mt * (dp == 32 ? 2 : 4) * 256; }
+
+template <int NTD>
+static void launch_rtz2_n(RtzArgs& a, int mt, int wgs, size_t sm, hipStream_t s) {
+    switch (mt) {
+        case 1: hipLaunchKernelGGL((k_rtz2<1, NTD>), dim3(wgs), dim3(256), sm, s, a); break;
+        case 2: hipLaunchKernelGGL((k_rtz2<2, NTD>), dim3(wgs), dim3(256), sm, s, a); break;
+        case 3: hipLaunchKernelGGL((k_rtz2<3, NTD>), dim3(wgs), dim3(256), sm, s, a); break;
+        case 4: hipLaunchKernelGGL((k_rtz2<4, NTD>), dim3(wgs), dim3(256), sm, s, a); break;
+        case 5: hipLaunchKernelGGL((k_rtz2<5, NTD>), dim3(wgs), dim3(256), sm, s, a); break;
+        case 6: hipLaunchKernelGGL((k_rtz2<6, NTD>), dim3(wgs), dim3(256), sm, s, a); break;
+        default: hipLaunchKernelGGL((k_rtz2<7, NTD>), dim3(wgs), dim3(256), sm, s, a); break;
+    }
+}
+
+void launch_rtz2(const RtzArgs& a_in, int wgs, hipStream_t s) {
+    RtzArgs a = a_in;
+    const int ntd = a.dp == 32 ? 2 : 4;
+    a.ldr = ((a.K16 + 31) / 32) * 32 + 16;          // row strides = 16 (mod 32) floats: conflict-free fragment reads
+    a.ldz = ((16 * ntd + 31) / 32) * 32 + 16;
+    const size_t sm = (size_t)2 * 16 * (a.ldr + a.ldz) * sizeof(float) + (256 + 64) * sizeof(int);
+    if (ntd == 2) launch_rtz2_n<2>(a, a.mt, wgs, sm, s);
+    else launch_rtz2_n<4>(a, a.mt, wgs, sm, s);
+}
+
+void launch_rtz2_reduce(const float* slab, int nslabs, int mt, int dp, int K16, int ld, double* out, const int* task_grp,
+                        hipStream_t s) {
+    const int ntd = dp == 32 ? 2 : 4;
+    const int seg_len = 32;
+    hipLaunchKernelGGL(k_rtz2_reduce, dim3(cdiv(mt * ntd * 256, 256), cdiv(nslabs, seg_len)), dim3(256), 0, s, slab, nslabs, mt,
+                       ntd, K16, ld, out, task_grp, seg_len);
+}
+
 void rtz_geometry(int mt, int ntd, int* nsub, int* slab_per_wave) {
     const int nsub_m = cdiv(mt, HMX_RTZ_MTW), nsub_n = cdiv(ntd, HMX_RTZ_NTW);
     *nsub = nsub_m * nsub_n;
@@ -1833,7 +2085,7 @@ void launch_order(const OrderArgs& a, hipStream_t s) {
     const size_t sm = (size_t)a.nblk * a.G * sizeof(int);
     hipLaunchKernelGGL(k_order_pass<0>, dim3(nchunks), dim3(64), sm, s, a);
     hipLaunchKernelGGL(k_order_scan, dim3(a.nblk * a.G), dim3(256), 0, s, a, nchunks);
-    hipLaunchKernelGGL(k_order_runs, dim3(1), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(k_order_runs, dim3(a.nblk * a.G), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_order_pass<1>, dim3(nchunks), dim3(64), sm, s, a);
 }
 
