@@ -119,6 +119,12 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line: libraries that print banners through C stdio (RCCL's
+    # version banner, for one) are sent to stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -191,6 +197,9 @@ def main():
         ho._engine.enable_timing(False)
 
     if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
         return
     ms_per_step = 1e3 * dt / args.steps
     value = N * world * args.steps / dt
@@ -234,7 +243,10 @@ def main():
         out["kernel_ms_total"] = fam_ms
     if args.cpu_sample > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(d, B, K, args.rounds, min(args.cpu_sample, N))
-    print(json.dumps(out))
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

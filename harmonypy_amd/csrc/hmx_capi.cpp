@@ -292,7 +292,7 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
     e->Kp = (e->K + 3) & ~3;
     e->mt = (e->K + 15) / 16;
     e->K16 = 16 * e->mt;
-    e->ntd = (e->d + 15) / 16;
+    e->ntd = (e->dp + 15) / 16;   // PC tiles cover the padded row (padding columns hold zeros)
     e->ldy = 16 * e->ntd;
     if (const char* ab = getenv("HMX_ABLATE")) e->ablate = atoi(ab);
     if (const char* tpw = getenv("HMX_TILES_PER_WAVE")) e->tiles_per_wave = std::max(1, atoi(tpw));
@@ -786,6 +786,7 @@ int hmx_moe_correct_ridge(hmx_engine* e) {
         a.R = e->R.p; a.Zorig = e->Zorig.p; a.W = e->W.p; a.Zcorr = e->Zcorr.p; a.Zcos = e->Zcos.p;
         a.cells = e->s_cells.p; a.tile_grp = e->s_tile_grp.p; a.n_tiles = e->n_s_tiles;
         a.Kp = e->Kp; a.K16 = e->K16; a.dp = e->dp; a.ldw = e->ldy; a.mtd = e->ntd;
+        if (rtz2) { a.task_tile0 = e->task_t0.p; a.task_tile1 = e->task_t1.p; a.task_grp = e->task_grp.p; a.ntasks = e->ntasks; }
         if (launch_ridge_apply(a, e->max_wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported n_pcs");
     }
     HIP_TRY(hipGetLastError());

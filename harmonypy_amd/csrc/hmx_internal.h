@@ -109,6 +109,10 @@ struct ApplyArgs {
     const int* tile_grp;
     int n_tiles;
     int Kp, K16, dp, ldw, mtd;
+    const int* task_tile0; // k_ridge_apply2: one workgroup per task (null: k_ridge_apply)
+    const int* task_tile1;
+    const int* task_grp;
+    int ntasks, ldw_lds;
 };
 
 struct OrderArgs {

@@ -1739,6 +1739,98 @@ __global__ __launch_bounds__(256) void k_ridge_apply(ApplyArgs a) {
 
 
 // ------------------------------------------------------------------------------------------
+// k_ridge_apply2: the same correction for K <= 112, d <= 64.  One workgroup per task (a run of
+// tiles of ONE group, the ridge-statistics tasks): the group's W (K16 x d, <= 36 KB) is staged in
+// LDS once, with a row stride of 16 (mod 32) floats so that the A-fragment reads are conflict-free;
+// every wave then streams pairs of tiles: 16-byte R row pieces straight into B-fragment layout,
+// MTD x 2 accumulators, Z_orig row pieces for the epilogue, Z_corr / Z_cos rows out as 16-byte stores.
+// ------------------------------------------------------------------------------------------
+template <int MTD, int KB>
+__global__ __launch_bounds__(256, 3) void k_ridge_apply2(ApplyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* Wl = reinterpret_cast<float*>(smem);                 // K16 x LDW
+    const int LDW = a.ldw_lds;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c16 = lane & 15, q = lane >> 4;
+    const int task = blockIdx.x;
+    if (task >= a.ntasks) return;
+    const int t0 = a.task_tile0[task], t1 = a.task_tile1[task], g = a.task_grp[task];
+    {
+        const float* Wg = a.W + (size_t)g * a.K16 * a.ldw;
+        const int w4 = (16 * MTD) >> 2;
+        for (int i = tid; i < a.K16 * w4; i += 256) {
+            const int row = i / w4, c4 = i - row * w4;
+            st4(Wl + (size_t)row * LDW + 4 * c4, ld4(Wg + (size_t)row * a.ldw + 4 * c4));
+        }
+    }
+    __syncthreads();
+    for (int t = t0 + 2 * wv; t < t1; t += 8) {
+        int cell[2];
+        f32x4 b[2][KB];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            cell[n] = (t + n < t1) ? a.cells[(size_t)(t + n) * 16 + c16] : -1;
+            const float* rr = a.R + (size_t)(cell[n] >= 0 ? cell[n] : 0) * a.Kp;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const int col0 = 16 * kb + 4 * q;
+                b[n][kb] = (cell[n] >= 0 && col0 < a.Kp) ? ld4(rr + col0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        f32x4 zo[2][MTD];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int mt = 0; mt < MTD; ++mt) {
+                const int col = 16 * mt + 4 * q;
+                zo[n][mt] = (cell[n] >= 0 && col < a.dp) ? ld4(a.Zorig + (size_t)cell[n] * a.dp + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        f32x4 acc[MTD][2];
+#pragma unroll
+        for (int mt = 0; mt < MTD; ++mt) acc[mt][0] = acc[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* wr = Wl + (size_t)(16 * kb + 4 * q + i) * LDW + c16;
+#pragma unroll
+                for (int mt = 0; mt < MTD; ++mt) {
+                    const float wa = wr[16 * mt];
+                    acc[mt][0] = MFMA16(wa, b[0][kb][i], acc[mt][0]);
+                    acc[mt][1] = MFMA16(wa, b[1][kb][i], acc[mt][1]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // one column block's W fragments live at a time
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const bool live = cell[n] >= 0;
+            const size_t row = (size_t)(live ? cell[n] : 0) * a.dp;
+            float ss = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MTD; ++mt) {
+                acc[mt][n] = zo[n][mt] - acc[mt][n];                               // :566
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ss += acc[mt][n][r] * acc[mt][n][r];
+            }
+            ss = wave_sum_q(ss);
+            const float nrm = sqrtf(ss);
+#pragma unroll
+            for (int mt = 0; mt < MTD; ++mt) {
+                const int col = 16 * mt + 4 * q;
+                if (live && col < a.dp) {
+                    st4(a.Zcorr + row + col, acc[mt][n]);
+                    f32x4 zc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) zc[r] = acc[mt][n][r] / nrm;       // :569
+                    st4(a.Zcos + row + col, zc);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Device-side update order (replaces torch.randperm + the gather/argsort of harmony.py:471-480,
 // 512-513 when the caller does not supply an order).
 //
@@ -2091,8 +2183,30 @@ void launch_order(const OrderArgs& a, hipStream_t s) {
 
 int order_chunks(int64_t N) { return cdiv(N, ORDER_CHUNK); }
 
-int launch_ridge_apply(const ApplyArgs& a, int max_wgs, hipStream_t s) {
+template <int MTD>
+static void launch_apply2_k(const ApplyArgs& a, int kb, size_t sm, hipStream_t s) {
+    switch (kb) {
+        case 1: hipLaunchKernelGGL((k_ridge_apply2<MTD, 1>), dim3(a.ntasks), dim3(256), sm, s, a); break;
+        case 2: hipLaunchKernelGGL((k_ridge_apply2<MTD, 2>), dim3(a.ntasks), dim3(256), sm, s, a); break;
+        case 3: hipLaunchKernelGGL((k_ridge_apply2<MTD, 3>), dim3(a.ntasks), dim3(256), sm, s, a); break;
+        case 4: hipLaunchKernelGGL((k_ridge_apply2<MTD, 4>), dim3(a.ntasks), dim3(256), sm, s, a); break;
+        case 5: hipLaunchKernelGGL((k_ridge_apply2<MTD, 5>), dim3(a.ntasks), dim3(256), sm, s, a); break;
+        case 6: hipLaunchKernelGGL((k_ridge_apply2<MTD, 6>), dim3(a.ntasks), dim3(256), sm, s, a); break;
+        default: hipLaunchKernelGGL((k_ridge_apply2<MTD, 7>), dim3(a.ntasks), dim3(256), sm, s, a); break;
+    }
+}
+
+int launch_ridge_apply(const ApplyArgs& a_in, int max_wgs, hipStream_t s) {
+    ApplyArgs a = a_in;
     if (a.n_tiles <= 0) return 0;
+    if (a.task_tile0 && rtz2_ok((a.K16 + 15) / 16, a.dp)) {
+        const int mtd = a.dp == 32 ? 2 : 4;
+        a.ldw_lds = ((16 * mtd + 31) / 32) * 32 + 16;
+        const size_t sm = (size_t)a.K16 * a.ldw_lds * sizeof(float);
+        if (mtd == 2) launch_apply2_k<2>(a, a.K16 / 16, sm, s);
+        else launch_apply2_k<4>(a, a.K16 / 16, sm, s);
+        return 0;
+    }
     constexpr int NT = 2;
     const int wgs = assign_grid(a.n_tiles, NT, max_wgs);
     if (a.mtd <= 4) hipLaunchKernelGGL((k_ridge_apply<4, NT>), dim3(wgs), dim3(256), 0, s, a);
