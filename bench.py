@@ -17,8 +17,8 @@ Workload at --gpus 1: BASELINE.json configs[2] (C3, the roofline point): synthet
 With N > 1 ranks every GPU holds one such shard (weak scaling).
 
 One JSON line on stdout (rank 0).  Besides the contract fields:
-  roofline     -- the dominant kernel (k_assign, one launch per update block): algorithmic bytes
-                  per launch (cells of a block x (4d + 4K + 4)) / average
+  roofline     -- the dominant kernel (k_round, one persistent launch per update_R sweep):
+                  algorithmic bytes per launch (cells x (4d + 4K + 4)) / average
                   launch time from HIP events on the engine's stream, against 8 TB/s HBM.
   cpu_baseline -- the NumPy oracle (a port of the reference's torch-CPU path) timed on this
                   box's host cores on a bounded sample of the same workload.
@@ -224,16 +224,29 @@ def main():
     if timing:
         tot, cnt = ktimes.get("assign_block", (0.0, 0))
         per_launch_ms = tot / max(cnt, 1)
-        cells_per_launch = N / 20.0
+        n_rounds = args.steps * args.rounds
+        sweep = cnt <= n_rounds          # k_round: one launch per update_R sweep; else one launch per block
+        cells_per_launch = N if sweep else N / 20.0
         alg_bytes = cells_per_launch * (4 * d + 4 * K + 4)
         achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
-        out["roofline"] = {"bound": "hbm", "kernel": "k_assign (per update block)", "achieved": achieved,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        kernel = ("k_round (one persistent launch per update_R sweep: all 20 blocks)" if sweep
+                  else "k_assign_lds (one launch per update block)")
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(ROOT, "profiles", "r01_v4_c3_pmc_hbm.json")
+        if sweep and args.config == "c3" and os.path.exists(pmc_file):
+            # HBM bytes per launch from the rocprofv3 --pmc passes of this configuration (FETCH_SIZE doubled
+            # for gfx950's half-counted 16-byte streams + WRITE_SIZE; scripts/gpu_pmc.sh), not re-collected here
+            pm = json.load(open(pmc_file))["kernels"]
+            for name, rec in pm.items():
+                if name.startswith("void k_round"):
+                    traffic, traffic_src = rec["hbm_bytes_corrected"], "profiles/r01_v4_c3_pmc_hbm.json"
+        out["roofline"] = {"bound": "hbm", "kernel": kernel, "achieved": achieved,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "traffic_source": traffic_src,
                            "avg_launch_us": per_launch_ms * 1e3, "launches": cnt,
                            "algorithmic_bytes_per_launch": alg_bytes}
         round_bytes = N * (4 * d + 8 * K + 8)
         fam_ms = {k: round(v[0], 3) for k, v in ktimes.items()}
-        n_rounds = args.steps * args.rounds
         t_round_kernels = sum(ktimes[k][0] for k in ("assign_block", "rtz_round", "rtz_reduce", "block_table")) / max(n_rounds, 1)
         out["roofline"]["round"] = {
             "algorithmic_bytes": round_bytes, "kernel_ms_per_round": t_round_kernels,
