@@ -135,13 +135,14 @@ def main():
     shard = None
     if world > 1 or os.environ.get("HMX_BENCH_FORCE_SHARD"):
         import torch.distributed as dist
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)   # several ranks on one GPU only happen in tests
         torch.cuda.set_device(local_rank)
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29512")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl")
+        dist.init_process_group(os.environ.get("HMX_BENCH_BACKEND", "nccl"))   # gloo: several ranks on one GPU (testing)
 
     N, d, B, K = CONFIGS[args.config]
     os.environ["HMX_UPDATE_ORDER"] = "device"
@@ -189,7 +190,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda")
+        t = torch.tensor([dt], device="cuda" if "nccl" in dist.get_backend() else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ktimes = ho._engine.kernel_times() if timing else {}
@@ -214,8 +215,10 @@ def main():
             "cells_per_gpu": N, "pcs": d, "batches": B, "clusters": K, "rounds_per_iteration": args.rounds,
             "update_order": "device (keyed bijection, generated inside the timed region)",
             "init": "k-means++ on a 50k-cell subsample, untimed",
-            "parallelism": (f"cells sharded over {world} ranks (1 per GPU), tables summed by {ho.transport} "
-                            f"all-reduce: 1 + 20 per round, 1 per ridge") if shard is not None else "single GPU",
+            "parallelism": (f"cells sharded over {world} ranks (1 per GPU), transport {ho.transport}: "
+                            + ("block sums exchanged inside the sweep kernel through peer boxes (xGMI), 1 all-reduce per "
+                               "round + 1 per ridge" if "+peer" in str(ho.transport) else
+                               "1 + 20 all-reduces per round, 1 per ridge")) if shard is not None else "single GPU",
             "cells_total": N * world,
             "cell_rounds_per_sec": N * world * args.steps * args.rounds / dt,
             "setup_s": t_setup,

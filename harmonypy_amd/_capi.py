@@ -25,7 +25,9 @@ EXPORTS = [
     "hmx_last_error", "hmx_abi_version", "hmx_create", "hmx_destroy", "hmx_upload", "hmx_init_cluster",
     "hmx_cluster_round", "hmx_cluster_round_seeded", "hmx_moe_correct_ridge", "hmx_get", "hmx_set", "hmx_sync", "hmx_device_ptr",
     "hmx_kernel_times", "hmx_enable_timing", "hmx_comm_unique_id", "hmx_comm_init", "hmx_set_host_allreduce",
+    "hmx_set_ranks", "hmx_peer_export", "hmx_peer_attach", "hmx_peer_selftest", "hmx_peer_enable",
 ]
+HMX_PEER_HANDLE_BYTES = 64
 HMX_ABI_VERSION = 2
 HMX_UNIQUE_ID_BYTES = 128
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
@@ -66,6 +68,11 @@ def load():
     lib.hmx_comm_unique_id.argtypes = [vp]
     lib.hmx_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.hmx_set_host_allreduce.argtypes = [vp, HOST_ALLREDUCE_FN, vp]
+    lib.hmx_set_ranks.argtypes = [vp, C.c_int, C.c_int]
+    lib.hmx_peer_export.argtypes = [vp, vp]
+    lib.hmx_peer_attach.argtypes = [vp, vp]
+    lib.hmx_peer_selftest.argtypes = [vp]
+    lib.hmx_peer_enable.argtypes = [vp, C.c_int]
     lib.hmx_init_cluster.argtypes = [vp, vp, vp]
     lib.hmx_cluster_round.argtypes = [vp, C.c_int, vp, i64, vp, i32, vp, vp]
     lib.hmx_cluster_round_seeded.argtypes = [vp, C.c_int, C.c_uint64, i64, vp]
@@ -145,6 +152,25 @@ class Engine:
         assert len(unique_id) == HMX_UNIQUE_ID_BYTES
         buf = C.create_string_buffer(unique_id, HMX_UNIQUE_ID_BYTES)
         _check(self._lib.hmx_comm_init(self._h, buf, int(n_ranks), int(rank)))
+
+    def set_ranks(self, n_ranks, rank):
+        _check(self._lib.hmx_set_ranks(self._h, int(n_ranks), int(rank)))
+
+    def peer_export(self) -> bytes:
+        """Inter-process handle of this engine's peer box (in-kernel exchange of the block sums)."""
+        buf = C.create_string_buffer(HMX_PEER_HANDLE_BYTES)
+        _check(self._lib.hmx_peer_export(self._h, buf))
+        return buf.raw
+
+    def peer_attach(self, handles: bytes):
+        buf = C.create_string_buffer(handles, len(handles))
+        _check(self._lib.hmx_peer_attach(self._h, buf))
+
+    def peer_selftest(self) -> bool:
+        return _check(self._lib.hmx_peer_selftest(self._h)) == 1
+
+    def peer_enable(self, on=True):
+        _check(self._lib.hmx_peer_enable(self._h, int(bool(on))))
 
     def set_host_allreduce(self, fn):
         """``fn(np.ndarray[float64])`` must sum the array over all ranks in place."""

@@ -100,6 +100,15 @@ struct hmx_engine {
     double* stage_host = nullptr;  // pinned staging buffer of the host transport
     size_t stage_n = 0;
     long n_collectives = 0;
+    // peer boxes: the in-kernel exchange of the per-block sums (k_round, cells sharded over ranks)
+    double* box = nullptr;               // this rank's box (device memory, exported to the peers)
+    size_t box_doubles = 0;
+    std::vector<void*> peer_ptrs;        // every rank's box as mapped here (own box included)
+    DevBuf<double*> peer_dev;            // the same array on the device
+    bool peers_attached = false, peers_enabled = false;
+    unsigned long long round_epoch = 0;  // flag base of the next sweep launch (+64 per launch, same on every rank)
+    unsigned long long selftest_token = 0x5EED0000ull;
+    int round_wgs_cap = 0;               // HMX_ROUND_WGS: cap of the sweep grid (tests with several engines on one GPU)
     int n_s_tiles = 0, ntasks = 0;
     std::vector<int> h_task_grp;
 
@@ -160,6 +169,16 @@ int rccl_load() {
 void comm_release(hmx_engine* e) {
     if (e->nccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(e->nccl_comm);
     e->nccl_comm = nullptr;
+}
+
+void peer_release(hmx_engine* e) {
+    for (size_t r = 0; r < e->peer_ptrs.size(); ++r)
+        if (e->peer_ptrs[r] && e->peer_ptrs[r] != (void*)e->box) (void)hipIpcCloseMemHandle(e->peer_ptrs[r]);
+    e->peer_ptrs.clear();
+    e->peer_dev.release();
+    if (e->box) (void)hipFree(e->box);
+    e->box = nullptr;
+    e->peers_attached = e->peers_enabled = false;
 }
 
 // Sum `count` doubles at device pointer `p` over all ranks, in place, ordered on the engine's stream.
@@ -297,6 +316,7 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
     if (const char* ab = getenv("HMX_ABLATE")) e->ablate = atoi(ab);
     if (const char* tpw = getenv("HMX_TILES_PER_WAVE")) e->tiles_per_wave = std::max(1, atoi(tpw));
     if (const char* rw = getenv("HMX_RTZ_WGS_PER_CU")) e->rtz_wgs_per_cu = std::max(1, std::min(8, atoi(rw)));
+    if (const char* rc_ = getenv("HMX_ROUND_WGS")) e->round_wgs_cap = std::max(0, atoi(rc_));
     if (const char* rm = getenv("HMX_ROUND_MODE")) e->round_mode = (std::string(rm) == "blocks") ? 0 : 1;
     int rc = 0;
     do {
@@ -365,6 +385,7 @@ void hmx_destroy(hmx_engine* e) {
     e->global_id.release(); e->Sslots.release(); e->sync_words.release();
     if (e->sync_host) (void)hipHostFree(e->sync_host);
     comm_release(e);
+    peer_release(e);
     if (e->stage_host) (void)hipHostFree(e->stage_host);
     if (e->obj_host) (void)hipHostFree(e->obj_host);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -522,7 +543,8 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         Timed t(e, F_RTZ_REDUCE);
         launch_y_normalize_d(e->Yacc64, e->Y.p, e->K, e->K16, e->d, e->ldy, e->stream);  // :444
     }
-    const bool mega = (flags & HMX_ROUND_UPDATE_R) && e->round_mode == 1 && !sharded(e) && e->mt <= 7 && round_row_floats(e->d) == e->dp &&
+    const bool mega = (flags & HMX_ROUND_UPDATE_R) && e->round_mode == 1 && (!sharded(e) || e->peers_enabled) && e->mt <= 7 &&
+                      round_row_floats(e->d) == e->dp &&
                       round_lds_bytes(e->K16, e->dp, e->G, e->B) <= 150 * 1024;
     if (mega) {
         // the whole sweep in one persistent launch (k_round); closes O, T and the objective itself
@@ -530,7 +552,15 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         HIP_TRY(hipMemsetAsync(e->sync_words.p, 0, 2 * sizeof(unsigned), e->stream));
         int max_upper = 0;
         for (int b = 0; b < e->nblk; ++b) max_upper = std::max(max_upper, tiles_upper[b]);
-        const int wgs = std::min(e->n_cus, std::max(1, (max_upper + 13) / 14));   // ~14 of a workgroup's 16 tile slots
+        const bool multi = e->peers_enabled && e->n_ranks > 1;
+        int wgs = std::min(e->n_cus - (multi ? 1 : 0), std::max(1, (max_upper + 13) / 14));   // ~14 of a workgroup's 16 tile slots
+        if (multi) {
+            // every rank must size its grid from its own share, but a rank whose share is small must not
+            // starve the others: the grid only decides how this rank's tiles are dealt out
+            if (e->round_wgs_cap > 0) wgs = std::min(wgs, e->round_wgs_cap);
+        } else if (e->round_wgs_cap > 0) {
+            wgs = std::min(wgs, e->round_wgs_cap);
+        }
         Timed t(e, F_ASSIGN_BLOCK);
         RoundArgs ra{};
         ra.Zcos = e->Zcos.p; ra.Y = e->Y.p; ra.sigma = e->sigma.p; ra.R = e->R.p;
@@ -540,13 +570,18 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         ra.counter = e->sync_words.p; ra.error = e->sync_words.p + 1;
         ra.K = e->K; ra.Kp = e->Kp; ra.K16 = e->K16; ra.dp = e->dp; ra.ldy = e->ldy; ra.G = e->G; ra.B = e->B; ra.V = e->V;
         ra.nblk = e->nblk;
+        if (multi) {
+            ra.peer_box = e->peer_dev.p; ra.my_box = e->box; ra.n_ranks = e->n_ranks; ra.rank = e->rank;
+            ra.epoch = e->round_epoch;
+            e->round_epoch += 64;
+        }
 #ifdef HMX_ROUND_PROF
         static DevBuf<unsigned long long> prof;
         static int prof_rounds = 0;
         if (prof.reserve((size_t)wgs * e->nblk * 16)) return -1;
         ra.prof = prof.p;
 #endif
-        if (launch_round(ra, e->mt, wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported shape for k_round");
+        if (launch_round(ra, e->mt, multi ? wgs + 1 : wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported shape for k_round");
 #ifdef HMX_ROUND_PROF
         if (++prof_rounds == 25) {   // one round in steady state: phase durations over workgroups and blocks
             std::vector<unsigned long long> h((size_t)wgs * e->nblk * 16);
@@ -587,6 +622,8 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         }
 #endif
         HIP_TRY(hipMemcpyAsync(e->sync_host, e->sync_words.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+        // the two objective sums (:399, :402) of this rank's cells; the cross-entropy term was formed from job-wide tables
+        if (multi && (rc = sum_over_ranks(e, e->objacc, 2 * HMX_OBJ_SLOTS))) return rc;
     } else if (flags & HMX_ROUND_UPDATE_R) {
         for (int b = 0; b < e->nblk; ++b) {
             {
@@ -733,6 +770,78 @@ int hmx_comm_init(hmx_engine* e, const void* unique_id, int n_ranks, int rank) {
     e->nccl_comm = comm;
     e->n_ranks = n_ranks;
     e->rank = rank;
+    return HMX_OK;
+}
+
+int hmx_set_ranks(hmx_engine* e, int n_ranks, int rank) {
+    if (!e) return fail(HMX_ERR_ARG, "null argument");
+    if (n_ranks < 1 || n_ranks > 8 || rank < 0 || rank >= n_ranks) return fail(HMX_ERR_ARG, "rank %d of %d (at most 8 ranks)", rank, n_ranks);
+    if (e->box) return fail(HMX_ERR_STATE, "peer boxes already exist");
+    e->n_ranks = n_ranks;
+    e->rank = rank;
+    return HMX_OK;
+}
+
+int hmx_peer_export(hmx_engine* e, void* out_handle) {
+    if (!e || !out_handle) return fail(HMX_ERR_ARG, "null argument");
+    if (e->n_ranks < 1 || e->n_ranks > 8) return fail(HMX_ERR_ARG, "peer boxes support at most 8 ranks");
+    static_assert(sizeof(hipIpcMemHandle_t) == HMX_PEER_HANDLE_BYTES, "handle size");
+    int rc;
+    if ((rc = use_device(e))) return rc;
+    peer_release(e);
+    const size_t GK = (size_t)e->G * e->K16;
+    e->box_doubles = peer_box_doubles(e->n_ranks, GK);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->box), e->box_doubles * sizeof(double)));
+    HIP_TRY(hipMemset(e->box, 0, e->box_doubles * sizeof(double)));
+    HIP_TRY(hipDeviceSynchronize());
+    hipIpcMemHandle_t h;
+    HIP_TRY(hipIpcGetMemHandle(&h, e->box));
+    std::memcpy(out_handle, &h, sizeof h);
+    return HMX_OK;
+}
+
+int hmx_peer_attach(hmx_engine* e, const void* handles) {
+    if (!e || !handles) return fail(HMX_ERR_ARG, "null argument");
+    if (!e->box) return fail(HMX_ERR_STATE, "hmx_peer_export must come first");
+    int rc;
+    if ((rc = use_device(e))) return rc;
+    e->peer_ptrs.assign(e->n_ranks, nullptr);
+    for (int r = 0; r < e->n_ranks; ++r) {
+        if (r == e->rank) { e->peer_ptrs[r] = e->box; continue; }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, (const char*)handles + (size_t)r * HMX_PEER_HANDLE_BYTES, sizeof h);
+        void* p = nullptr;
+        hipError_t he = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (he != hipSuccess || !p) {
+            (void)hipGetLastError();
+            return fail(HMX_ERR_COMM, "hipIpcOpenMemHandle(rank %d) failed: %s", r, hipGetErrorString(he));
+        }
+        e->peer_ptrs[r] = p;
+    }
+    if ((rc = e->peer_dev.reserve(e->n_ranks))) return rc;
+    HIP_TRY(hipMemcpy(e->peer_dev.p, e->peer_ptrs.data(), e->n_ranks * sizeof(double*), hipMemcpyHostToDevice));
+    e->peers_attached = true;
+    return HMX_OK;
+}
+
+int hmx_peer_selftest(hmx_engine* e) {
+    if (!e) return fail(HMX_ERR_ARG, "null argument");
+    if (!e->peers_attached) return fail(HMX_ERR_STATE, "hmx_peer_attach must come first");
+    int rc;
+    if ((rc = use_device(e))) return rc;
+    HIP_TRY(hipMemsetAsync(e->sync_words.p, 0, 2 * sizeof(unsigned), e->stream));
+    e->selftest_token += 1;
+    launch_peer_selftest(e->peer_dev.p, e->box, e->n_ranks, e->rank, (size_t)e->G * e->K16, e->selftest_token, e->sync_words.p, e->stream);
+    HIP_TRY(hipMemcpyAsync(e->sync_host, e->sync_words.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipGetLastError());
+    return e->sync_host[0] == 1u ? 1 : 0;
+}
+
+int hmx_peer_enable(hmx_engine* e, int on) {
+    if (!e) return fail(HMX_ERR_ARG, "null argument");
+    if (on && !e->peers_attached) return fail(HMX_ERR_STATE, "no peer boxes attached");
+    e->peers_enabled = on != 0;
     return HMX_OK;
 }
 

@@ -50,6 +50,11 @@ struct RoundArgs {
     unsigned* counter;       // arrivals (zeroed by the caller)
     unsigned* error;         // set to 1 when a wait gave up (zeroed by the caller)
     unsigned long long* prof;  // HMX_ROUND_PROF builds: wgs x nblk x 8 time stamps (or null)
+    // cells sharded over ranks: the block sums travel through peer boxes (null / 1: single engine)
+    double* const* peer_box;   // n_ranks box base pointers (own box included), device array
+    double* my_box;
+    unsigned long long epoch;  // flag value of block b in this launch = epoch + b + 1
+    int n_ranks, rank;
     int K, Kp, K16, dp, ldy, ldy_lds, G, B, V, nblk;
 };
 
@@ -132,6 +137,9 @@ struct OrderArgs {
 size_t round_lds_bytes(int K16, int dp, int G, int B);
 int round_row_floats(int d);
 int launch_round(const RoundArgs& a, int mt, int wgs, hipStream_t s);
+size_t peer_box_doubles(int n_ranks, size_t GK);
+void launch_peer_selftest(double* const* peer_box, double* my_box, int n_ranks, int rank, size_t GK, unsigned long long token,
+                          unsigned* result, hipStream_t s);
 void launch_order(const OrderArgs& a, hipStream_t s);
 int order_chunks(int64_t N);
 void launch_normalize_rows(const float* Z, float* Zc, int64_t N, int dp, hipStream_t s);

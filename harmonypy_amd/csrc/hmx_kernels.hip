@@ -550,6 +550,21 @@ __device__ __forceinline__ double ld_agent(const double* p) {
 __device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// peer boxes (other GPUs over xGMI): 8-byte system-scope atomics on both sides
+__device__ __forceinline__ double ld_sys(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_sys(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_sys(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// A rank's box: data [parity 2][source rank][G x K16] doubles, then flags [parity 2][source rank] u64,
+// then 2 x n_ranks u64 of self-test words.
+__device__ __host__ __forceinline__ size_t box_data(int n_ranks, size_t GK, int par, int src) { return ((size_t)par * n_ranks + src) * GK; }
+__device__ __host__ __forceinline__ size_t box_flags(int n_ranks, size_t GK) { return (size_t)2 * n_ranks * GK; }
 
 // KS = row length of Z_cos in 4-float k-steps (dp = 4 KS).  Lane (c16, q) takes the 16-byte pieces
 // q, q+4, .. of its cell's row -- piece j is exactly the B operand of the four k-steps of column
@@ -792,7 +807,40 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int c16 = lane & 15, q = lane >> 4;
-    const int wg = blockIdx.x, nwg = gridDim.x;
+    const bool multi = a.n_ranks > 1;
+    const int wg = blockIdx.x, nwg = multi ? gridDim.x - 1 : gridDim.x;   // compute workgroups
+    unsigned long long* my_flags = multi ? reinterpret_cast<unsigned long long*>(a.my_box + box_flags(a.n_ranks, GK)) : nullptr;
+
+    if (multi && wg == nwg) {
+        // ---- gateway workgroup: once every local workgroup has added its sums of block b, write the
+        //      rank's total into every rank's box (xGMI peer writes), then raise this rank's flag there.
+        bool gfail = false;
+        for (int b = 0; b < a.nblk; ++b) {
+            if (wv == 0) {
+                const unsigned want = (unsigned)(b + 1) * (unsigned)nwg;
+                unsigned spins = 0;
+                while (ld_agent(a.counter) < want) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 24)) { gfail = true; break; }
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < GK; i += ROUND_THREADS) {
+                const double* sn = a.S_new + (size_t)b * HMX_ROUND_SLOTS * GK + i;
+                double v = 0.0;
+#pragma unroll
+                for (int s = 0; s < HMX_ROUND_SLOTS; ++s) v += ld_agent(sn + (size_t)s * GK);
+                for (int r = 0; r < a.n_ranks; ++r) st_sys(a.peer_box[r] + box_data(a.n_ranks, GK, b & 1, a.rank) + i, v);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid < a.n_ranks)
+                st_sys(reinterpret_cast<unsigned long long*>(a.peer_box[tid] + box_flags(a.n_ranks, GK)) + (size_t)(b & 1) * a.n_ranks + a.rank,
+                       a.epoch + (unsigned long long)b + 1ull);
+        }
+        if (gfail && tid == 0) atomicExch(a.error, 1u);
+        return;
+    }
 
     for (int i = tid; i < a.B; i += ROUND_THREADS) {
         prb[i] = a.Pr_b[i];
@@ -869,11 +917,22 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         RSTAMP(8);
         // ---- wait until every workgroup has added its sums of block b-1 ---------------------
         if (b > 0 && wv == 0) {
-            const unsigned want = (unsigned)b * (unsigned)nwg;
             unsigned spins = 0;
-            while (ld_agent(a.counter) < want) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 24)) { failed = true; break; }
+            if (!multi) {
+                const unsigned want = (unsigned)b * (unsigned)nwg;
+                while (ld_agent(a.counter) < want) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 24)) { failed = true; break; }
+                }
+            } else {   // every rank's total of block b-1 has landed in this rank's box
+                const unsigned long long want = a.epoch + (unsigned long long)b;
+                const unsigned long long* fl = my_flags + (size_t)((b - 1) & 1) * a.n_ranks;
+                while (true) {
+                    const bool ok = lane >= a.n_ranks || ld_sys(fl + lane) >= want;
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 24)) { failed = true; break; }
+                }
             }
 #ifdef HMX_ROUND_PROF
             if (tid == 0 && a.prof) a.prof[((size_t)wg * a.nblk + b) * 16 + 10] = spins;
@@ -884,18 +943,24 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         RSTAMP(1);
         // ---- O without this block, with the previous block's new sums (:491-492, 506-507) ---
         for (int i = tid; i < GK; i += ROUND_THREADS) {
-            double add[HMX_ROUND_SLOTS];
+            double add[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) add[s] = 0.0;
             if (b > 0 && !(HMX_RABL & 8)) {
-                const double* sn = a.S_new + (size_t)(b - 1) * HMX_ROUND_SLOTS * GK + i;
+                if (!multi) {
+                    const double* sn = a.S_new + (size_t)(b - 1) * HMX_ROUND_SLOTS * GK + i;
 #pragma unroll
-                for (int s = 0; s < HMX_ROUND_SLOTS; ++s) add[s] = ld_agent(sn + (size_t)s * GK);   // independent loads
-            } else {
+                    for (int s = 0; s < HMX_ROUND_SLOTS; ++s) add[s] = ld_agent(sn + (size_t)s * GK);   // independent loads
+                } else {
+                    const double* bx = a.my_box + box_data(a.n_ranks, GK, (b - 1) & 1, 0) + i;
 #pragma unroll
-                for (int s = 0; s < HMX_ROUND_SLOTS; ++s) add[s] = 0.0;
+                    for (int s = 0; s < 8; ++s)
+                        if (s < a.n_ranks) add[s] = ld_sys(bx + (size_t)s * GK);
+                }
             }
             double o = Ocur[i] - a.S_old[(size_t)b * GK + i];
 #pragma unroll
-            for (int s = 0; s < HMX_ROUND_SLOTS; ++s) o += add[s];
+            for (int s = 0; s < 8; ++s) o += add[s];
             Ocur[i] = o;
             Sd[i] = 0.0;
         }
@@ -1021,19 +1086,35 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
 
     // ---- workgroup 0 closes the sweep: O, cluster mass, cross-entropy term (:405-411) -----------
     if (wv == 0) {
-        const unsigned want = (unsigned)a.nblk * (unsigned)nwg;
         unsigned spins = 0;
-        while (ld_agent(a.counter) < want) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 24)) { if (lane == 0) atomicExch(a.error, 1u); break; }
+        if (!multi) {
+            const unsigned want = (unsigned)a.nblk * (unsigned)nwg;
+            while (ld_agent(a.counter) < want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 24)) { if (lane == 0) atomicExch(a.error, 1u); break; }
+            }
+        } else {
+            const unsigned long long want = a.epoch + (unsigned long long)a.nblk;
+            const unsigned long long* fl = my_flags + (size_t)((a.nblk - 1) & 1) * a.n_ranks;
+            while (true) {
+                const bool ok = lane >= a.n_ranks || ld_sys(fl + lane) >= want;
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 24)) { if (lane == 0) atomicExch(a.error, 1u); break; }
+            }
         }
     }
     __syncthreads();
     for (int i = tid; i < GK; i += ROUND_THREADS) {
         double o = Ocur[i];
-        const double* sn = a.S_new + (size_t)(a.nblk - 1) * HMX_ROUND_SLOTS * GK + i;
+        if (!multi) {
+            const double* sn = a.S_new + (size_t)(a.nblk - 1) * HMX_ROUND_SLOTS * GK + i;
 #pragma unroll
-        for (int s = 0; s < HMX_ROUND_SLOTS; ++s) o += ld_agent(sn + (size_t)s * GK);
+            for (int s = 0; s < HMX_ROUND_SLOTS; ++s) o += ld_agent(sn + (size_t)s * GK);
+        } else {
+            const double* bx = a.my_box + box_data(a.n_ranks, GK, (a.nblk - 1) & 1, 0) + i;
+            for (int s = 0; s < a.n_ranks; ++s) o += ld_sys(bx + (size_t)s * GK);
+        }
         Ocur[i] = o;
         a.O_out[i] = o;
     }
@@ -2058,6 +2139,32 @@ size_t round_lds_bytes(int K16, int dp, int G, int B) {
     // sigma, -1/sigma, rp, lrp, rpc | O, S, T, objective scratch (fp64) | Pr_b, theta, group_cols (V <= 8), bgrp, block offsets
     return ((size_t)K16 * lds_ldy(dp) + 2 * (size_t)K16 + 2 * GK + (size_t)K16 * B) * 4 + (2 * GK + K16 + 2 * ROUND_WAVES) * 8 +
            (3 * (size_t)B + (size_t)G * 8 + 64) * 4;
+}
+
+size_t peer_box_doubles(int n_ranks, size_t GK) { return box_flags(n_ranks, GK) + 2 * (size_t)n_ranks + 2 * (size_t)n_ranks + 8; }
+
+// One exchange cycle over the peer boxes with a time-out: every rank writes `token` into its
+// self-test word in every rank's box, then waits until all ranks' words in ITS box carry the token.
+__global__ __launch_bounds__(64) void k_peer_selftest(double* const* peer_box, double* my_box, int n_ranks, int rank, size_t GK,
+                                                      unsigned long long token, unsigned* result) {
+    const int lane = threadIdx.x;
+    const size_t test0 = box_flags(n_ranks, GK) + 2 * (size_t)n_ranks;   // in doubles == in u64 words
+    if (lane < n_ranks) st_sys(reinterpret_cast<unsigned long long*>(peer_box[lane]) + test0 + rank, token);
+    const unsigned long long* mine = reinterpret_cast<const unsigned long long*>(my_box) + test0;
+    unsigned spins = 0;
+    bool ok_all = false;
+    while (true) {
+        const bool ok = lane >= n_ranks || ld_sys(mine + lane) == token;
+        if (__all(ok)) { ok_all = true; break; }
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 22)) break;
+    }
+    if (lane == 0) *result = ok_all ? 1u : 0u;
+}
+
+void launch_peer_selftest(double* const* peer_box, double* my_box, int n_ranks, int rank, size_t GK, unsigned long long token,
+                          unsigned* result, hipStream_t s) {
+    hipLaunchKernelGGL(k_peer_selftest, dim3(1), dim3(64), 0, s, peer_box, my_box, n_ranks, rank, GK, token, result);
 }
 
 // k_round is compiled for Z_cos rows of 32, 52 and 64 floats (d <= 32, <= 52, <= 64: the engine pads

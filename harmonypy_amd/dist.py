@@ -93,7 +93,50 @@ class Shard:
     def attach(self, engine):
         """Give ``engine`` (a ``_capi.Engine``) its transport.  If RCCL cannot be brought up on
         every rank, all ranks fall back to the host transport together (with a warning): a
-        sharded job never silently runs unsharded."""
+        sharded job never silently runs unsharded.  On top of either transport the per-block
+        sums of ``update_R`` travel through peer boxes inside the sweep kernel when every rank's
+        self-test of that exchange succeeds (``HMX_PEER_EXCHANGE=0`` disables the attempt)."""
+        name = self._attach_transport(engine)
+        self.peer_exchange = self._attach_peers(engine)
+        return name + ("+peer" if self.peer_exchange else "")
+
+    def _attach_peers(self, engine):
+        import logging
+        import os
+        from . import _capi
+        if os.environ.get("HMX_PEER_EXCHANGE", "1") == "0" or self.world > 8:
+            return False
+        ok, err, handle = 1, "", b""
+        try:
+            engine.set_ranks(self.world, self.rank)
+            handle = engine.peer_export()
+        except _capi.HmxError as exc:
+            ok, err = 0, str(exc)
+        handles = self.allgather_object(handle)
+        if ok and all(len(h) == _capi.HMX_PEER_HANDLE_BYTES for h in handles):
+            try:
+                engine.peer_attach(b"".join(handles))
+            except _capi.HmxError as exc:
+                ok, err = 0, str(exc)
+        else:
+            ok = 0
+        flag = np.array([ok], dtype=np.int64)
+        self.allreduce_(flag)                          # also a barrier: every box is mapped everywhere
+        if int(flag[0]) == self.world:
+            try:
+                ok = 1 if engine.peer_selftest() else 0
+            except _capi.HmxError as exc:
+                ok, err = 0, str(exc)
+            flag = np.array([ok], dtype=np.int64)
+            self.allreduce_(flag)
+        if int(flag[0]) == self.world:
+            engine.peer_enable(True)
+            return True
+        logging.getLogger("harmonypy_amd").warning(
+            f"rank {self.rank}: in-kernel peer exchange unavailable {err}; one collective per update block instead")
+        return False
+
+    def _attach_transport(self, engine):
         import logging
         from . import _capi
         if self.transport == "rccl":

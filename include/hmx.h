@@ -115,6 +115,22 @@ int hmx_comm_init(hmx_engine* e, const void* unique_id, int n_ranks, int rank);
 typedef int (*hmx_host_allreduce_fn)(void* ctx, double* buf, size_t count);
 int hmx_set_host_allreduce(hmx_engine* e, hmx_host_allreduce_fn fn, void* ctx);
 
+/* Peer exchange inside the sweep kernel.  The 20 per-block sums of a round (harmony.py:506-507)
+ * sit on the critical path of update_R; with peer boxes attached they are exchanged INSIDE the
+ * persistent sweep kernel -- every GPU writes its block sums straight into the other GPUs' boxes
+ * over xGMI -- instead of one collective launch per block.  Each rank exports the inter-process
+ * handle of its box (hmx_peer_export, HMX_PEER_HANDLE_BYTES bytes), the caller gathers the handles
+ * of all ranks in rank order and hands them to hmx_peer_attach.  hmx_peer_selftest runs one
+ * exchange cycle with a time-out and returns 1 when every peer's token arrived, 0 otherwise (the
+ * caller enables the in-kernel exchange only when all ranks report 1).  n_ranks / rank must be
+ * given first (hmx_comm_init, or hmx_set_ranks with a host transport). */
+#define HMX_PEER_HANDLE_BYTES 64
+int hmx_set_ranks(hmx_engine* e, int n_ranks, int rank);
+int hmx_peer_export(hmx_engine* e, void* out_handle);
+int hmx_peer_attach(hmx_engine* e, const void* handles /* n_ranks x HMX_PEER_HANDLE_BYTES */);
+int hmx_peer_selftest(hmx_engine* e);
+int hmx_peer_enable(hmx_engine* e, int on);
+
 /* harmony.py:376-392 given the k-means centres of harmony.py:370-373.
  * Y0: K x d row-major (centroids as rows, not yet normalised).
  * obj_out = {sum R*dist, sum sigma*R*log R, cross-entropy term, 0}, each rounded to

@@ -39,6 +39,9 @@ def launch(mode, case, outdir, world=2, opts=None, timeout=600):
                 q.kill()
             raise
         logs.append(out.decode(errors="replace"))
+    if os.environ.get("HMX_DEBUG_BOX"):
+        for r in range(world):
+            print(f"--- rank {r} log ---\n{logs[r][-3000:]}")
     for r, p in enumerate(procs):
         assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-4000:]}"
     return [dict(np.load(os.path.join(outdir, f"rank{r}.npz"), allow_pickle=False)) for r in range(world)]
