@@ -2143,28 +2143,61 @@ size_t round_lds_bytes(int K16, int dp, int G, int B) {
 
 size_t peer_box_doubles(int n_ranks, size_t GK) { return box_flags(n_ranks, GK) + 2 * (size_t)n_ranks + 2 * (size_t)n_ranks + 8; }
 
-// One exchange cycle over the peer boxes with a time-out: every rank writes `token` into its
-// self-test word in every rank's box, then waits until all ranks' words in ITS box carry the token.
-__global__ __launch_bounds__(64) void k_peer_selftest(double* const* peer_box, double* my_box, int n_ranks, int rank, size_t GK,
+// Self-test of the peer boxes, with time-outs: eight exchange cycles of exactly the pattern k_round
+// uses -- a payload of system-scope stores into every rank's box, s_waitcnt vmcnt(0), barrier, then
+// one flag word per peer -- and on the receiving side: poll the flag words, then read every rank's
+// payload with system-scope loads and compare.  A payload that is not complete when its flag is
+// visible (ordering over xGMI), a mapping that does not reach the peer, or a peer that never
+// answers all give result 0.  Acknowledge words keep a fast rank from overwriting a payload that a
+// slow rank is still checking.
+__global__ __launch_bounds__(256) void k_peer_selftest(double* const* peer_box, double* my_box, int n_ranks, int rank, size_t GK,
                                                       unsigned long long token, unsigned* result) {
-    const int lane = threadIdx.x;
-    const size_t test0 = box_flags(n_ranks, GK) + 2 * (size_t)n_ranks;   // in doubles == in u64 words
-    if (lane < n_ranks) st_sys(reinterpret_cast<unsigned long long*>(peer_box[lane]) + test0 + rank, token);
-    const unsigned long long* mine = reinterpret_cast<const unsigned long long*>(my_box) + test0;
-    unsigned spins = 0;
-    bool ok_all = false;
-    while (true) {
-        const bool ok = lane >= n_ranks || ld_sys(mine + lane) == token;
-        if (__all(ok)) { ok_all = true; break; }
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1u << 22)) break;
+    __shared__ int bad;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t tok0 = box_flags(n_ranks, GK) + 2 * (size_t)n_ranks;   // token words, then acknowledge words
+    const size_t ack0 = tok0 + n_ranks;
+    const int npay = (int)min((size_t)1024, GK);
+    unsigned long long* mine = reinterpret_cast<unsigned long long*>(my_box);
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    auto wait_all = [&](size_t word0, unsigned long long want) {   // wave 0: all ranks' words in MY box == want
+        if (wv == 0) {
+            unsigned spins = 0;
+            while (true) {
+                const bool ok = lane >= n_ranks || ld_sys(mine + word0 + lane) == want;
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 21)) { if (lane == 0) bad = 1; break; }
+            }
+        }
+        __syncthreads();
+    };
+    for (int it = 0; it < 8 && !bad; ++it) {
+        const unsigned long long tk = token * 16ull + (unsigned long long)it;
+        const int par = it & 1;
+        for (int r = 0; r < n_ranks; ++r)
+            for (int i = tid; i < npay; i += 256) st_sys(peer_box[r] + box_data(n_ranks, GK, par, rank) + i, (double)(tk % 1000003ull) + i);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid < n_ranks) st_sys(reinterpret_cast<unsigned long long*>(peer_box[tid]) + tok0 + rank, tk);
+        wait_all(tok0, tk);
+        if (bad) break;
+        int wrong = 0;
+        for (int r = 0; r < n_ranks; ++r)
+            for (int i = tid; i < npay; i += 256)
+                wrong |= ld_sys(my_box + box_data(n_ranks, GK, par, r) + i) != (double)(tk % 1000003ull) + i;
+        if (wrong) bad = 1;
+        __syncthreads();
+        if (tid < n_ranks) st_sys(reinterpret_cast<unsigned long long*>(peer_box[tid]) + ack0 + rank, tk);
+        wait_all(ack0, tk);
     }
-    if (lane == 0) *result = ok_all ? 1u : 0u;
+    __syncthreads();
+    if (tid == 0) *result = bad ? 0u : 1u;
 }
 
 void launch_peer_selftest(double* const* peer_box, double* my_box, int n_ranks, int rank, size_t GK, unsigned long long token,
                           unsigned* result, hipStream_t s) {
-    hipLaunchKernelGGL(k_peer_selftest, dim3(1), dim3(64), 0, s, peer_box, my_box, n_ranks, rank, GK, token, result);
+    hipLaunchKernelGGL(k_peer_selftest, dim3(1), dim3(256), 0, s, peer_box, my_box, n_ranks, rank, GK, token, result);
 }
 
 // k_round is compiled for Z_cos rows of 32, 52 and 64 floats (d <= 32, <= 52, <= 64: the engine pads
