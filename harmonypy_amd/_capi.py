@@ -25,7 +25,7 @@ EXPORTS = [
     "hmx_last_error", "hmx_abi_version", "hmx_create", "hmx_destroy", "hmx_upload", "hmx_init_cluster",
     "hmx_cluster_round", "hmx_cluster_round_seeded", "hmx_moe_correct_ridge", "hmx_get", "hmx_set", "hmx_sync", "hmx_device_ptr",
     "hmx_kernel_times", "hmx_enable_timing", "hmx_comm_unique_id", "hmx_comm_init", "hmx_set_host_allreduce",
-    "hmx_set_ranks", "hmx_peer_export", "hmx_peer_attach", "hmx_peer_selftest", "hmx_peer_enable",
+    "hmx_kmeans_lloyd", "hmx_set_ranks", "hmx_peer_export", "hmx_peer_attach", "hmx_peer_selftest", "hmx_peer_enable",
 ]
 HMX_PEER_HANDLE_BYTES = 64
 HMX_ABI_VERSION = 2
@@ -74,6 +74,7 @@ def load():
     lib.hmx_peer_selftest.argtypes = [vp]
     lib.hmx_peer_enable.argtypes = [vp, C.c_int]
     lib.hmx_init_cluster.argtypes = [vp, vp, vp]
+    lib.hmx_kmeans_lloyd.argtypes = [vp, vp, C.c_int, vp]
     lib.hmx_cluster_round.argtypes = [vp, C.c_int, vp, i64, vp, i32, vp, vp]
     lib.hmx_cluster_round_seeded.argtypes = [vp, C.c_int, C.c_uint64, i64, vp]
     lib.hmx_moe_correct_ridge.argtypes = [vp]
@@ -189,6 +190,14 @@ class Engine:
                 return 1
         self._host_cb = HOST_ALLREDUCE_FN(_cb)                  # keep the thunk alive
         _check(self._lib.hmx_set_host_allreduce(self._h, self._host_cb, None))
+
+    def kmeans_lloyd(self, centers, n_iter=25):
+        """Lloyd iterations over all cells of Z_cos on the device; centres K x d in and out."""
+        cin = _c(centers, np.float32)
+        assert cin.shape == (self.K, self.d)
+        out = np.empty((self.K, self.d), np.float32)
+        _check(self._lib.hmx_kmeans_lloyd(self._h, _ptr(cin), int(n_iter), _ptr(out)))
+        return out
 
     def init_cluster(self, Y0_rows):
         Y0 = _c(Y0_rows, np.float32)

@@ -83,6 +83,8 @@ struct hmx_engine {
     // Tables that are summed over ranks live in one allocation, laid out so that tables summed at the
     // same point of the algorithm are neighbours (one collective each):
     //   Sold [nblk][G][K16] | Yacc64 [K16][ldy] | Snew [nblk][G][K16] | objacc [2*SLOTS+2] | Sr [G][K16][ldy] | Oxr [G][K16]
+    DevBuf<float> km_hn;         // device k-means: half squared norms of the centres
+    DevBuf<double> km_sums;      // device k-means: K16 x (d+1) member sums and counts
     DevBuf<double> Sslots;       // k_round: nblk x HMX_ROUND_SLOTS x G x K16
     DevBuf<unsigned> sync_words; // k_round: {arrival counter, error flag}
     unsigned* sync_host = nullptr;  // pinned copy of sync_words
@@ -382,7 +384,7 @@ void hmx_destroy(hmx_engine* e) {
     e->r_cells.release(); e->r_tile_grp.release(); e->r_blk_start.release(); e->task_t0.release(); e->task_t1.release();
     e->task_grp.release(); e->gstart.release(); e->chunk_tab.release(); e->run_count.release(); e->run_start.release();
     e->Ogrp.release(); e->Tmass.release(); e->Ohist.release(); e->xch.release(); e->scratch.release();
-    e->global_id.release(); e->Sslots.release(); e->sync_words.release();
+    e->global_id.release(); e->Sslots.release(); e->sync_words.release(); e->km_hn.release(); e->km_sums.release();
     if (e->sync_host) (void)hipHostFree(e->sync_host);
     comm_release(e);
     peer_release(e);
@@ -472,6 +474,38 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipGetLastError());
     e->uploaded = true;
+    return HMX_OK;
+}
+
+int hmx_kmeans_lloyd(hmx_engine* e, const float* centers_in, int n_iter, float* centers_out) {
+    if (!e || !centers_in || !centers_out) return fail(HMX_ERR_ARG, "null argument");
+    if (!e->uploaded) return fail(HMX_ERR_STATE, "hmx_upload must come first");
+    if (n_iter < 0) return fail(HMX_ERR_ARG, "n_iter must be >= 0");
+    if (e->mt > 7 || e->dp > 64) return fail(HMX_ERR_ARG, "device k-means supports K <= 112 and d <= 64");
+    int rc;
+    if ((rc = use_device(e))) return rc;
+    const size_t nsum = (size_t)e->K16 * (e->d + 1);
+    const int wgs = std::min(2 * e->n_cus, std::max(1, (e->n_s_tiles + 7) / 8));
+    if ((rc = e->km_hn.reserve(e->K16)) || (rc = e->km_sums.reserve(nsum)) ||
+        (rc = e->slab.reserve(kmeans_slab_floats(wgs, e->K16, e->dp))))
+        return rc;
+    std::vector<float> y((size_t)e->K16 * e->ldy, 0.f);
+    for (int k = 0; k < e->K; ++k) std::memcpy(&y[(size_t)k * e->ldy], centers_in + (size_t)k * e->d, sizeof(float) * e->d);
+    HIP_TRY(hipMemcpyAsync(e->Yacc.p, y.data(), y.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemsetAsync(e->km_sums.p, 0, nsum * sizeof(double), e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    launch_kmeans_update(e->km_sums.p, e->Yacc.p, e->km_hn.p, e->K, e->K16, e->d, e->ldy, e->stream);   // counts 0: norms only
+    for (int it = 0; it < n_iter; ++it) {
+        if (launch_kmeans_step(e->Zcos.p, e->Yacc.p, e->km_hn.p, e->s_cells.p, e->n_s_tiles, e->slab.p, e->K, e->K16, e->dp,
+                               e->ldy, wgs, e->stream))
+            return fail(HMX_ERR_ARG, "unsupported shape for the device k-means");
+        launch_kmeans_sums(e->slab.p, wgs, e->K16, e->dp, e->d, e->km_sums.p, e->stream);
+        if ((rc = sum_over_ranks(e, e->km_sums.p, nsum))) return rc;
+        launch_kmeans_update(e->km_sums.p, e->Yacc.p, e->km_hn.p, e->K, e->K16, e->d, e->ldy, e->stream);
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy2D(centers_out, (size_t)e->d * 4, e->Yacc.p, (size_t)e->ldy * 4, (size_t)e->d * 4, e->K, hipMemcpyDeviceToHost));
     return HMX_OK;
 }
 

@@ -140,6 +140,11 @@ int launch_round(const RoundArgs& a, int mt, int wgs, hipStream_t s);
 size_t peer_box_doubles(int n_ranks, size_t GK);
 void launch_peer_selftest(double* const* peer_box, double* my_box, int n_ranks, int rank, size_t GK, unsigned long long token,
                           unsigned* result, hipStream_t s);
+size_t kmeans_slab_floats(int wgs, int K16, int dp);
+int launch_kmeans_step(const float* Zcos, const float* C, const float* hn, const int* cells, int n_tiles, float* slab, int K,
+                       int K16, int dp, int ldy, int wgs, hipStream_t s);
+void launch_kmeans_sums(const float* slab, int wgs, int K16, int dp, int d, double* sums, hipStream_t s);
+void launch_kmeans_update(const double* sums, float* C, float* hn, int K, int K16, int d, int ldy, hipStream_t s);
 void launch_order(const OrderArgs& a, hipStream_t s);
 int order_chunks(int64_t N);
 void launch_normalize_rows(const float* Z, float* Zc, int64_t N, int dp, hipStream_t s);

@@ -1914,6 +1914,157 @@ __global__ __launch_bounds__(256, 3) void k_ridge_apply2(ApplyArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Lloyd iterations of the initial k-means (harmony.py:369-373 runs sklearn KMeans on the host:
+// 18 s at 1M cells) on the device, for jobs too large for that.  Euclidean k-means on the
+// unit-length rows of Z_cos, as sklearn does: label = argmin ||z - c||^2 = argmax (z.c - ||c||^2/2),
+// centroid = mean of its members.
+//   k_kmeans_step   : workgroups of 8 waves walk the static tile list; centres (K16 x d) and their
+//                     half squared norms in LDS; one tile per wave per step: gather, f32 MFMA, per-cell
+//                     argmax (28 scores per lane, then two xor-shuffles); members' rows are added to an
+//                     LDS table of sums with ds_add_f32, flushed once per workgroup to a slab.
+//   k_kmeans_update : one workgroup per cluster sums the slabs in fp64 -> new centre (empty clusters keep
+//                     theirs), half squared norm.
+// Seeding (k-means++) stays on the host, on a subsample (harmonypy_amd/harmony.py).
+// ------------------------------------------------------------------------------------------
+struct KmeansArgs {
+    const float* Zcos;     // N x dp
+    const float* C;        // K16 x ldy centres (rows >= K zero)
+    const float* hn;       // K16 half squared norms (+inf for pads)
+    const int* cells;      // static list
+    int n_tiles;
+    float* slab;           // [wgs][K16 x ldc] sums, then [wgs][K16] counts
+    int K, K16, dp, ldy, ldy_lds, ldc;
+};
+
+template <int MT>
+__global__ __launch_bounds__(512, 2) void k_kmeans_step(KmeansArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int K16 = 16 * MT;
+    const int LDY = a.ldy_lds, LDC = a.ldc;
+    float* Ys = reinterpret_cast<float*>(smem);            // K16 x LDY
+    float* hn = Ys + (size_t)K16 * LDY;                    // K16
+    float* Cs = hn + K16;                                  // K16 x LDC sums of member rows
+    float* cnt = Cs + (size_t)K16 * LDC;                   // K16 member counts
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c16 = lane & 15, q = lane >> 4;
+    const int c4n = a.dp >> 2, kb_full = a.dp >> 4, tail = c4n - 4 * kb_full;
+    for (int i = tid; i < K16 * c4n; i += 512) {
+        const int row = i / c4n, c4 = i - row * c4n;
+        st4(Ys + (size_t)row * LDY + 4 * c4, ld4(a.C + (size_t)row * a.ldy + 4 * c4));
+    }
+    for (int i = tid; i < K16; i += 512) { hn[i] = a.hn[i]; cnt[i] = 0.f; }
+    for (int i = tid; i < K16 * LDC; i += 512) Cs[i] = 0.f;
+    __syncthreads();
+    for (int t = blockIdx.x * 8 + wv; t < a.n_tiles; t += gridDim.x * 8) {
+        const int cell = a.cells[(size_t)t * 16 + c16];
+        const bool live = cell >= 0;
+        const float* zr = a.Zcos + (size_t)(live ? cell : 0) * a.dp;
+        f32x4 zrow[4];
+        float ztail[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) zrow[j] = (j < kb_full) ? ld4(zr + 16 * j + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) ztail[s2] = (s2 < tail) ? zr[16 * kb_full + 4 * s2 + q] : 0.f;
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < kb_full) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const f32x4 ya = ld4(Ys + (size_t)(16 * mt + c16) * LDY + 16 * j + 4 * q);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[mt] = MFMA16(ya[i], zrow[j][i], acc[mt]);
+                }
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) {
+            if (s2 < tail) {
+                const int col = 16 * kb_full + 4 * s2 + q;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = MFMA16(Ys[(size_t)(16 * mt + c16) * LDY + col], ztail[s2], acc[mt]);
+            }
+        }
+        float best = -INFINITY;
+        int bk = 0;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 h = ld4(hn + 16 * mt + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sc = acc[mt][r] - h[r];
+                const int k = 16 * mt + 4 * q + r;
+                if (sc > best) { best = sc; bk = k; }
+            }
+        }
+#pragma unroll
+        for (int m = 16; m <= 32; m <<= 1) {   // the four q-lanes of a cell hold disjoint clusters
+            const float ob = __shfl_xor(best, m, 64);
+            const int ok = __shfl_xor(bk, m, 64);
+            if (ob > best || (ob == best && ok < bk)) { best = ob; bk = ok; }
+        }
+        if (live) {
+            float* row = Cs + (size_t)bk * LDC;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < kb_full) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) atomicAdd(row + 16 * j + 4 * q + i, zrow[j][i]);
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2)
+                if (s2 < tail) atomicAdd(row + 16 * kb_full + 4 * s2 + q, ztail[s2]);
+            if (q == 0) atomicAdd(cnt + bk, 1.0f);
+        }
+    }
+    __syncthreads();
+    float* out = a.slab + (size_t)blockIdx.x * K16 * LDC;
+    for (int i = tid; i < K16 * LDC; i += 512) out[i] = Cs[i];
+    float* outc = a.slab + (size_t)gridDim.x * K16 * LDC + (size_t)blockIdx.x * K16;
+    for (int i = tid; i < K16; i += 512) outc[i] = cnt[i];
+}
+
+// sums[k][0..d) and counts[k] over the workgroup slabs, in fp64 (one workgroup per cluster)
+__global__ __launch_bounds__(256) void k_kmeans_sums(const float* __restrict__ slab, int wgs, int K16, int ldc, int d,
+                                                     double* __restrict__ sums /* K16 x (d+1) */) {
+    __shared__ double red[256];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    for (int j = 0; j <= d; ++j) {
+        double acc = 0.0;
+        for (int w = tid; w < wgs; w += 256)
+            acc += (j < d) ? (double)slab[((size_t)w * K16 + k) * ldc + j] : (double)slab[(size_t)wgs * K16 * ldc + (size_t)w * K16 + k];
+        red[tid] = acc;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0) sums[(size_t)k * (d + 1) + j] = red[0];
+        __syncthreads();
+    }
+}
+
+// new centres from the (job-wide) sums: mean of the members; empty clusters keep their centre
+__global__ __launch_bounds__(64) void k_kmeans_update(const double* __restrict__ sums, float* __restrict__ C, float* __restrict__ hn,
+                                                      int K, int d, int ldy) {
+    const int k = blockIdx.x, lane = threadIdx.x;
+    const double n = (k < K) ? sums[(size_t)k * (d + 1) + d] : 0.0;
+    float ss = 0.f;
+    for (int j = lane; j < ldy; j += 64) {
+        float c = C[(size_t)k * ldy + j];
+        if (k < K && j < d && n > 0.0) c = (float)(sums[(size_t)k * (d + 1) + j] / n);
+        if (k >= K || j >= d) c = 0.f;
+        C[(size_t)k * ldy + j] = c;
+        ss += c * c;
+    }
+    for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
+    if (lane == 0) hn[k] = (k < K) ? 0.5f * ss : INFINITY;
+}
+
+// ------------------------------------------------------------------------------------------
 // Device-side update order (replaces torch.randperm + the gather/argsort of harmony.py:471-480,
 // 512-513 when the caller does not supply an order).
 //
@@ -2275,6 +2426,37 @@ void launch_rtz2_reduce(const float* slab, int nslabs, int mt, int dp, int K16, 
     const int seg_len = 32;
     hipLaunchKernelGGL(k_rtz2_reduce, dim3(cdiv(mt * ntd * 256, 256), cdiv(nslabs, seg_len)), dim3(256), 0, s, slab, nslabs, mt,
                        ntd, K16, ld, out, task_grp, seg_len);
+}
+
+// ---- device k-means (Lloyd) ---------------------------------------------------------------------
+size_t kmeans_slab_floats(int wgs, int K16, int dp) { return (size_t)wgs * K16 * (lds_ldy(dp) + 1); }
+
+int launch_kmeans_step(const float* Zcos, const float* C, const float* hn, const int* cells, int n_tiles, float* slab, int K,
+                       int K16, int dp, int ldy, int wgs, hipStream_t s) {
+    KmeansArgs a{};
+    a.Zcos = Zcos; a.C = C; a.hn = hn; a.cells = cells; a.n_tiles = n_tiles; a.slab = slab;
+    a.K = K; a.K16 = K16; a.dp = dp; a.ldy = ldy; a.ldy_lds = lds_ldy(dp); a.ldc = lds_ldy(dp);
+    const int mt = K16 / 16;
+    if (mt < 1 || mt > 7 || dp > 64) return -1;
+    const size_t sm = ((size_t)K16 * a.ldy_lds + K16 + (size_t)K16 * a.ldc + K16) * sizeof(float);
+    switch (mt) {
+        case 1: hipLaunchKernelGGL((k_kmeans_step<1>), dim3(wgs), dim3(512), sm, s, a); break;
+        case 2: hipLaunchKernelGGL((k_kmeans_step<2>), dim3(wgs), dim3(512), sm, s, a); break;
+        case 3: hipLaunchKernelGGL((k_kmeans_step<3>), dim3(wgs), dim3(512), sm, s, a); break;
+        case 4: hipLaunchKernelGGL((k_kmeans_step<4>), dim3(wgs), dim3(512), sm, s, a); break;
+        case 5: hipLaunchKernelGGL((k_kmeans_step<5>), dim3(wgs), dim3(512), sm, s, a); break;
+        case 6: hipLaunchKernelGGL((k_kmeans_step<6>), dim3(wgs), dim3(512), sm, s, a); break;
+        default: hipLaunchKernelGGL((k_kmeans_step<7>), dim3(wgs), dim3(512), sm, s, a); break;
+    }
+    return 0;
+}
+
+void launch_kmeans_sums(const float* slab, int wgs, int K16, int dp, int d, double* sums, hipStream_t s) {
+    hipLaunchKernelGGL(k_kmeans_sums, dim3(K16), dim3(256), 0, s, slab, wgs, K16, lds_ldy(dp), d, sums);
+}
+
+void launch_kmeans_update(const double* sums, float* C, float* hn, int K, int K16, int d, int ldy, hipStream_t s) {
+    hipLaunchKernelGGL(k_kmeans_update, dim3(K16), dim3(64), 0, s, sums, C, hn, K, d, ldy);
 }
 
 void rtz_geometry(int mt, int ntd, int* nsub, int* slab_per_wave) {

@@ -40,6 +40,13 @@ UPDATE_ORDER = "auto"
 AUTO_DEVICE_ORDER_CELLS = 200_000
 # sharded jobs: rank 0 fits the initial k-means on all cells up to this many, else on a subsample
 KMEANS_GATHER_CELLS = 2_000_000
+# Initial centroids (harmony.py:369-373).  "host": the reference's sklearn KMeans call on all cells
+# (bit-identical Y0; 18 s at 1M cells).  "device": k-means++ seeding by sklearn on a subsample of
+# KMEANS_SEED_CELLS cells, then the 25 Lloyd iterations on the GPU over all cells (all ranks when
+# sharded).  "auto": host up to KMEANS_DEVICE_CELLS cells, device above.  Override: HMX_KMEANS.
+KMEANS = "auto"
+KMEANS_DEVICE_CELLS = 200_000
+KMEANS_SEED_CELLS = 100_000
 
 # Test aids (never set by product code).  ``Y0``: d x K centroids used instead of the
 # sklearn call; ``forced_rounds``: list of k-means round counts replayed instead of the
@@ -494,6 +501,8 @@ class Harmony:
     def init_cluster(self, random_state):
         if _TEST_HOOKS["Y0"] is not None:
             Y0 = np.asarray(_TEST_HOOKS["Y0"], dtype=np.float32)                 # d x K
+        elif self._kmeans_mode() == "device":
+            Y0 = self._device_kmeans(random_state)
         else:
             if self.verbose:
                 logger.info("Computing initial centroids with sklearn.KMeans...")
@@ -525,6 +534,40 @@ class Harmony:
         self._pending_objective = triple
         self.compute_objective()
         self.objective_harmony.append(self.objective_kmeans[-1])                 # :392
+
+    def _kmeans_mode(self):
+        import os
+        mode = os.environ.get("HMX_KMEANS", KMEANS)
+        if mode not in ("auto", "host", "device"):
+            raise ValueError(f"HMX_KMEANS={mode!r}: expected auto, host or device")
+        if mode == "auto":
+            mode = "host" if self.N_global <= KMEANS_DEVICE_CELLS else "device"
+        if mode == "device" and (self.K > 112 or self.d > 64):
+            mode = "host"                                                        # shapes the device k-means is not built for
+        return mode
+
+    def _device_kmeans(self, random_state):
+        """k-means++ seeding on a subsample (host), Lloyd iterations over all cells (device)."""
+        if self.verbose:
+            logger.info("Computing initial centroids: k-means++ seeding on a subsample, Lloyd iterations on the GPU...")
+        n = max(1, int(round(KMEANS_SEED_CELLS * self.N / self.N_global)))
+        take = np.linspace(0, self.N - 1, min(n, self.N)).astype(np.int64)
+        sub = self._engine.get(_capi.HMX_Z_COS)[self._rank[take]] if len(take) < self.N else self.Z_cos
+        if self.shard is not None:
+            parts = self.shard.allgather_object(sub)
+            sub = np.concatenate(parts, axis=0) if self.shard.rank == 0 else None
+        centers = None
+        if sub is not None:
+            from sklearn.cluster import kmeans_plusplus
+            centers, _ = kmeans_plusplus(np.ascontiguousarray(sub, dtype=np.float32), n_clusters=self.K,
+                                         random_state=random_state)
+            centers = np.asarray(centers, dtype=np.float32)
+        if self.shard is not None:
+            centers = self.shard.broadcast_object(centers)
+        centers = self._engine.kmeans_lloyd(centers, 25)                         # max_iter=25, harmony.py:371
+        if self.verbose:
+            logger.info("KMeans initialization complete.")
+        return np.ascontiguousarray(centers.T)
 
     # ------------------------------------------------------------------
     # harmony.py:394-417: the three sums come back from the device with the round

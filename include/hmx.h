@@ -137,6 +137,14 @@ int hmx_peer_enable(hmx_engine* e, int on);
  * fp32 like the `.item()` calls of harmony.py:399-411. */
 int hmx_init_cluster(hmx_engine* e, const float* Y0, double obj_out[4]);
 
+/* Lloyd iterations of the initial k-means on the device.  The reference fits sklearn's KMeans on the
+ * host (harmony.py:369-373: k-means++ seeding + at most 25 Lloyd iterations; 18 s at 1M cells); for
+ * jobs too large for that the caller seeds on a subsample and lets the engine run the Lloyd
+ * iterations over all cells of Z_cos (Euclidean k-means, centroid = mean of its members, empty
+ * clusters keep their centre; sums over all ranks when cells are sharded).  centers_in / centers_out:
+ * K x d row-major; the result is what hmx_init_cluster takes as Y0. */
+int hmx_kmeans_lloyd(hmx_engine* e, const float* centers_in, int n_iter, float* centers_out);
+
 /* One pass of the loop body harmony.py:443-453.
  *   flags: HMX_ROUND_* bits; the reference's round is all three.
  *   cells / tile_group / block_tile_start describe this round's update order

@@ -182,3 +182,26 @@ def test_check_convergence_semantics():
     ho.objective_harmony = [5.0, 4.0]
     assert not ho.check_convergence(1)
     assert ho.check_convergence(2) is True
+
+
+def test_kmeans_mode_selection(monkeypatch):
+    """Initial centroids: the reference's host fit for small jobs, seeds + GPU Lloyd for large ones."""
+    from harmonypy_amd import harmony as H
+
+    class Fake:
+        _kmeans_mode = H.Harmony._kmeans_mode
+        K, d = 100, 50
+    f = Fake()
+    monkeypatch.delenv("HMX_KMEANS", raising=False)
+    f.N_global = H.KMEANS_DEVICE_CELLS
+    assert f._kmeans_mode() == "host"
+    f.N_global = H.KMEANS_DEVICE_CELLS + 1
+    assert f._kmeans_mode() == "device"
+    f.K = 200
+    assert f._kmeans_mode() == "host"           # outside the device k-means' shapes
+    f.K = 100
+    monkeypatch.setenv("HMX_KMEANS", "host")
+    assert f._kmeans_mode() == "host"
+    monkeypatch.setenv("HMX_KMEANS", "bogus")
+    with pytest.raises(ValueError):
+        f._kmeans_mode()
