@@ -202,6 +202,7 @@ def main():
     #      same cells (its own initialisation: k-means++ seeds on a subsample + Lloyd iterations on the GPU,
     #      natural round / iteration counts), outside the timed region of `value`
     conv = None
+    transport = str(getattr(ho, "transport", None))
     if not args.no_convergence:
         del ho
         fence_t = time.perf_counter()
@@ -240,9 +241,9 @@ def main():
             "cells_per_gpu": N, "pcs": d, "batches": B, "clusters": K, "rounds_per_iteration": args.rounds,
             "update_order": "device (keyed bijection, generated inside the timed region)",
             "init": "k-means++ on a 50k-cell subsample, untimed",
-            "parallelism": (f"cells sharded over {world} ranks (1 per GPU), transport {ho.transport}: "
+            "parallelism": (f"cells sharded over {world} ranks (1 per GPU), transport {transport}: "
                             + ("block sums exchanged inside the sweep kernel through peer boxes (xGMI), 1 all-reduce per "
-                               "round + 1 per ridge" if "+peer" in str(ho.transport) else
+                               "round + 1 per ridge" if "+peer" in transport else
                                "1 + 20 all-reduces per round, 1 per ridge")) if shard is not None else "single GPU",
             "cells_total": N * world,
             "cell_rounds_per_sec": N * world * args.steps * args.rounds / dt,

@@ -62,3 +62,21 @@ def test_rccl_transport_one_rank(tmp_path):
     assert str(res[0]["transport"]).startswith("rccl")
     assert_z_close(res[0]["Z_corr"], g["Z_corr"])
     np.testing.assert_allclose(res[0]["objective_kmeans"], g["objective_kmeans"], rtol=2e-5)
+
+
+def test_sharded_device_kmeans_and_device_order(tmp_path, monkeypatch):
+    """Everything a large sharded job uses at once: seeds on a gathered subsample + Lloyd iterations with
+    job-wide sums, device-side update order, peer exchange inside the sweep kernel, natural round
+    counts.  Not the reference's random stream, so: per-PC correlation with its output > 0.99, the
+    same history on both ranks."""
+    from scipy.stats import pearsonr
+    case = "pbmc_default"
+    data, meta, vars_use, kw, g = load_case(case)
+    monkeypatch.setenv("HMX_KMEANS", "device")
+    res = launch("engine", case, tmp_path, world=2, opts={"transport": "host", "order": "device", "Y0": False, "forced": False})
+    Z = np.concatenate([r["Z_corr"] for r in res], axis=0)
+    cors = [pearsonr(Z[:, j], g["Z_corr"][:, j])[0] for j in range(Z.shape[1])]
+    assert min(cors) > 0.99, min(cors)
+    np.testing.assert_array_equal(res[0]["objective_kmeans"], res[1]["objective_kmeans"])
+    assert list(res[0]["kmeans_rounds"]) == list(res[1]["kmeans_rounds"])
+    assert abs(res[0]["objective_harmony"][-1] / g["objective_harmony"][-1] - 1) < 2e-2
