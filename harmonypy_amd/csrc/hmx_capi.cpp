@@ -346,7 +346,9 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
             e->Sr = e->objacc + n_obj;
             e->Oxr = e->Sr + GK * e->ldy;
         }
-        if ((rc = e->Sslots.reserve(GK * e->nblk * HMX_ROUND_SLOTS)) || (rc = e->sync_words.reserve(2))) break;
+        if ((rc = e->Sslots.reserve(GK * e->nblk * HMX_ROUND_SLOTS + 1))) break;
+        e->sync_words.p = reinterpret_cast<unsigned*>(e->Sslots.p + GK * e->nblk * HMX_ROUND_SLOTS);   // borrowed tail
+        e->sync_words.n = 2;
         if (hipHostMalloc(reinterpret_cast<void**>(&e->sync_host), 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
             rc = fail(HMX_ERR_HIP, "hipHostMalloc failed");
             break;
@@ -384,7 +386,7 @@ void hmx_destroy(hmx_engine* e) {
     e->r_cells.release(); e->r_tile_grp.release(); e->r_blk_start.release(); e->task_t0.release(); e->task_t1.release();
     e->task_grp.release(); e->gstart.release(); e->chunk_tab.release(); e->run_count.release(); e->run_start.release();
     e->Ogrp.release(); e->Tmass.release(); e->Ohist.release(); e->xch.release(); e->scratch.release();
-    e->global_id.release(); e->Sslots.release(); e->sync_words.release(); e->km_hn.release(); e->km_sums.release();
+    e->global_id.release(); e->sync_words.p = nullptr; e->sync_words.n = 0; e->Sslots.release(); e->km_hn.release(); e->km_sums.release();
     if (e->sync_host) (void)hipHostFree(e->sync_host);
     comm_release(e);
     peer_release(e);
@@ -545,9 +547,8 @@ int hmx_init_cluster(hmx_engine* e, const float* Y0, double obj_out[4]) {
 static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::vector<int>& tiles_upper, double obj_out[4]) {
     int rc;
     const size_t GK = (size_t)e->G * e->K16;
-    HIP_TRY(hipMemsetAsync(e->Sold, 0, GK * e->nblk * sizeof(double), e->stream));
-    HIP_TRY(hipMemsetAsync(e->Snew, 0, GK * e->nblk * sizeof(double), e->stream));
-    HIP_TRY(hipMemsetAsync(e->objacc, 0, (2 * HMX_OBJ_SLOTS + 2) * sizeof(double), e->stream));
+    // Sold | Yacc64 | Snew | objacc are neighbours in xch: one fill instead of four
+    HIP_TRY(hipMemsetAsync(e->Sold, 0, (size_t)((e->objacc + 2 * HMX_OBJ_SLOTS + 2) - e->Sold) * sizeof(double), e->stream));
 
     // ---- pass over the old R: centroid numerators (:443) and per-block removal sums (:491-492)
     int nsub, spw;
@@ -567,7 +568,6 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
     }
     if (flags & HMX_ROUND_CENTROIDS) {
         Timed t(e, F_RTZ_REDUCE);
-        HIP_TRY(hipMemsetAsync(e->Yacc64, 0, (size_t)e->K16 * e->ldy * sizeof(double), e->stream));
         if (rtz2) launch_rtz2_reduce(e->slab.p, wgs, e->mt, e->dp, e->K16, e->ldy, e->Yacc64, nullptr, e->stream);
         else launch_rtz_reduce(e->slab.p, wgs * 4, e->mt, e->ntd, e->K16, e->ldy, e->Yacc64, nullptr, e->stream);
     }
@@ -582,8 +582,8 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
                       round_lds_bytes(e->K16, e->dp, e->G, e->B) <= 150 * 1024;
     if (mega) {
         // the whole sweep in one persistent launch (k_round); closes O, T and the objective itself
-        HIP_TRY(hipMemsetAsync(e->Sslots.p, 0, GK * e->nblk * HMX_ROUND_SLOTS * sizeof(double), e->stream));
-        HIP_TRY(hipMemsetAsync(e->sync_words.p, 0, 2 * sizeof(unsigned), e->stream));
+        // the slot tables and the two sync words (carved from the same allocation): one fill
+        HIP_TRY(hipMemsetAsync(e->Sslots.p, 0, (GK * e->nblk * HMX_ROUND_SLOTS + 1) * sizeof(double), e->stream));
         int max_upper = 0;
         for (int b = 0; b < e->nblk; ++b) max_upper = std::max(max_upper, tiles_upper[b]);
         const bool multi = e->peers_enabled && e->n_ranks > 1;
