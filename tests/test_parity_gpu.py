@@ -217,9 +217,11 @@ def test_object_api_surface():
 
 
 @pytest.mark.parametrize("N,d,K,B,bs", [(37, 5, 3, 2, 0.05), (16, 4, 2, 1, 0.3), (1000, 33, 17, 5, 0.13),
-                                        (2049, 64, 30, 4, 0.05)])
+                                        (2049, 64, 30, 4, 0.05), (900, 100, 150, 3, 0.05), (1500, 70, 20, 2, 0.1),
+                                        (640, 20, 120, 2, 0.05)])
 def test_edge_shapes_against_oracle(N, d, K, B, bs):
-    """Ragged sizes: N below a block/tile, a single batch, K and d off the tile sizes."""
+    """Ragged sizes: N below a block/tile, a single batch, K and d off the tile sizes, and shapes
+    beyond the LDS-resident kernels (K > 112 or d > 64: the generic kernels, BASELINE config 5's regime)."""
     from oracle import oracle_run_harmony
     rng = np.random.default_rng(N)
     Z = rng.normal(size=(N, d)).astype(np.float32) * (1.0 / np.sqrt(1 + np.arange(d))).astype(np.float32)
