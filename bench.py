@@ -42,6 +42,9 @@ CONFIGS = {
     # name: (cells per GPU, PCs, batches, clusters)
     "c2": (69_000, 50, 4, 30),
     "c3": (1_000_000, 50, 8, 100),
+    # per-GPU shards of the 8-GPU configurations (BASELINE configs[3], configs[4])
+    "c4": (1_250_000, 50, 16, 100),
+    "c5": (1_250_000, 200, 32, 200),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -235,7 +238,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": f"BASELINE configs[{2 if args.config == 'c3' else 1}] ({args.config.upper()}): "
+            "workload": f"BASELINE configs[{ {'c2': 1, 'c3': 2, 'c4': 3, 'c5': 4}[args.config] }] ({args.config.upper()}): "
                         f"{N} cells x {d} PCs, {B} batches, K={K} per GPU; step = 1 Harmony iteration = "
                         f"{args.rounds} k-means rounds (block_size 0.05 -> 20 blocks) + 1 ridge correction",
             "cells_per_gpu": N, "pcs": d, "batches": B, "clusters": K, "rounds_per_iteration": args.rounds,

@@ -2423,7 +2423,7 @@ void launch_rtz2(const RtzArgs& a_in, int wgs, hipStream_t s) {
 void launch_rtz2_reduce(const float* slab, int nslabs, int mt, int dp, int K16, int ld, double* out, const int* task_grp,
                         hipStream_t s) {
     const int ntd = dp == 32 ? 2 : 4;
-    const int seg_len = 32;
+    const int seg_len = 8;   // slabs summed serially by one thread: short chains, the loads are latency-bound
     hipLaunchKernelGGL(k_rtz2_reduce, dim3(cdiv(mt * ntd * 256, 256), cdiv(nslabs, seg_len)), dim3(256), 0, s, slab, nslabs, mt,
                        ntd, K16, ld, out, task_grp, seg_len);
 }
