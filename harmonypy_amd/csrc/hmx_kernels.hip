@@ -1187,20 +1187,22 @@ __global__ __launch_bounds__(256, 2) void k_rtz(RtzArgs a) {
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float csum[MTW];
+    double csum[MTW];   // four values per tile in fp32, tiles in fp64 (see k_rtz2)
 #pragma unroll
-    for (int mt = 0; mt < MTW; ++mt) csum[mt] = 0.f;
+    for (int mt = 0; mt < MTW; ++mt) csum[mt] = 0.0;
     int cur_g = -1, cur_b = 0;
 
     auto flush = [&]() {
         if (cur_g < 0 || !first_col_block || a.S_out == nullptr) return;
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) {
-            const float s = wave_sum_q(csum[mt]);
+            double s = csum[mt];
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
             const int k = 16 * (mt0 + mt) + c16;
-            if (q == 0 && k < a.K && s != 0.f)
-                atomicAdd(&a.S_out[((size_t)cur_b * a.G + cur_g) * a.K16 + k], (double)s);
-            csum[mt] = 0.f;
+            if (q == 0 && k < a.K && s != 0.0)
+                atomicAdd(&a.S_out[((size_t)cur_b * a.G + cur_g) * a.K16 + k], s);
+            csum[mt] = 0.0;
         }
     };
 
@@ -1215,6 +1217,9 @@ __global__ __launch_bounds__(256, 2) void k_rtz(RtzArgs a) {
             cur_g = g;
             cur_b = b;
         }
+        float tsum[MTW];
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) tsum[mt] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int cell = a.cells[(size_t)t * 16 + 4 * ks + q];
@@ -1223,7 +1228,7 @@ __global__ __launch_bounds__(256, 2) void k_rtz(RtzArgs a) {
             for (int mt = 0; mt < MTW; ++mt) {
                 const int col = 16 * (mt0 + mt) + c16;
                 av[mt] = (cell >= 0 && col < a.Kp) ? a.R[(size_t)cell * a.Kp + col] : 0.f;
-                csum[mt] += av[mt];
+                tsum[mt] += av[mt];
             }
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
@@ -1235,6 +1240,8 @@ __global__ __launch_bounds__(256, 2) void k_rtz(RtzArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MFMA16(av[mt], bv[nt], acc[mt][nt]);
         }
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) csum[mt] += (double)tsum[mt];
     }
     flush();
 
@@ -1321,9 +1328,11 @@ __global__ __launch_bounds__(256, 2) void k_rtz2(RtzArgs a) {
     f32x4 acc[MTW];
 #pragma unroll
     for (int i = 0; i < MTW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float csum[MTW];
+    // column sums of R (the removal sums): four values per tile in fp32, tiles in fp64 -- a long fp32
+    // accumulation would drop the many tiny entries of R and bias O by ~5e-8 per round
+    double csum[MTW];
 #pragma unroll
-    for (int i = 0; i < MTW; ++i) csum[i] = 0.f;
+    for (int i = 0; i < MTW; ++i) csum[i] = 0.0;
     int cur_g = -1, cur_b = 0;
     const bool sums = nt == 0 && a.S_out != nullptr;
     auto flush = [&]() {
@@ -1331,10 +1340,12 @@ __global__ __launch_bounds__(256, 2) void k_rtz2(RtzArgs a) {
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
             const int mt = ms + i * SPLIT;
-            const float sv = wave_sum_q(csum[i]);
+            double sv = csum[i];
+            sv += __shfl_xor(sv, 16, 64);
+            sv += __shfl_xor(sv, 32, 64);
             const int k = 16 * mt + c16;
-            if (q == 0 && mt < MT && k < a.K && sv != 0.f) atomicAdd(&a.S_out[((size_t)cur_b * a.G + cur_g) * a.K16 + k], (double)sv);
-            csum[i] = 0.f;
+            if (q == 0 && mt < MT && k < a.K && sv != 0.0) atomicAdd(&a.S_out[((size_t)cur_b * a.G + cur_g) * a.K16 + k], sv);
+            csum[i] = 0.0;
         }
     };
     auto ids_of = [&](int t, int (&id)[3]) {
@@ -1406,6 +1417,9 @@ __global__ __launch_bounds__(256, 2) void k_rtz2(RtzArgs a) {
         }
         const float* Rt = lds + (size_t)buf * tile_floats;
         const float* Zt = Rt + 16 * LDR;
+        float tsum[MTW];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) tsum[i] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const float bv = Zt[(4 * ks + q) * LDZ + 16 * nt + c16];
@@ -1414,10 +1428,14 @@ __global__ __launch_bounds__(256, 2) void k_rtz2(RtzArgs a) {
                 const int mt = ms + i * SPLIT;
                 if (mt < MT) {
                     const float av = Rt[(4 * ks + q) * LDR + 16 * mt + c16];
-                    csum[i] += av;
+                    tsum[i] += av;
                     acc[i] = MFMA16(av, bv, acc[i]);
                 }
             }
+        }
+        if (sums) {
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) csum[i] += (double)tsum[i];
         }
     }
     flush();

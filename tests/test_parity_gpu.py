@@ -380,3 +380,48 @@ def test_device_kmeans_initialisation_end_to_end(monkeypatch):
     cors = [pearsonr(Z[:, j], g["Z_corr"][:, j])[0] for j in range(Z.shape[1])]
     assert min(cors) > 0.99, min(cors)
     assert abs(ho.objective_harmony[-1] / g["objective_harmony"][-1] - 1) < 2e-2
+
+
+def test_config3_full_size_properties():
+    """BASELINE.json configs[2] at full size (1M cells x 50 PCs, 8 batches, K=100), the engine's
+    large-job defaults (device k-means initialisation, device update order, natural schedule):
+    size-independent properties of the path --
+      soft assignments are distributions; O's batch columns hold every cell exactly once
+      (sum_k O[k,b] = N_b) and E = T Pr_b; Z_cos rows and Y columns are unit vectors; the corrected
+      embedding is the original minus a combination of the group's correction vectors:
+      Z_orig - Z_corr = R W_g (checked on a sample against hmx_get(W)); the objective history of
+      every Harmony iteration decreases within the iteration's first rounds and the run converges;
+      the same seed reproduces the run."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synthetic_dataset
+    from harmonypy_amd import _capi
+    N, d, B, K = 1_000_000, 50, 8, 100
+    Z, meta = synthetic_dataset(N, d, B, K, seed=0)
+    ho = _hm().run_harmony(Z, meta, ["batch"], nclust=K, verbose=False, random_state=0, max_iter_harmony=3)
+    assert ho.update_order == "device" and (ho.N, ho.d, ho.K, ho.B) == (N, d, K, B)
+    assert len(ho.kmeans_rounds) >= 1 and all(5 <= r <= 20 for r in ho.kmeans_rounds)
+    obj = np.asarray(ho.objective_kmeans)
+    assert np.isfinite(obj).all() and obj[1] < obj[0]
+    assert ho.objective_harmony[-1] < ho.objective_harmony[0]
+    R = ho.R
+    np.testing.assert_allclose(R.sum(axis=1), 1.0, atol=5e-6)
+    assert R.min() >= 0.0
+    counts = np.bincount(meta["batch"].cat.codes, minlength=B)
+    np.testing.assert_allclose(ho.O.sum(axis=0), counts, rtol=2e-5)
+    Rsum = R.sum(axis=0, dtype=np.float64)
+    np.testing.assert_allclose(ho.O.sum(axis=1), Rsum, rtol=2e-5)        # O is carried incrementally over all rounds
+    np.testing.assert_allclose(ho.E, np.outer(Rsum, counts / N), rtol=2e-5)
+    np.testing.assert_allclose(np.linalg.norm(ho.Z_cos[::97], axis=1), 1.0, atol=3e-6)
+    np.testing.assert_allclose(np.linalg.norm(ho.Y, axis=0), 1.0, atol=3e-6)
+    np.testing.assert_array_equal(ho.Z_orig[::1009], Z[::1009])
+    # the ridge correction of a sample of cells from the device's own W (G x K x d)
+    W = ho._engine.get(_capi.HMX_W)
+    idx = np.arange(0, N, 4999)
+    grp = ho._gid_int[ho._rank[idx]]
+    corr = np.einsum("nk,nkd->nd", R[idx].astype(np.float64), W[grp].astype(np.float64))
+    np.testing.assert_allclose(ho.Z_orig[idx] - ho.Z_corr[idx], corr, rtol=0, atol=2e-5 * np.abs(Z).max())
+    # same seed, same run
+    ho2 = _hm().run_harmony(Z, meta, ["batch"], nclust=K, verbose=False, random_state=0, max_iter_harmony=3)
+    assert ho2.kmeans_rounds == ho.kmeans_rounds
+    np.testing.assert_allclose(ho2.Z_corr[::1009], ho.Z_corr[::1009], rtol=1e-3, atol=1e-4)
