@@ -766,8 +766,19 @@ int hmx_cluster_round_seeded(hmx_engine* e, int flags, uint64_t seed, int64_t ce
             upper[b] = size_b > 0 ? (int)((size_b + HMX_TILE - 1) / HMX_TILE) + e->G : 0;
             total += upper[b];
         }
+    } else if (e->peers_enabled && e->round_mode == 1 && e->mt <= 7 && round_row_floats(e->d) == e->dp) {
+        // a shard holds a random share of every block.  The sweep kernel and the R^T.Z pass read the
+        // tile offsets on the device and cope with any grid, so a generous estimate (mean + 8 sigma
+        // of a hypergeometric share) sizes the grids without a host round trip
+        for (int b = 0; b < e->nblk; ++b) {
+            const double size_b = (b == e->nblk - 1) ? (double)(e->Ng - cells_per_block * (e->nblk - 1)) : (double)cells_per_block;
+            const double p = (double)e->N / (double)e->Ng;
+            const double mean = size_b * p, sd = std::sqrt(std::max(size_b * p * (1.0 - p), 0.0));
+            upper[b] = size_b > 0 ? (int)((mean + 8.0 * sd + HMX_TILE - 1) / HMX_TILE) + e->G : 0;
+            total += upper[b];
+        }
     } else {
-        // a shard holds a random share of every block: read the tile offsets back (84 bytes)
+        // per-block launches need the exact tile counts: read the tile offsets back (84 bytes)
         std::vector<int> bs(e->nblk + 1);
         HIP_TRY(hipMemcpyAsync(bs.data(), e->r_blk_start.p, bs.size() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
