@@ -25,7 +25,7 @@ EXPORTS = [
     "hmx_last_error", "hmx_abi_version", "hmx_create", "hmx_destroy", "hmx_upload", "hmx_init_cluster",
     "hmx_cluster_round", "hmx_cluster_round_seeded", "hmx_moe_correct_ridge", "hmx_get", "hmx_set", "hmx_sync", "hmx_device_ptr",
     "hmx_kernel_times", "hmx_enable_timing", "hmx_comm_unique_id", "hmx_comm_init", "hmx_set_host_allreduce",
-    "hmx_kmeans_lloyd", "hmx_set_ranks", "hmx_peer_export", "hmx_peer_attach", "hmx_peer_selftest", "hmx_peer_enable",
+    "hmx_kmeans_lloyd", "hmx_get_rows", "hmx_set_ranks", "hmx_peer_export", "hmx_peer_attach", "hmx_peer_selftest", "hmx_peer_enable",
 ]
 HMX_PEER_HANDLE_BYTES = 64
 HMX_ABI_VERSION = 2
@@ -80,6 +80,7 @@ def load():
     lib.hmx_moe_correct_ridge.argtypes = [vp]
     lib.hmx_get.argtypes = [vp, C.c_int, vp, C.c_size_t]
     lib.hmx_set.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    lib.hmx_get_rows.argtypes = [vp, C.c_int, vp, i32, vp, C.c_size_t]
     lib.hmx_sync.argtypes = [vp]
     lib.hmx_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.hmx_kernel_times.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_char_p)]
@@ -241,6 +242,15 @@ class Engine:
         shape, dt = self._shape(which)
         out = np.empty(shape, dt)
         _check(self._lib.hmx_get(self._h, which, _ptr(out), out.nbytes))
+        return out
+
+    def get_rows(self, which, rows):
+        """A few rows of an N-sized float array (internal order), without downloading all of it."""
+        rows = _c(rows, np.int32)
+        shape, dt = self._shape(which)
+        assert dt == np.float32
+        out = np.empty((len(rows), shape[1]), np.float32)
+        _check(self._lib.hmx_get_rows(self._h, which, _ptr(rows), len(rows), _ptr(out), out.nbytes))
         return out
 
     def set(self, which, arr):

@@ -990,6 +990,31 @@ int hmx_get(hmx_engine* e, int which, void* host_out, size_t bytes) {
     return HMX_OK;
 }
 
+int hmx_get_rows(hmx_engine* e, int which, const int32_t* rows, int32_t n_rows, float* host_out, size_t bytes) {
+    if (!e || !rows || !host_out) return fail(HMX_ERR_ARG, "null argument");
+    if (which != HMX_Z_ORIG && which != HMX_Z_COS && which != HMX_Z_CORR && which != HMX_R) return fail(HMX_ERR_ARG, "hmx_get_rows: not an N-sized float array");
+    void* p; size_t need; int nrows, cols, ld, elem, rc;
+    if ((rc = locate(e, which, &p, &need, &nrows, &cols, &ld, &elem))) return rc;
+    if (n_rows < 0 || bytes != (size_t)n_rows * cols * sizeof(float)) return fail(HMX_ERR_ARG, "hmx_get_rows: output size mismatch");
+    for (int i = 0; i < n_rows; ++i)
+        if (rows[i] < 0 || rows[i] >= nrows) return fail(HMX_ERR_ARG, "hmx_get_rows: row %d out of range", rows[i]);
+    if (n_rows == 0) return HMX_OK;
+    if ((rc = use_device(e))) return rc;
+    DevBuf<int> d_rows;
+    DevBuf<float> d_out;
+    if ((rc = d_rows.reserve(n_rows)) || (rc = d_out.reserve((size_t)n_rows * cols))) { d_rows.release(); d_out.release(); return rc; }
+    hipError_t he = hipMemcpyAsync(d_rows.p, rows, (size_t)n_rows * sizeof(int), hipMemcpyHostToDevice, e->stream);
+    if (he == hipSuccess) {
+        launch_gather_rows((const float*)p, ld, cols, d_rows.p, n_rows, d_out.p, e->stream);
+        he = hipMemcpyAsync(host_out, d_out.p, bytes, hipMemcpyDeviceToHost, e->stream);
+    }
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    d_rows.release();
+    d_out.release();
+    if (he != hipSuccess) return fail(HMX_ERR_HIP, "hmx_get_rows: %s", hipGetErrorString(he));
+    return HMX_OK;
+}
+
 int hmx_set(hmx_engine* e, int which, const void* host_in, size_t bytes) {
     if (!e || !host_in) return fail(HMX_ERR_ARG, "null argument");
     if (which == HMX_W) return fail(HMX_ERR_ARG, "W is an output");

@@ -145,6 +145,7 @@ int launch_kmeans_step(const float* Zcos, const float* C, const float* hn, const
                        int K16, int dp, int ldy, int wgs, hipStream_t s);
 void launch_kmeans_sums(const float* slab, int wgs, int K16, int dp, int d, double* sums, hipStream_t s);
 void launch_kmeans_update(const double* sums, float* C, float* hn, int K, int K16, int d, int ldy, hipStream_t s);
+void launch_gather_rows(const float* src, int ld, int cols, const int* rows, int n_rows, float* dst, hipStream_t s);
 void launch_order(const OrderArgs& a, hipStream_t s);
 int order_chunks(int64_t N);
 void launch_normalize_rows(const float* Z, float* Zc, int64_t N, int dp, hipStream_t s);

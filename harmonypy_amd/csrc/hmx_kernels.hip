@@ -2230,6 +2230,15 @@ __global__ __launch_bounds__(256) void k_order_runs(OrderArgs a) {
     for (int t = tid; t < padded / 16; t += 256) a.tile_grp[start / 16 + t] = key % a.G;
 }
 
+// rows[i] of a row-major float array -> dense n_rows x cols
+__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ src, int ld, int cols, const int* __restrict__ rows,
+                                                     int n_rows, float* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)n_rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+    dst[i] = src[(size_t)rows[r] * ld + c];
+}
+
 // ------------------------------------------------------------------------------------------
 // host-side launchers (called from hmx_capi.cpp through hmx_internal.h)
 // ------------------------------------------------------------------------------------------
@@ -2524,6 +2533,11 @@ void launch_order(const OrderArgs& a, hipStream_t s) {
 }
 
 int order_chunks(int64_t N) { return cdiv(N, ORDER_CHUNK); }
+
+void launch_gather_rows(const float* src, int ld, int cols, const int* rows, int n_rows, float* dst, hipStream_t s) {
+    if (n_rows <= 0) return;
+    hipLaunchKernelGGL(k_gather_rows, dim3(cdiv((int64_t)n_rows * cols, 256)), dim3(256), 0, s, src, ld, cols, rows, n_rows, dst);
+}
 
 template <int MTD>
 static void launch_apply2_k(const ApplyArgs& a, int kb, size_t sm, hipStream_t s) {

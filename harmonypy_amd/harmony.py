@@ -42,11 +42,11 @@ AUTO_DEVICE_ORDER_CELLS = 200_000
 KMEANS_GATHER_CELLS = 2_000_000
 # Initial centroids (harmony.py:369-373).  "host": the reference's sklearn KMeans call on all cells
 # (bit-identical Y0; 18 s at 1M cells).  "device": k-means++ seeding by sklearn on a subsample of
-# KMEANS_SEED_CELLS cells, then the 25 Lloyd iterations on the GPU over all cells (all ranks when
+# KMEANS_SEED_CELLS cells (~300 per cluster at K=100), then the 25 Lloyd iterations on the GPU over all cells (all ranks when
 # sharded).  "auto": host up to KMEANS_DEVICE_CELLS cells, device above.  Override: HMX_KMEANS.
 KMEANS = "auto"
 KMEANS_DEVICE_CELLS = 200_000
-KMEANS_SEED_CELLS = 100_000
+KMEANS_SEED_CELLS = 32_768
 
 # Test aids (never set by product code).  ``Y0``: d x K centroids used instead of the
 # sklearn call; ``forced_rounds``: list of k-means round counts replayed instead of the
@@ -259,7 +259,10 @@ def build_layout(codes, combos=None):
     hold cells of every group.
     """
     N = codes.shape[0]
-    if combos is None:
+    if combos is None and codes.shape[1] == 1:       # one batch variable: groups are its levels (fast path)
+        levels, gid = np.unique(codes[:, 0], return_inverse=True)
+        combos = levels.reshape(-1, 1)
+    elif combos is None:
         combos, gid = np.unique(codes, axis=0, return_inverse=True)
     else:
         combos = np.asarray(combos, dtype=codes.dtype)
@@ -552,7 +555,7 @@ class Harmony:
             logger.info("Computing initial centroids: k-means++ seeding on a subsample, Lloyd iterations on the GPU...")
         n = max(1, int(round(KMEANS_SEED_CELLS * self.N / self.N_global)))
         take = np.linspace(0, self.N - 1, min(n, self.N)).astype(np.int64)
-        sub = self._engine.get(_capi.HMX_Z_COS)[self._rank[take]] if len(take) < self.N else self.Z_cos
+        sub = self._engine.get_rows(_capi.HMX_Z_COS, self._rank[take])          # unit rows of the sampled cells
         if self.shard is not None:
             parts = self.shard.allgather_object(sub)
             sub = np.concatenate(parts, axis=0) if self.shard.rank == 0 else None

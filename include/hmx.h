@@ -175,6 +175,9 @@ int hmx_moe_correct_ridge(hmx_engine* e);
 /* Copy a state array to / from the host (property getters harmony.py:288-351). */
 int hmx_get(hmx_engine* e, int which, void* host_out, size_t bytes);
 int hmx_set(hmx_engine* e, int which, const void* host_in, size_t bytes);
+/* n_rows rows (internal cell ids) of a float N-sized array (HMX_Z_ORIG / Z_COS / Z_CORR / R), gathered on
+ * the device: host_out receives n_rows x cols floats. */
+int hmx_get_rows(hmx_engine* e, int which, const int32_t* rows, int32_t n_rows, float* host_out, size_t bytes);
 
 /* Block until all queued work of the engine finished. */
 int hmx_sync(hmx_engine* e);

@@ -210,6 +210,11 @@ def test_object_api_surface():
     for attr in ("window_size", "epsilon_kmeans", "epsilon_harmony", "alpha", "lambda_estimation", "block_size",
                  "max_iter_harmony", "max_iter_kmeans", "verbose", "device"):
         assert hasattr(ho, attr)
+    # a few rows without downloading the array (hmx_get_rows)
+    from harmonypy_amd import _capi
+    pick = np.array([0, 5, 3499, 17, 17], dtype=np.int64)
+    np.testing.assert_array_equal(ho._engine.get_rows(_capi.HMX_Z_COS, ho._rank[pick]), ho.Z_cos[pick])
+    np.testing.assert_array_equal(ho._engine.get_rows(_capi.HMX_R, ho._rank[pick]), ho.R[pick])
     # the object can be driven further, like the reference's (harmony.py:419)
     n0 = len(ho.kmeans_rounds)
     ho.harmonize(1, verbose=False)
