@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -75,7 +76,17 @@ struct hmx_engine {
     bool uploaded = false, clustered = false, timing = false;
 
     DevBuf<float> Zorig, Zcos, Zcorr, R, Y, Yacc, sigma, theta, Pr_b, lamb, rp, lrp, slab, W;
-    DevBuf<int> group_cols, s_cells, s_tile_grp, r_cells, r_tile_grp, r_blk_start, task_t0, task_t1, task_grp;
+    DevBuf<int> group_cols, s_cells, s_tile_grp, task_t0, task_t1, task_grp;
+    // Update-order lists of a round, double buffered: while round r runs, the lists of round r+1 (a function of
+    // seed and round counter only) are built on a second stream -- the persistent sweep kernel leaves a few CUs idle.
+    struct Lists { DevBuf<int> cells, tile_grp, blk_start; };
+    Lists lists[2];
+    int cur = 0;                         // lists of the round in progress / last round
+    hipStream_t stream2 = nullptr;
+    hipEvent_t pre_event = nullptr;
+    bool pre_valid = false;              // lists[cur ^ 1] hold the round described by pre_*
+    uint64_t pre_seed = 0, pre_counter = 0;
+    int64_t pre_cpb = 0;
     DevBuf<int> gstart, chunk_tab, run_count, run_start, global_id;
     uint64_t seeded_rounds = 0;
     int64_t Ng = 0;              // cells of the whole job (all ranks)
@@ -110,6 +121,7 @@ struct hmx_engine {
     bool peers_attached = false, peers_enabled = false;
     unsigned long long round_epoch = 0;  // flag base of the next sweep launch (+64 per launch, same on every rank)
     unsigned long long selftest_token = 0x5EED0000ull;
+    int prefetch_lists = 1;              // HMX_PREFETCH_LISTS=0: build every round's lists on the main stream
     int round_wgs_cap = 0;               // HMX_ROUND_WGS: cap of the sweep grid (tests with several engines on one GPU)
     int n_s_tiles = 0, ntasks = 0;
     std::vector<int> h_task_grp;
@@ -319,12 +331,15 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
     if (const char* tpw = getenv("HMX_TILES_PER_WAVE")) e->tiles_per_wave = std::max(1, atoi(tpw));
     if (const char* rw = getenv("HMX_RTZ_WGS_PER_CU")) e->rtz_wgs_per_cu = std::max(1, std::min(8, atoi(rw)));
     if (const char* rc_ = getenv("HMX_ROUND_WGS")) e->round_wgs_cap = std::max(0, atoi(rc_));
+    if (const char* pl = getenv("HMX_PREFETCH_LISTS")) e->prefetch_lists = atoi(pl) != 0;
     if (const char* rm = getenv("HMX_ROUND_MODE")) e->round_mode = (std::string(rm) == "blocks") ? 0 : 1;
     int rc = 0;
     do {
         if ((rc = use_device(e))) break;
         (void)hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, cfg->device_id);
         if (e->n_cus <= 0) e->n_cus = 64;
+        (void)hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking);
+        (void)hipEventCreateWithFlags(&e->pre_event, hipEventDisableTiming);
         hipError_t se = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
         if (se != hipSuccess) { rc = fail(HMX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se)); break; }
         const size_t N = (size_t)e->N, GK = (size_t)e->G * e->K16;
@@ -334,7 +349,8 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
             (rc = e->theta.reserve(e->B)) || (rc = e->Pr_b.reserve(e->B)) || (rc = e->lamb.reserve(e->B + 1)) ||
             (rc = e->rp.reserve(GK)) || (rc = e->lrp.reserve(GK)) || (rc = e->group_cols.reserve((size_t)e->G * e->V)) ||
             (rc = e->Ogrp.reserve(GK)) || (rc = e->Tmass.reserve(e->K16)) || (rc = e->Ohist.reserve(GK * e->nblk)) ||
-            (rc = e->W.reserve(GK * e->ldy)) || (rc = e->r_blk_start.reserve(e->nblk + 1)))
+            (rc = e->W.reserve(GK * e->ldy)) || (rc = e->lists[0].blk_start.reserve(e->nblk + 1)) ||
+            (rc = e->lists[1].blk_start.reserve(e->nblk + 1)))
             break;
         {
             const size_t n_sold = GK * e->nblk, n_y = (size_t)e->K16 * e->ldy, n_obj = 2 * HMX_OBJ_SLOTS + 2;
@@ -383,7 +399,10 @@ void hmx_destroy(hmx_engine* e) {
     e->Zorig.release(); e->Zcos.release(); e->Zcorr.release(); e->R.release(); e->Y.release(); e->Yacc.release();
     e->sigma.release(); e->theta.release(); e->Pr_b.release(); e->lamb.release(); e->rp.release(); e->lrp.release();
     e->slab.release(); e->W.release(); e->group_cols.release(); e->s_cells.release(); e->s_tile_grp.release();
-    e->r_cells.release(); e->r_tile_grp.release(); e->r_blk_start.release(); e->task_t0.release(); e->task_t1.release();
+    for (auto& L : e->lists) { L.cells.release(); L.tile_grp.release(); L.blk_start.release(); }
+    if (e->stream2) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamDestroy(e->stream2); }
+    if (e->pre_event) (void)hipEventDestroy(e->pre_event);
+    e->task_t0.release(); e->task_t1.release();
     e->task_grp.release(); e->gstart.release(); e->chunk_tab.release(); e->run_count.release(); e->run_start.release();
     e->Ogrp.release(); e->Tmass.release(); e->Ohist.release(); e->xch.release(); e->scratch.release();
     e->global_id.release(); e->sync_words.p = nullptr; e->sync_words.n = 0; e->Sslots.release(); e->km_hn.release(); e->km_sums.release();
@@ -544,7 +563,8 @@ int hmx_init_cluster(hmx_engine* e, const float* Y0, double obj_out[4]) {
 
 // Kernel sequence of one round; the lists (cells, tile groups, block_tile_start) are already in
 // device memory.  tiles_upper[b] bounds the tile count of block b (grid sizing only).
-static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::vector<int>& tiles_upper, double obj_out[4]) {
+static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::vector<int>& tiles_upper, double obj_out[4],
+                      const std::function<int()>& before_sweep = nullptr) {
     int rc;
     const size_t GK = (size_t)e->G * e->K16;
     // Sold | Yacc64 | Snew | objacc are neighbours in xch: one fill instead of four
@@ -560,7 +580,7 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
     {
         Timed t(e, F_RTZ_ROUND);
         RtzArgs r{};
-        r.R = e->R.p; r.Z = e->Zcos.p; r.cells = e->r_cells.p; r.tile_grp = e->r_tile_grp.p; r.blk_start = e->r_blk_start.p;
+        r.R = e->R.p; r.Z = e->Zcos.p; r.cells = e->lists[e->cur].cells.p; r.tile_grp = e->lists[e->cur].tile_grp.p; r.blk_start = e->lists[e->cur].blk_start.p;
         r.S_out = e->Sold; r.slab = e->slab.p; r.n_tiles = n_tiles_upper; r.nblk = e->nblk;
         r.K = e->K; r.Kp = e->Kp; r.K16 = e->K16; r.G = e->G; r.mt = e->mt; r.dp = e->dp; r.ntd = e->ntd;
         if (rtz2) launch_rtz2(r, wgs, e->stream);
@@ -580,6 +600,7 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
     const bool mega = (flags & HMX_ROUND_UPDATE_R) && e->round_mode == 1 && (!sharded(e) || e->peers_enabled) && e->mt <= 7 &&
                       round_row_floats(e->d) == e->dp &&
                       round_lds_bytes(e->K16, e->dp, e->G, e->B) <= 150 * 1024;
+    if (before_sweep && (rc = before_sweep())) return rc;   // side-stream work that should run beside the sweep, not beside the R^T.Z pass
     if (mega) {
         // the whole sweep in one persistent launch (k_round); closes O, T and the objective itself
         // the slot tables and the two sync words (carved from the same allocation): one fill
@@ -598,7 +619,7 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         Timed t(e, F_ASSIGN_BLOCK);
         RoundArgs ra{};
         ra.Zcos = e->Zcos.p; ra.Y = e->Y.p; ra.sigma = e->sigma.p; ra.R = e->R.p;
-        ra.cells = e->r_cells.p; ra.tile_grp = e->r_tile_grp.p; ra.blk_start = e->r_blk_start.p;
+        ra.cells = e->lists[e->cur].cells.p; ra.tile_grp = e->lists[e->cur].tile_grp.p; ra.blk_start = e->lists[e->cur].blk_start.p;
         ra.O_start = e->Ogrp.p; ra.S_old = e->Sold; ra.S_new = e->Sslots.p; ra.O_out = e->Ogrp.p; ra.T_out = e->Tmass.p;
         ra.obj = e->objacc; ra.group_cols = e->group_cols.p; ra.Pr_b = e->Pr_b.p; ra.theta = e->theta.p;
         ra.counter = e->sync_words.p; ra.error = e->sync_words.p + 1;
@@ -673,8 +694,8 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
             if (tiles_upper[b] > 0) {
                 Timed t(e, F_ASSIGN_BLOCK);
                 AssignArgs a = assign_args(e);
-                a.cells = e->r_cells.p; a.tile_grp = e->r_tile_grp.p; a.S_out = e->Snew + GK * b;
-                a.blk_start = e->r_blk_start.p; a.blk = b;
+                a.cells = e->lists[e->cur].cells.p; a.tile_grp = e->lists[e->cur].tile_grp.p; a.S_out = e->Snew + GK * b;
+                a.blk_start = e->lists[e->cur].blk_start.p; a.blk = b;
                 a.tile_begin = 0; a.tile_end = tiles_upper[b];
                 if (launch_assign(a, true, e->max_wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported cluster count");
             }
@@ -721,10 +742,11 @@ int hmx_cluster_round(hmx_engine* e, int flags, const int32_t* cells, int64_t n_
         upper[b] = block_tile_start[b + 1] - block_tile_start[b];
     }
     if ((rc = use_device(e))) return rc;
-    if ((rc = e->r_cells.reserve(n_pos)) || (rc = e->r_tile_grp.reserve(n_tiles))) return rc;
-    HIP_TRY(hipMemcpyAsync(e->r_cells.p, cells, n_pos * sizeof(int), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->r_tile_grp.p, tile_group, n_tiles * sizeof(int), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->r_blk_start.p, block_tile_start, (e->nblk + 1) * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    e->pre_valid = false;   // caller-provided lists: whatever was prepared ahead is void
+    if ((rc = e->lists[e->cur].cells.reserve(n_pos)) || (rc = e->lists[e->cur].tile_grp.reserve(n_tiles))) return rc;
+    HIP_TRY(hipMemcpyAsync(e->lists[e->cur].cells.p, cells, n_pos * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->lists[e->cur].tile_grp.p, tile_group, n_tiles * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->lists[e->cur].blk_start.p, block_tile_start, (e->nblk + 1) * sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));  // host lists are borrowed for the call only
     return round_body(e, flags, n_tiles, upper, obj_out);
 }
@@ -737,26 +759,48 @@ int hmx_cluster_round_seeded(hmx_engine* e, int flags, uint64_t seed, int64_t ce
     const int nkeys = e->nblk * e->G;
     const int nchunks = order_chunks(e->N);
     const size_t pos_cap = (size_t)e->N + (size_t)nkeys * (HMX_TILE - 1) + HMX_TILE;
-    if ((rc = e->r_cells.reserve(pos_cap)) || (rc = e->r_tile_grp.reserve(pos_cap / HMX_TILE + 1)) ||
-        (rc = e->chunk_tab.reserve((size_t)nchunks * nkeys)) || (rc = e->run_count.reserve(nkeys)) ||
-        (rc = e->run_start.reserve(nkeys)))
+    for (auto& L : e->lists)
+        if ((rc = L.cells.reserve(pos_cap)) || (rc = L.tile_grp.reserve(pos_cap / HMX_TILE + 1))) return rc;
+    if ((rc = e->chunk_tab.reserve((size_t)nchunks * nkeys)) || (rc = e->run_count.reserve(nkeys)) || (rc = e->run_start.reserve(nkeys)))
         return rc;
-    OrderArgs o{};
-    o.N = e->N; o.Ng = e->Ng; o.cpb = cells_per_block; o.nblk = e->nblk; o.G = e->G;
-    o.global_id = e->global_id.p;
-    int bits = 1;
-    while (((int64_t)1 << bits) < e->Ng) ++bits;
-    o.half_bits = (bits + 1) / 2;
-    // splitmix64 of (seed, round counter) -> two 32-bit round keys
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (e->seeded_rounds + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    o.key0 = (uint32_t)z; o.key1 = (uint32_t)(z >> 32) | 1u;
-    e->seeded_rounds++;
-    o.gstart = e->gstart.p; o.chunk_tab = e->chunk_tab.p; o.run_count = e->run_count.p; o.run_start = e->run_start.p;
-    o.blk_start = e->r_blk_start.p; o.cells = e->r_cells.p; o.tile_grp = e->r_tile_grp.p;
-    launch_order(o, e->stream);
+    // build the lists of round `counter` into lists[which] on stream s
+    auto build = [&](uint64_t counter, int which, hipStream_t s) {
+        OrderArgs o{};
+        o.N = e->N; o.Ng = e->Ng; o.cpb = cells_per_block; o.nblk = e->nblk; o.G = e->G;
+        o.global_id = e->global_id.p;
+        int bits = 1;
+        while (((int64_t)1 << bits) < e->Ng) ++bits;
+        o.half_bits = (bits + 1) / 2;
+        // splitmix64 of (seed, round counter) -> two 32-bit round keys
+        uint64_t z = seed + 0x9E3779B97F4A7C15ull * (counter + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        o.key0 = (uint32_t)z; o.key1 = (uint32_t)(z >> 32) | 1u;
+        o.gstart = e->gstart.p; o.chunk_tab = e->chunk_tab.p; o.run_count = e->run_count.p; o.run_start = e->run_start.p;
+        o.blk_start = e->lists[which].blk_start.p; o.cells = e->lists[which].cells.p; o.tile_grp = e->lists[which].tile_grp.p;
+        launch_order(o, s);
+    };
+    const uint64_t counter = e->seeded_rounds++;
+    if (e->pre_valid && e->pre_seed == seed && e->pre_counter == counter && e->pre_cpb == cells_per_block) {
+        e->cur ^= 1;                                            // prepared while the previous round ran
+        HIP_TRY(hipStreamWaitEvent(e->stream, e->pre_event, 0));
+    } else {
+        if (e->pre_valid) HIP_TRY(hipStreamSynchronize(e->stream2));   // the scratch tables are shared
+        build(counter, e->cur, e->stream);
+    }
+    e->pre_valid = false;
+    // next round's lists depend on (seed, counter) only: they are built on the second stream beside the sweep
+    // kernel, which leaves a few CUs idle.  The scratch tables (chunk_tab, run_*) are free by then.
+    auto prefetch = [&]() -> int {
+        if (!e->prefetch_lists || !e->stream2) return 0;
+        HIP_TRY(hipEventRecord(e->pre_event, e->stream));
+        HIP_TRY(hipStreamWaitEvent(e->stream2, e->pre_event, 0));
+        build(counter + 1, e->cur ^ 1, e->stream2);
+        HIP_TRY(hipEventRecord(e->pre_event, e->stream2));
+        e->pre_valid = true; e->pre_seed = seed; e->pre_counter = counter + 1; e->pre_cpb = cells_per_block;
+        return 0;
+    };
     std::vector<int> upper(e->nblk);
     int total = 0;
     if (e->Ng == e->N) {
@@ -780,12 +824,12 @@ int hmx_cluster_round_seeded(hmx_engine* e, int flags, uint64_t seed, int64_t ce
     } else {
         // per-block launches need the exact tile counts: read the tile offsets back (84 bytes)
         std::vector<int> bs(e->nblk + 1);
-        HIP_TRY(hipMemcpyAsync(bs.data(), e->r_blk_start.p, bs.size() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(bs.data(), e->lists[e->cur].blk_start.p, bs.size() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
         for (int b = 0; b < e->nblk; ++b) upper[b] = bs[b + 1] - bs[b];
         total = bs[e->nblk];
     }
-    return round_body(e, flags, total, upper, obj_out);
+    return round_body(e, flags, total, upper, obj_out, prefetch);
 }
 
 int hmx_comm_unique_id(void* out_id) {
@@ -968,7 +1012,8 @@ int hmx_get(hmx_engine* e, int which, void* host_out, size_t bytes) {
     if (!e || !host_out) return fail(HMX_ERR_ARG, "null argument");
     void* p; size_t need; int rows, cols, ld, elem, rc;
     if (which == HMX_ROUND_BLOCK_START || which == HMX_ROUND_CELLS || which == HMX_ROUND_TILE_GROUP) {
-        DevBuf<int>& b = which == HMX_ROUND_BLOCK_START ? e->r_blk_start : which == HMX_ROUND_CELLS ? e->r_cells : e->r_tile_grp;
+        hmx_engine::Lists& L = e->lists[e->cur];
+        DevBuf<int>& b = which == HMX_ROUND_BLOCK_START ? L.blk_start : which == HMX_ROUND_CELLS ? L.cells : L.tile_grp;
         if (bytes > b.n * sizeof(int)) return fail(HMX_ERR_ARG, "round list holds %zu bytes, caller asked for %zu", b.n * sizeof(int), bytes);
         if ((rc = use_device(e))) return rc;
         HIP_TRY(hipStreamSynchronize(e->stream));
