@@ -264,14 +264,14 @@ def main():
         kernel = ("k_round (one persistent launch per update_R sweep: all 20 blocks)" if sweep
                   else "k_assign_lds (one launch per update block)")
         traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_v5_c3_pmc_hbm.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r01_v6_c3_pmc_hbm.json")
         if sweep and args.config == "c3" and os.path.exists(pmc_file):
             # HBM bytes per launch from the rocprofv3 --pmc passes of this configuration (FETCH_SIZE doubled
             # for gfx950's half-counted 16-byte streams + WRITE_SIZE; scripts/gpu_pmc.sh), not re-collected here
             pm = json.load(open(pmc_file))["kernels"]
             for name, rec in pm.items():
                 if name.startswith("void k_round"):
-                    traffic, traffic_src = rec["hbm_bytes_corrected"], "profiles/r01_v5_c3_pmc_hbm.json"
+                    traffic, traffic_src = rec["hbm_bytes_corrected"], "profiles/r01_v6_c3_pmc_hbm.json"
         out["roofline"] = {"bound": "hbm", "kernel": kernel, "achieved": achieved,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                            "traffic_source": traffic_src,
