@@ -608,7 +608,7 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         int max_upper = 0;
         for (int b = 0; b < e->nblk; ++b) max_upper = std::max(max_upper, tiles_upper[b]);
         const bool multi = e->peers_enabled && e->n_ranks > 1;
-        int wgs = std::min(e->n_cus - (multi ? 1 : 0), std::max(1, (max_upper + 13) / 14));   // ~14 of a workgroup's 16 tile slots
+        int wgs = std::min(e->n_cus - (multi ? 1 : 0), std::max(1, (max_upper + 13) / 14));   // ~14 of a workgroup's 16 tile slots: 224 of 256 CUs at C3, the rest serve the second stream
         if (multi) {
             // every rank must size its grid from its own share, but a rank whose share is small must not
             // starve the others: the grid only decides how this rank's tiles are dealt out
