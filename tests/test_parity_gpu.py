@@ -430,3 +430,54 @@ def test_config3_full_size_properties():
     ho2 = _hm().run_harmony(Z, meta, ["batch"], nclust=K, verbose=False, random_state=0, max_iter_harmony=3)
     assert ho2.kmeans_rounds == ho.kmeans_rounds
     np.testing.assert_allclose(ho2.Z_corr[::1009], ho.Z_corr[::1009], rtol=1e-3, atol=1e-4)
+
+
+def test_abi_call_order_and_argument_errors():
+    """Error behaviour of the C ABI on a live engine: call order, sizes, unsupported requests --
+    negative status + message, never a crash; the engine stays usable."""
+    import ctypes as C
+    from harmonypy_amd import _capi
+    lib = _capi.load()
+    eng = _capi.Engine(64, 5, 3, 2, 2, 1, 20)
+    out4 = np.zeros(4)
+    assert lib.hmx_cluster_round_seeded(eng._h, 7, 0, 3, _capi._ptr(out4)) == -3          # no upload / assignment yet
+    assert b"hmx_init_cluster" in lib.hmx_last_error()
+    assert lib.hmx_moe_correct_ridge(eng._h) == -3
+    y0 = np.zeros((3, 5), np.float32)
+    assert lib.hmx_init_cluster(eng._h, _capi._ptr(y0), _capi._ptr(out4)) == -3           # upload must come first
+    assert lib.hmx_kmeans_lloyd(eng._h, _capi._ptr(y0), 1, _capi._ptr(y0)) == -3
+    buf = np.zeros(10, np.float32)
+    assert lib.hmx_get(eng._h, _capi.HMX_R, _capi._ptr(buf), buf.nbytes) == -1            # wrong size
+    assert lib.hmx_get(eng._h, 99, _capi._ptr(buf), buf.nbytes) == -1                     # unknown array
+    assert lib.hmx_peer_attach(eng._h, _capi._ptr(buf)) == -3                             # export first
+    assert lib.hmx_peer_enable(eng._h, 1) == -3
+    assert lib.hmx_set_ranks(eng._h, 9, 0) == -1                                          # at most 8 ranks
+    rows = np.array([0, 64], np.int32)
+    assert lib.hmx_get_rows(eng._h, _capi.HMX_Z_COS, _capi._ptr(rows), 2, _capi._ptr(buf), 2 * 5 * 4) == -1   # row out of range
+    # a proper sequence still works afterwards
+    rng = np.random.default_rng(0)
+    Z = rng.normal(size=(64, 5)).astype(np.float32)
+    codes = np.repeat([0, 1], 32).astype(np.int32)[:, None]
+    from harmonypy_amd.harmony import build_layout
+    gc, order, rank, gid, cells, tg = build_layout(codes)
+    eng.upload(Z[order], cells, tg, gc, np.array([0.5, 0.5], np.float32), np.array([2, 2], np.float32),
+               np.full(3, 0.1, np.float32), np.array([0, 1, 1], np.float32))
+    bad_cells = cells.copy()
+    bad_cells[0] = 1000
+    with pytest.raises(_capi.HmxError):
+        eng.upload(Z[order], bad_cells, tg, gc, np.array([0.5, 0.5], np.float32), np.array([2, 2], np.float32),
+                   np.full(3, 0.1, np.float32), np.array([0, 1, 1], np.float32))
+    obj = eng.init_cluster(Z[:3])
+    assert np.isfinite(obj[:3]).all()
+    with pytest.raises(_capi.HmxError):
+        eng.cluster_round_seeded(0, 10_000)                                               # cells_per_block out of range
+    obj = eng.cluster_round_seeded(0, 3)
+    assert np.isfinite(obj[:3]).all()
+    eng.moe_correct_ridge()
+    assert np.isfinite(eng.get(_capi.HMX_Z_CORR)).all()
+    eng.close()
+    # K or d beyond the build's limits, and a missing device
+    with pytest.raises(_capi.HmxError):
+        _capi.Engine(64, 300, 3, 2, 2, 1, 20)
+    with pytest.raises(_capi.HmxError):
+        _capi.Engine(64, 5, 3, 2, 2, 1, 20, device_id=99)
