@@ -108,9 +108,13 @@ __global__ __launch_bounds__(256) void k_assign(AssignArgs a) {
     const int ntiles = tile_end - tile_begin;
     int per = (ntiles + nwaves - 1) / nwaves;
     per = ((per + NT - 1) / NT) * NT;
-    const int t0 = tile_begin + wave * per;
+    const int t0 = min(tile_begin + wave * per, tile_end);
     const int t1 = min(t0 + per, tile_end);
-    if (t0 >= t1) return;
+    // Every wave of the workgroup walks `per / NT` steps (empty ones included): the centroid columns of a
+    // k-step are staged ONCE per workgroup in LDS (coalesced 16-byte loads, double buffered) instead of being
+    // fetched from L2 by every wave -- at K = 200, d = 200 the table is 160 KB, far beyond the L1.
+    __shared__ __attribute__((aligned(16))) float Ysh[2][16 * MT][20];
+    const int tid = threadIdx.x;
 
     float sg[MT][4];
 #pragma unroll
@@ -148,7 +152,9 @@ __global__ __launch_bounds__(256) void k_assign(AssignArgs a) {
         }
     };
 
-    for (int t = t0; t < t1; t += NT) {
+    int stage = 0;
+    for (int step = 0; step < per; step += NT) {
+        const int t = t0 + step;
         int cell[NT], grp[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -163,21 +169,45 @@ __global__ __launch_bounds__(256) void k_assign(AssignArgs a) {
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         // ---- distance GEMM over the PC dimension --------------------------------------
+        // software pipeline over the 16-column k-steps: the centroid columns and the Z_cos pieces of step
+        // kb+1 travel (registers) while step kb multiplies from LDS
+        constexpr int YPT = (16 * MT * 4 + 255) / 256;       // 16-byte pieces of a centroid chunk per thread
+        f32x4 ynext[YPT];
+        f32x4 bnext[NT];
+        auto fetch_step = [&](int kb) {
+#pragma unroll
+            for (int p2 = 0; p2 < YPT; ++p2) {
+                const int i = tid + 256 * p2;
+                const int row = i >> 2, c4 = i & 3;
+                ynext[p2] = (i < 16 * mtn * 4) ? ld4(a.Y + (size_t)row * a.ldy + 16 * kb + 4 * c4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                bnext[nt] = (cell[nt] >= 0) ? ld4(a.Zcos + (size_t)cell[nt] * a.dp + 16 * kb + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        };
+        if (kb_full > 0) fetch_step(0);
         for (int kb = 0; kb < kb_full; ++kb) {
             f32x4 b[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                b[nt] = (cell[nt] >= 0) ? ld4(a.Zcos + (size_t)cell[nt] * a.dp + 16 * kb + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < NT; ++nt) b[nt] = bnext[nt];
+#pragma unroll
+            for (int p2 = 0; p2 < YPT; ++p2) {
+                const int i = tid + 256 * p2;
+                if (i < 16 * mtn * 4) st4(&Ysh[stage][i >> 2][4 * (i & 3)], ynext[p2]);
+            }
+            if (kb + 1 < kb_full) fetch_step(kb + 1);
+            __syncthreads();
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 if (mt < mtn) {
-                    const f32x4 ya = ld4(a.Y + (size_t)(16 * mt + c16) * a.ldy + 16 * kb + 4 * q);
+                    const f32x4 ya = ld4(&Ysh[stage][16 * mt + c16][4 * q]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA16(ya[i], b[nt][i], acc[mt][nt]);
                 }
             }
+            stage ^= 1;   // the other buffer is free: every wave passed the barrier of the previous k-step
         }
         for (int s = 0; s < tail; ++s) {
             const int col = 16 * kb_full + 4 * s + q;
@@ -197,7 +227,7 @@ __global__ __launch_bounds__(256) void k_assign(AssignArgs a) {
         // ---- per tile: softmax, penalty, write-back, running sums ---------------------
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            if (grp[nt] < 0) continue;  // wave-uniform
+            if (grp[nt] < 0) continue;  // wave-uniform (also: no tile in this step)
             if (grp[nt] != cur_g) {
                 flush(cur_g);
                 cur_g = grp[nt];
