@@ -260,7 +260,11 @@ def build_layout(codes, combos=None):
     """
     N = codes.shape[0]
     if combos is None and codes.shape[1] == 1:       # one batch variable: groups are its levels (fast path)
-        levels, gid = np.unique(codes[:, 0], return_inverse=True)
+        col = codes[:, 0]
+        levels = np.flatnonzero(np.bincount(col))   # codes are small non-negative integers
+        lut = np.full(int(levels[-1]) + 1 if len(levels) else 1, -1, dtype=np.int32)
+        lut[levels] = np.arange(len(levels), dtype=np.int32)
+        gid = lut[col]
         combos = levels.reshape(-1, 1)
     elif combos is None:
         combos, gid = np.unique(codes, axis=0, return_inverse=True)
@@ -273,7 +277,10 @@ def build_layout(codes, combos=None):
         gid = inv[combos.shape[0]:]
     gid = gid.reshape(-1).astype(np.int32)
     G = combos.shape[0]
-    order = np.argsort(gid, kind="stable").astype(np.int64)
+    if G <= 64:                                      # counting sort: G passes beat a comparison sort of N keys
+        order = np.concatenate([np.flatnonzero(gid == g) for g in range(G)]).astype(np.int64) if N else np.zeros(0, np.int64)
+    else:
+        order = np.argsort(gid, kind="stable").astype(np.int64)
     rank = np.empty(N, dtype=np.int32)
     rank[order] = np.arange(N, dtype=np.int32)
     counts = np.bincount(gid, minlength=G)
