@@ -205,3 +205,26 @@ def test_kmeans_mode_selection(monkeypatch):
     monkeypatch.setenv("HMX_KMEANS", "bogus")
     with pytest.raises(ValueError):
         f._kmeans_mode()
+
+
+@pytest.mark.parametrize("n", [1, 2, 17, 1000, 4097, 100003])
+def test_device_order_restatement_is_a_permutation(n):
+    """oracle/device_order.py (the checker of the GPU's update-order lists): positions are a bijection of
+    [0, n) for every round key, rounds differ, and the lists hold every cell once with one group per tile."""
+    from oracle.device_order import block_lists, positions
+    ids = np.arange(n)
+    p0 = positions(ids, n, 7, 0)
+    assert np.array_equal(np.sort(p0), ids)
+    if n > 16:
+        assert not np.array_equal(p0, positions(ids, n, 7, 1))
+        assert not np.array_equal(p0, positions(ids, n, 8, 0))
+    grp = (ids * 3 // max(n, 1)) % 3
+    nb, cpb = 20, int(n * 0.05)
+    cells, tg, bs = block_lists(ids, grp, 3, n, 7, 0, cpb, nb)
+    live = cells[cells >= 0]
+    assert np.array_equal(np.sort(live), ids) and bs[0] == 0 and bs[-1] * 16 == cells.size and tg.size == bs[-1]
+    assert np.array_equal(np.repeat(tg, 16)[cells >= 0], grp[live])
+    for b in range(nb):
+        blk = cells[bs[b] * 16: bs[b + 1] * 16]
+        want = (n - cpb * (nb - 1)) if b == nb - 1 else cpb
+        assert (blk >= 0).sum() == want

@@ -481,3 +481,38 @@ def test_abi_call_order_and_argument_errors():
         _capi.Engine(64, 300, 3, 2, 2, 1, 20)
     with pytest.raises(_capi.HmxError):
         _capi.Engine(64, 5, 3, 2, 2, 1, 20, device_id=99)
+
+
+@pytest.mark.parametrize("N,B,bs,offset,extra", [(3500, 3, 0.05, 0, 0), (1237, 4, 0.07, 0, 0), (100003, 5, 0.05, 0, 0),
+                                                   (4000, 3, 0.05, 2500, 7000)])
+def test_device_order_lists_match_numpy_restatement(N, B, bs, offset, extra):
+    """Bit-exact: the lists the GPU builds for a round (keyed inverse-Feistel positions, blocks, grouping,
+    padding) equal oracle/device_order.py's integer restatement -- also for a shard that holds cells
+    [offset, offset + N) of a larger job (global ids, blocks cut from the job-wide order)."""
+    from harmonypy_amd import _capi
+    from harmonypy_amd.harmony import build_layout
+    from oracle.device_order import block_lists
+    rng = np.random.default_rng(N + offset)
+    d, K = 6, 4
+    n_global = N + extra if extra else N
+    codes = rng.integers(0, B, size=(N, 1)).astype(np.int32)
+    codes[:B, 0] = np.arange(B)
+    gc, order, rank, gid_int, s_cells, s_tg = build_layout(codes)
+    G = gc.shape[0]
+    nb = int(np.ceil(1.0 / bs))
+    cpb = int(n_global * bs)
+    eng = _capi.Engine(N, d, K, B, G, 1, nb, n_cells_global=n_global)
+    Z = rng.normal(size=(N, d)).astype(np.float32)
+    gids = (offset + order).astype(np.int32)
+    eng.upload(Z[order], s_cells, s_tg, gc, np.full(B, 1.0 / B, np.float32), np.full(B, 2.0, np.float32),
+               np.full(K, 0.1, np.float32), np.concatenate([[0], np.ones(B)]).astype(np.float32), global_id=gids)
+    eng.init_cluster(Z[:K])
+    seed = 12345
+    for counter in range(3):                       # the engine counts its seeded rounds from 0
+        eng.cluster_round_seeded(seed, cpb)
+        cells, tg, bstart = eng.round_lists()
+        want_cells, want_tg, want_bs = block_lists(gids, gid_int, G, n_global, seed, counter, cpb, nb)
+        np.testing.assert_array_equal(bstart, want_bs)
+        np.testing.assert_array_equal(tg, want_tg)
+        np.testing.assert_array_equal(cells, want_cells)
+    eng.close()
