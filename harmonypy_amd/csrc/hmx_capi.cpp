@@ -321,7 +321,7 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
     e->N = cfg->n_cells; e->d = cfg->n_pcs; e->K = cfg->n_clusters; e->B = cfg->n_batches; e->G = cfg->n_groups;
     e->V = cfg->n_vars; e->nblk = cfg->n_blocks;
     e->Ng = cfg->n_cells_global > 0 ? cfg->n_cells_global : cfg->n_cells;
-    e->dp = round_row_floats(e->d) ? round_row_floats(e->d) : ((e->d + 3) & ~3);   // rows of 32 / 52 / 64 floats feed k_round
+    e->dp = round_row_floats(e->d) ? round_row_floats(e->d) : ((e->d + 15) & ~15);   // rows of 32 / 52 / 64 floats feed k_round; wide rows: whole 16-column k-steps
     e->Kp = (e->K + 3) & ~3;
     e->mt = (e->K + 15) / 16;
     e->K16 = 16 * e->mt;

@@ -702,12 +702,12 @@ __device__ __forceinline__ f32x2 fast_exp2(f32x2 x) {   // fast_exp on a pair, f
     return __builtin_elementwise_fma(p, tl * 0.693147182464599609375f, p);
 }
 
-template <int MT>
+template <int MT, bool PENALTY = true>
 __device__ __forceinline__ void round_post_pass1(const float* sig, const float* rpT, const float* lrpT, int q,
                                                  RoundTile<MT>& T, float& scl, double& km_acc, double& ent_acc) {
     constexpr int K16 = 16 * MT;
-    const float* rp = rpT + (size_t)T.grp * K16;
-    const float* lrp = lrpT + (size_t)T.grp * K16;
+    const float* rp = PENALTY ? rpT + (size_t)T.grp * K16 : nullptr;
+    const float* lrp = PENALTY ? lrpT + (size_t)T.grp * K16 : nullptr;
 #if HMX_PACKED
     f32x2 e1v = {0.f, 0.f}, uv = {0.f, 0.f}, a1v = {0.f, 0.f}, a2v = {0.f, 0.f}, a3v = {0.f, 0.f};
 #pragma unroll
@@ -737,8 +737,8 @@ __device__ __forceinline__ void round_post_pass1(const float* sig, const float* 
     float e1 = 0.f, us = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const f32x4 pw = ld4(rp + 16 * mt + 4 * q);
-        const f32x4 lp = ld4(lrp + 16 * mt + 4 * q);
+        const f32x4 pw = PENALTY ? ld4(rp + 16 * mt + 4 * q) : (f32x4){1.f, 1.f, 1.f, 1.f};   // no penalty: init_cluster (:383-385)
+        const f32x4 lp = PENALTY ? ld4(lrp + 16 * mt + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
         const f32x4 sg = ld4(sig + 16 * mt + 4 * q);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -771,12 +771,12 @@ __device__ __forceinline__ void round_post_pass1(const float* sig, const float* 
 // the block's (group, cluster) table.  Tiles of one group (the usual case: a wave's tiles are
 // neighbours in the block's group-sorted list) share one cross-lane reduction.
 template <int MT>
-__device__ __forceinline__ void round_post_pass2(const RoundArgs& a, double* Sd, int c16, int q, const RoundTile<MT>& T0,
+__device__ __forceinline__ void round_post_pass2(float* R, int Kp, double* Sd, int c16, int q, const RoundTile<MT>& T0,
                                                  float scl0, bool has1, const RoundTile<MT>& T1, float scl1) {
     constexpr int K16 = 16 * MT;
     const bool live0 = T0.cell >= 0, live1 = has1 && T1.cell >= 0;
-    float* row0 = a.R + (size_t)(live0 ? T0.cell : 0) * a.Kp;
-    float* row1 = a.R + (size_t)(live1 ? T1.cell : 0) * a.Kp;
+    float* row0 = R + (size_t)(live0 ? T0.cell : 0) * Kp;
+    float* row1 = R + (size_t)(live1 ? T1.cell : 0) * Kp;
     const bool joint = has1 && T1.grp == T0.grp;           // wave-uniform
     double* sd0 = Sd + (size_t)T0.grp * K16;
     double* sd1 = Sd + (size_t)T1.grp * K16;
@@ -787,8 +787,8 @@ __device__ __forceinline__ void round_post_pass2(const RoundArgs& a, double* Sd,
         const f32x4 rv0 = T0.arg[mt] * scl0;               // :503
         const f32x4 rv1 = T1.arg[mt] * scl1;
 #if !(HMX_RABL & 2)
-        if (live0 && col < a.Kp) st4(row0 + col, rv0);
-        if (live1 && col < a.Kp) st4(row1 + col, rv1);
+        if (live0 && col < Kp) st4(row0 + col, rv0);
+        if (live1 && col < Kp) st4(row1 + col, rv1);
 #endif
 #if !(HMX_RABL & 1)
         if (joint) {
@@ -817,6 +817,131 @@ __device__ __forceinline__ void round_post_pass2(const RoundArgs& a, double* Sd,
         }
 #endif
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_assign_wide: the assignment of one block (or of all cells: init_cluster) for shapes beyond the
+// LDS-resident kernels -- K up to 208, d up to 208 (BASELINE config 5: 200 x 200): the MFMA-bound
+// regime (2 d K flop per cell against 4 (d + K) bytes).  The centroid table (160 KB) does not fit
+// the LDS next to anything else, so the PC dimension is walked in 16-column k-steps: a step's
+// centroid columns (K16 x 16 floats, 13 KB) are staged once per workgroup, double buffered, the
+// next step's columns and Z_cos pieces travelling in registers while the current step multiplies
+// (52 MFMAs per wave and step).  Eight waves, one tile each per pass, 8 tiles per staged step;
+// the finishing passes are k_round's (one exp per entry, objective sums in the same pass).
+// Rows of Z_cos are padded to a multiple of 16 floats for these shapes (no tail steps).
+// ------------------------------------------------------------------------------------------
+#define WIDE_WAVES 8
+template <int MT, bool PENALTY>
+__global__ __launch_bounds__(64 * WIDE_WAVES, 2) void k_assign_wide(AssignArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int K16 = 16 * MT;
+    float* Ysh = reinterpret_cast<float*>(smem);                         // 2 x K16 x 20
+    float* nis = Ysh + 2 * K16 * 20;                                     // K16: -1/sigma (-60 for pads)
+    float* sig = nis + K16;                                              // K16
+    double* Sd = reinterpret_cast<double*>(sig + K16);                   // G x K16 block sums (when they fit)
+    double* objw = Sd + (a.tables_in_lds ? (size_t)a.G * K16 : 0);       // waves x 2
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c16 = lane & 15, q = lane >> 4;
+    const int nkb = a.dp >> 4;
+    const int GK = a.G * K16;
+    const int tile_begin = a.blk_start ? a.blk_start[a.blk] : a.tile_begin;
+    const int tile_end = a.blk_start ? a.blk_start[a.blk + 1] : a.tile_end;
+    const int ntiles = tile_end - tile_begin;
+
+    for (int i = tid; i < K16; i += 64 * WIDE_WAVES) {
+        const float sgm = (i < a.K) ? a.sigma[i] : 0.f;
+        sig[i] = sgm;
+        nis[i] = (i < a.K) ? -1.0f / sgm : -60.f;       // pads: Y row 0 -> dist 2 -> arg -120 -> exp == 0
+    }
+    if (a.tables_in_lds)
+        for (int i = tid; i < GK; i += 64 * WIDE_WAVES) Sd[i] = 0.0;
+    __syncthreads();
+
+    constexpr int YPT = (K16 * 4 + 64 * WIDE_WAVES - 1) / (64 * WIDE_WAVES);   // 16-byte pieces of a step per thread
+    double km_acc = 0.0, ent_acc = 0.0;
+    int stage = 0;
+    for (int base = blockIdx.x * WIDE_WAVES; base < ntiles; base += gridDim.x * WIDE_WAVES) {   // workgroup-uniform trip count
+        const int t = tile_begin + base + wv;
+        const bool has = base + wv < ntiles;
+        RoundTile<MT> T;
+        T.cell = has ? a.cells[(size_t)t * 16 + c16] : -1;
+        T.grp = has ? a.tile_grp[t] : 0;
+        const float* zr = a.Zcos + (size_t)(T.cell >= 0 ? T.cell : 0) * a.dp;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) T.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 ynext[YPT], bnext;
+        auto fetch_step = [&](int kb) {
+#pragma unroll
+            for (int p2 = 0; p2 < YPT; ++p2) {
+                const int i = tid + 64 * WIDE_WAVES * p2;
+                ynext[p2] = (i < K16 * 4) ? ld4(a.Y + (size_t)(i >> 2) * a.ldy + 16 * kb + 4 * (i & 3)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            bnext = ld4(zr + 16 * kb + 4 * q);
+        };
+        fetch_step(0);
+        for (int kb = 0; kb < nkb; ++kb) {
+            const f32x4 b = bnext;
+#pragma unroll
+            for (int p2 = 0; p2 < YPT; ++p2) {
+                const int i = tid + 64 * WIDE_WAVES * p2;
+                if (i < K16 * 4) st4(Ysh + (size_t)stage * K16 * 20 + (i >> 2) * 20 + 4 * (i & 3), ynext[p2]);
+            }
+            if (kb + 1 < nkb) fetch_step(kb + 1);
+            __syncthreads();
+            const float* Yst = Ysh + (size_t)stage * K16 * 20;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f32x4 ya = ld4(Yst + (16 * mt + c16) * 20 + 4 * q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) T.arg[mt] = MFMA16(ya[i], b[i], T.arg[mt]);
+            }
+            stage ^= 1;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 ni = ld4(nis + 16 * mt + 4 * q);
+            const f32x4 one = (f32x4){1.f, 1.f, 1.f, 1.f};
+            T.arg[mt] = (2.f * (one - T.arg[mt])) * ni;      // dist = 2 (1 - Y.Z) (:447), arg = -dist / sigma (:466)
+        }
+        if (has) {
+            float scl;
+            round_post_pass1<MT, PENALTY>(sig, a.rp, a.lrp, q, T, scl, km_acc, ent_acc);
+            if (a.tables_in_lds) {
+                round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T, scl, false, T, 0.f);
+            } else {   // the (group, cluster) table does not fit the LDS: fp64 atomics straight to memory
+                const bool live = T.cell >= 0;
+                float* row = a.R + (size_t)(live ? T.cell : 0) * a.Kp;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int col = 16 * mt + 4 * q;
+                    const f32x4 rv = T.arg[mt] * scl;
+                    if (live && col < a.Kp) st4(row + col, rv);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float sv = row16_sum(rv[r]);
+                        if (c16 == 0 && sv != 0.f) atomicAdd(&a.S_out[(size_t)T.grp * K16 + col + r], (double)sv);
+                    }
+                }
+            }
+        }
+    }
+    km_acc = wave_sum_all(km_acc);
+    ent_acc = wave_sum_all(ent_acc);
+    if (lane == 0) {
+        objw[2 * wv] = km_acc;
+        objw[2 * wv + 1] = ent_acc;
+    }
+    __syncthreads();
+    if (tid < 2) {
+        double v = 0.0;
+        for (int w = 0; w < WIDE_WAVES; ++w) v += objw[2 * w + tid];
+        if (v != 0.0) atomicAdd(&a.obj[2 * (blockIdx.x & (HMX_OBJ_SLOTS - 1)) + tid], v);
+    }
+    if (a.tables_in_lds)
+        for (int i = tid; i < GK; i += 64 * WIDE_WAVES) {
+            const double v = Sd[i];
+            if (v != 0.0) atomicAdd(&a.S_out[i], v);
+        }
 }
 
 template <int MT, int KS>
@@ -1051,7 +1176,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             if (has1) round_post_pass1<MT>(sig, rpT, lrpT, q, T[1], scl1, km_acc, ent_acc);
             __builtin_amdgcn_sched_barrier(0);
-            round_post_pass2<MT>(a, Sd, c16, q, T[0], scl0, has1, T[1], scl1);
+            round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T[0], scl0, has1, T[1], scl1);
         }
         for (int j = j_first + j_slot; j < ntl; j += j_slot) {   // blocks larger than the grid carries
 #pragma unroll 1
@@ -1065,7 +1190,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                 round_compute<MT, KS>(Ys, nis, LDY, c16, q, XZ, X);
                 float sclx;
                 round_post_pass1<MT>(sig, rpT, lrpT, q, X, sclx, km_acc, ent_acc);
-                round_post_pass2<MT>(a, Sd, c16, q, X, sclx, false, X, 0.f);
+                round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, X, sclx, false, X, 0.f);
             }
         }
         wg_barrier_lds();
@@ -2327,6 +2452,24 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
             }
             return 0;
         }
+    }
+    if (a.dp % 16 == 0 && a.mt >= 1 && a.mt <= 13 && (a.mt > 7 || a.dp > 64)) {
+        // wide shapes: k-step staged centroid columns, 8 tiles per workgroup pass
+        const size_t gk_bytes = (size_t)a.G * a.K16 * sizeof(double);
+        a.tables_in_lds = gk_bytes <= 64 * 1024 ? 1 : 0;
+        const size_t sm = ((size_t)2 * a.K16 * 20 + 2 * a.K16) * sizeof(float) + (a.tables_in_lds ? gk_bytes : 0) + 2 * WIDE_WAVES * sizeof(double);
+        const int wgs = std::max(1, std::min(2 * 256, cdiv(ntiles, WIDE_WAVES)));
+#define HMX_WIDE_CASE(M)                                                                                          \
+    case M:                                                                                                       \
+        if (penalty) hipLaunchKernelGGL((k_assign_wide<M, true>), dim3(wgs), dim3(64 * WIDE_WAVES), sm, s, a);    \
+        else hipLaunchKernelGGL((k_assign_wide<M, false>), dim3(wgs), dim3(64 * WIDE_WAVES), sm, s, a);           \
+        break;
+        switch (a.mt) {
+            HMX_WIDE_CASE(1) HMX_WIDE_CASE(2) HMX_WIDE_CASE(3) HMX_WIDE_CASE(4) HMX_WIDE_CASE(5) HMX_WIDE_CASE(6) HMX_WIDE_CASE(7)
+            HMX_WIDE_CASE(8) HMX_WIDE_CASE(9) HMX_WIDE_CASE(10) HMX_WIDE_CASE(11) HMX_WIDE_CASE(12) HMX_WIDE_CASE(13)
+        }
+#undef HMX_WIDE_CASE
+        return 0;
     }
     if (a.mt <= 7) {
         constexpr int NT = 2;
