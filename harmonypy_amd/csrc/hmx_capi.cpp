@@ -477,7 +477,8 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
     // ridge tasks: runs of tiles of one group; with k_rtz2 a task is one workgroup's share, sized
     // for about four tasks per CU (k_rtz: one task per wave, <= 64 tiles)
     std::vector<int> t0, t1, tg;
-    const int CH = rtz2_ok(e->mt, e->dp) ? std::max(16, (n_static_tiles + 2 * e->rtz_wgs_per_cu * e->n_cus - 1) / (2 * e->rtz_wgs_per_cu * e->n_cus)) : 64;
+    const int CH = rtz2_ok(e->mt, e->dp) ? std::max(16, (n_static_tiles + 2 * e->rtz_wgs_per_cu * e->n_cus - 1) / (2 * e->rtz_wgs_per_cu * e->n_cus))
+                   : rtz_wide_ok(e->mt, e->dp) ? std::max(16, (n_static_tiles + 2 * e->n_cus - 1) / (2 * e->n_cus)) : 64;
     for (int i = 0; i < n_static_tiles;) {
         int j = i;
         while (j < n_static_tiles && j - i < CH && static_tile_group[j] == static_tile_group[i]) ++j;
@@ -574,9 +575,13 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
     int nsub, spw;
     rtz_geometry(e->mt, e->ntd, &nsub, &spw);
     const bool rtz2 = rtz2_ok(e->mt, e->dp) && e->round_mode == 1;
+    const bool rtzw = !rtz2 && rtz_wide_ok(e->mt, e->dp);
     int wgs = rtz2 ? std::min(e->rtz_wgs_per_cu * e->n_cus, std::max(1, (n_tiles_upper + 7) / 8))
-                   : std::min(256, std::max(1, (n_tiles_upper + 31) / 32));
-    if ((rc = e->slab.reserve(rtz2 ? (size_t)wgs * rtz2_slab_floats(e->mt, e->dp) : (size_t)wgs * 4 * spw))) return rc;
+              : rtzw ? std::min(e->n_cus, std::max(1, (n_tiles_upper + 7) / 8))
+                     : std::min(256, std::max(1, (n_tiles_upper + 31) / 32));
+    if ((rc = e->slab.reserve(rtz2 ? (size_t)wgs * rtz2_slab_floats(e->mt, e->dp)
+                              : rtzw ? (size_t)wgs * rtz_wide_slab_floats(e->mt, e->dp) : (size_t)wgs * 4 * spw)))
+        return rc;
     {
         Timed t(e, F_RTZ_ROUND);
         RtzArgs r{};
@@ -584,11 +589,13 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         r.S_out = e->Sold; r.slab = e->slab.p; r.n_tiles = n_tiles_upper; r.nblk = e->nblk;
         r.K = e->K; r.Kp = e->Kp; r.K16 = e->K16; r.G = e->G; r.mt = e->mt; r.dp = e->dp; r.ntd = e->ntd;
         if (rtz2) launch_rtz2(r, wgs, e->stream);
+        else if (rtzw) launch_rtz_wide(r, wgs, e->stream);
         else launch_rtz(r, wgs, e->stream);
     }
     if (flags & HMX_ROUND_CENTROIDS) {
         Timed t(e, F_RTZ_REDUCE);
         if (rtz2) launch_rtz2_reduce(e->slab.p, wgs, e->mt, e->dp, e->K16, e->ldy, e->Yacc64, nullptr, e->stream);
+        else if (rtzw) launch_rtz_wide_reduce(e->slab.p, wgs, e->mt, e->dp, e->K16, e->ldy, e->Yacc64, nullptr, e->stream);
         else launch_rtz_reduce(e->slab.p, wgs * 4, e->mt, e->ntd, e->K16, e->ldy, e->Yacc64, nullptr, e->stream);
     }
     // removal sums of every block and the centroid numerators: one collective (neighbours in xch)
@@ -951,7 +958,10 @@ int hmx_moe_correct_ridge(hmx_engine* e) {
     int nsub, spw;
     rtz_geometry(e->mt, e->ntd, &nsub, &spw);
     const bool rtz2 = rtz2_ok(e->mt, e->dp);   // tasks were cut for it in hmx_upload
-    if ((rc = e->slab.reserve((size_t)std::max(e->ntasks, 1) * (rtz2 ? rtz2_slab_floats(e->mt, e->dp) : spw)))) return rc;
+    const bool rtzw = !rtz2 && rtz_wide_ok(e->mt, e->dp);
+    if ((rc = e->slab.reserve((size_t)std::max(e->ntasks, 1) * (rtz2 ? rtz2_slab_floats(e->mt, e->dp)
+                                                                     : rtzw ? rtz_wide_slab_floats(e->mt, e->dp) : spw))))
+        return rc;
     HIP_TRY(hipMemsetAsync(e->Sr, 0, GK * e->ldy * sizeof(double), e->stream));
     HIP_TRY(hipMemsetAsync(e->Oxr, 0, GK * sizeof(double), e->stream));
     {
@@ -964,6 +974,9 @@ int hmx_moe_correct_ridge(hmx_engine* e) {
         if (rtz2) {
             launch_rtz2(r, e->ntasks, e->stream);
             launch_rtz2_reduce(e->slab.p, e->ntasks, e->mt, e->dp, e->K16, e->ldy, e->Sr, e->task_grp.p, e->stream);
+        } else if (rtzw) {
+            launch_rtz_wide(r, e->ntasks, e->stream);
+            launch_rtz_wide_reduce(e->slab.p, e->ntasks, e->mt, e->dp, e->K16, e->ldy, e->Sr, e->task_grp.p, e->stream);
         } else {
             launch_rtz(r, (e->ntasks + 3) / 4, e->stream);
             launch_rtz_reduce(e->slab.p, e->ntasks, e->mt, e->ntd, e->K16, e->ldy, e->Sr, e->task_grp.p, e->stream);

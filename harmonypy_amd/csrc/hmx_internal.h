@@ -153,6 +153,10 @@ void launch_y_normalize(const float* src, float* dst, int K, int K16, int d, int
 int launch_assign(const AssignArgs& a, bool penalty, int max_wgs, hipStream_t s);
 void rtz_geometry(int mt, int ntd, int* nsub, int* slab_per_wave);
 bool rtz2_ok(int mt, int dp);
+bool rtz_wide_ok(int mt, int dp);
+int rtz_wide_slab_floats(int mt, int dp);
+void launch_rtz_wide(const RtzArgs& a, int wgs, hipStream_t s);
+void launch_rtz_wide_reduce(const float* slab, int nslabs, int mt, int dp, int K16, int ld, double* out, const int* task_grp, hipStream_t s);
 int rtz2_slab_floats(int mt, int dp);
 void launch_rtz2(const RtzArgs& a, int wgs, hipStream_t s);
 void launch_rtz2_reduce(const float* slab, int nslabs, int mt, int dp, int K16, int ld, double* out, const int* task_grp, hipStream_t s);

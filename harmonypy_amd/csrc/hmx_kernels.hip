@@ -1605,6 +1605,201 @@ __global__ __launch_bounds__(256, 2) void k_rtz2(RtzArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_rtz_wide: k_rtz2's scheme for K up to 208 / d up to 208 (13 x 13 output tiles): eight waves,
+// wave w owns the PC column blocks w and w + 8 and all cluster tiles (26 accumulators of 4 registers),
+// tiles of 16 cells staged through double-buffered LDS with 16-byte row loads, one workgroup per CU.
+// ------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(512, 2) void k_rtz_wide(RtzArgs a) {
+    const int NTD = a.ntd;                          // PC column blocks (<= 16)
+    constexpr int NB = 2;                           // PC column blocks per wave: wave w owns blocks w, w + 8 and ALL cluster tiles
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* lds = reinterpret_cast<float*>(smem);
+    const int LDR = a.ldr, LDZ = a.ldz;
+    const int tile_floats = 16 * (LDR + LDZ);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c16 = lane & 15, q = lane >> 4;
+    const int wg = blockIdx.x;
+
+    int t0, t1;
+    if (a.task_tile0) {
+        if (wg >= a.ntasks) return;
+        t0 = a.task_tile0[wg];
+        t1 = a.task_tile1[wg];
+    } else {
+        const int n_tiles = a.blk_start ? a.blk_start[a.nblk] : a.n_tiles;
+        const int per = (n_tiles + gridDim.x - 1) / gridDim.x;
+        t0 = min(wg * per, n_tiles);
+        t1 = min(t0 + per, n_tiles);
+    }
+
+    // this thread's (up to 4) 16-byte pieces of a tile: fixed (array, row, column), only the cell changes
+    const int kp4 = a.Kp >> 2, dp4 = a.dp >> 2;
+    const int nR = 16 * kp4, nZ = 16 * dp4;
+    int it_row[4], it_src[4], it_dst[4];   // row in the tile; float offset inside the source row (-1: none; bit 30: Z); LDS float offset
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int i = tid + 512 * s;
+        if (i < nR) {
+            it_row[s] = i / kp4;
+            it_src[s] = 4 * (i - it_row[s] * kp4);
+            it_dst[s] = it_row[s] * LDR + it_src[s];
+        } else if (i < nR + nZ) {
+            const int j = i - nR;
+            it_row[s] = j / dp4;
+            const int c = 4 * (j - it_row[s] * dp4);
+            it_src[s] = c | (1 << 30);
+            it_dst[s] = 16 * LDR + it_row[s] * LDZ + c;
+        } else {
+            it_row[s] = 0;
+            it_src[s] = -1;
+            it_dst[s] = 0;
+        }
+    }
+    for (int i = tid; i < 2 * tile_floats; i += 512) lds[i] = 0.f;   // the padding columns stay zero
+    // per-tile bookkeeping (group, block) comes from LDS copies: a dependent global load per tile
+    // would cost a full memory round trip on the critical path
+    int* grp_l = reinterpret_cast<int*>(lds + 2 * tile_floats);      // 256 tile groups
+    int* bs_l = grp_l + 256;                                          // nblk + 1 tile offsets
+    const int task_g = a.task_tile0 ? a.task_grp[wg] : -1;
+    if (a.blk_start)
+        for (int i = tid; i <= a.nblk; i += 512) bs_l[i] = a.blk_start[i];
+
+    f32x4 acc[NB][MT];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int MTW = MT;
+    // column sums of R (the removal sums): four values per tile in fp32, tiles in fp64 -- a long fp32
+    // accumulation would drop the many tiny entries of R and bias O by ~5e-8 per round
+    double csum[MT];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) csum[i] = 0.0;
+    int cur_g = -1, cur_b = 0;
+    const bool sums = wv == 0 && a.S_out != nullptr;
+    auto flush = [&]() {
+        if (cur_g < 0 || !sums) return;
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            const int mt = i;
+            double sv = csum[i];
+            sv += __shfl_xor(sv, 16, 64);
+            sv += __shfl_xor(sv, 32, 64);
+            const int k = 16 * mt + c16;
+            if (q == 0 && mt < MT && k < a.K && sv != 0.0) atomicAdd(&a.S_out[((size_t)cur_b * a.G + cur_g) * a.K16 + k], sv);
+            csum[i] = 0.0;
+        }
+    };
+    auto ids_of = [&](int t, int (&id)[4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) id[s] = (t < t1 && it_src[s] != -1) ? a.cells[(size_t)t * 16 + it_row[s]] : -1;
+    };
+    auto fetch = [&](const int (&id)[4], f32x4 (&v)[4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            v[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (id[s] >= 0) {
+                const bool isz = (it_src[s] >> 30) & 1;
+                const int off = it_src[s] & 0xFFFFFF;
+                v[s] = isz ? ld4(a.Z + (size_t)id[s] * a.dp + off) : ld4(a.R + (size_t)id[s] * a.Kp + off);
+            }
+        }
+    };
+    auto stash = [&](int buf, const f32x4 (&v)[4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (it_src[s] != -1) st4(lds + (size_t)buf * tile_floats + it_dst[s], v[s]);
+    };
+
+    // software pipeline: tile t multiplies from LDS while tile t+1 is written to the other LDS buffer,
+    // the loads of tiles t+2 .. t+RTZ_DEPTH travel in registers and the cell ids of tile
+    // t+RTZ_DEPTH+1 are on their way
+    constexpr int RTZ_DEPTH = 2;
+    int id_n[4];
+    f32x4 v[RTZ_DEPTH][4];
+    __syncthreads();
+    if (t0 < t1) {
+        ids_of(t0, id_n);
+        fetch(id_n, v[0]);
+        stash(0, v[0]);
+#pragma unroll
+        for (int dpt = 0; dpt < RTZ_DEPTH; ++dpt) {
+            ids_of(t0 + 1 + dpt, id_n);
+            fetch(id_n, v[dpt]);          // tiles t0+1 .. t0+RTZ_DEPTH travelling
+        }
+        ids_of(t0 + 1 + RTZ_DEPTH, id_n);
+    }
+    for (int t = t0; t < t1; ++t) {
+        const int buf = (t - t0) & 1;
+        __syncthreads();          // tile t is complete in lds[buf]; nobody reads lds[buf ^ 1] any more
+        stash(buf ^ 1, v[0]);     // tile t+1 (its loads were issued RTZ_DEPTH iterations ago)
+#pragma unroll
+        for (int dpt = 0; dpt + 1 < RTZ_DEPTH; ++dpt)
+#pragma unroll
+            for (int s3 = 0; s3 < 4; ++s3) v[dpt][s3] = v[dpt + 1][s3];
+        fetch(id_n, v[RTZ_DEPTH - 1]);        // tile t+1+RTZ_DEPTH
+        ids_of(t + 2 + RTZ_DEPTH, id_n);      // ids for the fetch of the next iteration
+        int g = task_g;
+        if (task_g < 0) {
+            if (((t - t0) & 255) == 0) {          // refill the group window (workgroup-uniform)
+                __syncthreads();
+                if (tid < 256 && t + tid < t1) grp_l[tid] = a.tile_grp[t + tid];
+                __syncthreads();
+            }
+            g = grp_l[(t - t0) & 255];
+        }
+        int b = cur_b;
+        if (a.blk_start) {
+            while (t >= bs_l[b + 1]) ++b;         // lists are block-major, so b only grows
+        }
+        if (g != cur_g || b != cur_b) {
+            flush();
+            cur_g = g;
+            cur_b = b;
+        }
+        const float* Rt = lds + (size_t)buf * tile_floats;
+        const float* Zt = Rt + 16 * LDR;
+        float tsum[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) tsum[i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float bv[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int nt = wv + 8 * j;
+                bv[j] = (nt < NTD) ? Zt[(4 * ks + q) * LDZ + 16 * nt + c16] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const float av = Rt[(4 * ks + q) * LDR + 16 * i + c16];
+                tsum[i] += av;
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    if (wv + 8 * j < NTD) acc[j][i] = MFMA16(av, bv[j], acc[j][i]);   // wave-uniform
+            }
+        }
+        if (sums) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) csum[i] += (double)tsum[i];
+        }
+    }
+    flush();
+    float* slab = a.slab + (size_t)wg * (MT * NTD * 256);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int nt = wv + 8 * j;
+        if (nt < NTD) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[((i * NTD + nt) * 4 + r) * 64 + lane] = acc[j][i][r];
+        }
+    }
+}
+
 // Sum the per-workgroup slabs of k_rtz2 in fp64 (same contract as k_rtz_reduce).
 __global__ __launch_bounds__(256) void k_rtz2_reduce(const float* __restrict__ slab, int nslabs, int MT, int NTD, int K16,
                                                      int ld, double* __restrict__ out, const int* __restrict__ task_grp,
@@ -2657,6 +2852,41 @@ void launch_kmeans_sums(const float* slab, int wgs, int K16, int dp, int d, doub
 
 void launch_kmeans_update(const double* sums, float* C, float* hn, int K, int K16, int d, int ldy, hipStream_t s) {
     hipLaunchKernelGGL(k_kmeans_update, dim3(K16), dim3(64), 0, s, sums, C, hn, K, d, ldy);
+}
+
+bool rtz_wide_ok(int mt, int dp) { return mt >= 1 && mt <= 13 && dp % 16 == 0 && dp <= 208 && (mt > 7 || dp > 64); }
+int rtz_wide_slab_floats(int mt, int dp) { return mt * (dp / 16) * 256; }
+
+void launch_rtz_wide(const RtzArgs& a_in, int wgs, hipStream_t s) {
+    RtzArgs a = a_in;
+    const int ntd = a.dp / 16;
+    a.ntd = ntd;
+    a.ldr = ((a.K16 + 31) / 32) * 32 + 16;
+    a.ldz = ((16 * ntd + 31) / 32) * 32 + 16;
+    const size_t sm = (size_t)2 * 16 * (a.ldr + a.ldz) * sizeof(float) + (256 + 64) * sizeof(int);
+    switch (a.mt) {
+        case 1: hipLaunchKernelGGL((k_rtz_wide<1>), dim3(wgs), dim3(512), sm, s, a); break;
+        case 2: hipLaunchKernelGGL((k_rtz_wide<2>), dim3(wgs), dim3(512), sm, s, a); break;
+        case 3: hipLaunchKernelGGL((k_rtz_wide<3>), dim3(wgs), dim3(512), sm, s, a); break;
+        case 4: hipLaunchKernelGGL((k_rtz_wide<4>), dim3(wgs), dim3(512), sm, s, a); break;
+        case 5: hipLaunchKernelGGL((k_rtz_wide<5>), dim3(wgs), dim3(512), sm, s, a); break;
+        case 6: hipLaunchKernelGGL((k_rtz_wide<6>), dim3(wgs), dim3(512), sm, s, a); break;
+        case 7: hipLaunchKernelGGL((k_rtz_wide<7>), dim3(wgs), dim3(512), sm, s, a); break;
+        case 8: hipLaunchKernelGGL((k_rtz_wide<8>), dim3(wgs), dim3(512), sm, s, a); break;
+        case 9: hipLaunchKernelGGL((k_rtz_wide<9>), dim3(wgs), dim3(512), sm, s, a); break;
+        case 10: hipLaunchKernelGGL((k_rtz_wide<10>), dim3(wgs), dim3(512), sm, s, a); break;
+        case 11: hipLaunchKernelGGL((k_rtz_wide<11>), dim3(wgs), dim3(512), sm, s, a); break;
+        case 12: hipLaunchKernelGGL((k_rtz_wide<12>), dim3(wgs), dim3(512), sm, s, a); break;
+        default: hipLaunchKernelGGL((k_rtz_wide<13>), dim3(wgs), dim3(512), sm, s, a); break;
+    }
+}
+
+void launch_rtz_wide_reduce(const float* slab, int nslabs, int mt, int dp, int K16, int ld, double* out, const int* task_grp,
+                            hipStream_t s) {
+    const int ntd = dp / 16;
+    const int seg_len = 8;
+    hipLaunchKernelGGL(k_rtz2_reduce, dim3(cdiv(mt * ntd * 256, 256), cdiv(nslabs, seg_len)), dim3(256), 0, s, slab, nslabs, mt,
+                       ntd, K16, ld, out, task_grp, seg_len);
 }
 
 void rtz_geometry(int mt, int ntd, int* nsub, int* slab_per_wave) {
