@@ -997,7 +997,7 @@ int hmx_moe_correct_ridge(hmx_engine* e) {
         a.R = e->R.p; a.Zorig = e->Zorig.p; a.W = e->W.p; a.Zcorr = e->Zcorr.p; a.Zcos = e->Zcos.p;
         a.cells = e->s_cells.p; a.tile_grp = e->s_tile_grp.p; a.n_tiles = e->n_s_tiles;
         a.Kp = e->Kp; a.K16 = e->K16; a.dp = e->dp; a.ldw = e->ldy; a.mtd = e->ntd;
-        if (rtz2) { a.task_tile0 = e->task_t0.p; a.task_tile1 = e->task_t1.p; a.task_grp = e->task_grp.p; a.ntasks = e->ntasks; }
+        if (rtz2 || rtzw) { a.task_tile0 = e->task_t0.p; a.task_tile1 = e->task_t1.p; a.task_grp = e->task_grp.p; a.ntasks = e->ntasks; }
         if (launch_ridge_apply(a, e->max_wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported n_pcs");
     }
     HIP_TRY(hipGetLastError());

@@ -2433,6 +2433,96 @@ __global__ __launch_bounds__(64) void k_kmeans_update(const double* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
+// k_ridge_apply_wide: the correction for K up to 208 / d up to 208.  One workgroup (8 waves) per task
+// (tiles of one group); the group's W (K16 x d, up to 170 KB) is walked in k-steps of 16 clusters: a
+// step's 16 rows (16 x dp floats, 13 KB) are staged in LDS, double buffered, the next step's rows and
+// R pieces travelling in registers; every wave multiplies its own tile (52 MFMAs per step), then
+// subtracts from its Z_orig rows and renormalises (harmony.py:566, 569).
+// ------------------------------------------------------------------------------------------
+template <int MTD>
+__global__ __launch_bounds__(64 * WIDE_WAVES, 2) void k_ridge_apply_wide(ApplyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* Wsh = reinterpret_cast<float*>(smem);                 // 2 x 16 x LDW
+    const int LDW = a.ldw_lds;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c16 = lane & 15, q = lane >> 4;
+    const int task = blockIdx.x;
+    if (task >= a.ntasks) return;
+    const int t0 = a.task_tile0[task], t1 = a.task_tile1[task], g = a.task_grp[task];
+    const float* Wg = a.W + (size_t)g * a.K16 * a.ldw;
+    const int nkb = a.K16 >> 4;
+    const int w4 = (16 * MTD) >> 2;                              // 16-byte pieces of a W row
+    constexpr int WPT = (16 * 16 * MTD / 4 + 64 * WIDE_WAVES - 1) / (64 * WIDE_WAVES);
+    int stage = 0;
+    for (int base = t0; base < t1; base += WIDE_WAVES) {        // workgroup-uniform trip count
+        const int t = base + wv;
+        const bool has = t < t1;
+        const int cell = has ? a.cells[(size_t)t * 16 + c16] : -1;
+        const bool live = cell >= 0;
+        const float* rr = a.R + (size_t)(live ? cell : 0) * a.Kp;
+        f32x4 acc[MTD];
+#pragma unroll
+        for (int mt = 0; mt < MTD; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 wnext[WPT], bnext;
+        auto fetch_step = [&](int kb) {
+#pragma unroll
+            for (int p2 = 0; p2 < WPT; ++p2) {
+                const int i = tid + 64 * WIDE_WAVES * p2;
+                const int row = i / w4, c4 = i - row * w4;
+                wnext[p2] = (i < 16 * w4) ? ld4(Wg + (size_t)(16 * kb + row) * a.ldw + 4 * c4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            const int col0 = 16 * kb + 4 * q;
+            bnext = (live && col0 < a.Kp) ? ld4(rr + col0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        };
+        fetch_step(0);
+        for (int kb = 0; kb < nkb; ++kb) {
+            const f32x4 b = bnext;
+#pragma unroll
+            for (int p2 = 0; p2 < WPT; ++p2) {
+                const int i = tid + 64 * WIDE_WAVES * p2;
+                const int row = i / w4, c4 = i - row * w4;
+                if (i < 16 * w4) st4(Wsh + (size_t)stage * 16 * LDW + row * LDW + 4 * c4, wnext[p2]);
+            }
+            if (kb + 1 < nkb) fetch_step(kb + 1);
+            __syncthreads();
+            const float* Wst = Wsh + (size_t)stage * 16 * LDW;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* wr = Wst + (4 * q + i) * LDW + c16;
+#pragma unroll
+                for (int mt = 0; mt < MTD; ++mt) acc[mt] = MFMA16(wr[16 * mt], b[i], acc[mt]);
+            }
+            stage ^= 1;
+        }
+        if (has) {
+            const size_t row = (size_t)(live ? cell : 0) * a.dp;
+            float ss = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MTD; ++mt) {
+                const int col = 16 * mt + 4 * q;
+                const f32x4 zo = (live && col < a.dp) ? ld4(a.Zorig + row + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc[mt] = zo - acc[mt];                                               // :566
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ss += acc[mt][r] * acc[mt][r];
+            }
+            ss = wave_sum_q(ss);
+            const float nrm = sqrtf(ss);
+#pragma unroll
+            for (int mt = 0; mt < MTD; ++mt) {
+                const int col = 16 * mt + 4 * q;
+                if (live && col < a.dp) {
+                    st4(a.Zcorr + row + col, acc[mt]);
+                    f32x4 zc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) zc[r] = acc[mt][r] / nrm;             // :569
+                    st4(a.Zcos + row + col, zc);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Device-side update order (replaces torch.randperm + the gather/argsort of harmony.py:471-480,
 // 512-513 when the caller does not supply an order).
 //
@@ -2958,6 +3048,18 @@ static void launch_apply2_k(const ApplyArgs& a, int kb, size_t sm, hipStream_t s
 int launch_ridge_apply(const ApplyArgs& a_in, int max_wgs, hipStream_t s) {
     ApplyArgs a = a_in;
     if (a.n_tiles <= 0) return 0;
+    if (a.task_tile0 && rtz_wide_ok((a.K16 + 15) / 16, a.dp)) {
+        const int mtd = a.dp / 16;
+        a.ldw_lds = ((16 * mtd + 31) / 32) * 32 + 16;
+        const size_t sm = (size_t)2 * 16 * a.ldw_lds * sizeof(float);
+#define HMX_AW(M) case M: hipLaunchKernelGGL((k_ridge_apply_wide<M>), dim3(a.ntasks), dim3(64 * WIDE_WAVES), sm, s, a); break;
+        switch (mtd) {
+            HMX_AW(1) HMX_AW(2) HMX_AW(3) HMX_AW(4) HMX_AW(5) HMX_AW(6) HMX_AW(7) HMX_AW(8) HMX_AW(9) HMX_AW(10) HMX_AW(11) HMX_AW(12)
+            default: hipLaunchKernelGGL((k_ridge_apply_wide<13>), dim3(a.ntasks), dim3(64 * WIDE_WAVES), sm, s, a); break;
+        }
+#undef HMX_AW
+        return 0;
+    }
     if (a.task_tile0 && rtz2_ok((a.K16 + 15) / 16, a.dp)) {
         const int mtd = a.dp == 32 ? 2 : 4;
         a.ldw_lds = ((16 * mtd + 31) / 32) * 32 + 16;
