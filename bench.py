@@ -253,8 +253,9 @@ def main():
         conv = {"wall_s": t_init + t_loop, "setup_and_init_s": t_init, "harmonize_loop_s": t_loop,
                 "harmony_iterations": len(ho2.kmeans_rounds), "kmeans_rounds": [int(r) for r in ho2.kmeans_rounds],
                 "converged": bool(ho2.check_convergence(1)), "cells_total": N * world,
-                "init": "upload + k-means++ seeds on a 32k-cell subsample (host, sklearn) + 25 Lloyd iterations over all "
-                        "cells (GPU) + init_cluster; not part of `value`"}
+                "setup_breakdown_s": {k: round(v, 4) for k, v in ho2.timing.items() if k != "harmonize"},
+                "init": "upload (rows regrouped on the GPU) + k-means++ seeds on a 32k-cell subsample (GPU) + 25 Lloyd "
+                        "iterations over all cells (GPU) + init_cluster; not part of `value`"}
     if rank != 0:
         if dist is not None:
             dist.barrier()

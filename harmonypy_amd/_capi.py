@@ -25,10 +25,10 @@ EXPORTS = [
     "hmx_last_error", "hmx_abi_version", "hmx_create", "hmx_destroy", "hmx_upload", "hmx_init_cluster",
     "hmx_cluster_round", "hmx_cluster_round_seeded", "hmx_moe_correct_ridge", "hmx_get", "hmx_set", "hmx_sync", "hmx_device_ptr",
     "hmx_kernel_times", "hmx_enable_timing", "hmx_comm_unique_id", "hmx_comm_init", "hmx_set_host_allreduce",
-    "hmx_kmeans_lloyd", "hmx_get_rows", "hmx_set_ranks", "hmx_peer_export", "hmx_peer_attach", "hmx_peer_selftest", "hmx_peer_enable",
+    "hmx_kmeans_lloyd", "hmx_kmeans_seed", "hmx_get_rows", "hmx_set_ranks", "hmx_peer_export", "hmx_peer_attach", "hmx_peer_selftest", "hmx_peer_enable",
 ]
 HMX_PEER_HANDLE_BYTES = 64
-HMX_ABI_VERSION = 2
+HMX_ABI_VERSION = 3
 HMX_UNIQUE_ID_BYTES = 128
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
 
@@ -64,7 +64,8 @@ def load():
     lib.hmx_create.argtypes = [C.POINTER(HmxConfig), C.POINTER(vp)]
     lib.hmx_destroy.argtypes = [vp]
     lib.hmx_destroy.restype = None
-    lib.hmx_upload.argtypes = [vp, vp, vp, i64, vp, i32, vp, vp, vp, vp, vp, vp]
+    lib.hmx_upload.argtypes = [vp, vp, vp, i64, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.hmx_kmeans_seed.argtypes = [vp, vp, i64, C.c_uint64, vp, vp]
     lib.hmx_comm_unique_id.argtypes = [vp]
     lib.hmx_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.hmx_set_host_allreduce.argtypes = [vp, HOST_ALLREDUCE_FN, vp]
@@ -136,9 +137,12 @@ class Engine:
         except Exception:
             pass
 
-    def upload(self, Z, static_cells, static_tile_group, group_cols, Pr_b, theta, sigma, lamb, global_id=None):
+    def upload(self, Z, static_cells, static_tile_group, group_cols, Pr_b, theta, sigma, lamb, global_id=None,
+               source_row=None):
+        """Z: N x d; with ``source_row`` in the caller's order (internal cell i = Z[source_row[i]])."""
         Z = _c(Z, np.float32)
         global_id = None if global_id is None else _c(global_id, np.int32)
+        source_row = None if source_row is None else _c(source_row, np.int32)
         sc = _c(static_cells, np.int32)
         tg = _c(static_tile_group, np.int32)
         gc = _c(group_cols, np.int32)
@@ -146,7 +150,7 @@ class Engine:
         assert Z.shape == (self.N, self.d)
         _check(self._lib.hmx_upload(self._h, _ptr(Z), _ptr(sc), sc.size, _ptr(tg), tg.size, _ptr(gc),
                                     _ptr(_c(Pr_b, np.float32)), _ptr(_c(theta, np.float32)),
-                                    _ptr(_c(sigma, np.float32)), _ptr(lamb), _ptr(global_id)))
+                                    _ptr(_c(sigma, np.float32)), _ptr(lamb), _ptr(global_id), _ptr(source_row)))
 
     # ---- transports of a sharded job (include/hmx.h) ------------------------------------------
     def comm_init(self, unique_id: bytes, n_ranks: int, rank: int):
@@ -191,6 +195,15 @@ class Engine:
                 return 1
         self._host_cb = HOST_ALLREDUCE_FN(_cb)                  # keep the thunk alive
         _check(self._lib.hmx_set_host_allreduce(self._h, self._host_cb, None))
+
+    def kmeans_seed(self, points, seed=0):
+        """k-means++ seeding on the device over ``points`` (n x d unit rows); returns (centres K x d, chosen)."""
+        pts = _c(points, np.float32)
+        assert pts.ndim == 2 and pts.shape[1] == self.d
+        out = np.empty((self.K, self.d), np.float32)
+        chosen = np.empty(self.K, np.int32)
+        _check(self._lib.hmx_kmeans_seed(self._h, _ptr(pts), pts.shape[0], int(seed) & (2**64 - 1), _ptr(out), _ptr(chosen)))
+        return out, chosen
 
     def kmeans_lloyd(self, centers, n_iter=25):
         """Lloyd iterations over all cells of Z_cos on the device; centres K x d in and out."""

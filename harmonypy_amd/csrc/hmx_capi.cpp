@@ -417,7 +417,8 @@ void hmx_destroy(hmx_engine* e) {
 
 int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64_t n_static_pos,
                const int32_t* static_tile_group, int32_t n_static_tiles, const int32_t* group_cols, const float* Pr_b,
-               const float* theta, const float* sigma, const float* lamb, const int32_t* global_id) {
+               const float* theta, const float* sigma, const float* lamb, const int32_t* global_id,
+               const int32_t* source_row) {
     if (!e || !Z || !static_cells || !static_tile_group || !group_cols || !Pr_b || !theta || !sigma)
         return fail(HMX_ERR_ARG, "null argument");
     if (!e->cfg.lambda_estimation && !lamb) return fail(HMX_ERR_ARG, "lamb is required unless lambda_estimation");
@@ -441,13 +442,22 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
     } else {
         e->global_id.release();
     }
-    // Z rows padded to dp
+    if (source_row)
+        for (int64_t i = 0; i < e->N; ++i)
+            if (source_row[i] < 0 || source_row[i] >= e->N) return fail(HMX_ERR_ARG, "source_row[%lld] out of range", (long long)i);
+    // Z travels as it is (N x d); the device pads the rows to dp and, with source_row, brings them
+    // into the group-sorted order.  Z_corr's storage is the landing area (N x d <= N x dp floats).
     {
-        std::vector<float> zp((size_t)e->N * e->dp, 0.f);
-        for (int64_t i = 0; i < e->N; ++i) std::memcpy(&zp[(size_t)i * e->dp], Z + (size_t)i * e->d, sizeof(float) * e->d);
-        HIP_TRY(hipMemcpyAsync(e->Zorig.p, zp.data(), zp.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(hipMemcpyAsync(e->Zcorr.p, e->Zorig.p, zp.size() * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+        DevBuf<int> srow;
+        if (source_row) {
+            if ((rc = srow.reserve(e->N))) return rc;
+            HIP_TRY(hipMemcpyAsync(srow.p, source_row, e->N * sizeof(int), hipMemcpyHostToDevice, e->stream));
+        }
+        HIP_TRY(hipMemcpyAsync(e->Zcorr.p, Z, (size_t)e->N * e->d * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        launch_load_rows(e->Zcorr.p, e->d, srow.p, e->Zorig.p, e->dp, e->N, e->stream);
+        HIP_TRY(hipMemcpyAsync(e->Zcorr.p, e->Zorig.p, (size_t)e->N * e->dp * sizeof(float), hipMemcpyDeviceToDevice, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
+        srow.release();
     }
     launch_normalize_rows(e->Zorig.p, e->Zcos.p, e->N, e->dp, e->stream);  // harmony.py:238
     std::vector<float> sg(e->K16, 0.f);
@@ -496,6 +506,41 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipGetLastError());
     e->uploaded = true;
+    return HMX_OK;
+}
+
+int hmx_kmeans_seed(hmx_engine* e, const float* points, int64_t n_points, uint64_t seed, float* centers_out, int32_t* chosen_out) {
+    if (!e || !points || !centers_out) return fail(HMX_ERR_ARG, "null argument");
+    if (n_points < 1 || n_points > (int64_t)1 << 24) return fail(HMX_ERR_ARG, "n_points must be in [1, 2^24]");
+    int rc;
+    if ((rc = use_device(e))) return rc;
+    const int n = (int)n_points, d = e->d, K = e->K;
+    const int nchunks = (n + 255) / 256;
+    DevBuf<float> X, Xt, closest, cand_min, centers;
+    DevBuf<unsigned long long> chunk_sum, pots;
+    DevBuf<int> cand, chosen;
+    struct Release {
+        DevBuf<float>&a, &b, &c, &d2, &f; DevBuf<unsigned long long>&g, &h; DevBuf<int>&i, &j;
+        ~Release() { a.release(); b.release(); c.release(); d2.release(); f.release(); g.release(); h.release(); i.release(); j.release(); }
+    } guard{X, Xt, closest, cand_min, centers, chunk_sum, pots, cand, chosen};
+    if ((rc = X.reserve((size_t)n * d)) || (rc = Xt.reserve((size_t)n * d)) || (rc = closest.reserve(n)) ||
+        (rc = cand_min.reserve((size_t)HMX_SEED_SLOTS * n)) || (rc = centers.reserve((size_t)K * d)) ||
+        (rc = chunk_sum.reserve(nchunks)) || (rc = pots.reserve((size_t)K * HMX_SEED_SLOTS)) ||
+        (rc = cand.reserve((size_t)K * HMX_SEED_SLOTS)) || (rc = chosen.reserve(K)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(X.p, points, (size_t)n * d * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemsetAsync(pots.p, 0, (size_t)K * HMX_SEED_SLOTS * sizeof(unsigned long long), e->stream));
+    HIP_TRY(hipMemsetAsync(cand.p, 0, (size_t)K * HMX_SEED_SLOTS * sizeof(int), e->stream));
+    SeedArgs a{};
+    a.X = X.p; a.Xt = Xt.p; a.n = n; a.d = d;
+    a.n_trials = std::min(HMX_SEED_SLOTS, 2 + (int)std::log((double)K));       // sklearn: 2 + int(log(n_clusters))
+    a.seed = seed; a.closest = closest.p; a.cand_min = cand_min.p; a.chunk_sum = chunk_sum.p; a.pots = pots.p;
+    a.cand = cand.p; a.chosen = chosen.p; a.centers = centers.p;
+    launch_kmeans_seed(a, K, e->stream);
+    HIP_TRY(hipMemcpyAsync(centers_out, centers.p, (size_t)K * d * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if (chosen_out) HIP_TRY(hipMemcpyAsync(chosen_out, chosen.p, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipGetLastError());
     return HMX_OK;
 }
 

@@ -140,6 +140,23 @@ int launch_round(const RoundArgs& a, int mt, int wgs, hipStream_t s);
 size_t peer_box_doubles(int n_ranks, size_t GK);
 void launch_peer_selftest(double* const* peer_box, double* my_box, int n_ranks, int rank, size_t GK, unsigned long long token,
                           unsigned* result, hipStream_t s);
+// k-means++ seeding on the device (k_seed_*): n points of d floats, row-major X and its transpose Xt
+struct SeedArgs {
+    const float* X;               // n x d
+    float* Xt;                    // d x n
+    int n, d, n_trials;
+    unsigned long long seed;
+    float* closest;               // n: squared distance to the closest centre so far
+    float* cand_min;              // 8 x n: min(closest, distance to candidate j)
+    unsigned long long* chunk_sum;// ceil(n/256) fixed-point sums of closest
+    unsigned long long* pots;     // K x 8 candidate potentials (zeroed by the caller)
+    int* cand;                    // K x 8 candidate point indices
+    int* chosen;                  // K chosen point indices
+    float* centers;               // K x d
+};
+#define HMX_SEED_SLOTS 8
+void launch_kmeans_seed(const SeedArgs& a, int K, hipStream_t s);
+void launch_load_rows(const float* src, int d, const int* source_row, float* dst, int dp, int64_t N, hipStream_t s);
 size_t kmeans_slab_floats(int wgs, int K16, int dp);
 int launch_kmeans_step(const float* Zcos, const float* C, const float* hn, const int* cells, int n_tiles, float* slab, int K,
                        int K16, int dp, int ldy, int wgs, hipStream_t s);

@@ -2679,6 +2679,168 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ s
     dst[i] = src[(size_t)rows[r] * ld + c];
 }
 
+// Upload path: rows of the caller's matrix (n x d, caller's order) into the engine's padded,
+// group-sorted layout: dst[i][0..dp) = src[source_row[i]][0..d), 0 beyond d.
+__global__ __launch_bounds__(256) void k_load_rows(const float* __restrict__ src, int d, const int* __restrict__ source_row,
+                                                   float* __restrict__ dst, int dp, int64_t N) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * dp) return;
+    const int64_t r = i / dp;
+    const int c = (int)(i - r * dp);
+    const int64_t sr = source_row ? (int64_t)source_row[r] : r;
+    dst[i] = c < d ? src[sr * d + c] : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------
+// k-means++ seeding on the device (the greedy k-means++ of sklearn 1.7's `_kmeans_plusplus`, which
+// the reference reaches through KMeans(init='k-means++'), harmony.py:370): the first centre uniform,
+// then per centre SEED_TRIALS candidates drawn with probability proportional to the squared distance
+// to the closest centre so far; the candidate that leaves the smallest total is kept.
+// Everything that decides an index is integer arithmetic: squared distances are accumulated in a
+// fixed order without contraction (bit-equal to a NumPy float32 loop), potentials are 32.32
+// fixed-point sums (order-independent, so atomics are exact), the draws come from a counter-based
+// generator, and a draw is located by an exact prefix search.  oracle/kmeans_seed.py restates it.
+// Three small launches per centre: pick (1 workgroup) -> eval (one thread per point) -> commit.
+// ------------------------------------------------------------------------------------------
+#define SEED_TRIALS 8          // slots per step; the first n_trials are used
+__device__ __forceinline__ unsigned long long seed_rand(unsigned long long seed, int step, int trial) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(1 + step * SEED_TRIALS + trial);
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+__device__ __forceinline__ unsigned long long seed_fx(float v) { return (unsigned long long)(v * 4294967296.0f); }
+
+// 256-thread inclusive scan of one unsigned long long per thread (LDS scratch of 256 words)
+__device__ __forceinline__ unsigned long long seed_scan256(unsigned long long v, unsigned long long* sh, int tid) {
+    sh[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const unsigned long long o = tid >= off ? sh[tid - off] : 0ull;
+        __syncthreads();
+        sh[tid] += o;
+        __syncthreads();
+    }
+    const unsigned long long r = sh[tid];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_seed_transpose(const float* __restrict__ X, int n, int d, float* __restrict__ Xt) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)n * d) return;
+    const int c = (int)(i / n), r = (int)(i - (int64_t)c * n);
+    Xt[i] = X[(size_t)r * d + c];
+}
+
+// candidates of one step -> a.cand[step*SEED_TRIALS + j]
+__global__ __launch_bounds__(256) void k_seed_pick(SeedArgs a, int step) {
+    __shared__ unsigned long long sh[256];
+    __shared__ unsigned long long tot_s;
+    __shared__ int chunk_s;
+    __shared__ unsigned long long rem_s;
+    const int tid = threadIdx.x;
+    int* cand = a.cand + step * SEED_TRIALS;
+    if (step == 0) {
+        if (tid == 0) cand[0] = (int)__umul64hi(seed_rand(a.seed, 0, 0), (unsigned long long)a.n);
+        return;
+    }
+    const int nchunks = (a.n + 255) / 256;
+    // prefix over the chunk sums (nchunks <= 256 * 16: a thread owns up to 16 consecutive chunks)
+    const int per = (nchunks + 255) / 256;
+    unsigned long long mine = 0;
+    for (int c = 0; c < per; ++c) { const int ch = tid * per + c; if (ch < nchunks) mine += a.chunk_sum[ch]; }
+    const unsigned long long incl = seed_scan256(mine, sh, tid);
+    if (tid == 255) tot_s = incl;
+    __syncthreads();
+    const unsigned long long total = tot_s;
+    for (int j = 0; j < a.n_trials; ++j) {
+        const unsigned long long u = seed_rand(a.seed, step, j);
+        if (total == 0ull) {                                       // every point coincides with a centre
+            if (tid == 0) cand[j] = (int)__umul64hi(u, (unsigned long long)a.n);
+            continue;
+        }
+        const unsigned long long target = __umul64hi(u, total);    // uniform in [0, total)
+        const unsigned long long excl = incl - mine;
+        if (target >= excl && target < incl) {                     // exactly one thread
+            unsigned long long acc = excl;
+            int ch = tid * per;
+            for (int c = 0; c < per; ++c, ++ch) {
+                const unsigned long long v = a.chunk_sum[ch];
+                if (target < acc + v) break;
+                acc += v;
+            }
+            chunk_s = ch; rem_s = target - acc;
+        }
+        __syncthreads();
+        const int ch = chunk_s;
+        const unsigned long long rem = rem_s;
+        const int i = ch * 256 + tid;
+        const unsigned long long v = i < a.n ? seed_fx(a.closest[i]) : 0ull;
+        const unsigned long long inc2 = seed_scan256(v, sh, tid);
+        if (rem >= inc2 - v && rem < inc2) cand[j] = i;
+        __syncthreads();
+    }
+}
+
+// squared distance of every point to every candidate of the step, kept as min(closest, .)
+__global__ __launch_bounds__(256) void k_seed_eval(SeedArgs a, int step) {
+    extern __shared__ float cs[];                                   // n_trials x d candidate rows
+    __shared__ unsigned long long red[4 * SEED_TRIALS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nc = step == 0 ? 1 : a.n_trials;
+    const int* cand = a.cand + step * SEED_TRIALS;
+    for (int i = tid; i < nc * a.d; i += 256) { const int j = i / a.d, c = i - j * a.d; cs[i] = a.X[(size_t)cand[j] * a.d + c]; }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + tid;
+    const bool live = i < a.n;
+    float acc[SEED_TRIALS];
+#pragma unroll
+    for (int j = 0; j < SEED_TRIALS; ++j) acc[j] = 0.f;
+    for (int c = 0; c < a.d; ++c) {
+        const float x = live ? a.Xt[(size_t)c * a.n + i] : 0.f;
+#pragma unroll
+        for (int j = 0; j < SEED_TRIALS; ++j)
+            if (j < nc) { const float df = __fsub_rn(x, cs[j * a.d + c]); acc[j] = __fadd_rn(acc[j], __fmul_rn(df, df)); }
+    }
+    const float cl = (live && step > 0) ? a.closest[i] : __builtin_inff();
+#pragma unroll
+    for (int j = 0; j < SEED_TRIALS; ++j) {
+        if (j >= nc) break;
+        const float m = fminf(cl, acc[j]);
+        if (live) a.cand_min[(size_t)j * a.n + i] = m;
+        unsigned long long f = live ? seed_fx(m) : 0ull;
+        for (int off = 32; off; off >>= 1) f += __shfl_xor(f, off);
+        if (lane == 0) red[wv * SEED_TRIALS + j] = f;
+    }
+    __syncthreads();
+    if (tid < nc) atomicAdd(a.pots + step * SEED_TRIALS + tid, red[tid] + red[SEED_TRIALS + tid] + red[2 * SEED_TRIALS + tid] + red[3 * SEED_TRIALS + tid]);
+}
+
+// keep the best candidate: closest <- its minima, chunk sums for the next draw, centre row out
+__global__ __launch_bounds__(256) void k_seed_commit(SeedArgs a, int step) {
+    __shared__ unsigned long long red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nc = step == 0 ? 1 : a.n_trials;
+    int best = 0;
+    unsigned long long bp = a.pots[step * SEED_TRIALS];
+    for (int j = 1; j < nc; ++j) { const unsigned long long pj = a.pots[step * SEED_TRIALS + j]; if (pj < bp) { bp = pj; best = j; } }
+    const int i = blockIdx.x * 256 + tid;
+    float m = 0.f;
+    if (i < a.n) { m = a.cand_min[(size_t)best * a.n + i]; a.closest[i] = m; }
+    unsigned long long f = i < a.n ? seed_fx(m) : 0ull;
+    for (int off = 32; off; off >>= 1) f += __shfl_xor(f, off);
+    if (lane == 0) red[wv] = f;
+    __syncthreads();
+    if (tid == 0) a.chunk_sum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (blockIdx.x == 0) {
+        const int src = a.cand[step * SEED_TRIALS + best];
+        if (tid == 0) a.chosen[step] = src;
+        for (int c = tid; c < a.d; c += 256) a.centers[(size_t)step * a.d + c] = a.X[(size_t)src * a.d + c];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host-side launchers (called from hmx_capi.cpp through hmx_internal.h)
 // ------------------------------------------------------------------------------------------
@@ -3042,6 +3204,22 @@ static void launch_apply2_k(const ApplyArgs& a, int kb, size_t sm, hipStream_t s
         case 5: hipLaunchKernelGGL((k_ridge_apply2<MTD, 5>), dim3(a.ntasks), dim3(256), sm, s, a); break;
         case 6: hipLaunchKernelGGL((k_ridge_apply2<MTD, 6>), dim3(a.ntasks), dim3(256), sm, s, a); break;
         default: hipLaunchKernelGGL((k_ridge_apply2<MTD, 7>), dim3(a.ntasks), dim3(256), sm, s, a); break;
+    }
+}
+
+void launch_load_rows(const float* src, int d, const int* source_row, float* dst, int dp, int64_t N, hipStream_t s) {
+    if (N <= 0) return;
+    hipLaunchKernelGGL(k_load_rows, dim3(cdiv(N * dp, 256)), dim3(256), 0, s, src, d, source_row, dst, dp, N);
+}
+
+void launch_kmeans_seed(const SeedArgs& a, int K, hipStream_t s) {
+    const int wgs = cdiv(a.n, 256);
+    hipLaunchKernelGGL(k_seed_transpose, dim3(cdiv((int64_t)a.n * a.d, 256)), dim3(256), 0, s, a.X, a.n, a.d, a.Xt);
+    const size_t sm = (size_t)SEED_TRIALS * a.d * sizeof(float);
+    for (int step = 0; step < K; ++step) {
+        hipLaunchKernelGGL(k_seed_pick, dim3(1), dim3(256), 0, s, a, step);
+        hipLaunchKernelGGL(k_seed_eval, dim3(wgs), dim3(256), sm, s, a, step);
+        hipLaunchKernelGGL(k_seed_commit, dim3(wgs), dim3(256), 0, s, a, step);
     }
 }
 

@@ -16,6 +16,8 @@ from __future__ import annotations
 
 import logging
 
+import time
+
 import numpy as np
 import pandas as pd
 
@@ -41,12 +43,16 @@ AUTO_DEVICE_ORDER_CELLS = 200_000
 # sharded jobs: rank 0 fits the initial k-means on all cells up to this many, else on a subsample
 KMEANS_GATHER_CELLS = 2_000_000
 # Initial centroids (harmony.py:369-373).  "host": the reference's sklearn KMeans call on all cells
-# (bit-identical Y0; 18 s at 1M cells).  "device": k-means++ seeding by sklearn on a subsample of
+# (bit-identical Y0; 18 s at 1M cells).  "device": k-means++ seeding on a subsample of
 # KMEANS_SEED_CELLS cells (~300 per cluster at K=100), then the 25 Lloyd iterations on the GPU over all cells (all ranks when
 # sharded).  "auto": host up to KMEANS_DEVICE_CELLS cells, device above.  Override: HMX_KMEANS.
 KMEANS = "auto"
 KMEANS_DEVICE_CELLS = 200_000
 KMEANS_SEED_CELLS = 32_768
+# Who seeds the device k-means: "device" = the engine's k-means++ (hmx_kmeans_seed, counter-based
+# draws), "sklearn" = sklearn.cluster.kmeans_plusplus on the host (NumPy's generator; ~0.15-0.5 s
+# for 32k cells).  Override: HMX_KMEANS_SEEDS.
+KMEANS_SEEDS = "device"
 
 # Test aids (never set by product code).  ``Y0``: d x K centroids used instead of the
 # sklearn call; ``forced_rounds``: list of k-means round counts replayed instead of the
@@ -396,9 +402,19 @@ class Harmony:
         self.update_order = mode
         self._seed = int(random_state) if random_state is not None else 0
 
+        # where the wall-clock of the constructor went (seconds per phase); read by bench.py
+        self.timing = {}
+        self._t_last = time.perf_counter()
         self.allocate_buffers(Z)
         self.init_cluster(random_state)
+        self._lap("init_cluster")
         self.harmonize(self.max_iter_harmony, self.verbose)
+        self._lap("harmonize")
+
+    def _lap(self, name):
+        now = time.perf_counter()
+        self.timing[name] = self.timing.get(name, 0.0) + now - getattr(self, "_t_last", now)
+        self._t_last = now
 
     # ------------------------------------------------------------------
     # device state (replaces harmony.py:234-271 uploads and :357-364 buffers)
@@ -413,6 +429,7 @@ class Harmony:
             combos = np.unique(np.vstack(parts), axis=0)
         (self._group_cols, self._order, self._rank, self._gid_int,
          self._static_cells, self._static_tile_grp) = build_layout(codes, combos)
+        self._lap("group_layout")
         self._G = self._group_cols.shape[0]
         self._n_blocks = int(np.ceil(1.0 / self.block_size))                     # harmony.py:474
         self._cells_per_block = int(self.N_global * self.block_size)             # harmony.py:475
@@ -421,13 +438,16 @@ class Harmony:
                                     lambda_estimation=self.lambda_estimation, alpha=self.alpha,
                                     device_id=_device_index(self.device), n_cells_global=self.N_global)
         self.transport = None if self.shard is None else self.shard.attach(self._engine)
+        self._lap("engine_create")
         if Z is not None:
-            Zi = np.ascontiguousarray(Z.T[self._order])                          # N x d, internal order
-            # a cell's id in the whole job = its row in the unsharded input
-            gid = (self._offset + self._order).astype(np.int32)
-            self._engine.upload(Zi, self._static_cells, self._static_tile_grp, self._group_cols,
-                                self._Pr_b, self._theta, self._sigma,
-                                None if self.lambda_estimation else self._lamb, global_id=gid)
+            # Z travels cells x d in the caller's order; the device regroups it (source_row).
+            # A cell's id in the whole job = its row in the unsharded input.
+            src = self._order.astype(np.int32)
+            gid = src if self._offset == 0 else (self._offset + self._order).astype(np.int32)
+            self._engine.upload(np.ascontiguousarray(Z.T), self._static_cells, self._static_tile_grp,
+                                self._group_cols, self._Pr_b, self._theta, self._sigma,
+                                None if self.lambda_estimation else self._lamb, global_id=gid, source_row=src)
+            self._lap("upload")
 
     # ------------------------------------------------------------------
     # read-back (harmony.py:288-355): fresh float32 NumPy arrays, cells x features
@@ -567,14 +587,22 @@ class Harmony:
             parts = self.shard.allgather_object(sub)
             sub = np.concatenate(parts, axis=0) if self.shard.rank == 0 else None
         centers = None
-        if sub is not None:
+        import os
+        seeds = os.environ.get("HMX_KMEANS_SEEDS", KMEANS_SEEDS)
+        if seeds not in ("device", "sklearn"):
+            raise ValueError(f"HMX_KMEANS_SEEDS={seeds!r}: expected device or sklearn")
+        if sub is not None and seeds == "device":
+            centers, _ = self._engine.kmeans_seed(sub, 0 if random_state is None else int(random_state))
+        elif sub is not None:
             from sklearn.cluster import kmeans_plusplus
             centers, _ = kmeans_plusplus(np.ascontiguousarray(sub, dtype=np.float32), n_clusters=self.K,
                                          random_state=random_state)
             centers = np.asarray(centers, dtype=np.float32)
         if self.shard is not None:
             centers = self.shard.broadcast_object(centers)
+        self._lap("kmeans_seeds")
         centers = self._engine.kmeans_lloyd(centers, 25)                         # max_iter=25, harmony.py:371
+        self._lap("kmeans_lloyd")
         if self.verbose:
             logger.info("KMeans initialization complete.")
         return np.ascontiguousarray(centers.T)

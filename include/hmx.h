@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HMX_ABI_VERSION 2
+#define HMX_ABI_VERSION 3
 #define HMX_TILE 16 /* cells per tile */
 
 typedef enum hmx_status {
@@ -83,8 +83,10 @@ int hmx_abi_version(void);
 int hmx_create(const hmx_config* cfg, hmx_engine** out);
 void hmx_destroy(hmx_engine* e);
 
-/* Upload inputs (harmony.py:234-271).  Z: N x d row-major, internal order; the
- * engine derives Z_cos (harmony.py:238).  static_cells/static_tile_group: the
+/* Upload inputs (harmony.py:234-271).  Z: N x d row-major; the engine derives Z_cos
+ * (harmony.py:238).  source_row: for every internal (group-sorted) cell its row in Z,
+ * so that Z travels in the caller's order and is regrouped on the device; NULL = Z is
+ * already in internal order.  static_cells/static_tile_group: the
  * group-sorted identity list padded to tiles (n_static_pos = 16*n_static_tiles).
  * group_cols: G x V Phi-row indices of every group.  lamb: B+1 floats, ignored
  * when lambda_estimation.  Pr_b (harmony.py:170) is the batch proportion over the
@@ -93,7 +95,7 @@ void hmx_destroy(hmx_engine* e);
 int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64_t n_static_pos,
                const int32_t* static_tile_group, int32_t n_static_tiles, const int32_t* group_cols,
                const float* Pr_b, const float* theta, const float* sigma, const float* lamb,
-               const int32_t* global_id);
+               const int32_t* global_id, const int32_t* source_row);
 
 /* ---- cells sharded over several engines (one process per GPU) -------------------------
  * Every cross-cell quantity of the path is a small fp64 table -- centroid numerators K x d
@@ -136,6 +138,18 @@ int hmx_peer_enable(hmx_engine* e, int on);
  * obj_out = {sum R*dist, sum sigma*R*log R, cross-entropy term, 0}, each rounded to
  * fp32 like the `.item()` calls of harmony.py:399-411. */
 int hmx_init_cluster(hmx_engine* e, const float* Y0, double obj_out[4]);
+
+/* k-means++ seeding on the device: K = n_clusters centres chosen among `points` (n_points x d
+ * row-major host floats, rows of unit length -- a subsample of Z_cos) by the greedy k-means++ that
+ * sklearn's KMeans(init='k-means++') runs for the reference (harmony.py:370; sklearn 1.7
+ * `_kmeans_plusplus`: first centre uniform, then 2+int(log K) candidates per centre drawn with
+ * probability proportional to the squared distance to the closest centre, the one with the smallest
+ * remaining potential kept).  The draws come from a counter-based generator keyed by `seed`, not
+ * from NumPy's, so the centres are statistically, not bitwise, those of sklearn; the selection is
+ * integer arithmetic and reproducible (oracle/kmeans_seed.py).  centers_out: K x d; chosen_out
+ * (may be NULL): the K point indices.  Does not need hmx_upload. */
+int hmx_kmeans_seed(hmx_engine* e, const float* points, int64_t n_points, uint64_t seed, float* centers_out,
+                    int32_t* chosen_out);
 
 /* Lloyd iterations of the initial k-means on the device.  The reference fits sklearn's KMeans on the
  * host (harmony.py:369-373: k-means++ seeding + at most 25 Lloyd iterations; 18 s at 1M cells); for
