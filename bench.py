@@ -45,7 +45,10 @@ CONFIGS = {
     # per-GPU shards of the 8-GPU configurations (BASELINE configs[3], configs[4])
     "c4": (1_250_000, 50, 16, 100),
     "c5": (1_250_000, 200, 32, 200),
+    # all 10M cells of BASELINE configs[3] on ONE GPU (R = 4.5 GB of the 288 GB)
+    "c4x1": (10_000_000, 50, 16, 100),
 }
+CONFIG_INDEX = {"c2": 1, "c3": 2, "c4": 3, "c5": 4, "c4x1": 3}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -135,7 +138,7 @@ def side_config(name, rounds, steps, warmup, device):
         step()
     ho._engine.sync()
     dt = time.perf_counter() - t0
-    return {"workload": f"BASELINE configs[{ {'c2': 1, 'c3': 2, 'c4': 3, 'c5': 4}[name] }] ({name.upper()}): {N} cells x {d} PCs, "
+    return {"workload": f"BASELINE configs[{CONFIG_INDEX[name]}] ({name.upper()}): {N} cells x {d} PCs, "
                         f"{B} batches, K={K}; step = {rounds} k-means rounds + 1 ridge correction",
             "value": N * steps / dt, "unit": "cells/sec/Harmony-iteration", "ms_per_step": 1e3 * dt / steps, "steps": steps}
 
@@ -268,7 +271,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": f"BASELINE configs[{ {'c2': 1, 'c3': 2, 'c4': 3, 'c5': 4}[args.config] }] ({args.config.upper()}): "
+            "workload": f"BASELINE configs[{CONFIG_INDEX[args.config]}] ({args.config.upper()}): "
                         f"{N} cells x {d} PCs, {B} batches, K={K} per GPU; step = 1 Harmony iteration = "
                         f"{args.rounds} k-means rounds (block_size 0.05 -> 20 blocks) + 1 ridge correction",
             "cells_per_gpu": N, "pcs": d, "batches": B, "clusters": K, "rounds_per_iteration": args.rounds,

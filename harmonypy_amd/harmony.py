@@ -258,16 +258,19 @@ def _prepare_inputs(data_mat, meta_data, vars_use, theta=None, lamb=None, sigma=
 def build_layout(codes, combos=None):
     """Group cells by their multi-hot batch pattern.
 
-    Returns (group_cols G x V, order internal->original, rank original->internal,
+    Returns (group_cols G x V, order internal->original,
     gid_int group of every internal cell, static_cells, static_tile_grp): the static list is
     the identity over the group-sorted cells with every group padded to whole tiles.
     ``combos`` (sorted unique rows) fixes the groups of the whole job for a shard that may not
     hold cells of every group.
     """
     N = codes.shape[0]
+    counts = None
     if combos is None and codes.shape[1] == 1:       # one batch variable: groups are its levels (fast path)
         col = codes[:, 0]
-        levels = np.flatnonzero(np.bincount(col))   # codes are small non-negative integers
+        per_code = np.bincount(col)                 # codes are small non-negative integers
+        levels = np.flatnonzero(per_code)
+        counts = per_code[levels]
         lut = np.full(int(levels[-1]) + 1 if len(levels) else 1, -1, dtype=np.int32)
         lut[levels] = np.arange(len(levels), dtype=np.int32)
         gid = lut[col]
@@ -283,13 +286,11 @@ def build_layout(codes, combos=None):
         gid = inv[combos.shape[0]:]
     gid = gid.reshape(-1).astype(np.int32)
     G = combos.shape[0]
-    if G <= 64:                                      # counting sort: G passes beat a comparison sort of N keys
-        order = np.concatenate([np.flatnonzero(gid == g) for g in range(G)]).astype(np.int64) if N else np.zeros(0, np.int64)
-    else:
-        order = np.argsort(gid, kind="stable").astype(np.int64)
-    rank = np.empty(N, dtype=np.int32)
-    rank[order] = np.arange(N, dtype=np.int32)
-    counts = np.bincount(gid, minlength=G)
+    # NumPy's stable sort of 8/16-bit keys is a radix sort: one O(N) pass per key byte
+    key = gid.astype(np.uint8) if G <= 256 else gid.astype(np.uint16) if G <= 65536 else gid
+    order = np.asarray(np.argsort(key, kind="stable"), dtype=np.int64)
+    if counts is None:
+        counts = np.bincount(gid, minlength=G)
     cells, tile_grp = [], []
     start = 0
     for g, c in enumerate(counts):
@@ -299,8 +300,15 @@ def build_layout(codes, combos=None):
         cells.append(seg)
         tile_grp.append(np.full(nt, g, dtype=np.int32))
         start += int(c)
-    return (np.ascontiguousarray(combos, dtype=np.int32), order, rank, gid[order],
+    return (np.ascontiguousarray(combos, dtype=np.int32), order, gid[order],
             np.concatenate(cells), np.concatenate(tile_grp))
+
+
+def inverse_order(order):
+    """rank: original cell -> internal (group-sorted) position."""
+    rank = np.empty(order.shape[0], dtype=np.int32)
+    rank[order] = np.arange(order.shape[0], dtype=np.int32)
+    return rank
 
 
 def build_block_lists(update_order, rank, gid_int, n_blocks, cells_per_block, G, offset=0):
@@ -427,8 +435,9 @@ class Harmony:
         if self.shard is not None:   # the groups of the whole job
             parts = self.shard.allgather_object(np.unique(codes, axis=0))
             combos = np.unique(np.vstack(parts), axis=0)
-        (self._group_cols, self._order, self._rank, self._gid_int,
+        (self._group_cols, self._order, self._gid_int,
          self._static_cells, self._static_tile_grp) = build_layout(codes, combos)
+        self._rank_cache = None
         self._lap("group_layout")
         self._G = self._group_cols.shape[0]
         self._n_blocks = int(np.ceil(1.0 / self.block_size))                     # harmony.py:474
@@ -453,7 +462,17 @@ class Harmony:
     # read-back (harmony.py:288-355): fresh float32 NumPy arrays, cells x features
     # ------------------------------------------------------------------
     def _rows(self, which):
-        return self._engine.get(which)[self._rank]
+        out = self._engine.get(which)
+        res = np.empty_like(out)
+        res[self._order] = out                    # internal (group-sorted) rows back to the caller's order
+        return res
+
+    @property
+    def _rank(self):
+        """original cell -> internal position (built on first use: the host update order, tests)."""
+        if self._rank_cache is None:
+            self._rank_cache = inverse_order(self._order)
+        return self._rank_cache
 
     @property
     def Z_corr(self):
@@ -581,8 +600,9 @@ class Harmony:
         if self.verbose:
             logger.info("Computing initial centroids: k-means++ seeding on a subsample, Lloyd iterations on the GPU...")
         n = max(1, int(round(KMEANS_SEED_CELLS * self.N / self.N_global)))
+        # evenly spaced over the group-sorted cells: every batch group in proportion
         take = np.linspace(0, self.N - 1, min(n, self.N)).astype(np.int64)
-        sub = self._engine.get_rows(_capi.HMX_Z_COS, self._rank[take])          # unit rows of the sampled cells
+        sub = self._engine.get_rows(_capi.HMX_Z_COS, take)                       # unit rows of the sampled cells
         if self.shard is not None:
             parts = self.shard.allgather_object(sub)
             sub = np.concatenate(parts, axis=0) if self.shard.rank == 0 else None

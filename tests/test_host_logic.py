@@ -116,10 +116,11 @@ def test_batch_codes_dense_roundtrip():
 
 
 def test_layout_groups_and_static_tiles():
-    from harmonypy_amd.harmony import TILE, build_layout
+    from harmonypy_amd.harmony import TILE, build_layout, inverse_order
     rng = np.random.default_rng(1)
     codes = np.stack([rng.integers(0, 3, 1000), 3 + rng.integers(0, 2, 1000)], axis=1).astype(np.int32)
-    group_cols, order, rank, gid_int, cells, tile_grp = build_layout(codes)
+    group_cols, order, gid_int, cells, tile_grp = build_layout(codes)
+    rank = inverse_order(order)
     G = group_cols.shape[0]
     assert G == len(np.unique(codes, axis=0))
     np.testing.assert_array_equal(rank[order], np.arange(1000))
@@ -136,10 +137,11 @@ def test_layout_groups_and_static_tiles():
 @pytest.mark.parametrize("N,block_size", [(3500, 0.05), (1237, 0.07), (37, 0.05), (16, 0.3), (1000, 0.13)])
 def test_block_lists_reproduce_reference_blocks(N, block_size):
     """Blocks of harmony.py:474-484 as sets; (block, group) runs padded to tiles."""
-    from harmonypy_amd.harmony import TILE, build_block_lists, build_layout
+    from harmonypy_amd.harmony import TILE, build_block_lists, build_layout, inverse_order
     rng = np.random.default_rng(N)
     codes = rng.integers(0, 4, N).astype(np.int32)[:, None]
-    group_cols, order, rank, gid_int, _, _ = build_layout(codes)
+    group_cols, order, gid_int, _, _ = build_layout(codes)
+    rank = inverse_order(order)
     G = group_cols.shape[0]
     upd = rng.permutation(N)
     nb = int(np.ceil(1.0 / block_size))

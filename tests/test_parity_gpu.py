@@ -459,7 +459,7 @@ def test_abi_call_order_and_argument_errors():
     Z = rng.normal(size=(64, 5)).astype(np.float32)
     codes = np.repeat([0, 1], 32).astype(np.int32)[:, None]
     from harmonypy_amd.harmony import build_layout
-    gc, order, rank, gid, cells, tg = build_layout(codes)
+    gc, order, gid, cells, tg = build_layout(codes)
     eng.upload(Z[order], cells, tg, gc, np.array([0.5, 0.5], np.float32), np.array([2, 2], np.float32),
                np.full(3, 0.1, np.float32), np.array([0, 1, 1], np.float32))
     bad_cells = cells.copy()
@@ -497,7 +497,7 @@ def test_device_order_lists_match_numpy_restatement(N, B, bs, offset, extra):
     n_global = N + extra if extra else N
     codes = rng.integers(0, B, size=(N, 1)).astype(np.int32)
     codes[:B, 0] = np.arange(B)
-    gc, order, rank, gid_int, s_cells, s_tg = build_layout(codes)
+    gc, order, gid_int, s_cells, s_tg = build_layout(codes)
     G = gc.shape[0]
     nb = int(np.ceil(1.0 / bs))
     cpb = int(n_global * bs)

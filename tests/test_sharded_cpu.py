@@ -85,20 +85,22 @@ def test_sharded_front_end_equals_unsharded(tmp_path):
 def test_block_lists_of_shards_partition_the_unsharded_lists():
     """harmony.py:471-484 with cells sharded: one permutation of all cells, every shard keeps its
     members of every block -- together exactly the unsharded blocks."""
-    from harmonypy_amd.harmony import TILE, build_block_lists, build_layout
+    from harmonypy_amd.harmony import TILE, build_block_lists, build_layout, inverse_order
     rng = np.random.default_rng(5)
     N, B, nb = 1003, 3, 20
     codes = rng.integers(0, B, size=(N, 1)).astype(np.int32)
     combos = np.unique(codes, axis=0)
     order = rng.permutation(N)
     cpb = int(N * 0.05)
-    _, _, rank_all, gid_all, _, _ = build_layout(codes)
+    _, order_all, gid_all, _, _ = build_layout(codes)
+    rank_all = inverse_order(order_all)
     cells_all, tg_all, bs_all = build_block_lists(order, rank_all, gid_all, nb, cpb, B)
     inv_all = np.argsort(rank_all)                                    # internal -> original
     cut = 431
     members = [set() for _ in range(nb)]
     for lo, hi in ((0, cut), (cut, N)):
-        _, order_loc, rank_loc, gid_loc, _, _ = build_layout(codes[lo:hi], combos)
+        _, order_loc, gid_loc, _, _ = build_layout(codes[lo:hi], combos)
+        rank_loc = inverse_order(order_loc)
         cells, tg, bs = build_block_lists(order, rank_loc, gid_loc, nb, cpb, B, offset=lo)
         assert bs[0] == 0 and bs[-1] * TILE == cells.size
         for b in range(nb):
@@ -116,7 +118,7 @@ def test_layout_with_job_wide_groups():
     from harmonypy_amd.harmony import build_layout
     codes = np.array([[0, 3], [1, 3], [1, 4], [0, 3]], dtype=np.int32)
     combos = np.array([[0, 3], [0, 4], [1, 3], [1, 4]], dtype=np.int32)   # the job has a group this shard lacks
-    gc, order, rank, gid, cells, tg = build_layout(codes, combos)
+    gc, order, gid, cells, tg = build_layout(codes, combos)
     assert gc.shape == (4, 2) and set(gid.tolist()) == {0, 2, 3}
     assert np.array_equal(np.sort(cells[cells >= 0]), np.arange(4))
     with pytest.raises(ValueError):
