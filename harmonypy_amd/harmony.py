@@ -631,11 +631,18 @@ class Harmony:
     # harmony.py:394-417: the three sums come back from the device with the round
     # ------------------------------------------------------------------
     def compute_objective(self):
-        if self._pending_objective is None:
-            raise RuntimeError("compute_objective() needs the sums produced by the preceding "
-                               "update_R()/init_cluster() call on the device")
-        kmeans_error, _entropy, _cross_entropy = (float(x) for x in self._pending_objective[:3])
-        self._pending_objective = None
+        """Appends the objective of the current state to the history lists (harmony.py:394-417).
+
+        The three sums are produced on the device by the sweep that last changed R, O and E
+        (``update_R`` / ``init_cluster``).  The reference evaluates them from ``_R``, ``_dist_mat``,
+        ``_O`` and ``_E``, none of which change between such sweeps (``moe_correct_ridge`` touches
+        only Z_corr / Z_cos / W), so a further call appends the same values again -- as there."""
+        if self._pending_objective is not None:
+            self._last_objective = tuple(float(x) for x in self._pending_objective[:3])
+            self._pending_objective = None
+        if getattr(self, "_last_objective", None) is None:
+            raise RuntimeError("compute_objective() needs init_cluster() or update_R() first")
+        kmeans_error, _entropy, _cross_entropy = self._last_objective
         norm_const = 2000.0 / self.N_global
         self.objective_kmeans.append((kmeans_error + _entropy + _cross_entropy) * norm_const)
         self.objective_kmeans_dist.append(kmeans_error * norm_const)

@@ -219,6 +219,14 @@ def test_object_api_surface():
     n0 = len(ho.kmeans_rounds)
     ho.harmonize(1, verbose=False)
     assert len(ho.kmeans_rounds) == n0 + 1
+    # compute_objective() on an unchanged state repeats the last entry, as in the reference (harmony.py:394-417)
+    last = ho.objective_kmeans[-1]
+    ho.compute_objective()
+    assert ho.objective_kmeans[-1] == last and len(ho.objective_kmeans_cross) == len(ho.objective_kmeans)
+    # update_R() alone is one more sweep with its own objective (harmony.py:464-513)
+    ho.update_R()
+    ho.compute_objective()
+    assert np.isfinite(ho.objective_kmeans[-1]) and abs(ho.objective_kmeans[-1] - last) < 0.05 * abs(last)
 
 
 @pytest.mark.parametrize("N,d,K,B,bs", [(37, 5, 3, 2, 0.05), (16, 4, 2, 1, 0.3), (1000, 33, 17, 5, 0.13),
