@@ -3,10 +3,12 @@
 Drop-in for the hot path of slowkow/harmonypy: ``run_harmony`` / ``Harmony`` keep the
 reference's signatures (harmonypy/__init__.py:1-4, harmony.py:49-67, 218-229); the
 ``harmonize()`` loop runs as hand-written HIP kernels for gfx950 behind a C ABI
-(include/hmx.h, harmonypy_amd/libhmx.so).
+(include/hmx.h, harmonypy_amd/libhmx.so).  ``compute_lisi`` (lisi.py:24-66) is the
+reference's integration metric on the same device.
 """
 from .harmony import Harmony, run_harmony, BatchCodes  # noqa: F401
 from .dist import Shard  # noqa: F401
+from .lisi import compute_lisi  # noqa: F401
 
 __version__ = "0.1.0"
-__all__ = ["Harmony", "run_harmony", "BatchCodes", "Shard", "__version__"]
+__all__ = ["Harmony", "run_harmony", "BatchCodes", "Shard", "compute_lisi", "__version__"]

@@ -25,7 +25,7 @@ EXPORTS = [
     "hmx_last_error", "hmx_abi_version", "hmx_create", "hmx_destroy", "hmx_upload", "hmx_init_cluster",
     "hmx_cluster_round", "hmx_cluster_round_seeded", "hmx_moe_correct_ridge", "hmx_get", "hmx_set", "hmx_sync", "hmx_device_ptr",
     "hmx_kernel_times", "hmx_enable_timing", "hmx_comm_unique_id", "hmx_comm_init", "hmx_set_host_allreduce",
-    "hmx_kmeans_lloyd", "hmx_kmeans_seed", "hmx_get_rows", "hmx_set_ranks", "hmx_peer_export", "hmx_peer_attach", "hmx_peer_selftest", "hmx_peer_enable",
+    "hmx_kmeans_lloyd", "hmx_kmeans_seed", "hmx_compute_lisi", "hmx_get_rows", "hmx_set_ranks", "hmx_peer_export", "hmx_peer_attach", "hmx_peer_selftest", "hmx_peer_enable",
 ]
 HMX_PEER_HANDLE_BYTES = 64
 HMX_ABI_VERSION = 3
@@ -66,6 +66,7 @@ def load():
     lib.hmx_destroy.restype = None
     lib.hmx_upload.argtypes = [vp, vp, vp, i64, vp, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.hmx_kmeans_seed.argtypes = [vp, vp, i64, C.c_uint64, vp, vp]
+    lib.hmx_compute_lisi.argtypes = [i32, vp, i64, i32, vp, i32, C.c_double, vp, vp, vp]
     lib.hmx_comm_unique_id.argtypes = [vp]
     lib.hmx_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.hmx_set_host_allreduce.argtypes = [vp, HOST_ALLREDUCE_FN, vp]

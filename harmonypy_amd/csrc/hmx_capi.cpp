@@ -509,6 +509,60 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
     return HMX_OK;
 }
 
+int hmx_compute_lisi(int32_t device_id, const double* X, int64_t n, int32_t d, const int32_t* label_codes, int32_t n_labels,
+                     double perplexity, double* lisi_out, double* knn_dist_out, int32_t* knn_idx_out) {
+    if (!X || !label_codes || !lisi_out) return fail(HMX_ERR_ARG, "null argument");
+    if ((knn_dist_out == nullptr) != (knn_idx_out == nullptr)) return fail(HMX_ERR_ARG, "knn_dist_out and knn_idx_out go together");
+    if (n < 1 || n > (int64_t)1 << 31) return fail(HMX_ERR_ARG, "n out of range");
+    if (d < 1 || d > 208) return fail(HMX_ERR_ARG, "d must be in [1, 208]");
+    if (n_labels < 1) return fail(HMX_ERR_ARG, "n_labels must be >= 1");
+    const int nn = (int)(perplexity * 3);                                     // lisi.py:53
+    if (!(perplexity > 0) || nn < 2 || nn > LISI_KEEP)
+        return fail(HMX_ERR_ARG, "3*perplexity must be in [2, %d] neighbours", LISI_KEEP);
+    if (nn > n) return fail(HMX_ERR_ARG, "Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld", nn, (long long)n);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(HMX_ERR_ARG, "device %d not present (%d devices)", device_id, ndev);
+    HIP_TRY(hipSetDevice(device_id));
+    const int dp = (d + 15) & ~15;
+    const int64_t npad = (n + 255) & ~(int64_t)255;
+    const int M = nn - 1;
+    DevBuf<double> X64, sums, out, kd;
+    DevBuf<float> X32, cn;
+    DevBuf<unsigned long long> lists;
+    DevBuf<int> counts, labels, ki;
+    struct Release {
+        DevBuf<double>&a, &b, &c, &d2; DevBuf<float>&f, &g; DevBuf<unsigned long long>&h; DevBuf<int>&i, &j, &k;
+        ~Release() { a.release(); b.release(); c.release(); d2.release(); f.release(); g.release(); h.release(); i.release(); j.release(); k.release(); }
+    } guard{X64, sums, out, kd, X32, cn, lists, counts, labels, ki};
+    int rc;
+    if ((rc = X64.reserve((size_t)n * d)) || (rc = sums.reserve(d)) || (rc = out.reserve((size_t)n * n_labels)) ||
+        (rc = X32.reserve((size_t)npad * dp)) || (rc = cn.reserve(npad)) || (rc = lists.reserve((size_t)npad * LISI_CAP)) ||
+        (rc = counts.reserve(n)) || (rc = labels.reserve((size_t)n * n_labels)))
+        return rc;
+    if (knn_dist_out && ((rc = kd.reserve((size_t)n * M)) || (rc = ki.reserve((size_t)n * M)))) return rc;
+    hipStream_t s = nullptr;                                                  // the device's default stream
+    HIP_TRY(hipMemcpyAsync(X64.p, X, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(labels.p, label_codes, (size_t)n * n_labels * sizeof(int), hipMemcpyHostToDevice, s));
+    launch_lisi_prepare(X64.p, n, npad, d, dp, sums.p, X32.p, cn.p, s);
+    LisiKnnArgs ka{};
+    ka.X = X32.p; ka.cn = cn.p; ka.n = n; ka.npad = npad; ka.dp = dp; ka.lists = lists.p; ka.counts = counts.p;
+    if (launch_lisi_knn(ka, s)) return fail(HMX_ERR_ARG, "unsupported d");
+    LisiFinishArgs fa{};
+    fa.X = X64.p; fa.n = n; fa.d = d; fa.nn = nn; fa.n_labels = n_labels; fa.lists = lists.p; fa.counts = counts.p;
+    fa.labels = labels.p; fa.perplexity = perplexity; fa.tol = 1e-5;         // lisi.py:75
+    fa.out = out.p; fa.knn_dist = kd.p; fa.knn_idx = ki.p;
+    launch_lisi_finish(fa, s);
+    HIP_TRY(hipMemcpyAsync(lisi_out, out.p, (size_t)n * n_labels * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (knn_dist_out) {
+        HIP_TRY(hipMemcpyAsync(knn_dist_out, kd.p, (size_t)n * M * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(knn_idx_out, ki.p, (size_t)n * M * sizeof(int), hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipGetLastError());
+    return HMX_OK;
+}
+
 int hmx_kmeans_seed(hmx_engine* e, const float* points, int64_t n_points, uint64_t seed, float* centers_out, int32_t* chosen_out) {
     if (!e || !points || !centers_out) return fail(HMX_ERR_ARG, "null argument");
     if (n_points < 1 || n_points > (int64_t)1 << 24) return fail(HMX_ERR_ARG, "n_points must be in [1, 2^24]");

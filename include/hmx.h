@@ -139,6 +139,19 @@ int hmx_peer_enable(hmx_engine* e, int on);
  * fp32 like the `.item()` calls of harmony.py:399-411. */
 int hmx_init_cluster(hmx_engine* e, const float* Y0, double obj_out[4]);
 
+/* LISI, the integration metric of the reference (harmonypy/lisi.py:24-133 `compute_lisi` +
+ * `compute_simpson`), on the device.  X: n x d row-major float64 (host).  label_codes: n_labels x n
+ * category codes (one row per label column, as pd.Categorical(...).codes).  perplexity: as the
+ * reference's; the search asks for int(3*perplexity) neighbours (the cell itself included, then
+ * dropped, lisi.py:53-60), at most 128.  lisi_out: n x n_labels row-major float64 (-1 where the
+ * reference returns -1).  knn_dist_out / knn_idx_out (both or neither, may be NULL): the
+ * int(3*perplexity)-1 neighbours of every cell, nearest first, n x (nn-1).
+ * Neighbours are exact: a float32 MFMA pass preselects 128 candidates per cell, float64 distances
+ * from direct differences rank them.  Independent of any engine handle. */
+int hmx_compute_lisi(int32_t device_id, const double* X, int64_t n, int32_t d, const int32_t* label_codes,
+                     int32_t n_labels, double perplexity, double* lisi_out, double* knn_dist_out,
+                     int32_t* knn_idx_out);
+
 /* k-means++ seeding on the device: K = n_clusters centres chosen among `points` (n_points x d
  * row-major host floats, rows of unit length -- a subsample of Z_cos) by the greedy k-means++ that
  * sklearn's KMeans(init='k-means++') runs for the reference (harmony.py:370; sklearn 1.7
