@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=10, help="k-means rounds per Harmony iteration")
     ap.add_argument("--cpu-sample", type=int, default=200_000, help="cells of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-lisi", action="store_true", help="skip the LISI of the embedding before / after the run to convergence")
+    ap.add_argument("--lisi-cells", type=int, default=1_000_000, help="cells of the LISI measurement (evenly spaced subsample above that)")
     ap.add_argument("--no-convergence", action="store_true", help="skip the untimed end-to-end run to convergence")
     args = ap.parse_args()
 
@@ -321,6 +323,19 @@ def main():
         out["kernel_ms_total"] = fam_ms
     if conv is not None:
         out["convergence"] = conv
+    if conv is not None and world == 1 and not args.no_lisi:
+        # the reference's integration metric (lisi.py) on the same device: batch mixing of the embedding
+        # before and after the run to convergence above (perplexity 30 -> 89 exact neighbours per cell)
+        take = np.arange(N) if N <= args.lisi_cells else np.linspace(0, N - 1, args.lisi_cells).astype(np.int64)
+        meta_l = meta.iloc[take]
+        harmonypy_amd.compute_lisi(Z[take[:4096]], meta_l.iloc[:4096], ["batch"], 30, device=f"cuda:{local_rank}")   # warm-up
+        t_l = time.perf_counter()
+        before = harmonypy_amd.compute_lisi(Z[take], meta_l, ["batch"], 30, device=f"cuda:{local_rank}")
+        t_l = time.perf_counter() - t_l
+        after = harmonypy_amd.compute_lisi(ho2.Z_corr[take], meta_l, ["batch"], 30, device=f"cuda:{local_rank}")
+        out["lisi"] = {"cells": int(len(take)), "pcs": d, "perplexity": 30, "seconds": t_l, "cells_per_sec": len(take) / t_l,
+                       "batches": B, "batch_lisi_before": float(before.mean()), "batch_lisi_after": float(after.mean()),
+                       "note": "host float64 input to host output, exact neighbours; not part of `value`"}
     if world == 1 and args.config == "c3" and not args.no_convergence:
         # BASELINE configs[1] (69k cells x 50 PCs, 4 batches, K=30) measured the same way, for reference: it is
         # latency-bound (its working set lives in the L3; 20 sequential hand-offs per round), so the headline
