@@ -547,7 +547,23 @@ int hmx_compute_lisi(int32_t device_id, const double* X, int64_t n, int32_t d, c
     launch_lisi_prepare(X64.p, n, npad, d, dp, sums.p, X32.p, cn.p, s);
     LisiKnnArgs ka{};
     ka.X = X32.p; ka.cn = cn.p; ka.n = n; ka.npad = npad; ka.dp = dp; ka.lists = lists.p; ka.counts = counts.p;
+#ifdef LISI_PROF
+    DevBuf<unsigned long long> prof;
+    if ((rc = prof.reserve(8))) return rc;
+    HIP_TRY(hipMemsetAsync(prof.p, 0, 8 * sizeof(unsigned long long), s));
+    ka.prof = prof.p;
+#endif
     if (launch_lisi_knn(ka, s)) return fail(HMX_ERR_ARG, "unsupported d");
+#ifdef LISI_PROF
+    {
+        unsigned long long h[8];
+        HIP_TRY(hipMemcpy(h, prof.p, sizeof h, hipMemcpyDeviceToHost));
+        const double waves = (double)npad / 64.0, tiles = (double)((n + 15) / 16);
+        fprintf(stderr, "[lisi prof] cycles per tile per wave: loads-issue %.0f, fragments+MFMA %.0f, store pieces (load wait) %.0f, append %.0f, barrier %.0f\n",
+                h[0] / waves / tiles, h[1] / waves / tiles, h[2] / waves / tiles, h[3] / waves / tiles, h[4] / waves / tiles);
+        prof.release();
+    }
+#endif
     LisiFinishArgs fa{};
     fa.X = X64.p; fa.n = n; fa.d = d; fa.nn = nn; fa.n_labels = n_labels; fa.lists = lists.p; fa.counts = counts.p;
     fa.labels = labels.p; fa.perplexity = perplexity; fa.tol = 1e-5;         // lisi.py:75

@@ -152,6 +152,7 @@ struct LisiKnnArgs {
     int dp;
     unsigned long long* lists;      // npad x LISI_CAP (order bits of the key << 32 | candidate)
     int* counts;                    // n: entries of the final, sorted list
+    unsigned long long* prof;       // cycle sums per loop segment (LISI_PROF builds), else null
 };
 struct LisiFinishArgs {
     const double* X;                // n x d float64 input

@@ -6,7 +6,7 @@
 //                                   squared norms (padding rows get +inf and never qualify)
 //   k_lisi_knn<KS16, QT>          : brute-force neighbour search.  A wave owns 16*QT queries whose
 //                                   fragments stay in registers and streams every 16-candidate tile
-//                                   through f32 MFMA (dot products), turns them into
+//                                   (shared by the workgroup's waves through LDS) through f32 MFMA, turns them into
 //                                   |c|^2 - 2 q.c, and appends the candidates below the query's
 //                                   current threshold to the query's list in global memory (an LDS
 //                                   counter hands out the slots).  A list that is nearly full is
@@ -94,17 +94,18 @@ __device__ __forceinline__ void wave_sort256(unsigned long long* scr, int lane) 
 }
 
 template <int KS16, int QT>
-__global__ __launch_bounds__(64 * LISI_KNN_WAVES) void k_lisi_knn(LisiKnnArgs a) {
+__global__ __launch_bounds__(64 * LISI_KNN_WAVES, 3) void k_lisi_knn(LisiKnnArgs a) {
     __shared__ unsigned long long scr_all[LISI_KNN_WAVES][LISI_CAP];
     __shared__ int cnt_all[LISI_KNN_WAVES][16 * QT];
     __shared__ float tau_all[LISI_KNN_WAVES][16 * QT];
+    constexpr int LDW = 16 * KS16 + 4;                       // padded row: conflict-free 16-byte fragment reads
+    __shared__ __attribute__((aligned(16))) float stage[2][16 * LDW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c16 = lane & 15, q = lane >> 4;
     unsigned long long* scr = scr_all[wv];
     int* cnt = cnt_all[wv];
     float* tau = tau_all[wv];
-    const int64_t qbase = ((int64_t)blockIdx.x * LISI_KNN_WAVES + wv) * (16 * QT);
-    if (qbase >= a.npad) return;
+    const int64_t qbase = ((int64_t)blockIdx.x * LISI_KNN_WAVES + wv) * (16 * QT);   // < npad: npad is a multiple of 256
     for (int i = lane; i < 16 * QT; i += 64) { cnt[i] = 0; tau[i] = __builtin_inff(); }
     wave_fence();
 
@@ -135,48 +136,153 @@ __global__ __launch_bounds__(64 * LISI_KNN_WAVES) void k_lisi_knn(LisiKnnArgs a)
         wave_fence();
     };
 
-    // No register prefetch of the next tile: the list stores keep the compiler from counting
-    // outstanding loads (loads and stores retire out of order), so the latency of a tile's loads is
-    // covered by the other waves of the SIMD instead (2-4 resident, depending on KS16).
+    // Software pipeline over the candidate tiles.  The workgroup's four waves share every tile
+    // through LDS (one global read per workgroup instead of one per wave: the float32 matrix is
+    // streamed by every workgroup, so the reuse decides whether the loop is L2/MALL- or MFMA-bound):
+    //   iteration t:  issue the global loads of tile t+2's pieces  ->  fragments of tile t from
+    //   LDS, MFMAs of tile t  ->  pieces of tile t+1 (issued an iteration ago) into the other LDS
+    //   buffer  ->  tile t-1's products into keys, the qualifying ones appended to the
+    //   lists  ->  barrier.
+    // The list stores are issued from inline assembly on purpose: with ordinary stores in the loop the
+    // compiler waits for vmcnt(0) before every use of a loaded value (it cannot bound a counter that
+    // loads and stores leave out of order).  Its "at most as many outstanding as loads issued after
+    // the wanted one" is still sufficient: loads return in order among themselves, so while a wanted
+    // load is outstanding every younger load is too and the counter stays above the bound; a store
+    // in flight can only lengthen the wait.
     const int ntiles = (int)((a.n + 15) / 16);
-    for (int ct = 0; ct < ntiles; ++ct) {
-        f32x4 ac[KS16];
+    constexpr int NPC = (64 * KS16 + 64 * LISI_KNN_WAVES - 1) / (64 * LISI_KNN_WAVES);   // 16-byte pieces per thread
+    f32x4 pre[2][NPC], af[KS16], acc[2][QT];
+    auto fetch_pieces = [&](int ps, int tile) {
 #pragma unroll
-        for (int m = 0; m < KS16; ++m) ac[m] = ld4(a.X + (size_t)(16 * ct + c16) * a.dp + 16 * m + 4 * q);
-        const f32x4 cn4 = ld4(a.cn + 16 * ct + 4 * q);
-        f32x4 acc[QT];
+        for (int j = 0; j < NPC; ++j) {
+            const int i = tid + 64 * LISI_KNN_WAVES * j;
+            const int row = i / (4 * KS16), c4 = i - row * (4 * KS16);
+            if (i < 64 * KS16) pre[ps][j] = ld4(a.X + (size_t)(16 * tile + row) * a.dp + 4 * c4);
+        }
+    };
+    auto store_pieces = [&](int ps, int sb) {
 #pragma unroll
-        for (int t = 0; t < QT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NPC; ++j) {
+            const int i = tid + 64 * LISI_KNN_WAVES * j;
+            const int row = i / (4 * KS16), c4 = i - row * (4 * KS16);
+            if (i < 64 * KS16) *reinterpret_cast<f32x4*>(&stage[sb][row * LDW + 4 * c4]) = pre[ps][j];
+        }
+    };
+    auto read_fragments = [&](int sb) {
+#pragma unroll
+        for (int m = 0; m < KS16; ++m) af[m] = *reinterpret_cast<const f32x4*>(&stage[sb][c16 * LDW + 16 * m + 4 * q]);
+    };
+    auto multiply = [&](int p) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) acc[p][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < KS16; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int t = 0; t < QT; ++t) acc[t] = MFMA16(ac[m][r], bq[t][m][r], acc[t]);
-        bool full = false;
+                for (int t = 0; t < QT; ++t) acc[p][t] = MFMA16(af[m][r], bq[t][m][r], acc[p][t]);
+    };
+    // Tile products -> keys -> list entries.  Most tiles add nothing once the thresholds are tight: one
+    // wave-wide test leaves early.  A qualifying value takes its list position from the query's LDS
+    // counter and is stored from inline assembly (see below); the positions handed out tell whether a
+    // list is about to overflow, so the counters are not read back.
+    auto append = [&](int p, const f32x4 cn4, int tile) {
+        bool any = false;
+        float key[QT][4];
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            unsigned long long* lst = a.lists + (size_t)(qbase + 16 * t + c16) * LISI_CAP;
+        for (int t = 0; t < QT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float key = cn4[r] - 2.f * acc[t][r];          // |c|^2 - 2 q.c (+inf for padding rows)
-                if (key < th[t]) {
-                    const int slot = atomicAdd(&cnt[16 * t + c16], 1);
-                    lst[slot] = ((unsigned long long)order_bits(key) << 32) | (unsigned)(16 * ct + 4 * q + r);
-                }
+                key[t][r] = cn4[r] - 2.f * acc[p][t][r];                 // |c|^2 - 2 q.c (+inf for padding rows)
+                any |= key[t][r] < th[t];
+            }
+        if (!__any(any)) return;                                        // the common case once the thresholds are tight
+        // Qualifying values are few and scattered: every lane walks the set bits of its own 16-value
+        // mask, so the wave loops as often as its busiest lane has entries (once, typically) instead
+        // of branching around sixteen value slots.
+        unsigned mask = 0;
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mask |= (key[t][r] < th[t]) ? (1u << (4 * t + r)) : 0u;
+        bool full = false;
+        while (__any(mask != 0)) {
+            if (mask != 0) {
+                const int j = __ffs(mask) - 1;
+                mask &= mask - 1;
+                float kv = key[0][0];
+#pragma unroll
+                for (int jj = 1; jj < 4 * QT; ++jj) kv = (j == jj) ? key[jj >> 2][jj & 3] : kv;
+                const int t = j >> 2, r = j & 3;
+                const int slot = atomicAdd(&cnt[16 * t + c16], 1);
+                const unsigned long long ent = ((unsigned long long)order_bits(kv) << 32) | (unsigned)(16 * tile + 4 * q + r);
+                unsigned long long* dst = a.lists + (size_t)(qbase + 16 * t + c16) * LISI_CAP + slot;
+                asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(ent) : "memory");
+                full |= slot >= LISI_CAP - 16;                          // the list now holds more than CAP-16 entries
             }
         }
-        wave_fence();
-#pragma unroll
-        for (int t = 0; t < QT; ++t) full |= cnt[16 * t + c16] > LISI_CAP - 16;
         if (__any(full)) {
+            wave_fence();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the list entries are in L2
             for (int slot = 0; slot < 16 * QT; ++slot)
                 if (cnt[slot] > LISI_CAP - 16) compact(slot);           // wave-uniform
 #pragma unroll
             for (int t = 0; t < QT; ++t) th[t] = tau[16 * t + c16];
         }
+    };
+    // the query fragments must have landed before the loop: a wait for them left inside the loop
+    // would also wait for the prefetches issued there
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int m = 0; m < KS16; ++m) asm volatile("" ::"v"(bq[t][m][3]));
+    fetch_pieces(0, 0);
+    store_pieces(0, 0);
+    if (ntiles > 1) fetch_pieces(1, 1);
+    __syncthreads();
+#ifdef LISI_PROF   // cycle stamps per phase segment (timing experiments only)
+    unsigned long long pf[6] = {0, 0, 0, 0, 0, 0}, pt = __builtin_amdgcn_s_memtime();
+#define LISI_STAMP(k) { const unsigned long long now = __builtin_amdgcn_s_memtime(); pf[k] += now - pt; pt = now; }
+#else
+#define LISI_STAMP(k)
+#endif
+    for (int ct = 0; ct < ntiles; ct += 2) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int t = ct + p;
+            if (t < ntiles) {                                           // workgroup-uniform
+                const bool more = t + 1 < ntiles;
+                // addresses of both loads first, in registers of their own: the compiler otherwise recycles
+                // the first load's address registers for the second and waits for the first load to return
+                int cn_off = 16 * (t > 0 ? t - 1 : 0) + 4 * q;
+                asm volatile("" : "+v"(cn_off));
+                if (t + 2 < ntiles) fetch_pieces(p, t + 2);             // two tiles ahead: a round trip can exceed one MFMA phase
+                const f32x4 cn_prev = ld4(a.cn + cn_off);               // norms of the tile appended below
+                __builtin_amdgcn_sched_barrier(0);                      // loads first: their latency runs under the MFMAs
+                LISI_STAMP(0)
+                read_fragments(p);
+                multiply(p);
+                __builtin_amdgcn_sched_barrier(0);
+                LISI_STAMP(1)
+                if (more) store_pieces(p ^ 1, p ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                LISI_STAMP(2)
+                if (t > 0) append(p ^ 1, cn_prev, t - 1);
+                LISI_STAMP(3)
+                __syncthreads();
+                LISI_STAMP(4)
+            }
+        }
     }
+#ifdef LISI_PROF
+    if (lane == 0 && a.prof) for (int k = 0; k < 6; ++k) atomicAdd(a.prof + k, pf[k]);
+#endif
+    {
+        const f32x4 cn_last = ld4(a.cn + 16 * (ntiles - 1) + 4 * q);
+        if ((ntiles - 1) & 1) append(1, cn_last, ntiles - 1);
+        else append(0, cn_last, ntiles - 1);
+    }
+    wave_fence();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int slot = 0; slot < 16 * QT; ++slot) {
         compact(slot);
