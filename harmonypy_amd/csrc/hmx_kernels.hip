@@ -2569,21 +2569,24 @@ __device__ __forceinline__ int group_of_cell(const int* __restrict__ gstart, int
 
 #define ORDER_CHUNK 256  /* cells per wave: short chunks = many waves to hide the serial LDS chain */
 
-// mode 0: write per-chunk histograms; mode 1: scatter cells using chunk offsets
+// mode 0: write per-chunk histograms; mode 1: scatter cells using chunk offsets.
+// chunk_tab is laid out [key][chunk] so that the scan below reads contiguous counts.
 template <int MODE>
 __global__ __launch_bounds__(64) void k_order_pass(OrderArgs a) {
     extern __shared__ int cnt[];  // nkeys running counters of this chunk
     const int lane = threadIdx.x;
-    const int chunk = blockIdx.x;
+    const int chunk = blockIdx.x, nchunks = gridDim.x;
     const int nkeys = a.nblk * a.G;
-    for (int i = lane; i < nkeys; i += 64) cnt[i] = (MODE == 1) ? a.chunk_tab[(size_t)chunk * nkeys + i] : 0;
+    for (int i = lane; i < nkeys; i += 64) cnt[i] = (MODE == 1) ? a.chunk_tab[(size_t)i * nchunks + chunk] : 0;
     __syncthreads();
+    int key_bits = 1;
+    while ((1 << key_bits) < nkeys) ++key_bits;
     const int64_t base = (int64_t)chunk * ORDER_CHUNK;
     for (int s = 0; s < ORDER_CHUNK / 64; ++s) {
         const int64_t ci = base + s * 64 + lane;
         const bool live = ci < a.N;
         const int cell = (int)ci;
-        int key = -1;
+        int key = 0;
         if (live) {
             const uint32_t gid = a.global_id ? (uint32_t)a.global_id[cell] : (uint32_t)cell;
             const int64_t p = feistel_position(gid, (uint32_t)a.Ng, a.half_bits, a.key0, a.key1);
@@ -2594,39 +2597,36 @@ __global__ __launch_bounds__(64) void k_order_pass(OrderArgs a) {
             if (live) atomicAdd(&cnt[key], 1);
             continue;
         }
-        // rank among the lanes of this step that share the key, in cell order
-        unsigned long long todo = __ballot(live);
-        int rank = 0, cnt_before = 0;
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int k0 = __shfl(key, leader, 64);
-            const unsigned long long same = __ballot(live && key == k0);
-            if (live && key == k0) {
-                rank = __popcll(same & ((1ull << lane) - 1ull));
-                cnt_before = cnt[k0];
-            }
-            __syncthreads();
-            if (lane == leader) cnt[k0] += __popcll(same);
-            __syncthreads();
-            todo &= ~same;
+        // lanes of this step that share the key: one ballot per key bit instead of one round per
+        // distinct key; the rank among them in cell order is a population count
+        unsigned long long same = __ballot(live);
+        for (int bit = 0; bit < key_bits; ++bit) {
+            const unsigned long long set = __ballot((key >> bit) & 1);
+            same &= ((key >> bit) & 1) ? set : ~set;
         }
-        if (MODE == 1 && live) a.cells[a.run_start[key] + cnt_before + rank] = cell;
+        if (live) {
+            const int rank = __popcll(same & ((1ull << lane) - 1ull));
+            const int before = cnt[key];
+            a.cells[a.run_start[key] + before + rank] = cell;
+            if ((same >> lane) <= 1ull) cnt[key] = before + __popcll(same);   // the group's last lane moves the counter on
+        }
+        __syncthreads();
     }
     if (MODE == 0) {
         __syncthreads();
-        for (int i = lane; i < nkeys; i += 64) a.chunk_tab[(size_t)chunk * nkeys + i] = cnt[i];
+        for (int i = lane; i < nkeys; i += 64) a.chunk_tab[(size_t)i * nchunks + chunk] = cnt[i];
     }
 }
 
 // One workgroup per key: exclusive scan of the per-chunk counts (in place) and the run length.
 __global__ __launch_bounds__(256) void k_order_scan(OrderArgs a, int nchunks) {
     __shared__ int part[256];
-    const int nkeys = a.nblk * a.G;
     const int key = blockIdx.x, tid = threadIdx.x;
+    int* tab = a.chunk_tab + (size_t)key * nchunks;
     const int per = (nchunks + 255) / 256;
     const int c0 = min(tid * per, nchunks), c1 = min(c0 + per, nchunks);
     int sum = 0;
-    for (int c = c0; c < c1; ++c) sum += a.chunk_tab[(size_t)c * nkeys + key];
+    for (int c = c0; c < c1; ++c) sum += tab[c];
     part[tid] = sum;
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {   // inclusive Hillis-Steele scan of the 256 partial sums
@@ -2637,8 +2637,8 @@ __global__ __launch_bounds__(256) void k_order_scan(OrderArgs a, int nchunks) {
     }
     int run = part[tid] - sum;                   // exclusive prefix of this thread's chunk range
     for (int c = c0; c < c1; ++c) {
-        const int v = a.chunk_tab[(size_t)c * nkeys + key];
-        a.chunk_tab[(size_t)c * nkeys + key] = run;
+        const int v = tab[c];
+        tab[c] = run;
         run += v;
     }
     if (tid == 255) a.run_count[key] = part[255];
