@@ -586,21 +586,22 @@ int hmx_kmeans_seed(hmx_engine* e, const float* points, int64_t n_points, uint64
     if ((rc = use_device(e))) return rc;
     const int n = (int)n_points, d = e->d, K = e->K;
     const int nchunks = (n + 255) / 256;
-    DevBuf<float> X, Xt, closest, cand_min, centers;
-    DevBuf<unsigned long long> chunk_sum, pots;
-    DevBuf<int> cand, chosen;
-    struct Release {
-        DevBuf<float>&a, &b, &c, &d2, &f; DevBuf<unsigned long long>&g, &h; DevBuf<int>&i, &j;
-        ~Release() { a.release(); b.release(); c.release(); d2.release(); f.release(); g.release(); h.release(); i.release(); j.release(); }
-    } guard{X, Xt, closest, cand_min, centers, chunk_sum, pots, cand, chosen};
-    if ((rc = X.reserve((size_t)n * d)) || (rc = Xt.reserve((size_t)n * d)) || (rc = closest.reserve(n)) ||
-        (rc = cand_min.reserve((size_t)HMX_SEED_SLOTS * n)) || (rc = centers.reserve((size_t)K * d)) ||
-        (rc = chunk_sum.reserve(nchunks)) || (rc = pots.reserve((size_t)K * HMX_SEED_SLOTS)) ||
-        (rc = cand.reserve((size_t)K * HMX_SEED_SLOTS)) || (rc = chosen.reserve(K)))
-        return rc;
+    // one allocation for all temporaries (hipMalloc / hipFree synchronise the device: once, not nine times)
+    auto up = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+    const size_t bX = up((size_t)n * d * 4), bClosest = up((size_t)n * 4), bMin = up((size_t)HMX_SEED_SLOTS * n * 4),
+                 bCenters = up((size_t)K * d * 4), bChunk = up((size_t)nchunks * 8), bPots = up((size_t)K * HMX_SEED_SLOTS * 8),
+                 bCand = up((size_t)K * HMX_SEED_SLOTS * 4), bChosen = up((size_t)K * 4);
+    DevBuf<unsigned char> arena;
+    struct Release { DevBuf<unsigned char>& a; ~Release() { a.release(); } } guard{arena};
+    if ((rc = arena.reserve(2 * bX + bClosest + bMin + bCenters + bChunk + bPots + bCand + bChosen))) return rc;
+    unsigned char* cur = arena.p;
+    auto take = [&](size_t bytes) { unsigned char* p = cur; cur += bytes; return p; };
+    struct { float* p; } X{(float*)take(bX)}, Xt{(float*)take(bX)}, closest{(float*)take(bClosest)}, cand_min{(float*)take(bMin)},
+        centers{(float*)take(bCenters)};
+    struct { unsigned long long* p; } chunk_sum{(unsigned long long*)take(bChunk)}, pots{(unsigned long long*)take(bPots)};
+    struct { int* p; } cand{(int*)take(bCand)}, chosen{(int*)take(bChosen)};
     HIP_TRY(hipMemcpyAsync(X.p, points, (size_t)n * d * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemsetAsync(pots.p, 0, (size_t)K * HMX_SEED_SLOTS * sizeof(unsigned long long), e->stream));
-    HIP_TRY(hipMemsetAsync(cand.p, 0, (size_t)K * HMX_SEED_SLOTS * sizeof(int), e->stream));
+    HIP_TRY(hipMemsetAsync(pots.p, 0, bPots + bCand, e->stream));              // pots and cand are neighbours
     SeedArgs a{};
     a.X = X.p; a.Xt = Xt.p; a.n = n; a.d = d;
     a.n_trials = std::min(HMX_SEED_SLOTS, 2 + (int)std::log((double)K));       // sklearn: 2 + int(log(n_clusters))
