@@ -34,6 +34,43 @@ def test_engine_fails_loudly_without_gpu():
     assert "HIP" in str(ei.value) or "device" in str(ei.value)
 
 
+def test_lisi_fails_loudly_without_gpu_and_checks_arguments():
+    """compute_lisi has no CPU path either; argument errors are reported before any device work."""
+    import pandas as pd
+    import torch
+    import harmonypy_amd as hm
+    from harmonypy_amd import _capi
+    X = np.random.default_rng(0).normal(size=(200, 4))
+    meta = pd.DataFrame({"a": ["x", "y"] * 100})
+    with pytest.raises(ValueError):
+        hm.compute_lisi(X, meta.iloc[:10], ["a"], 30)                 # metadata rows != cells
+    with pytest.raises(ValueError):
+        hm.compute_lisi(X, meta, ["a"], 30, device="cpu")
+    with pytest.raises(ValueError):
+        hm.compute_lisi(X[:50], meta.iloc[:50], ["a"], 30)            # 90 neighbours of 50 points (sklearn's ValueError text)
+    with pytest.raises(_capi.HmxError):
+        hm.compute_lisi(X, meta, ["a"], 50)                           # 150 > 128 candidates kept by the search
+    if not torch.cuda.is_available():
+        with pytest.raises(_capi.HmxError) as ei:
+            hm.compute_lisi(X, meta, ["a"], 30)
+        assert "HIP" in str(ei.value) or "device" in str(ei.value)
+
+
+def test_inverse_order_and_radix_layout():
+    from harmonypy_amd.harmony import build_layout, inverse_order
+    rng = np.random.default_rng(3)
+    for G in (1, 7, 300):                                             # uint8 and uint16 radix keys
+        codes = rng.integers(0, G, size=(5000, 1)).astype(np.int32)
+        _, order, gid_int, cells, tile_grp = build_layout(codes)
+        assert np.array_equal(np.sort(order), np.arange(5000))
+        assert np.all(np.diff(gid_int) >= 0)                          # grouped
+        same = gid_int[1:] == gid_int[:-1]
+        assert np.all(np.diff(order)[same] > 0)                       # stable inside a group
+        rank = inverse_order(order)
+        assert np.array_equal(rank[order], np.arange(5000))
+        assert np.array_equal(cells[cells >= 0], np.arange(5000))
+
+
 def test_bad_arguments_are_rejected_by_the_abi():
     import ctypes as C
     from harmonypy_amd import _capi
