@@ -1433,7 +1433,7 @@ __global__ __launch_bounds__(256, 2) void k_rtz2(RtzArgs a) {
     const int tile_floats = 16 * (LDR + LDZ);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c16 = lane & 15, q = lane >> 4;
-    const int nt = wv % NTD, ms = wv / NTD;
+    const int nt = wv % NTD, ms = SPLIT == 1 ? 0 : wv / NTD;   // SPLIT == 1: a compile-time 0 keeps `mt < MT` out of the loop
     const int wg = blockIdx.x;
 
     int t0, t1;
@@ -1451,24 +1451,30 @@ __global__ __launch_bounds__(256, 2) void k_rtz2(RtzArgs a) {
     // this thread's (up to 3) 16-byte pieces of a tile: fixed (array, row, column), only the cell changes
     const int kp4 = a.Kp >> 2, dp4 = a.dp >> 2;
     const int nR = 16 * kp4, nZ = 16 * dp4;
-    int it_row[3], it_src[3], it_dst[3];   // row in the tile; float offset inside the source row (-1: none; bit 30: Z); LDS float offset
+    // Pieces a thread does not have (the last slots of a narrow tile) and padding cells are handled without
+    // branches: they load a valid address, are masked to zero and land in a padding column of the R tile
+    // that nobody reads, so the loop body stays one straight block the scheduler can interleave.
+    int it_row[3], it_dst[3], it_stride[3];
+    const float* it_base[3];
+    bool it_ok[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         const int i = tid + 256 * s;
         if (i < nR) {
             it_row[s] = i / kp4;
-            it_src[s] = 4 * (i - it_row[s] * kp4);
-            it_dst[s] = it_row[s] * LDR + it_src[s];
+            const int c = 4 * (i - it_row[s] * kp4);
+            it_base[s] = a.R + c; it_stride[s] = a.Kp; it_ok[s] = true;
+            it_dst[s] = it_row[s] * LDR + c;
         } else if (i < nR + nZ) {
             const int j = i - nR;
             it_row[s] = j / dp4;
             const int c = 4 * (j - it_row[s] * dp4);
-            it_src[s] = c | (1 << 30);
+            it_base[s] = a.Z + c; it_stride[s] = a.dp; it_ok[s] = true;
             it_dst[s] = 16 * LDR + it_row[s] * LDZ + c;
         } else {
             it_row[s] = 0;
-            it_src[s] = -1;
-            it_dst[s] = 0;
+            it_base[s] = a.R; it_stride[s] = 0; it_ok[s] = false;
+            it_dst[s] = a.K16;                       // row 0, first padding column (LDR >= K16 + 16)
         }
     }
     for (int i = tid; i < 2 * tile_floats; i += 256) lds[i] = 0.f;   // the padding columns stay zero
@@ -1503,55 +1509,58 @@ __global__ __launch_bounds__(256, 2) void k_rtz2(RtzArgs a) {
             csum[i] = 0.0;
         }
     };
-    auto ids_of = [&](int t, int (&id)[3]) {
+    // the loaded id is not touched here either: `live` says whether it counts, fetch() combines the two
+    auto ids_of = [&](int t, int (&id)[3], bool& live) {
+        const int tc = min(t, t1 - 1);                 // always a valid tile; tiles past the end are masked
 #pragma unroll
-        for (int s = 0; s < 3; ++s) id[s] = (t < t1 && it_src[s] != -1) ? a.cells[(size_t)t * 16 + it_row[s]] : -1;
+        for (int s = 0; s < 3; ++s) id[s] = a.cells[(size_t)tc * 16 + it_row[s]];
+        live = t < t1;
     };
-    auto fetch = [&](const int (&id)[3], f32x4 (&v)[3]) {
+    // the loaded value is not touched before it is written to LDS (a mask applied at load time would
+    // wait for the load at once); the ids travel with it and mask it there
+    auto fetch = [&](const int (&id)[3], bool live, f32x4 (&v)[3], int (&idv)[3]) {
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            v[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (id[s] >= 0) {
-                const bool isz = (it_src[s] >> 30) & 1;
-                const int off = it_src[s] & 0xFFFFFF;
-                v[s] = isz ? ld4(a.Z + (size_t)id[s] * a.dp + off) : ld4(a.R + (size_t)id[s] * a.Kp + off);
-            }
+            const int c = (live && it_ok[s]) ? id[s] : -1;
+            v[s] = ld4(it_base[s] + (size_t)max(c, 0) * it_stride[s]);
+            idv[s] = c;
         }
     };
-    auto stash = [&](int buf, const f32x4 (&v)[3]) {
+    auto stash = [&](int buf, const f32x4 (&v)[3], const int (&idv)[3]) {
 #pragma unroll
         for (int s = 0; s < 3; ++s)
-            if (it_src[s] != -1) st4(lds + (size_t)buf * tile_floats + it_dst[s], v[s]);
+            st4(lds + (size_t)buf * tile_floats + it_dst[s], idv[s] >= 0 ? v[s] : (f32x4){0.f, 0.f, 0.f, 0.f});
     };
 
     // software pipeline: tile t multiplies from LDS while tile t+1 is written to the other LDS buffer,
     // the loads of tiles t+2 .. t+RTZ_DEPTH travel in registers and the cell ids of tile
     // t+RTZ_DEPTH+1 are on their way
     constexpr int RTZ_DEPTH = 2;
-    int id_n[3];
+    int id_n[3], idv[RTZ_DEPTH][3];
+    bool live_n = false;
     f32x4 v[RTZ_DEPTH][3];
     __syncthreads();
     if (t0 < t1) {
-        ids_of(t0, id_n);
-        fetch(id_n, v[0]);
-        stash(0, v[0]);
+        ids_of(t0, id_n, live_n);
+        fetch(id_n, live_n, v[0], idv[0]);
+        stash(0, v[0], idv[0]);
 #pragma unroll
         for (int dpt = 0; dpt < RTZ_DEPTH; ++dpt) {
-            ids_of(t0 + 1 + dpt, id_n);
-            fetch(id_n, v[dpt]);          // tiles t0+1 .. t0+RTZ_DEPTH travelling
+            ids_of(t0 + 1 + dpt, id_n, live_n);
+            fetch(id_n, live_n, v[dpt], idv[dpt]);          // tiles t0+1 .. t0+RTZ_DEPTH travelling
         }
-        ids_of(t0 + 1 + RTZ_DEPTH, id_n);
+        ids_of(t0 + 1 + RTZ_DEPTH, id_n, live_n);
     }
     for (int t = t0; t < t1; ++t) {
         const int buf = (t - t0) & 1;
         __syncthreads();          // tile t is complete in lds[buf]; nobody reads lds[buf ^ 1] any more
-        stash(buf ^ 1, v[0]);     // tile t+1 (its loads were issued RTZ_DEPTH iterations ago)
+        stash(buf ^ 1, v[0], idv[0]);     // tile t+1 (its loads were issued RTZ_DEPTH iterations ago)
 #pragma unroll
         for (int dpt = 0; dpt + 1 < RTZ_DEPTH; ++dpt)
 #pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) v[dpt][s3] = v[dpt + 1][s3];
-        fetch(id_n, v[RTZ_DEPTH - 1]);        // tile t+1+RTZ_DEPTH
-        ids_of(t + 2 + RTZ_DEPTH, id_n);      // ids for the fetch of the next iteration
+            for (int s3 = 0; s3 < 3; ++s3) { v[dpt][s3] = v[dpt + 1][s3]; idv[dpt][s3] = idv[dpt + 1][s3]; }
+        fetch(id_n, live_n, v[RTZ_DEPTH - 1], idv[RTZ_DEPTH - 1]);        // tile t+1+RTZ_DEPTH
+        ids_of(t + 2 + RTZ_DEPTH, id_n, live_n);      // ids for the fetch of the next iteration
         int g = task_g;
         if (task_g < 0) {
             if (((t - t0) & 255) == 0) {          // refill the group window (workgroup-uniform)
