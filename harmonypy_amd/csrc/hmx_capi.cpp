@@ -15,6 +15,9 @@
 
 #include "hmx.h"
 #include "hmx_internal.h"
+#ifdef RTZ_PROF
+void rtz_prof_dump();
+#endif
 
 struct hmx_nccl_id { char internal[HMX_UNIQUE_ID_BYTES]; };   // layout of ncclUniqueId (rccl.h)
 
@@ -705,6 +708,9 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         r.S_out = e->Sold; r.slab = e->slab.p; r.n_tiles = n_tiles_upper; r.nblk = e->nblk;
         r.K = e->K; r.Kp = e->Kp; r.K16 = e->K16; r.G = e->G; r.mt = e->mt; r.dp = e->dp; r.ntd = e->ntd;
         if (rtz2) launch_rtz2(r, wgs, e->stream);
+#ifdef RTZ_PROF
+        if (rtz2) { static int calls = 0; if (++calls % 40 == 0) rtz_prof_dump(); }
+#endif
         else if (rtzw) launch_rtz_wide(r, wgs, e->stream);
         else launch_rtz(r, wgs, e->stream);
     }

@@ -1423,7 +1423,13 @@ __global__ __launch_bounds__(256, 2) void k_rtz(RtzArgs a) {
 //   * two workgroups per CU (512 in all) so that one's MFMA phase covers the other's memory phase.
 // Per-workgroup accumulators go to a slab in fragment order [tile][r][lane] (reduced by k_rtz2_reduce).
 // ------------------------------------------------------------------------------------------
-template <int MT, int NTD>
+#ifdef RTZ_PROF   // cycle stamps per loop segment of k_rtz2 (timing experiments only)
+__device__ unsigned long long g_rtz_prof[8];
+#define RTZ_STAMP(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pf_[k] += now_ - pt_; pt_ = now_; }
+#else
+#define RTZ_STAMP(k)
+#endif
+template <int MT, int NTD, bool ONES>
 __global__ __launch_bounds__(256, 2) void k_rtz2(RtzArgs a) {
     constexpr int SPLIT = 4 / NTD;                  // waves sharing one PC column block
     constexpr int MTW = (MT + SPLIT - 1) / SPLIT;   // cluster tiles per wave
@@ -1478,10 +1484,19 @@ __global__ __launch_bounds__(256, 2) void k_rtz2(RtzArgs a) {
         }
     }
     for (int i = tid; i < 2 * tile_floats; i += 256) lds[i] = 0.f;   // the padding columns stay zero
+    if (ONES) {
+        // ... except the last one, which holds 1 for every cell: the MFMAs then deliver the column sums of R
+        // (the removal sums) in PC column 16*NTD-1 for free, instead of 28 additions per tile and wave
+        static_assert(!ONES || NTD == 4, "the ones column needs a wave that owns a whole column block");
+        __syncthreads();
+        if (tid < 32) lds[(size_t)(tid >> 4) * tile_floats + 16 * LDR + (tid & 15) * LDZ + 16 * NTD - 1] = 1.f;
+    }
     // per-tile bookkeeping (group, block) comes from LDS copies: a dependent global load per tile
     // would cost a full memory round trip on the critical path
-    int* grp_l = reinterpret_cast<int*>(lds + 2 * tile_floats);      // 256 tile groups
+    int* grp_l = reinterpret_cast<int*>(lds + 2 * tile_floats);      // window of 256 tiles: key = block * G + group
     int* bs_l = grp_l + 256;                                          // nblk + 1 tile offsets
+    double* sd = reinterpret_cast<double*>(bs_l + 64);                // ONES: K16 running column sums (fp64), owned by the last wave
+    if (ONES) for (int i = tid; i < a.K16; i += 256) sd[i] = 0.0;
     const int task_g = a.task_tile0 ? a.task_grp[wg] : -1;
     if (a.blk_start)
         for (int i = tid; i <= a.nblk; i += 256) bs_l[i] = a.blk_start[i];
@@ -1494,10 +1509,35 @@ __global__ __launch_bounds__(256, 2) void k_rtz2(RtzArgs a) {
     double csum[MTW];
 #pragma unroll
     for (int i = 0; i < MTW; ++i) csum[i] = 0.0;
-    int cur_g = -1, cur_b = 0;
-    const bool sums = nt == 0 && a.S_out != nullptr;
-    auto flush = [&]() {
-        if (cur_g < 0 || !sums) return;
+    int cur_key = -1;                              // block * G + group of the running column sums
+    const bool sums = a.S_out != nullptr && (ONES ? nt == NTD - 1 : nt == 0);
+    auto flush = [&](bool final_flush) {
+        if (ONES) {
+            // the sums sit in the accumulators of the last column block, PC column 16*NTD-1 (lanes c16 == 15):
+            // short fp32 runs (16 tiles) are moved into fp64 LDS sums -- a long fp32 accumulation drops the
+            // many tiny entries of R and biases O -- and the LDS sums go out when the (block, group) changes
+            if (nt != NTD - 1) return;
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sv = acc[i][r];
+                    if (c16 == 15) {
+                        if (sv != 0.f) atomicAdd(&sd[16 * i + 4 * q + r], (double)sv);
+                        acc[i][r] = 0.f;
+                    }
+                }
+            if (!final_flush) return;
+            for (int k = lane; k < a.K16; k += 64) {        // this wave's own LDS operations: in order, no barrier
+                const double v = sd[k];
+                if (v != 0.0) {
+                    if (sums && cur_key >= 0 && k < a.K) atomicAdd(&a.S_out[(size_t)cur_key * a.K16 + k], v);
+                    sd[k] = 0.0;
+                }
+            }
+            return;
+        }
+        if (cur_key < 0 || !sums) return;
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
             const int mt = ms + i * SPLIT;
@@ -1505,7 +1545,7 @@ __global__ __launch_bounds__(256, 2) void k_rtz2(RtzArgs a) {
             sv += __shfl_xor(sv, 16, 64);
             sv += __shfl_xor(sv, 32, 64);
             const int k = 16 * mt + c16;
-            if (q == 0 && mt < MT && k < a.K && sv != 0.0) atomicAdd(&a.S_out[((size_t)cur_b * a.G + cur_g) * a.K16 + k], sv);
+            if (q == 0 && mt < MT && k < a.K && sv != 0.0) atomicAdd(&a.S_out[(size_t)cur_key * a.K16 + k], sv);
             csum[i] = 0.0;
         }
     };
@@ -1536,7 +1576,7 @@ __global__ __launch_bounds__(256, 2) void k_rtz2(RtzArgs a) {
     // the loads of tiles t+2 .. t+RTZ_DEPTH travel in registers and the cell ids of tile
     // t+RTZ_DEPTH+1 are on their way
     constexpr int RTZ_DEPTH = 2;
-    int id_n[3], idv[RTZ_DEPTH][3];
+    int id_n[3], idv[RTZ_DEPTH][3], key_nxt = 0;
     bool live_n = false;
     f32x4 v[RTZ_DEPTH][3];
     __syncthreads();
@@ -1551,9 +1591,14 @@ __global__ __launch_bounds__(256, 2) void k_rtz2(RtzArgs a) {
         }
         ids_of(t0 + 1 + RTZ_DEPTH, id_n, live_n);
     }
+#ifdef RTZ_PROF
+    unsigned long long pf_[6] = {0, 0, 0, 0, 0, 0}, pt_ = __builtin_amdgcn_s_memtime();
+#endif
     for (int t = t0; t < t1; ++t) {
         const int buf = (t - t0) & 1;
+        RTZ_STAMP(0)
         __syncthreads();          // tile t is complete in lds[buf]; nobody reads lds[buf ^ 1] any more
+        RTZ_STAMP(1)
         stash(buf ^ 1, v[0], idv[0]);     // tile t+1 (its loads were issued RTZ_DEPTH iterations ago)
 #pragma unroll
         for (int dpt = 0; dpt + 1 < RTZ_DEPTH; ++dpt)
@@ -1561,24 +1606,32 @@ __global__ __launch_bounds__(256, 2) void k_rtz2(RtzArgs a) {
             for (int s3 = 0; s3 < 3; ++s3) { v[dpt][s3] = v[dpt + 1][s3]; idv[dpt][s3] = idv[dpt + 1][s3]; }
         fetch(id_n, live_n, v[RTZ_DEPTH - 1], idv[RTZ_DEPTH - 1]);        // tile t+1+RTZ_DEPTH
         ids_of(t + 2 + RTZ_DEPTH, id_n, live_n);      // ids for the fetch of the next iteration
-        int g = task_g;
-        if (task_g < 0) {
-            if (((t - t0) & 255) == 0) {          // refill the group window (workgroup-uniform)
+        RTZ_STAMP(2)
+        int key;
+        if (task_g >= 0) {
+            key = task_g;                         // a task is one group, block 0
+        } else {
+            if (((t - t0) & 255) == 0) {          // refill the key window (workgroup-uniform)
                 __syncthreads();
-                if (t + tid < t1) grp_l[tid] = a.tile_grp[t + tid];
+                if (t + tid < t1) {
+                    int b = 0;
+                    if (a.blk_start) while (t + tid >= bs_l[b + 1]) ++b;   // lists are block-major
+                    grp_l[tid] = b * a.G + a.tile_grp[t + tid];
+                }
                 __syncthreads();
+                key = grp_l[0];
+            } else {
+                key = key_nxt;
             }
-            g = grp_l[(t - t0) & 255];
+            key_nxt = grp_l[(t - t0 + 1) & 255];   // next tile's key: its LDS latency runs under this tile's work
         }
-        int b = cur_b;
-        if (a.blk_start) {
-            while (t >= bs_l[b + 1]) ++b;         // lists are block-major, so b only grows
+        if (key != cur_key) {
+            flush(true);
+            cur_key = key;
+        } else if (ONES && ((t - t0) & 15) == 15) {
+            flush(false);
         }
-        if (g != cur_g || b != cur_b) {
-            flush();
-            cur_g = g;
-            cur_b = b;
-        }
+        RTZ_STAMP(3)
         const float* Rt = lds + (size_t)buf * tile_floats;
         const float* Zt = Rt + 16 * LDR;
         float tsum[MTW];
@@ -1592,17 +1645,21 @@ __global__ __launch_bounds__(256, 2) void k_rtz2(RtzArgs a) {
                 const int mt = ms + i * SPLIT;
                 if (mt < MT) {
                     const float av = Rt[(4 * ks + q) * LDR + 16 * mt + c16];
-                    tsum[i] += av;
+                    if (!ONES) tsum[i] += av;
                     acc[i] = MFMA16(av, bv, acc[i]);
                 }
             }
         }
-        if (sums) {
+        if (!ONES && sums) {
 #pragma unroll
             for (int i = 0; i < MTW; ++i) csum[i] += (double)tsum[i];
         }
+        RTZ_STAMP(4)
     }
-    flush();
+#ifdef RTZ_PROF
+    if (lane == 0) { for (int k = 0; k < 5; ++k) atomicAdd(&g_rtz_prof[k], pf_[k]); atomicAdd(&g_rtz_prof[5], (unsigned long long)(t1 - t0)); }
+#endif
+    flush(true);
     float* slab = a.slab + (size_t)wg * (MT * NTD * 256);
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
@@ -3053,27 +3110,41 @@ int launch_round(const RoundArgs& a_in, int mt, int wgs, hipStream_t s) {
 bool rtz2_ok(int mt, int dp) { return mt >= 1 && mt <= 7 && (dp == 32 || dp == 52 || dp == 64); }
 int rtz2_slab_floats(int mt, int dp) { return mt * (dp == 32 ? 2 : 4) * 256; }
 
-template <int NTD>
+template <int NTD, bool ONES>
 static void launch_rtz2_n(RtzArgs& a, int mt, int wgs, size_t sm, hipStream_t s) {
     switch (mt) {
-        case 1: hipLaunchKernelGGL((k_rtz2<1, NTD>), dim3(wgs), dim3(256), sm, s, a); break;
-        case 2: hipLaunchKernelGGL((k_rtz2<2, NTD>), dim3(wgs), dim3(256), sm, s, a); break;
-        case 3: hipLaunchKernelGGL((k_rtz2<3, NTD>), dim3(wgs), dim3(256), sm, s, a); break;
-        case 4: hipLaunchKernelGGL((k_rtz2<4, NTD>), dim3(wgs), dim3(256), sm, s, a); break;
-        case 5: hipLaunchKernelGGL((k_rtz2<5, NTD>), dim3(wgs), dim3(256), sm, s, a); break;
-        case 6: hipLaunchKernelGGL((k_rtz2<6, NTD>), dim3(wgs), dim3(256), sm, s, a); break;
-        default: hipLaunchKernelGGL((k_rtz2<7, NTD>), dim3(wgs), dim3(256), sm, s, a); break;
+        case 1: hipLaunchKernelGGL((k_rtz2<1, NTD, ONES>), dim3(wgs), dim3(256), sm, s, a); break;
+        case 2: hipLaunchKernelGGL((k_rtz2<2, NTD, ONES>), dim3(wgs), dim3(256), sm, s, a); break;
+        case 3: hipLaunchKernelGGL((k_rtz2<3, NTD, ONES>), dim3(wgs), dim3(256), sm, s, a); break;
+        case 4: hipLaunchKernelGGL((k_rtz2<4, NTD, ONES>), dim3(wgs), dim3(256), sm, s, a); break;
+        case 5: hipLaunchKernelGGL((k_rtz2<5, NTD, ONES>), dim3(wgs), dim3(256), sm, s, a); break;
+        case 6: hipLaunchKernelGGL((k_rtz2<6, NTD, ONES>), dim3(wgs), dim3(256), sm, s, a); break;
+        default: hipLaunchKernelGGL((k_rtz2<7, NTD, ONES>), dim3(wgs), dim3(256), sm, s, a); break;
     }
 }
+
+#ifdef RTZ_PROF
+void rtz_prof_dump() {
+    unsigned long long h[8];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rtz_prof), sizeof h);
+    const double n = (double)h[5];   // wave-tiles
+    fprintf(stderr, "[k_rtz2 prof] cycles per tile per wave: pre-barrier %.0f, barrier %.0f, stash+fetch issue %.0f, bookkeeping %.0f, LDS reads+MFMA %.0f\n",
+            h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n);
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rtz_prof), z, sizeof z);
+}
+#endif
 
 void launch_rtz2(const RtzArgs& a_in, int wgs, hipStream_t s) {
     RtzArgs a = a_in;
     const int ntd = a.dp == 32 ? 2 : 4;
     a.ldr = ((a.K16 + 31) / 32) * 32 + 16;          // row strides = 16 (mod 32) floats: conflict-free fragment reads
     a.ldz = ((16 * ntd + 31) / 32) * 32 + 16;
-    const size_t sm = (size_t)2 * 16 * (a.ldr + a.ldz) * sizeof(float) + (256 + 64) * sizeof(int);
-    if (ntd == 2) launch_rtz2_n<2>(a, a.mt, wgs, sm, s);
-    else launch_rtz2_n<4>(a, a.mt, wgs, sm, s);
+    const size_t sm = (size_t)2 * 16 * (a.ldr + a.ldz) * sizeof(float) + (256 + 64) * sizeof(int) + (size_t)a.K16 * sizeof(double);
+    if (ntd == 2) launch_rtz2_n<2, false>(a, a.mt, wgs, sm, s);
+    else if (a.dp < 64) launch_rtz2_n<4, true>(a, a.mt, wgs, sm, s);     // a padding column carries the column sums of R
+    else launch_rtz2_n<4, false>(a, a.mt, wgs, sm, s);
 }
 
 void launch_rtz2_reduce(const float* slab, int nslabs, int mt, int dp, int K16, int ld, double* out, const int* task_grp,
