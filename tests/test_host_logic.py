@@ -229,6 +229,7 @@ def test_kmeans_mode_selection(monkeypatch):
 
     class Fake:
         _kmeans_mode = H.Harmony._kmeans_mode
+        _wide_shape = H.Harmony._wide_shape
         K, d = 100, 50
     f = Fake()
     monkeypatch.delenv("HMX_KMEANS", raising=False)
@@ -236,8 +237,9 @@ def test_kmeans_mode_selection(monkeypatch):
     assert f._kmeans_mode() == "host"
     f.N_global = H.KMEANS_DEVICE_CELLS + 1
     assert f._kmeans_mode() == "device"
+    assert not f._wide_shape()
     f.K = 200
-    assert f._kmeans_mode() == "host"           # outside the device k-means' shapes
+    assert f._kmeans_mode() == "device" and f._wide_shape()   # device seeds, Lloyd on the subsample (no host fit of all cells)
     f.K = 100
     monkeypatch.setenv("HMX_KMEANS", "host")
     assert f._kmeans_mode() == "host"

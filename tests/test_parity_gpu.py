@@ -395,6 +395,28 @@ def test_device_kmeans_initialisation_end_to_end(monkeypatch):
     assert abs(ho.objective_harmony[-1] / g["objective_harmony"][-1] - 1) < 2e-2
 
 
+def test_device_kmeans_initialisation_wide_shapes(monkeypatch):
+    """K > 112 / d > 64 (BASELINE config 5's regime): HMX_KMEANS=device seeds on the GPU and runs the Lloyd
+    iterations on the subsample instead of fitting all cells on the host; the run ends where the host-initialised
+    one does (objective within 2 %, embeddings correlated per PC)."""
+    from scipy.stats import pearsonr
+    rng = np.random.default_rng(5)
+    N, d, K, B = 3000, 80, 120, 3
+    cent = rng.normal(size=(40, d)) * 2.0
+    batch = rng.integers(0, B, size=N)
+    Z = (cent[rng.integers(0, 40, size=N)] + rng.normal(size=(N, d)) + 0.5 * batch[:, None]).astype(np.float32)
+    meta = pd.DataFrame({"b": [f"b{i}" for i in batch]})
+    monkeypatch.setenv("HMX_KMEANS", "host")
+    ref = _hm().run_harmony(Z, meta, ["b"], nclust=K, verbose=False, max_iter_harmony=5)
+    monkeypatch.setenv("HMX_KMEANS", "device")
+    ho = _hm().run_harmony(Z, meta, ["b"], nclust=K, verbose=False, max_iter_harmony=5)
+    assert ho._wide_shape() and ho._kmeans_mode() == "device"
+    assert np.isfinite(ho.Z_corr).all()
+    assert abs(ho.objective_harmony[-1] / ref.objective_harmony[-1] - 1) < 2e-2
+    cors = [pearsonr(ho.Z_corr[:, j], ref.Z_corr[:, j])[0] for j in range(0, d, 7)]
+    assert min(cors) > 0.98, min(cors)
+
+
 def test_config3_full_size_properties():
     """BASELINE.json configs[2] at full size (1M cells x 50 PCs, 8 batches, K=100), the engine's
     large-job defaults (device k-means initialisation, device update order, natural schedule):
