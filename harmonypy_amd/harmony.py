@@ -15,7 +15,7 @@ There is no CPU fallback: without ``libhmx.so`` and a visible MI355X this module
 from __future__ import annotations
 
 import logging
-
+import os
 import time
 
 import numpy as np
@@ -402,7 +402,6 @@ class Harmony:
         self._pending_objective = None
         self._forced_rounds = (list(_TEST_HOOKS["forced_rounds"])
                                if _TEST_HOOKS["forced_rounds"] is not None else None)
-        import os
         mode = os.environ.get("HMX_UPDATE_ORDER", UPDATE_ORDER)
         if mode not in ("auto", "torch", "device"):
             raise ValueError(f"HMX_UPDATE_ORDER={mode!r}: expected auto, torch or device")
@@ -586,7 +585,6 @@ class Harmony:
         self.objective_harmony.append(self.objective_kmeans[-1])                 # :392
 
     def _kmeans_mode(self):
-        import os
         mode = os.environ.get("HMX_KMEANS", KMEANS)
         if mode not in ("auto", "host", "device"):
             raise ValueError(f"HMX_KMEANS={mode!r}: expected auto, host or device")
@@ -614,7 +612,6 @@ class Harmony:
             parts = self.shard.allgather_object(sub)
             sub = np.concatenate(parts, axis=0) if self.shard.rank == 0 else None
         centers = None
-        import os
         seeds = os.environ.get("HMX_KMEANS_SEEDS", KMEANS_SEEDS)
         if seeds not in ("device", "sklearn"):
             raise ValueError(f"HMX_KMEANS_SEEDS={seeds!r}: expected device or sklearn")
