@@ -626,7 +626,7 @@ int hmx_kmeans_lloyd(hmx_engine* e, const float* centers_in, int n_iter, float* 
     int rc;
     if ((rc = use_device(e))) return rc;
     const size_t nsum = (size_t)e->K16 * (e->d + 1);
-    const int wgs = std::min(2 * e->n_cus, std::max(1, (e->n_s_tiles + 7) / 8));
+    const int wgs = std::min(e->n_cus, std::max(1, (e->n_s_tiles + 7) / 8));   // one workgroup of 8 waves per CU (86 KB of LDS)
     if ((rc = e->km_hn.reserve(e->K16)) || (rc = e->km_sums.reserve(nsum)) ||
         (rc = e->slab.reserve(kmeans_slab_floats(wgs, e->K16, e->dp))))
         return rc;

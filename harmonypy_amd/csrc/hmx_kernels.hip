@@ -2370,8 +2370,14 @@ struct KmeansArgs {
     int K, K16, dp, ldy, ldy_lds, ldc;
 };
 
+// Member sums without per-element atomics: the tile's rows go through a per-wave LDS tile, the hard
+// assignment becomes a one-hot matrix (clusters x cells) built from the winners, and
+// sums += onehot . Z runs on the MFMA pipe into 7 x 4 accumulator tiles per wave (K16 x 64 floats);
+// the accumulators meet in the workgroup's LDS table once, at the end.  (52 ds_add_f32 per cell made
+// the first version of this kernel LDS-atomic-bound: 340 us per iteration at 1M cells.)
+#define KM_LDZ 68             /* row stride of the per-wave Z tile: 64 dims + 4 (conflict-free column reads) */
 template <int MT>
-__global__ __launch_bounds__(512, 2) void k_kmeans_step(KmeansArgs a) {
+__global__ __launch_bounds__(512, 1) void k_kmeans_step(KmeansArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int K16 = 16 * MT;
     const int LDY = a.ldy_lds, LDC = a.ldc;
@@ -2379,26 +2385,57 @@ __global__ __launch_bounds__(512, 2) void k_kmeans_step(KmeansArgs a) {
     float* hn = Ys + (size_t)K16 * LDY;                    // K16
     float* Cs = hn + K16;                                  // K16 x LDC sums of member rows
     float* cnt = Cs + (size_t)K16 * LDC;                   // K16 member counts
+    float* Zt_all = cnt + K16;                             // 8 waves x 16 x KM_LDZ: the waves' Z tiles
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c16 = lane & 15, q = lane >> 4;
+    float* Zt = Zt_all + (size_t)wv * 16 * KM_LDZ;
     const int c4n = a.dp >> 2, kb_full = a.dp >> 4, tail = c4n - 4 * kb_full;
+    const int ntd = (a.dp + 15) >> 4;                      // 16-dim column blocks (<= 4)
     for (int i = tid; i < K16 * c4n; i += 512) {
         const int row = i / c4n, c4 = i - row * c4n;
         st4(Ys + (size_t)row * LDY + 4 * c4, ld4(a.C + (size_t)row * a.ldy + 4 * c4));
     }
     for (int i = tid; i < K16; i += 512) { hn[i] = a.hn[i]; cnt[i] = 0.f; }
     for (int i = tid; i < K16 * LDC; i += 512) Cs[i] = 0.f;
+    for (int i = tid; i < 8 * 16 * KM_LDZ; i += 512) Zt_all[i] = 0.f;   // the columns beyond dp stay zero
     __syncthreads();
-    for (int t = blockIdx.x * 8 + wv; t < a.n_tiles; t += gridDim.x * 8) {
-        const int cell = a.cells[(size_t)t * 16 + c16];
+    f32x4 sacc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) sacc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the next tile's cell ids are requested at the top of an iteration and its rows once the ids are there
+    // (after the distance product), so both round trips run under the MFMAs of the current tile
+    auto load_rows = [&](int cell, f32x4 (&zr4)[4], float (&zt)[3]) {
+        const float* zr = a.Zcos + (size_t)(cell >= 0 ? cell : 0) * a.dp;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) zr4[j] = (j < kb_full) ? ld4(zr + 16 * j + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) zt[s2] = (s2 < tail) ? zr[16 * kb_full + 4 * s2 + q] : 0.f;
+    };
+    const int t_first = blockIdx.x * 8 + wv, t_step = gridDim.x * 8;
+    int cell_n = t_first < a.n_tiles ? a.cells[(size_t)t_first * 16 + c16] : -1;
+    f32x4 zrow_n[4];
+    float ztail_n[3];
+    load_rows(cell_n, zrow_n, ztail_n);
+    for (int t = t_first; t < a.n_tiles; t += t_step) {
+        const int cell = cell_n;
         const bool live = cell >= 0;
-        const float* zr = a.Zcos + (size_t)(live ? cell : 0) * a.dp;
         f32x4 zrow[4];
         float ztail[3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) zrow[j] = (j < kb_full) ? ld4(zr + 16 * j + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) zrow[j] = zrow_n[j];
 #pragma unroll
-        for (int s2 = 0; s2 < 3; ++s2) ztail[s2] = (s2 < tail) ? zr[16 * kb_full + 4 * s2 + q] : 0.f;
+        for (int s2 = 0; s2 < 3; ++s2) ztail[s2] = ztail_n[s2];
+        const int t_next = t + t_step;
+        cell_n = t_next < a.n_tiles ? a.cells[(size_t)t_next * 16 + c16] : -1;
+        // the rows also go to this wave's LDS tile (cell-major), from where the second product reads columns
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < kb_full) st4(Zt + c16 * KM_LDZ + 16 * j + 4 * q, zrow[j]);
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2)
+            if (s2 < tail) Zt[c16 * KM_LDZ + 16 * kb_full + 4 * s2 + q] = ztail[s2];
         f32x4 acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -2439,21 +2476,44 @@ __global__ __launch_bounds__(512, 2) void k_kmeans_step(KmeansArgs a) {
             const int ok = __shfl_xor(bk, m, 64);
             if (ob > best || (ob == best && ok < bk)) { best = ob; bk = ok; }
         }
-        if (live) {
-            float* row = Cs + (size_t)bk * LDC;
+        if (!live) bk = -1;                    // padding cells belong to no cluster
+        load_rows(cell_n, zrow_n, ztail_n);    // next tile's rows: their latency runs under the second product
+        if (live && q == 0) atomicAdd(cnt + bk, 1.0f);
+        // sums += onehot(16 cells -> K16 clusters)^T . Z tile
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j < kb_full) {
+        for (int ks = 0; ks < 4; ++ks) {
+            const int win = __shfl(bk, 4 * ks + q, 64);              // winner of cell 4ks+q (held by lane 4ks+q)
+            float bz[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) atomicAdd(row + 16 * j + 4 * q + i, zrow[j][i]);
+            for (int nt = 0; nt < 4; ++nt) bz[nt] = (nt < ntd) ? Zt[(4 * ks + q) * KM_LDZ + 16 * nt + c16] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float oh = (win == 16 * mt + c16) ? 1.f : 0.f;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    if (nt < ntd) sacc[mt][nt] = MFMA16(oh, bz[nt], sacc[mt][nt]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the tile is rewritten by the next iteration
+        __builtin_amdgcn_wave_barrier();
+    }
+    // the waves' accumulators meet in the workgroup's table: lane (c16, q) holds sums[16mt+4q+r][16nt+c16]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int col = 16 * nt + c16;
+            if (nt < ntd && col < a.dp) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = sacc[mt][nt][r];
+                    if (v != 0.f) atomicAdd(Cs + (size_t)(16 * mt + 4 * q + r) * LDC + col, v);
                 }
             }
-#pragma unroll
-            for (int s2 = 0; s2 < 3; ++s2)
-                if (s2 < tail) atomicAdd(row + 16 * kb_full + 4 * s2 + q, ztail[s2]);
-            if (q == 0) atomicAdd(cnt + bk, 1.0f);
         }
-    }
     __syncthreads();
     float* out = a.slab + (size_t)blockIdx.x * K16 * LDC;
     for (int i = tid; i < K16 * LDC; i += 512) out[i] = Cs[i];
@@ -3165,7 +3225,7 @@ int launch_kmeans_step(const float* Zcos, const float* C, const float* hn, const
     a.K = K; a.K16 = K16; a.dp = dp; a.ldy = ldy; a.ldy_lds = lds_ldy(dp); a.ldc = lds_ldy(dp);
     const int mt = K16 / 16;
     if (mt < 1 || mt > 7 || dp > 64) return -1;
-    const size_t sm = ((size_t)K16 * a.ldy_lds + K16 + (size_t)K16 * a.ldc + K16) * sizeof(float);
+    const size_t sm = ((size_t)K16 * a.ldy_lds + K16 + (size_t)K16 * a.ldc + K16 + (size_t)8 * 16 * KM_LDZ) * sizeof(float);
     switch (mt) {
         case 1: hipLaunchKernelGGL((k_kmeans_step<1>), dim3(wgs), dim3(512), sm, s, a); break;
         case 2: hipLaunchKernelGGL((k_kmeans_step<2>), dim3(wgs), dim3(512), sm, s, a); break;
