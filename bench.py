@@ -119,15 +119,11 @@ def side_config(name, rounds, steps, warmup, device):
     from harmonypy_amd import harmony as H
     N, d, B, K = CONFIGS[name]
     Z, meta = synthetic_dataset(N, d, B, K, seed=0, cell_seed=0)
-    H._TEST_HOOKS["Y0"] = quick_centroids(Z, K, seed=0)
-    try:
-        ho = H.run_harmony(Z, meta, ["batch"], nclust=K, max_iter_harmony=0, verbose=False, random_state=0, device=device)
-    finally:
-        H._TEST_HOOKS["Y0"] = None
+    ho = H.run_harmony(Z, meta, ["batch"], nclust=K, max_iter_harmony=0, verbose=False, random_state=0, device=device,
+                       _y0=quick_centroids(Z, K, seed=0))
 
     def step():
-        ho._forced_rounds = [rounds]
-        ho.cluster()
+        ho.cluster(_rounds=rounds)
         ho.moe_correct_ridge()
         ho.check_convergence(1)
     for _ in range(warmup):
@@ -194,16 +190,13 @@ def main():
     if dist is not None:
         shard = harmonypy_amd.Shard()            # nccl group -> the engine's own RCCL communicator
         Y0 = shard.broadcast_object(Y0)
-    H._TEST_HOOKS["Y0"] = Y0
     t_setup = time.perf_counter()
     ho = H.run_harmony(Z, meta, ["batch"], nclust=K, max_iter_harmony=0, verbose=False, random_state=0,
-                       device=f"cuda:{local_rank}", shard=shard)
-    H._TEST_HOOKS["Y0"] = None
+                       device=f"cuda:{local_rank}", shard=shard, _y0=Y0)
     t_setup = time.perf_counter() - t_setup
 
     def step():
-        ho._forced_rounds = [args.rounds]
-        ho.cluster()
+        ho.cluster(_rounds=args.rounds)
         ho.moe_correct_ridge()
         try:
             ho.check_convergence(1)

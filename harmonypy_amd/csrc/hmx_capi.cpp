@@ -88,6 +88,7 @@ struct hmx_engine {
     hipStream_t stream2 = nullptr;
     hipEvent_t pre_event = nullptr;
     bool pre_valid = false;              // lists[cur ^ 1] hold the round described by pre_*
+    bool pre_outstanding = false;        // a build was enqueued on stream2 and nothing has waited for it yet
     uint64_t pre_seed = 0, pre_counter = 0;
     int64_t pre_cpb = 0;
     DevBuf<int> gstart, chunk_tab, run_count, run_start, global_id;
@@ -307,11 +308,11 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
     if (cfg->n_cells <= 0 || cfg->n_pcs <= 0 || cfg->n_clusters <= 0 || cfg->n_batches <= 0 || cfg->n_groups <= 0 ||
         cfg->n_vars <= 0 || cfg->n_blocks <= 0)
         return fail(HMX_ERR_ARG, "sizes must be positive");
-    if (cfg->n_clusters > 208) return fail(HMX_ERR_ARG, "n_clusters=%d > 208 not supported by this build", cfg->n_clusters);
-    if (cfg->n_pcs > 208) return fail(HMX_ERR_ARG, "n_pcs=%d > 208 not supported by this build", cfg->n_pcs);
+    if (cfg->n_clusters > HMX_MAX_CLUSTERS) return fail(HMX_ERR_ARG, "n_clusters=%d > %d not supported by this build", cfg->n_clusters, HMX_MAX_CLUSTERS);
+    if (cfg->n_pcs > HMX_MAX_PCS) return fail(HMX_ERR_ARG, "n_pcs=%d > %d not supported by this build", cfg->n_pcs, HMX_MAX_PCS);
     if (cfg->n_cells > (int64_t)2000000000) return fail(HMX_ERR_ARG, "n_cells too large for 32-bit cell ids");
-    if (cfg->n_blocks > 60) return fail(HMX_ERR_ARG, "n_blocks=%d > 60 not supported by this build", cfg->n_blocks);
-    if (cfg->n_vars > 8) return fail(HMX_ERR_ARG, "n_vars=%d > 8 not supported by this build", cfg->n_vars);
+    if (cfg->n_blocks > HMX_MAX_BLOCKS) return fail(HMX_ERR_ARG, "n_blocks=%d > %d not supported by this build", cfg->n_blocks, HMX_MAX_BLOCKS);
+    if (cfg->n_vars > HMX_MAX_VARS) return fail(HMX_ERR_ARG, "n_vars=%d > %d not supported by this build", cfg->n_vars, HMX_MAX_VARS);
     if (cfg->n_cells_global != 0 && (cfg->n_cells_global < cfg->n_cells || cfg->n_cells_global > (int64_t)2000000000))
         return fail(HMX_ERR_ARG, "n_cells_global must lie in [n_cells, 2e9]");
     int ndev = 0;
@@ -432,6 +433,12 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
         if (static_tile_group[i] < 0 || static_tile_group[i] >= e->G) return fail(HMX_ERR_ARG, "static_tile_group[%d] out of range", i);
     for (int i = 0; i < e->G * e->V; ++i)
         if (group_cols[i] < 0 || group_cols[i] >= e->B) return fail(HMX_ERR_ARG, "group_cols[%d] out of range", i);
+    if (e->V == 1) {
+        // one batch variable: group g IS batch g (the closed-form ridge solve and the sweep's tables index by it)
+        if (e->G != e->B) return fail(HMX_ERR_ARG, "one batch variable needs n_groups == n_batches (%d != %d): drop batch levels without cells", e->G, e->B);
+        for (int g = 0; g < e->G; ++g)
+            if (group_cols[g] != g) return fail(HMX_ERR_ARG, "one batch variable needs group_cols[g] == g (group_cols[%d] = %d)", g, group_cols[g]);
+    }
     if (!global_id && e->Ng != e->N) return fail(HMX_ERR_ARG, "global_id is required when n_cells_global != n_cells");
     if (global_id)
         for (int64_t i = 0; i < e->N; ++i)
@@ -870,7 +877,21 @@ int hmx_cluster_round(hmx_engine* e, int flags, const int32_t* cells, int64_t n_
         if (block_tile_start[b + 1] < block_tile_start[b]) return fail(HMX_ERR_ARG, "block_tile_start must be non-decreasing");
         upper[b] = block_tile_start[b + 1] - block_tile_start[b];
     }
+    {
+        int64_t live = 0;
+        for (int64_t i = 0; i < n_pos; ++i) {
+            if (cells[i] < -1 || cells[i] >= e->N) return fail(HMX_ERR_ARG, "cells[%lld] = %d out of range", (long long)i, cells[i]);
+            live += cells[i] >= 0;
+        }
+        if (live != e->N) return fail(HMX_ERR_ARG, "the update-order list holds %lld cells, the engine %lld: every cell must appear exactly once", (long long)live, (long long)e->N);
+        for (int i = 0; i < n_tiles; ++i)
+            if (tile_group[i] < 0 || tile_group[i] >= e->G) return fail(HMX_ERR_ARG, "tile_group[%d] out of range", i);
+    }
     if ((rc = use_device(e))) return rc;
+    if (e->pre_outstanding) {   // a list build may still be running on the second stream: it shares the scratch tables
+        HIP_TRY(hipStreamSynchronize(e->stream2));
+        e->pre_outstanding = false;
+    }
     e->pre_valid = false;   // caller-provided lists: whatever was prepared ahead is void
     if ((rc = e->lists[e->cur].cells.reserve(n_pos)) || (rc = e->lists[e->cur].tile_grp.reserve(n_tiles))) return rc;
     HIP_TRY(hipMemcpyAsync(e->lists[e->cur].cells.p, cells, n_pos * sizeof(int), hipMemcpyHostToDevice, e->stream));
@@ -915,10 +936,11 @@ int hmx_cluster_round_seeded(hmx_engine* e, int flags, uint64_t seed, int64_t ce
         e->cur ^= 1;                                            // prepared while the previous round ran
         HIP_TRY(hipStreamWaitEvent(e->stream, e->pre_event, 0));
     } else {
-        if (e->pre_valid) HIP_TRY(hipStreamSynchronize(e->stream2));   // the scratch tables are shared
+        if (e->pre_outstanding) HIP_TRY(hipStreamSynchronize(e->stream2));   // the scratch tables are shared
         build(counter, e->cur, e->stream);
     }
     e->pre_valid = false;
+    e->pre_outstanding = false;   // either the main stream now waits for it, or stream2 was drained
     // next round's lists depend on (seed, counter) only: they are built on the second stream beside the sweep
     // kernel, which leaves a few CUs idle.  The scratch tables (chunk_tab, run_*) are free by then.
     auto prefetch = [&]() -> int {
@@ -927,6 +949,7 @@ int hmx_cluster_round_seeded(hmx_engine* e, int flags, uint64_t seed, int64_t ce
         HIP_TRY(hipStreamWaitEvent(e->stream2, e->pre_event, 0));
         build(counter + 1, e->cur ^ 1, e->stream2);
         HIP_TRY(hipEventRecord(e->pre_event, e->stream2));
+        e->pre_outstanding = true;
         e->pre_valid = true; e->pre_seed = seed; e->pre_counter = counter + 1; e->pre_cpb = cells_per_block;
         return 0;
     };

@@ -55,11 +55,6 @@ KMEANS_SEED_CELLS = 32_768
 # for 32k cells).  Override: HMX_KMEANS_SEEDS.
 KMEANS_SEEDS = "device"
 
-# Test aids (never set by product code).  ``Y0``: d x K centroids used instead of the
-# sklearn call; ``forced_rounds``: list of k-means round counts replayed instead of the
-# objective thresholds (whose margins are a few fp32 ulps).
-_TEST_HOOKS = {"Y0": None, "forced_rounds": None}
-
 TILE = _capi.HMX_TILE
 
 
@@ -126,6 +121,8 @@ def run_harmony(
     device=None,
     *,
     shard=None,
+    _y0=None,
+    _schedule=None,
 ):
     """Run Harmony batch-effect correction on an MI355X.
 
@@ -138,7 +135,14 @@ def run_harmony(
     the process group then passes ITS slice of the cells (rank r holds the r-th contiguous
     slice) and gets back an object over those cells; batch proportions, cluster count, blocks,
     centroids and corrections are those of the whole job (``dist.py``).
+
+    ``_y0`` / ``_schedule`` (keyword only, not in the reference): replay aids of the parity tests
+    and of ``bench.py`` -- ``_y0`` is a d x K matrix of initial centroids used instead of the
+    k-means initialisation (harmony.py:369-373), ``_schedule`` a list of k-means round counts,
+    one per Harmony iteration, replayed instead of the objective thresholds of harmony.py:455-458
+    (which the reference decides on a few fp32 ulps).
     """
+    _validate_arguments(nclust, block_size, meta_data, vars_use)
     p = _prepare_inputs(data_mat, meta_data, vars_use, theta, lamb, sigma, nclust, tau, shard=shard)
     dev = _device_index(device)
     if verbose:
@@ -168,8 +172,20 @@ def run_harmony(
         p["theta"], p["lamb"], alpha, p["lambda_estimation"],
         max_iter_harmony, max_iter_kmeans,
         epsilon_cluster, epsilon_harmony, p["K"], block_size, verbose,
-        random_state, device, shard=shard,
+        random_state, device, shard=shard, _y0=_y0, _schedule=_schedule,
     )
+
+
+def _validate_arguments(nclust, block_size, meta_data, vars_use):
+    """Limits of this build, reported as ValueError before any engine exists (the reference has none:
+    harmony.py:123-124 caps only the default cluster count)."""
+    if nclust is not None and not (1 <= int(nclust) <= _capi.HMX_MAX_CLUSTERS):
+        raise ValueError(f"nclust={nclust}: this build supports 1..{_capi.HMX_MAX_CLUSTERS} clusters")
+    if not (0 < float(block_size) <= 1) or int(np.ceil(1.0 / float(block_size))) > _capi.HMX_MAX_BLOCKS:
+        raise ValueError(f"block_size={block_size}: must lie in [1/{_capi.HMX_MAX_BLOCKS}, 1]")
+    n_vars = 1 if isinstance(vars_use, str) else len(vars_use)
+    if not (1 <= n_vars <= _capi.HMX_MAX_VARS):
+        raise ValueError(f"{n_vars} batch variables: this build supports 1..{_capi.HMX_MAX_VARS}")
 
 
 def _prepare_inputs(data_mat, meta_data, vars_use, theta=None, lamb=None, sigma=0.1, nclust=None, tau=0, shard=None):
@@ -184,6 +200,8 @@ def _prepare_inputs(data_mat, meta_data, vars_use, theta=None, lamb=None, sigma=
         data_mat = data_mat.T
     assert data_mat.shape[1] == N, \
         "data_mat and meta_data do not have the same number of cells"
+    if data_mat.shape[0] > _capi.HMX_MAX_PCS:
+        raise ValueError(f"{data_mat.shape[0]} PCs: this build supports up to {_capi.HMX_MAX_PCS}")
 
     N_all = N
     if shard is not None:
@@ -202,14 +220,22 @@ def _prepare_inputs(data_mat, meta_data, vars_use, theta=None, lamb=None, sigma=
     phi_n = []
     offset = 0
     for v, name in enumerate(vars_use):
-        cat = pd.Categorical(meta_data[name])
+        # levels that are declared but hold no cell (a subsetted categorical column) get no Phi row:
+        # harmony.py:134 counts the levels present (describe()["unique"]), and an empty batch would
+        # leave a group without cells
+        full = pd.Categorical(meta_data[name])
+        cat = full.remove_unused_categories()
         if shard is not None:
-            # the levels of the whole job: identical declared categories are kept as they are,
-            # otherwise the sorted union (what pd.Categorical would find on the unsharded column)
-            levels = shard.allgather_object(list(cat.categories))
-            if any(lv != levels[0] for lv in levels):
-                merged = sorted(set().union(*levels))
-                cat = pd.Categorical(meta_data[name], categories=merged)
+            # the levels of the whole job: identical declared categories keep their declared order
+            # (minus the levels no rank uses), otherwise the sorted union of the levels in use
+            used = np.bincount(full.codes[full.codes >= 0], minlength=len(full.categories))
+            parts = shard.allgather_object((list(full.categories), used))
+            if all(lv == parts[0][0] for lv, _ in parts):
+                total = np.sum([u for _, u in parts], axis=0)
+                levels = [lv for lv, n in zip(parts[0][0], total) if n > 0]
+            else:
+                levels = sorted(set().union(*[[lv for lv, n in zip(lvs, u) if n > 0] for lvs, u in parts]))
+            cat = pd.Categorical(meta_data[name], categories=levels)
         if (cat.codes < 0).any():
             raise ValueError(f"meta_data[{name!r}] has missing values")
         codes[:, v] = cat.codes.astype(np.int32) + offset
@@ -360,7 +386,7 @@ class Harmony:
             self, Z, Phi, Pr_b, sigma, theta, lamb, alpha, lambda_estimation,
             max_iter_harmony, max_iter_kmeans,
             epsilon_kmeans, epsilon_harmony, K, block_size, verbose,
-            random_state, device, shard=None
+            random_state, device, shard=None, *, _y0=None, _schedule=None
     ):
         self.device = device
         self.shard = shard
@@ -400,8 +426,9 @@ class Harmony:
         self.objective_kmeans_cross = []
         self.kmeans_rounds = []
         self._pending_objective = None
-        self._forced_rounds = (list(_TEST_HOOKS["forced_rounds"])
-                               if _TEST_HOOKS["forced_rounds"] is not None else None)
+        # replay aids (see run_harmony): initial centroids and a fixed round schedule
+        self._y0 = None if _y0 is None else np.asarray(_y0, dtype=np.float32)
+        self._schedule = None if _schedule is None else [int(r) for r in _schedule]
         mode = os.environ.get("HMX_UPDATE_ORDER", UPDATE_ORDER)
         if mode not in ("auto", "torch", "device"):
             raise ValueError(f"HMX_UPDATE_ORDER={mode!r}: expected auto, torch or device")
@@ -548,8 +575,8 @@ class Harmony:
     # harmony.py:366-392
     # ------------------------------------------------------------------
     def init_cluster(self, random_state):
-        if _TEST_HOOKS["Y0"] is not None:
-            Y0 = np.asarray(_TEST_HOOKS["Y0"], dtype=np.float32)                 # d x K
+        if self._y0 is not None:
+            Y0 = self._y0                                                        # d x K
         elif self._kmeans_mode() == "device":
             Y0 = self._device_kmeans(random_state)
         else:
@@ -680,9 +707,10 @@ class Harmony:
     # ------------------------------------------------------------------
     # harmony.py:437-462
     # ------------------------------------------------------------------
-    def cluster(self):
+    def cluster(self, *, _rounds=None):
+        """``_rounds`` (keyword only, not in the reference): run exactly that many rounds."""
         rounds = 0
-        forced = self._forced_rounds.pop(0) if self._forced_rounds else None
+        forced = _rounds if _rounds is not None else (self._schedule.pop(0) if self._schedule else None)
         for i in range(self.max_iter_kmeans if forced is None else forced):
             self._round(_capi.HMX_ROUND_ALL)                                     # :443-450
             self.compute_objective()                                             # :453

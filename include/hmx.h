@@ -31,6 +31,11 @@ extern "C" {
 
 #define HMX_ABI_VERSION 3
 #define HMX_TILE 16 /* cells per tile */
+/* limits of this build, checked by hmx_create (the reference has none: harmony.py:123-124 caps only the default K) */
+#define HMX_MAX_CLUSTERS 208
+#define HMX_MAX_PCS 208
+#define HMX_MAX_BLOCKS 60
+#define HMX_MAX_VARS 8
 
 typedef enum hmx_status {
     HMX_OK = 0,

@@ -273,9 +273,12 @@ class OracleHarmony:
         self.last_order = order
         n_blocks = int(np.ceil(1.0 / self.block_size))                   # :474
         per_block = int(self.N * self.block_size)                        # :475
-        R_p = self.R[:, order]                                           # :478
-        scale_p = scale[:, order]                                        # :479
-        Phi_p = self.Phi[:, order]                                       # :480
+        # NumPy's fancy indexing hands back column-major copies; torch's gathers are row-major, and
+        # only then are the fp32 row sums below pairwise like torch's (a strided fp32 sum runs
+        # sequentially, drops R's many tiny entries and biases E by ~3e-5 per round at 150k cells)
+        R_p = np.ascontiguousarray(self.R[:, order])                     # :478
+        scale_p = np.ascontiguousarray(scale[:, order])                  # :479
+        Phi_p = np.ascontiguousarray(self.Phi[:, order])                 # :480
         for blk in range(n_blocks):
             lo = blk * per_block                                         # :483
             hi = self.N if blk == n_blocks - 1 else (blk + 1) * per_block  # :484

@@ -102,13 +102,14 @@ class ShardedOracle(OracleHarmony):
             hi = self.N_global if blk == n_blocks - 1 else (blk + 1) * per_block
             members = order[lo:hi]
             mine = members[(members >= self._offset) & (members < self._offset + self.N)] - self._offset
-            R_b, Phi_b = self.R[:, mine], self.Phi[:, mine]
+            # row-major gathers: fp32 row sums are then pairwise like torch's (harmony_oracle.update_R)
+            R_b, Phi_b = np.ascontiguousarray(self.R[:, mine]), np.ascontiguousarray(self.Phi[:, mine])
             self.E = self.E - np.outer(self._sum(R_b.sum(axis=1, dtype=F32)), self.Pr_b).astype(F32)
             self.O = self.O - self._sum(R_b @ Phi_b.T)
             OE = np.maximum(self.O + self.E, F32(1e-8))
             ratio = np.clip(self.E / OE, F32(1e-8), F32(1.0))
             ratio_pow = _col_pow(ratio, self.theta)
-            R_new = scale[:, mine] * (ratio_pow @ Phi_b)
+            R_new = np.ascontiguousarray(scale[:, mine]) * (ratio_pow @ Phi_b)
             col = np.maximum(R_new.sum(axis=0, dtype=F32), F32(1e-8))
             R_new = (R_new / col).astype(F32)
             self.E = self.E + np.outer(self._sum(R_new.sum(axis=1, dtype=F32)), self.Pr_b).astype(F32)

@@ -67,9 +67,8 @@ def main():
         if opts.get("order"):
             os.environ["HMX_UPDATE_ORDER"] = opts["order"]
         shard = Shard(transport=opts.get("transport", "host"))
-        H._TEST_HOOKS["Y0"] = g["Y0"] if opts.get("Y0", True) else None
-        H._TEST_HOOKS["forced_rounds"] = rounds
-        ho = H.run_harmony(Z_loc, meta_loc, vars_use, verbose=False, shard=shard, **kw)
+        ho = H.run_harmony(Z_loc, meta_loc, vars_use, verbose=False, shard=shard,
+                           _y0=g["Y0"] if opts.get("Y0", True) else None, _schedule=rounds, **kw)
         out = dict(Z_corr=ho.Z_corr, objective_kmeans=ho.objective_kmeans, objective_harmony=ho.objective_harmony,
                    kmeans_rounds=ho.kmeans_rounds, K=ho.K, Pr_b=ho.Pr_b, theta=ho.theta, O=ho.O, E=ho.E, Y=ho.Y,
                    R_colsum_local=ho.R.sum(axis=0), transport=str(ho.transport))

@@ -20,13 +20,7 @@ def _hm():
 
 def _run_engine(data, meta, vars_use, Y0=None, forced_rounds=None, **kw):
     from harmonypy_amd import harmony as H
-    H._TEST_HOOKS["Y0"] = Y0
-    H._TEST_HOOKS["forced_rounds"] = forced_rounds
-    try:
-        return H.run_harmony(data, meta, vars_use, verbose=False, **kw)
-    finally:
-        H._TEST_HOOKS["Y0"] = None
-        H._TEST_HOOKS["forced_rounds"] = None
+    return H.run_harmony(data, meta, vars_use, verbose=False, _y0=Y0, _schedule=forced_rounds, **kw)
 
 
 def _oracle_state(data, meta, vars_use, Y0, random_state=0, **kw):
@@ -143,25 +137,45 @@ def test_forced_schedule_vs_reference_golden(case):
     np.testing.assert_allclose(ho.R.sum(axis=0), g["R_colsum"], rtol=3e-4, atol=3e-4)
 
 
+_NATURAL_OUTCOME = {}   # case -> report line of test_natural_run_vs_reference_golden
+
+
 @pytest.mark.parametrize("case", ALL_CASES)
 def test_natural_run_vs_reference_golden(case):
-    """Free-running thresholds.  Same schedule => Z_corr within 1e-4; a different schedule is
-    accepted only from an iteration on whose reference decision sat within 5 % of the
-    threshold (harmony.py:523 decides on a few fp32 ulps there)."""
+    """Free-running thresholds, no replayed schedule.  Same schedule => Z_corr within 1e-4; a different
+    schedule is accepted only from an iteration on whose reference decision sat within 5 % of the
+    threshold (harmony.py:523 decides on a few fp32 ulps there).  Which branch a case
+    took is printed and collected; test_natural_run_report fails when no pbmc case took the first."""
     data, meta, vars_use, kw, g = load_case(case)
     ho = _run_engine(data, meta, vars_use, Y0=g["Y0"], **kw)
     ref_rounds = [int(r) for r in g["kmeans_rounds"]]
     if ho.kmeans_rounds == ref_rounds:
-        assert_z_close(ho.Z_corr, g["Z_corr"])
+        rel_f, max_rel = assert_z_close(ho.Z_corr, g["Z_corr"])
+        _NATURAL_OUTCOME[case] = f"{case}: same schedule {ref_rounds}, relF={rel_f:.2e} max={max_rel:.2e}"
+        print(_NATURAL_OUTCOME[case])
         return
     first_bad = next(i for i, (a, b) in enumerate(zip(ho.kmeans_rounds + [None] * 99, ref_rounds + [None] * 99))
                      if a != b)
     thin = thin_margin_iteration(g)
+    _NATURAL_OUTCOME[case] = (f"{case}: diverged at iteration {first_bad} (engine {ho.kmeans_rounds}, reference {ref_rounds}; "
+                              f"first reference decision within 5 % of the threshold: iteration {thin})")
+    print(_NATURAL_OUTCOME[case])
     assert thin is not None and thin <= first_bad, (
         f"{case}: schedule {ho.kmeans_rounds} != {ref_rounds} although no decision was marginal")
     # everything before the marginal decision must still agree
     n_before = 1 + sum(ref_rounds[:first_bad])
     np.testing.assert_allclose(ho.objective_kmeans[:n_before], g["objective_kmeans"][:n_before], rtol=2e-5)
+
+
+def test_natural_run_report():
+    """At least one free-running pbmc_3500 case must end on the reference's own schedule with Z_corr
+    within 1e-4 -- no injected schedule (runs after the cases above; the report is printed)."""
+    if not _NATURAL_OUTCOME:
+        pytest.skip("test_natural_run_vs_reference_golden did not run in this session")
+    report = "\n".join(_NATURAL_OUTCOME[c] for c in ALL_CASES if c in _NATURAL_OUTCOME)
+    print(report)
+    same = [c for c, line in _NATURAL_OUTCOME.items() if c.startswith("pbmc") and "same schedule" in line]
+    assert same, "no free-running pbmc case reproduced the reference's schedule:\n" + report
 
 
 def test_reference_ci_test_pearson_vs_R():
@@ -279,6 +293,71 @@ def test_config2_shape_properties_and_oracle():
     np.testing.assert_allclose(np.linalg.norm(ho.Y, axis=0), 1.0, atol=3e-6)
 
 
+def _device_perm_source(N, seed):
+    """The engine's device-side update order as the permutation stream the oracle consumes
+    (harmony.py:471): position p of round r holds the cell whose keyed-bijection position is p."""
+    from oracle.device_order import positions
+    state = {"counter": 0}
+
+    def perm(n):
+        assert n == N
+        pos = positions(np.arange(N), N, seed, state["counter"])
+        state["counter"] += 1
+        return np.argsort(pos, kind="stable")
+    return perm
+
+
+def _bench_path_case(N, d, B, K, monkeypatch, ridge_dtype, rounds=(5, 5)):
+    """What bench.py times -- hmx_cluster_round_seeded (update order built on the device, next round's
+    lists on the side stream) + ridge -- against the oracle fed with the same order."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import quick_centroids, synthetic_dataset
+    from oracle.harmony_oracle import OracleHarmony, prepare_inputs
+    monkeypatch.setenv("HMX_UPDATE_ORDER", "device")
+    seed = 11
+    Z, meta = synthetic_dataset(N, d, B, K, seed=3)
+    Y0 = quick_centroids(Z, K, seed=3, sample=20_000)
+    p = prepare_inputs(Z, meta, ["batch"], nclust=K)
+    oo = OracleHarmony(p["Z"], p["phi"], p["Pr_b"], p["sigma"], p["theta"], p["lamb"], K=K, run=False,
+                       perm_source=_device_perm_source(N, seed), forced_rounds=list(rounds), ridge_dtype=ridge_dtype)
+    oo.init_cluster(seed, Y0)
+    ho = _run_engine(Z, meta, ["batch"], Y0=Y0, nclust=K, max_iter_harmony=0, random_state=seed)
+    assert ho.update_order == "device"
+    for it, r in enumerate(rounds):
+        oo.cluster()
+        ho.cluster(_rounds=r)
+        n = 1 + sum(rounds[:it + 1])
+        np.testing.assert_allclose(ho.objective_kmeans[:n], oo.objective_kmeans[:n], rtol=2e-5, err_msg=f"iteration {it}")
+        Rg, Ro = ho.R, oo.R.T
+        rel_r = np.linalg.norm(Rg - Ro) / np.linalg.norm(Ro)
+        assert rel_r <= 1e-4, f"R after iteration {it}: relF={rel_r:.2e}"
+        np.testing.assert_allclose(ho.O, oo.O, rtol=1e-4, atol=2e-3)
+        np.testing.assert_allclose(ho.Y, oo.Y, rtol=0, atol=5e-6)
+        oo.moe_correct_ridge()
+        ho.moe_correct_ridge()
+        rel_f, max_rel = assert_z_close(ho.Z_corr, oo.result(), what=f"Z_corr after iteration {it}")
+        print(f"bench path {N}x{d} K={K} B={B} iteration {it}: R relF={rel_r:.2e}  Z_corr relF={rel_f:.2e} max={max_rel:.2e}")
+    return ho
+
+
+def test_bench_path_parity_c3_shape(monkeypatch):
+    """BASELINE configs[2]'s shape (d=50, K=100, 8 batches -> the k_round<7,13> instantiation bench.py
+    times) at 150k cells: seeded device-order rounds vs the oracle on the same per-round permutation
+    (oracle/device_order.py): objectives 2e-5, R 1e-4, Z_corr 1e-4 over two Harmony iterations.  The
+    ridge equations are evaluated in float64 by the oracle (cluster mass ~1500: the fp32 inverse of
+    harmony.py:553 is not reproducible at 1e-4 there, tests/golden/ridge_conditioning.json)."""
+    _bench_path_case(150_000, 50, 8, 100, monkeypatch, ridge_dtype=np.float64)
+
+
+def test_bench_path_parity_c5_shape(monkeypatch):
+    """BASELINE configs[4]'s exact shape (d=200, K=200, 32 batches: the wide kernels) at 40k cells,
+    seeded device-order rounds vs the plain fp32 oracle (cluster mass 200: the fp32 ridge is well
+    conditioned)."""
+    ho = _bench_path_case(40_000, 200, 32, 200, monkeypatch, ridge_dtype=np.float32)
+    assert ho._wide_shape()
+
+
 # ------------------------------------------------------------------------------------------
 # device-side update order (hmx_cluster_round_seeded)
 # ------------------------------------------------------------------------------------------
@@ -358,11 +437,7 @@ def test_device_lloyd_matches_numpy_lloyd(N, d, K, monkeypatch):
     Z = (cent[lab] + rng.normal(size=(N, d)) * 0.3).astype(np.float32)
     batch = rng.integers(0, 2, size=N)
     meta = pd.DataFrame({"b": [f"b{i}" for i in batch]})
-    H._TEST_HOOKS["Y0"] = cent.T.astype(np.float32)
-    try:
-        ho = H.run_harmony(Z, meta, ["b"], nclust=K, max_iter_harmony=0, verbose=False)
-    finally:
-        H._TEST_HOOKS["Y0"] = None
+    ho = H.run_harmony(Z, meta, ["b"], nclust=K, max_iter_harmony=0, verbose=False, _y0=cent.T.astype(np.float32))
     Zc = ho.Z_cos.astype(np.float64)
     C0 = Zc[rng.choice(N, size=K, replace=False)].astype(np.float32)
     C = C0.astype(np.float64)
