@@ -14,8 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhmx.so")
-SOURCES = ["hmx_kernels.hip", "hmx_lisi.hip", "hmx_capi.cpp"]
-HEADERS = [os.path.join(CSRC, "hmx_internal.h"), os.path.join(ROOT, "include", "hmx.h")]
+SOURCES = ["hmx_kernels.hip", "hmx_sweep.hip", "hmx_lisi.hip", "hmx_capi.cpp"]
+HEADERS = [os.path.join(CSRC, "hmx_internal.h"), os.path.join(CSRC, "hmx_device.h"), os.path.join(ROOT, "include", "hmx.h")]
 
 
 def _hipcc() -> str:

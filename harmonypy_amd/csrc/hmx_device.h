@@ -1,0 +1,96 @@
+// hmx_device.h -- device-side helpers shared by the kernel files (hmx_kernels.hip, hmx_sweep.hip).
+//
+// Fragment conventions of v_mfma_f32_16x16x4_f32 (cdna_hip_programming.md §3):
+//   A operand: lane l holds A[i = l&15][k = l>>4]
+//   B operand: lane l holds B[k = l>>4][j = l&15]
+//   C/D      : lane l, reg r holds C[row = 4*(l>>4) + r][col = l&15]
+// Throughout: c16 = lane & 15, q = lane >> 4.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float wave_sum_q(float v) {
+    // sum over the 4 lanes that share c16 (q = 0..3)
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum_c16(float v) {
+    // sum over the 16 lanes that share q
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_all(double v) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// sum over the 16 lanes of a DPP row (the lanes that share q); every lane of the row gets the total
+#define DPP_F(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xF, 0xF, true))
+__device__ __forceinline__ float row16_sum(float v) {
+    v += DPP_F(v, 0xB1);   // quad_perm [1,0,3,2]
+    v += DPP_F(v, 0x4E);   // quad_perm [2,3,0,1]
+    v += DPP_F(v, 0x141);  // row_half_mirror
+    v += DPP_F(v, 0x140);  // row_mirror
+    return v;
+}
+
+// exp(x) as 2^(x log2 e) for finite x: the product is split into a rounded head and an fma tail so
+// that the relative error stays ~1 ulp over the whole range of arguments (|x| up to ~100 would
+// otherwise lose 2^-24 * |x| log2 e).  v_exp_f32 is the hardware exp2.
+__device__ __forceinline__ float fast_exp_finite(float x) {
+    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f;
+    const float th = x * L2E_HI;
+    const float tl = fmaf(x, L2E_LO, fmaf(x, L2E_HI, -th));
+    const float p = __builtin_amdgcn_exp2f(th);
+    return fmaf(p, tl * 0.693147182464599609375f, p);
+}
+// r ** t for r in [1e-8, 1], t >= 0 as 2^(t log2 r): v_log_f32 / v_exp_f32 (1 ulp each) with the
+// product split into a rounded head and an fma tail.  Relative error ~3e-7 t (measured against powf
+// over the clamp range), far below what moves a round decision.
+__device__ __forceinline__ float pow_unit(float r, float t) {
+    const float l = __builtin_amdgcn_logf(r);            // log2 r <= 0
+    const float hi = t * l;
+    const float lo = fmaf(t, l, -hi);
+    const float p = __builtin_amdgcn_exp2f(hi);
+    return fmaf(p, lo * 0.693147182464599609375f, p);
+}
+
+// ---- hand-off between workgroups: 8-byte agent-scope atomics on both sides (Guideline 16) ----
+__device__ __forceinline__ double ld_agent(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// peer boxes (other GPUs over xGMI): 8-byte system-scope atomics on both sides
+__device__ __forceinline__ double ld_sys(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_sys(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_sys(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// A rank's box: data [parity 2][source rank][G x K16] doubles, then flags [parity 2][source rank] u64,
+// then 2 x n_ranks u64 of self-test words.
+__device__ __host__ __forceinline__ size_t box_data(int n_ranks, size_t GK, int par, int src) { return ((size_t)par * n_ranks + src) * GK; }
+__device__ __host__ __forceinline__ size_t box_flags(int n_ranks, size_t GK) { return (size_t)2 * n_ranks * GK; }
+
+__device__ __forceinline__ void wg_barrier_lds() {
+    // workgroup barrier that orders LDS traffic only: global loads already in flight (the next
+    // tiles' operands) keep travelling instead of being drained as __syncthreads() would
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}

@@ -50,11 +50,11 @@ hh.KMeans = _FixedKMeans
 _inv = torch.linalg.inv
 
 
-def run(threads, inv64=False, N=69_000, d=50, B=4, K=30):
+def run(threads, inv64=False, N=69_000, d=50, B=4, K=30, seed=0):
     torch.set_num_threads(threads)
-    Z, meta = synthetic_dataset(N, d, B, K, seed=0)
-    if _state["Y0"] is None:
-        _state["Y0"] = quick_centroids(Z, K, seed=0)
+    Z, meta = synthetic_dataset(N, d, B, K, seed=seed)
+    if _state["Y0"] is None or _state["Y0"].shape != (d, K):
+        _state["Y0"] = quick_centroids(Z, K, seed=seed, sample=20_000 if seed else 50_000)
 
     def inv(x):
         _state["conds"].append(float(np.linalg.cond(x.double().numpy())))
@@ -73,19 +73,31 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / np.linalg.norm(b))
 
 
-def main():
-    R1, Z1 = run(1)
+def case(label, **shape):
+    _state["conds"].clear()
+    R1, Z1 = run(1, **shape)
     conds = list(_state["conds"])
-    R8, Z8 = run(8)
-    _, Z64 = run(1, inv64=True)
-    out = {
-        "shape": "69000 cells x 50 PCs, 4 batches, K=30 (BASELINE configs[1]); 5 rounds + 1 ridge, same Y0, same randperm stream",
-        "reference": "harmonypy v0.2.0 at /root/reference, device='cpu', torch " + torch.__version__,
+    R8, Z8 = run(8, **shape)
+    _, Z64 = run(1, inv64=True, **shape)
+    return {
+        "shape": label + "; 5 rounds + 1 ridge, same Y0, same randperm stream",
         "R_relF_1_vs_8_threads": rel(R8, R1),
         "Zcorr_relF_1_vs_8_threads": rel(Z8, Z1),
         "Zcorr_maxabs_over_max_1_vs_8_threads": float(np.abs(Z8 - Z1).max() / np.abs(Z1).max()),
         "Zcorr_relF_f32_vs_f64_inverse": rel(Z1, Z64),
+        "Zcorr_maxabs_over_max_f32_vs_f64_inverse": float(np.abs(Z1 - Z64).max() / np.abs(Z64).max()),
         "cond_cov_median": float(np.median(conds)), "cond_cov_max": float(np.max(conds)),
+    }
+
+
+def main():
+    out = {
+        "reference": "harmonypy v0.2.0 at /root/reference, device='cpu', torch " + torch.__version__,
+        "configs_1": case("69000 cells x 50 PCs, 4 batches, K=30 (BASELINE configs[1])"),
+        # shape of tests/test_parity_gpu.py::test_bench_path_parity_c5_shape: lamb[0] = 0 (harmony.py:150-152) leaves
+        # cov[0,0] = the cluster's mass, and K=200 clusters over 100 cell types leave many clusters nearly empty
+        "configs_4_shape": case("40000 cells x 200 PCs, 32 batches, K=200 (BASELINE configs[4] shape)",
+                                N=40_000, d=200, B=32, K=200, seed=3),
     }
     with open(os.path.join(HERE, "ridge_conditioning.json"), "w") as f:
         json.dump(out, f, indent=1)
