@@ -106,10 +106,8 @@ struct hmx_engine {
     int n_cus = 0;
     int rtz_wgs_per_cu = 4;      // k_rtz2 grid (HMX_RTZ_WGS_PER_CU)
     int round_mode = 1;          // 1: persistent sweep kernel when the shape allows it, 0: one launch per block (HMX_ROUND_MODE=blocks)
-    int sweep_kernel = 1;        // 1: k_sweep (hmx_sweep.hip), 0: k_round + separate R^T.Z pass (HMX_SWEEP=0; comparison runs)
+    int sweep_kernel = 0;        // 0: k_round + R^T.Z pass with the removal sums (faster at C3: DESIGN.md §3), 1: k_sweep (hmx_sweep.hip; HMX_SWEEP=1)
     unsigned spin_limit = 1u << 24;  // polls a grid-wide wait may take (HMX_SPIN_LIMIT; tests shrink it to force the fall-back)
-    bool ynum_valid = false;     // Yacc64 holds sum R (x) Z_cos of the current R and Z_cos (left there by the last k_sweep)
-    DevBuf<float> yslab;         // k_sweep: per-wave slabs of the next round's centroid numerators
     long n_sweep_fallbacks = 0;  // rounds repeated through the per-block path after a wait timed out
     DevBuf<double> xch;
     double *Sold = nullptr, *Yacc64 = nullptr, *Snew = nullptr, *objacc = nullptr, *Sr = nullptr, *Oxr = nullptr;
@@ -330,7 +328,10 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
     e->N = cfg->n_cells; e->d = cfg->n_pcs; e->K = cfg->n_clusters; e->B = cfg->n_batches; e->G = cfg->n_groups;
     e->V = cfg->n_vars; e->nblk = cfg->n_blocks;
     e->Ng = cfg->n_cells_global > 0 ? cfg->n_cells_global : cfg->n_cells;
-    e->dp = sweep_row_floats(e->d) ? sweep_row_floats(e->d) : ((e->d + 15) & ~15);   // rows of 32 / 64 floats (128 / 256 bytes: whole cache lines) feed k_sweep; wide rows: whole 16-column k-steps
+    // rows of 32 / 52 / 64 floats feed the sweep kernels; wide rows: whole 16-column k-steps.  (Rows of 256 bytes for
+    // d = 50 -- whole cache lines -- were measured: k_round 391 us instead of 374, k_rtz2 228 instead of 187 at C3: the
+    // kernels compute on the padding)
+    e->dp = round_row_floats(e->d) ? round_row_floats(e->d) : ((e->d + 15) & ~15);
     e->Kp = (e->K + 3) & ~3;
     e->mt = (e->K + 15) / 16;
     e->K16 = 16 * e->mt;
@@ -417,7 +418,7 @@ void hmx_destroy(hmx_engine* e) {
     e->task_t0.release(); e->task_t1.release();
     e->task_grp.release(); e->gstart.release(); e->chunk_tab.release(); e->run_count.release(); e->run_start.release();
     e->Ogrp.release(); e->Tmass.release(); e->Ohist.release(); e->xch.release(); e->scratch.release();
-    e->global_id.release(); e->yslab.release(); e->sync_words.p = nullptr; e->sync_words.n = 0; e->Sslots.release(); e->km_hn.release(); e->km_sums.release();
+    e->global_id.release(); e->sync_words.p = nullptr; e->sync_words.n = 0; e->Sslots.release(); e->km_hn.release(); e->km_sums.release();
     if (e->sync_host) (void)hipHostFree(e->sync_host);
     comm_release(e);
     peer_release(e);
@@ -524,7 +525,6 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipGetLastError());
     e->uploaded = true;
-    e->ynum_valid = false;
     return HMX_OK;
 }
 
@@ -694,13 +694,11 @@ int hmx_init_cluster(hmx_engine* e, const float* Y0, double obj_out[4]) {
         launch_block_table(ta, e->K16, e->stream);
     }
     e->clustered = true;
-    e->ynum_valid = false;
     return read_objective(e, obj_out);
 }
 
 // Centroid numerators sum_cells R (x) Z_cos (harmony.py:443) of this rank's cells into Yacc64, by a pass over the
-// static list.  Only the first round after Z_cos or R changed outside a sweep needs it: k_sweep leaves the next
-// round's numerators behind.
+// static list (k_rtz2 without the removal sums: those are formed inside k_sweep).
 static int centroid_pass(hmx_engine* e) {
     int rc, nsub, spw;
     rtz_geometry(e->mt, e->ntd, &nsub, &spw);
@@ -736,8 +734,8 @@ static bool sweep_shape_ok(const hmx_engine* e) {
            sweep_lds_bytes(e->K16, e->d, e->G, e->B, e->V, e->nblk) <= 156 * 1024;
 }
 
-// One k-means round on k_sweep (hmx_sweep.hip): [centroids from the numerators the last sweep left, or from a pass
-// over R] -> ONE persistent launch (update_R over all blocks, objective, next round's numerators) -> slab reduction.
+// One k-means round on k_sweep (hmx_sweep.hip): centroids from a pass over R (k_rtz2 without the removal sums) ->
+// ONE persistent launch (update_R over all blocks with the removal sums formed inside, objective).
 // Returns 1 when a grid-wide wait of the kernel timed out on any rank (the caller repeats the round block by block).
 static int round_sweep(hmx_engine* e, int flags, const std::vector<int>& tiles_upper, double obj_out[4],
                        const std::function<int()>& before_sweep) {
@@ -745,34 +743,32 @@ static int round_sweep(hmx_engine* e, int flags, const std::vector<int>& tiles_u
     const size_t GK = (size_t)e->G * e->K16, n_y = (size_t)e->K16 * e->ldy;
     HIP_TRY(hipMemsetAsync(e->objacc, 0, (2 * HMX_OBJ_SLOTS + 2) * sizeof(double), e->stream));
     if (flags & HMX_ROUND_CENTROIDS) {
-        if (!e->ynum_valid && (rc = centroid_pass(e))) return rc;
+        if ((rc = centroid_pass(e))) return rc;
         if ((rc = sum_over_ranks(e, e->Yacc64, n_y))) return rc;
         Timed t(e, F_RTZ_REDUCE);
         launch_y_normalize_d(e->Yacc64, e->Y.p, e->K, e->K16, e->d, e->ldy, e->stream);  // :444
     }
-    e->ynum_valid = false;
     if (before_sweep && (rc = before_sweep())) return rc;   // side-stream work that should run beside the sweep
     // the hand-off tables and the two sync words (carved from the same allocation): one fill
     HIP_TRY(hipMemsetAsync(e->Sslots.p, 0, (GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 1) * sizeof(double), e->stream));
     int max_upper = 0;
     for (int b = 0; b < e->nblk; ++b) max_upper = std::max(max_upper, tiles_upper[b]);
     const bool multi = e->peers_enabled && e->n_ranks > 1;
-    // one workgroup of 4 waves per CU; a few CUs stay free for the second stream (next round's lists) and the
+    // one workgroup of 8 waves per CU; a few CUs stay free for the second stream (next round's lists) and the
     // gateway workgroup.  Smallest grid that reaches the lowest tiles-per-wave count of the largest block.
     const int waves = sweep_waves();
     int wgs_max = std::max(1, e->n_cus - (multi ? 1 : 0) - (e->prefetch_lists ? 12 : 0));
     if (e->round_wgs_cap > 0) wgs_max = std::min(wgs_max, e->round_wgs_cap);
     const int per_wave = std::max(1, (max_upper + waves * wgs_max - 1) / (waves * wgs_max));
     const int wgs = std::max(1, std::min(wgs_max, (max_upper + waves * per_wave - 1) / (waves * per_wave)));
-    if ((rc = e->yslab.reserve((size_t)wgs * waves * sweep_slab_floats(e->mt, e->d)))) return rc;
     {
         Timed t(e, F_ASSIGN_BLOCK);
         SweepArgs sa{};
         sa.Zcos = e->Zcos.p; sa.Y = e->Y.p; sa.sigma = e->sigma.p; sa.R = e->R.p;
-        sa.cells = e->lists[e->cur].cells.p; sa.tile_grp = e->lists[e->cur].tile_grp.p; sa.blk_start = e->lists[e->cur].blk_start.p;
+        sa.cells = e->lists[e->cur].cells.p; sa.blk_start = e->lists[e->cur].blk_start.p; sa.gstart = e->gstart.p;
         sa.O_start = e->Ogrp.p; sa.D_slots = e->Sslots.p; sa.O_out = e->Ogrp.p; sa.T_out = e->Tmass.p;
         sa.obj = e->objacc; sa.group_cols = e->group_cols.p; sa.Pr_b = e->Pr_b.p; sa.theta = e->theta.p;
-        sa.counter = e->sync_words.p; sa.error = e->sync_words.p + 1; sa.yslab = e->yslab.p;
+        sa.counter = e->sync_words.p; sa.error = e->sync_words.p + 1;
         sa.spin_limit = e->spin_limit; sa.n_cells = e->N;
         sa.K = e->K; sa.Kp = e->Kp; sa.K16 = e->K16; sa.ldz = e->dp; sa.ldy = e->ldy; sa.G = e->G; sa.B = e->B; sa.V = e->V;
         sa.nblk = e->nblk; sa.n_ranks = 1;
@@ -784,47 +780,37 @@ static int round_sweep(hmx_engine* e, int flags, const std::vector<int>& tiles_u
 #ifdef HMX_SWEEP_PROF
         static DevBuf<unsigned long long> prof;
         static int prof_rounds = 0;
-        if (prof.reserve((size_t)wgs * e->nblk * 8)) return -1;
+        if (prof.reserve((size_t)wgs * e->nblk * 16)) return -1;
         sa.prof = prof.p;
 #endif
         if (launch_sweep(sa, e->mt, e->d, multi ? wgs + 1 : wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported shape for k_sweep");
 #ifdef HMX_SWEEP_PROF
-        if (++prof_rounds == 25) {   // one round in steady state: phase durations (ticks of s_memtime = 10 ns) over workgroups and blocks
-            std::vector<unsigned long long> h((size_t)wgs * e->nblk * 8);
+        if (++prof_rounds == 25) {   // one round in steady state: phase durations (shader cycles) of wave 0 over workgroups and blocks
+            std::vector<unsigned long long> h((size_t)wgs * e->nblk * 16);
             (void)hipStreamSynchronize(e->stream);
             (void)hipMemcpy(h.data(), prof.p, h.size() * 8, hipMemcpyDeviceToHost);
-            const char* names[7] = {"wait", "apply+table", "finish(first)", "tiles..last finish", "publish", "last phase", "-"};
-            for (int ph = 0; ph < 6; ++ph) {
-                double sum = 0, mx = 0;
+            auto mean = [&](int from, int to) {
+                double sum = 0;
                 for (int w = 0; w < wgs; ++w)
-                    for (int b = 0; b < e->nblk; ++b) {
-                        const double dtk = (double)(h[((size_t)w * e->nblk + b) * 8 + ph + 1] - h[((size_t)w * e->nblk + b) * 8 + ph]);
-                        sum += dtk; mx = std::max(mx, dtk);
-                    }
-                fprintf(stderr, "[k_sweep prof] %-14s mean %.0f ticks  max %.0f\n", names[ph], sum / (wgs * e->nblk), mx);
-            }
+                    for (int b = 0; b < e->nblk; ++b) sum += (double)(h[((size_t)w * e->nblk + b) * 16 + to] - h[((size_t)w * e->nblk + b) * 16 + from]);
+                return sum / (wgs * e->nblk);
+            };
+            fprintf(stderr, "[k_sweep prof] wait %.0f | apply+table %.0f | first tile stream %.0f | other tiles, old-R tail %.0f | publish %.0f | after publish %.0f\n",
+                    mean(0, 1), mean(1, 2), mean(2, 3), mean(3, 4), mean(4, 5), mean(5, 6));
             double tot = 0;
-            for (int w = 0; w < wgs; ++w) tot += (double)(h[((size_t)w * e->nblk + e->nblk - 1) * 8 + 6] - h[(size_t)w * e->nblk * 8]);
-            fprintf(stderr, "[k_sweep prof] whole sweep (block loop) mean %.0f ticks over %d workgroups\n", tot / wgs, wgs);
+            for (int w = 0; w < wgs; ++w) tot += (double)(h[((size_t)w * e->nblk + e->nblk - 1) * 16 + 6] - h[(size_t)w * e->nblk * 16]);
+            fprintf(stderr, "[k_sweep prof] block loop mean %.0f cycles over %d workgroups\n", tot / wgs, wgs);
         }
 #endif
     }
     HIP_TRY(hipMemcpyAsync(e->sync_host, e->sync_words.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
-    {
-        // next round's centroid numerators of this rank's cells (summed over ranks when that round starts)
-        Timed t(e, F_RTZ_REDUCE);
-        HIP_TRY(hipMemsetAsync(e->Yacc64, 0, n_y * sizeof(double), e->stream));
-        launch_rtz2_reduce(e->yslab.p, wgs * waves, e->mt, e->dp, e->K16, e->ldy, e->Yacc64, nullptr, e->stream);
-    }
     // the two objective sums (:399, :402) of this rank's cells; the cross-entropy term was formed from job-wide tables.
     // A rank whose wait timed out poisons its sums with NaN: every rank then sees the failure in the very same all-reduce.
     if (sharded(e) && (rc = sum_over_ranks(e, e->objacc, 2 * HMX_OBJ_SLOTS))) return rc;
     if ((rc = read_objective(e, obj_out))) return rc;
     const bool timed_out = e->sync_host[1] != 0 || obj_out[0] != obj_out[0] || obj_out[1] != obj_out[1];
     e->sync_host[1] = 0;
-    if (timed_out) return 1;
-    e->ynum_valid = true;
-    return 0;
+    return timed_out ? 1 : 0;
 }
 
 // Kernel sequence of one round; the lists (cells, tile groups, block_tile_start) are already in
@@ -850,7 +836,6 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         if ((rc = sum_over_ranks(e, e->Ogrp.p, GK))) return rc;
         side_work_done = true;
     }
-    e->ynum_valid = false;
     // Sold | Yacc64 | Snew | objacc are neighbours in xch: one fill instead of four
     HIP_TRY(hipMemsetAsync(e->Sold, 0, (size_t)((e->objacc + 2 * HMX_OBJ_SLOTS + 2) - e->Sold) * sizeof(double), e->stream));
     const bool legacy_persistent = persistent && !side_work_done && !e->sweep_kernel;
@@ -1256,7 +1241,6 @@ int hmx_moe_correct_ridge(hmx_engine* e) {
     if (!e->clustered) return fail(HMX_ERR_STATE, "no soft assignment yet");
     int rc;
     if ((rc = use_device(e))) return rc;
-    e->ynum_valid = false;   // Z_cos changes: the numerators the last sweep left behind are void
     const size_t GK = (size_t)e->G * e->K16;
     int nsub, spw;
     rtz_geometry(e->mt, e->ntd, &nsub, &spw);
@@ -1384,7 +1368,6 @@ int hmx_set(hmx_engine* e, int which, const void* host_in, size_t bytes) {
     if (bytes != need) return fail(HMX_ERR_ARG, "array %d holds %zu bytes, caller passed %zu", which, need, bytes);
     if (!e->uploaded) return fail(HMX_ERR_STATE, "hmx_upload must come first");
     if ((rc = use_device(e))) return rc;
-    e->ynum_valid = false;
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemset(p, 0, (size_t)rows * ld * elem));
     HIP_TRY(hipMemcpy2D(p, (size_t)ld * elem, host_in, (size_t)cols * elem, (size_t)cols * elem, rows, hipMemcpyHostToDevice));

@@ -20,6 +20,15 @@ __device__ __forceinline__ float wave_sum_q(float v) {
     v += __shfl_xor(v, 32, 64);
     return v;
 }
+// the same sum without the LDS crossbar: v_permlane32_swap / v_permlane16_swap (gfx950) exchange 32-lane halves and
+// 16-lane rows between two registers; with both operands = v the two results add up to v[l] + v[l ^ 32] (then ^ 16)
+// in every lane.  Two VALU instructions per step, no lgkmcnt wait.
+__device__ __forceinline__ float wave_sum_q_swap(float v) {
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 __device__ __forceinline__ float wave_sum_c16(float v) {
     // sum over the 16 lanes that share q
     v += __shfl_xor(v, 1, 64);

@@ -58,16 +58,16 @@ struct RoundArgs {
     int K, Kp, K16, dp, ldy, ldy_lds, G, B, V, nblk;
 };
 
-// One whole k-means round's pass over the cells in one persistent launch (k_sweep, hmx_sweep.hip): update_R over all
-// blocks, objective sums, the next round's centroid numerators, the removal sums of every block.
+// One whole update_R sweep (all blocks) in one persistent launch (k_sweep, hmx_sweep.hip): distance product, reassignment,
+// objective sums, and the removal sums of every block (old R rows through LDS-DMA).
 struct SweepArgs {
     const float* Zcos;       // N x ldz
     const float* Y;          // K16 x ldy unit rows
     const float* sigma;      // K16
     float* R;                // N x Kp, followed by K16 floats the kernel may scribble on
     const int* cells;        // block-major padded list
-    const int* tile_grp;
     const int* blk_start;    // nblk+1 tile offsets (device)
+    const int* gstart;       // G+1: first internal cell of every group
     const double* O_start;   // G x K16: O at the start of the round
     double* D_slots;         // (nblk+1) x HMX_ROUND_SLOTS x G x K16 hand-off tables, zeroed by the caller
     double* O_out;           // G x K16: O after the round
@@ -78,14 +78,13 @@ struct SweepArgs {
     const float* theta;
     unsigned* counter;       // arrivals (zeroed by the caller)
     unsigned* error;         // set to 1 when a wait gave up (zeroed by the caller)
-    float* yslab;            // (workgroups x 4 waves) x sweep_slab_floats(): next round's centroid numerators per wave
     // cells sharded over ranks: the hand-off tables travel through peer boxes (null / 1: single engine)
     double* const* peer_box;   // n_ranks box base pointers (own box included), device array
     double* my_box;
     unsigned long long epoch;  // flag value of hand-off p in this launch = epoch + p + 1
-    unsigned spin_limit;       // polls a wait may take before it gives up
-    unsigned long long* prof;  // HMX_SWEEP_PROF builds: workgroups x nblk x 8 time stamps (or null)
+    unsigned long long* prof;  // HMX_SWEEP_PROF builds: workgroups x nblk x 16 time stamps (or null)
     int64_t n_cells;
+    unsigned spin_limit;       // polls a wait may take before it gives up
     int n_ranks, rank;
     int K, Kp, K16, ldz, ldy, G, B, V, nblk;
 };
@@ -168,7 +167,6 @@ struct OrderArgs {
 
 size_t sweep_lds_bytes(int K16, int d, int G, int B, int V, int nblk);
 int sweep_row_floats(int d);
-int sweep_slab_floats(int mt, int d);
 int sweep_waves();
 int launch_sweep(const SweepArgs& a, int mt, int d, int wgs, hipStream_t s);
 size_t round_lds_bytes(int K16, int dp, int G, int B);

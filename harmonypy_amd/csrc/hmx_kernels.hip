@@ -3048,9 +3048,9 @@ void launch_peer_selftest(double* const* peer_box, double* my_box, int n_ranks, 
     hipLaunchKernelGGL(k_peer_selftest, dim3(1), dim3(256), 0, s, peer_box, my_box, n_ranks, rank, GK, token, result);
 }
 
-// k_round is compiled for Z_cos rows of 32 and 64 floats (the engine's row lengths for d <= 32 / <= 64,
-// whole cache lines) and 1..7 cluster tiles.
-int round_row_floats(int d) { return d <= 32 ? 32 : d <= 64 ? 64 : 0; }
+// k_round is compiled for Z_cos rows of 32, 52 and 64 floats (d <= 32, <= 52, <= 64: the engine pads
+// its rows to the next of these) and 1..7 cluster tiles.
+int round_row_floats(int d) { return d <= 32 ? 32 : d <= 52 ? 52 : d <= 64 ? 64 : 0; }
 
 template <int MT, int KS>
 static void launch_round_t(const RoundArgs& a, int wgs, size_t sm, hipStream_t s) {

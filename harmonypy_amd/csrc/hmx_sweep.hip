@@ -1,45 +1,40 @@
-// hmx_sweep.hip -- k_sweep: one whole update_R sweep (harmony.py:464-513) in ONE persistent launch,
-// and with it everything else a k-means round needs from the N-sized arrays:
+// hmx_sweep.hip -- k_sweep: one whole update_R sweep (harmony.py:464-513) in ONE persistent launch:
 //
 //   * the distance GEMM against the LDS-resident centroids (harmony.py:447; never materialised),
 //   * the diversity-penalised reassignment of every block (:466-468, 495-503) with the block's own
 //     old assignments taken out of O / E first (:491-492) and its new ones put back (:506-507),
 //   * the objective sums (:399, :402; the cross-entropy term :405-411 is closed by workgroup 0),
-//   * the NEXT round's centroid numerators  Y_next = sum_cells R_new[cell] (x) Z_cos[cell]  (:443) --
-//     the freshly written R tile is still in registers in exactly the layout the second MFMA
-//     product wants, so R is never read again for it,
-//   * the removal sums of block b+1 (column sums of the OLD R rows of its cells), formed while
-//     block b is being finished: the only second access to R in a round, and no separate pass.
+//   * the removal sums of block b+1 (column sums of the OLD R rows of its cells), formed while block b
+//     is being finished: the rows travel global -> LDS by DMA, no separate pass and no registers.
 //
-// Per round the N-sized traffic is: Z_cos row (read), R row (read old, write new), 20 bytes of
-// list entries per cell: 4 ld_z + 8 K + 20 bytes (harmony.py's own figure is 4d + 8K + 8).
+// Per sweep the N-sized traffic is: Z_cos row (read), R row (read old, write new), 20 bytes of list
+// entries per cell.
 //
-// Shape of the launch: one workgroup of FOUR waves per CU (one wave per SIMD, 512 registers per
-// lane: the 28 accumulators of the running distance tile, the 28 registers of the tile being
-// finished and the 112 accumulators of Y_next live together), at most #CUs workgroups so that
-// every workgroup is resident.  A wave owns a contiguous chunk of every block's tile list.
+// Shape of the launch: one workgroup of EIGHT waves per CU (two per SIMD, 256 registers per lane), at
+// most #CUs workgroups so that every workgroup is resident.  A wave owns a contiguous chunk of every
+// block's tile list and runs ONE instruction stream per tile s:
+//       finish of tile s (VALU: exp, penalty, renormalise, R rows out)   interleaved piece by piece with
+//       the 91 MFMAs of the distance product of tile s+1                  and the loads of tiles s+2, s+3.
+// The order inside a stream is pinned (TIE_*, below); the two waves of a SIMD run their streams out of
+// step, so one wave's VALU pieces and waits fill the issue slots next to the other's MFMAs.
+// (Measured alternatives, DESIGN.md §3: the same stream with the next round's centroid numerators
+// R_new^T.Z_cos fused in needs 112 more accumulators = 415 registers = one wave per SIMD, which then eats
+// every LDS / memory latency itself: 664-880 us per sweep at C3 against 561 us for sweep + separate pass.)
 //
-// Orientation of the products (hmx_device.h conventions; lane = (c, q), c = lane & 15, q = lane >> 4):
-//   distance:  D[cell][cluster]  A = Z_cos tile (i = cell), B = Y (j = cluster)
-//              -> lane (c, q) holds clusters 16 mt + c of cells 4q + r, r = 0..3  (register r of tile mt)
-//   Y_next:    out[cluster][pc] += sum_cells R[cell][cluster] Z[cell][pc]
-//              A = R_new: register r of lane (c, q) IS A[i = c][k = q] of the k-step that pairs k = q
-//              with cell 4q + r (the reduction runs over cells, any pairing of k-steps and cells is a
-//              sum over the same 16 cells) -- no data movement;  B = the Z tile read back transposed
-//              from a per-wave LDS copy (lane (c, q): Z[cell 4q + r][16 nt + c]).
+// Orientation of the product (hmx_device.h conventions; lane = (c, q), c = lane & 15, q = lane >> 4):
+//   D[cell][cluster]: A = Z_cos tile (i = cell), B = Y (j = cluster)
+//   -> lane (c, q) holds clusters 16 mt + c of cells 4q + r, r = 0..3 (register r of accumulator mt):
+//      the softmax sums run over the 16 lanes of a DPP row, a cell's 4 x MT entries share the lane's
+//      table values, the block sums are 3 additions + one 4-lane reduction per cluster tile.
 //
 // The 20 blocks are sequential through a G x K table only (O).  Hand-off p (p = 0 .. nblk) carries
 //   D[p] = (new sums of block p-1) - (old sums of block p)      per (group, cluster),
 // accumulated by every workgroup into one of four fp64 slot tables with agent-scope atomics, then one
-// arrival counter; O for block b = O_start + D[0] + .. + D[b].  A wave finishes its first tile of a
-// block only after hand-off b is complete; the table-independent work of that tile (distance GEMM of
-// the tile after it, Y_next of the tile before it: 203 MFMAs) is issued before the wait and covers
-// the grid-wide round trip.  Cells sharded over ranks: an extra gateway workgroup pushes the rank's
-// D[p] into every rank's peer box, as k_round did.
+// arrival counter; O for block b = O_start + D[0] + .. + D[b].  Cells sharded over ranks: an extra gateway
+// workgroup pushes the rank's D[p] into every rank's peer box.
 //
-// Waits are bounded (spin_limit); on a time-out a.error is set, the workgroup keeps going with
-// whatever it has (every later wait times out quickly) and the host repeats the round through the
-// per-block path (hmx_capi.cpp).
+// Waits are bounded (spin_limit); on a time-out a.error is set, the workgroup keeps going with whatever
+// it has (every later wait gives up at once) and the host repeats the round through the per-block path.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -50,16 +45,17 @@
 #include "hmx_device.h"
 
 #ifdef HMX_SWEEP_PROF   /* timing experiments only: per-workgroup phase stamps (s_memtime) of wave 0 */
-#define SSTAMP(slot) do { if (tid == 0 && a.prof) a.prof[((size_t)wg * a.nblk + b) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define SSTAMP(slot) do { if (tid == 0 && a.prof) a.prof[((size_t)wg * a.nblk + b) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define SSTAMP(slot) do { } while (0)
 #endif
 #ifndef HMX_SABL
-#define HMX_SABL 0   /* timing experiments only (results become wrong): 1 no old-R loads, 2 no R stores, 4 no MFMA phase, 8 no exp chain */
+#define HMX_SABL 0   /* timing experiments only (results become wrong): 1 no old-R loads, 2 no R stores, 4 no MFMAs */
 #endif
-#define SWEEP_WAVES 4
+#ifndef SWEEP_WAVES
+#define SWEEP_WAVES 8
+#endif
 #define SWEEP_THREADS (64 * SWEEP_WAVES)
-#define SWEEP_RING 2   /* Z tiles a wave keeps in LDS: the one being written (s+1) and the one being read (s) */
 
 namespace {
 
@@ -84,28 +80,20 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define TIE_ACC(acc, x) do { } while (0)
 #else
 #define TIE_VV(x, y) asm("" : "+v"(x), "+v"(y))
-#define TIE_ACC(acc, x) asm("" : "+a"(acc), "+v"(x))
+#define TIE_ACC(acc, x) asm("" : "+v"(acc), "+v"(x))
 #endif
 
 template <int MT, int KS>
 struct SweepShape {
     static constexpr int K16 = 16 * MT;
     static constexpr int NF = KS / 4, NT = KS % 4;
-    static constexpr int LDZ = KS <= 8 ? 32 : 64;        // row of Z_cos in HBM (floats)
-    static constexpr int NTD = LDZ / 16;                 // PC tiles of Y_next
-    static constexpr int LDT = LDZ + 4;                  // row of a wave's LDS tile: (LDT / 4) odd -> conflict-free transposed reads
-    static constexpr int LDY = (KS & 1) ? 4 * KS : 4 * KS + 4;   // row of Y in LDS: (LDY / 4) odd
+    static constexpr int LDZ = 4 * KS;                           // row of Z_cos in HBM (floats): 32, 52 or 64 (the engine's row lengths)
+    static constexpr int LDY = (KS & 1) ? 4 * KS : 4 * KS + 4;   // row of Y in LDS: (LDY / 4) odd -> conflict-free 16-byte reads
+    static constexpr int GSTEPS = NF + (NT > 0 ? 1 : 0);         // k-step groups of the distance product (16 columns each)
 };
 
-template <int MT>
-struct TileIds {
-    int cell16;      // list entry c of the tile (A-operand rows of the distance GEMM)
-    i32x4 cell4;     // list entries 4q .. 4q+3 (the cells whose assignments this lane holds)
-    int grp;
-    bool valid;      // wave-uniform
-};
 template <int KS>
-struct ZRegs {
+struct ZRegs {   // a cell's Z_cos row as this lane's A fragments: 16-byte pieces q, q+4, .. + one float per tail k-step
     static constexpr int NF = KS / 4, NT = KS % 4;
     f32x4 zp[NF > 0 ? NF : 1];
     float zt[NT > 0 ? NT : 1];
@@ -113,23 +101,49 @@ struct ZRegs {
 template <int MT>
 struct ArgTile {
     f32x4 arg[MT];   // [mt][r]: -dist / sigma of cluster 16 mt + c, cell 4q + r
-    i32x4 cell4;
+    i32x4 cell4;     // list entries 4q .. 4q+3 (the cells whose assignments this lane holds)
     int grp;
-    int slot;        // LDS ring slot of the tile's Z rows
-    bool valid;
 };
+template <int MT>
+struct FinishTables { float pw[MT], lp[MT], sg[MT]; };
+// working registers of one cell's finish when it is cut into pieces
+template <int MT>
+struct FinishRow {
+    float arg[MT], th[MT], tl[MT], ex[MT], tt[MT], ts[MT];
+    float e1, us, a1, a2, a3, den, scl, lden, rc, pin;
+    int row_id;
+};
+// the register piece k of a cell's finish starts from / ends in (what the order pins hold on to): 5 pieces per cluster
+// tile, then the closing pieces (row sums, scale, objective terms, row address, one store per cluster tile)
+template <int MT>
+__device__ __forceinline__ float& fin_in(FinishRow<MT>& W, int k) {
+    if (k < 5 * MT) {
+        const int mt = k / 5, p = k % 5;
+        return p == 0 ? W.pin : p == 1 ? W.th[mt] : p == 2 ? W.ex[mt] : p == 3 ? W.tt[mt] : W.ts[mt];
+    }
+    const int u = k - 5 * MT;
+    return u < 4 ? W.e1 : u == 4 ? W.us : u == 5 ? W.rc : u == 6 ? W.scl : u == 7 ? W.lden : u == 8 ? W.scl : W.tt[u - 9 < MT ? u - 9 : 0];
+}
+template <int MT>
+__device__ __forceinline__ float& fin_out(FinishRow<MT>& W, int k) {
+    if (k < 5 * MT) {
+        const int mt = k / 5, p = k % 5;
+        return p == 0 ? W.tl[mt] : p == 1 ? W.ex[mt] : p == 2 ? W.ts[mt] : p == 3 ? W.a2 : W.a3;
+    }
+    const int u = k - 5 * MT;
+    return u < 4 ? W.us : u == 4 ? W.rc : u == 5 ? W.lden : u == 6 ? W.a1 : u == 7 ? W.a2 : u == 8 ? W.scl : W.tt[u - 9 < MT ? u - 9 : 0];
+}
 
 }  // namespace
 
 template <int MT, int KS>
 __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(SweepArgs a) {
     using S = SweepShape<MT, KS>;
-    constexpr int K16 = S::K16, NF = S::NF, NT = S::NT, LDZ = S::LDZ, NTD = S::NTD, LDT = S::LDT, LDY = S::LDY;
+    constexpr int K16 = S::K16, NF = S::NF, NT = S::NT, LDZ = S::LDZ, LDY = S::LDY, GSTEPS = S::GSTEPS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int GK = a.G * K16;
     float* Ys = reinterpret_cast<float*>(smem);                           // K16 x LDY
-    float* ztile = Ys + (size_t)K16 * LDY;                                // waves x RING x 16 x LDT
-    float* remtile = ztile + (size_t)SWEEP_WAVES * SWEEP_RING * 16 * LDT; // waves x (4 MT) x 64: landing zone of the old R rows (LDS-DMA)
+    float* remtile = Ys + (size_t)K16 * LDY;                              // waves x (4 MT) x 64: landing zone of the old R rows (LDS-DMA)
     float* sig = remtile + (size_t)SWEEP_WAVES * 4 * MT * 64;             // K16
     float* nis = sig + K16;                                               // K16: -1/sigma (-60 for pads)
     float* rpT = nis + K16;                                               // G x K16
@@ -142,7 +156,8 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(SweepArgs a) {
     float* prb = reinterpret_cast<float*>(objw + 2 * SWEEP_WAVES);        // B
     float* tht = prb + a.B;                                               // B
     int* gcol = reinterpret_cast<int*>(tht + a.B);                        // G x V
-    int* chunk_j0 = gcol + a.G * a.V;                                     // waves x (nblk + 1): first tile of the wave's chunk
+    int* gst = gcol + a.G * a.V;                                          // G + 1: first cell of every group (cells are stored group-sorted)
+    int* chunk_j0 = gst + a.G + 1;                                        // waves x (nblk + 1): first tile of the wave's chunk
     int* chunk_n = chunk_j0 + SWEEP_WAVES * (a.nblk + 1);                 // waves x (nblk + 1): tiles in the chunk
 
     const int tid = threadIdx.x;
@@ -189,6 +204,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(SweepArgs a) {
         tht[i] = a.theta[i];
     }
     for (int i = tid; i < a.G * a.V; i += SWEEP_THREADS) gcol[i] = a.group_cols[i];
+    for (int i = tid; i <= a.G; i += SWEEP_THREADS) gst[i] = a.gstart[i];
     for (int i = tid; i < K16; i += SWEEP_THREADS) {
         const float sgm = (i < a.K) ? a.sigma[i] : 0.f;
         sig[i] = sgm;
@@ -202,7 +218,6 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(SweepArgs a) {
         const int row = i / KS, c4 = i - row * KS;
         st4(Ys + (size_t)row * LDY + 4 * c4, ld4(a.Y + (size_t)row * a.ldy + 4 * c4));
     }
-    for (int i = tid; i < SWEEP_WAVES * SWEEP_RING * 16 * LDT; i += SWEEP_THREADS) ztile[i] = 0.f;   // padding columns stay zero
     {
         // this wave's chunk of every block's tile list: balanced, contiguous (wave w of nw: the first
         // `extra` waves take one tile more); entry nblk is an empty sentinel
@@ -225,130 +240,47 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(SweepArgs a) {
     const int* my_n = chunk_n + wv * (a.nblk + 1);
     auto chunk_first = [&](int b) { return __builtin_amdgcn_readfirstlane(my_j0[b]); };
     auto chunk_count = [&](int b) { return __builtin_amdgcn_readfirstlane(my_n[b]); };
-    float* zt_wave = ztile + (size_t)wv * SWEEP_RING * 16 * LDT;
+
+    // group of a tile = group of its first list entry (never padding), found in the table of first cells: no memory
+    // access that could miss (reading the tile_group list: one vector load + vmcnt(0) + readfirstlane per tile, the wait
+    // also draining the row stores just issued -- 5k cycles -- or one scalar load, ~1k cycles on a miss)
+    const int gst_lane = (lane + 1 < a.G) ? gst[lane + 1] : 0x7fffffff;   // lane l: first cell of group l + 1 (G <= 64)
+    auto group_of = [&](int first_cell) {
+        const int cellu = __builtin_amdgcn_readfirstlane(first_cell);
+        return (int)__popcll(__ballot(cellu >= gst_lane));
+    };
 
     // ---- building blocks ------------------------------------------------------------------------------
-    auto load_ids = [&](int j, bool valid) {
-        TileIds<MT> t;
-        t.valid = valid;
-        t.cell16 = valid ? a.cells[(size_t)j * 16 + c] : -1;
-        t.cell4 = valid ? *reinterpret_cast<const i32x4*>(a.cells + (size_t)j * 16 + 4 * q) : (i32x4){-1, -1, -1, -1};
-        t.grp = valid ? a.tile_grp[j] : 0;
-        return t;
-    };
-    // rows of dead list entries (padding) read cell 0: finite values that meet a zero factor later
-    auto issue_z = [&](const TileIds<MT>& t, ZRegs<KS>& Z) {
-        const float* zr = a.Zcos + (size_t)(t.cell16 >= 0 ? t.cell16 : 0) * LDZ;
+    auto cell_of = [&](int j) { return j >= 0 ? a.cells[(size_t)j * 16 + c] : -1; };
+    // rows of dead list entries (padding, or no tile at all) read cell 0: finite values that meet a zero factor later
+    auto row_of = [&](int cell16) { return a.Zcos + (size_t)(cell16 >= 0 ? cell16 : 0) * LDZ; };
+    auto issue_rows = [&](const float* zr, ZRegs<KS>& Z) {
 #pragma unroll
         for (int j = 0; j < NF; ++j) Z.zp[j] = ld4(zr + 16 * j + 4 * q);
 #pragma unroll
         for (int s = 0; s < NT; ++s) Z.zt[s] = zr[16 * NF + 4 * s + q];
     };
-    // distance GEMM of one tile (harmony.py:447) -> exponent arguments (:466); the tile's rows also go to
-    // the wave's LDS ring for the transposed read of the Y_next product
-    // (split into steps so that the fused path below can interleave it with the other two products)
-    constexpr int GSTEPS = NF + (NT > 0 ? 1 : 0);
-    auto gemm_begin = [&](const ZRegs<KS>& Z, int slot, ArgTile<MT>& T) __attribute__((always_inline)) {
-        float* zt = zt_wave + (size_t)slot * 16 * LDT + (size_t)c * LDT;
-#pragma unroll
-        for (int j = 0; j < NF; ++j) st4(zt + 16 * j + 4 * q, Z.zp[j]);
-#pragma unroll
-        for (int s = 0; s < NT; ++s) zt[16 * NF + 4 * s + q] = Z.zt[s];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) T.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        T.slot = slot;
-    };
-    // centroid fragments of k-step group j (B operand): 16 bytes per cluster tile, or one float for a tail k-step
-    struct YFrag { f32x4 v[MT]; };
-    auto load_ya = [&](int j) __attribute__((always_inline)) {
-        YFrag y;
-        if (j < NF) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) y.v[mt] = ld4(Ys + (size_t)(16 * mt + c) * LDY + 16 * j + 4 * q);
-        } else {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                y.v[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < NT; ++s) y.v[mt][s] = Ys[(size_t)(16 * mt + c) * LDY + 16 * NF + 4 * s + q];
-            }
-        }
-        return y;
-    };
-    // the MFMAs of group j: consecutive instructions go to different accumulators (no dependent back-to-back pairs)
-    auto gemm_mfma = [&](const ZRegs<KS>& Z, ArgTile<MT>& T, const YFrag& y, int j) __attribute__((always_inline)) {
-        if (j < NF) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) T.arg[mt] = MFMA16(Z.zp[j < NF ? j : 0][i], y.v[mt][i], T.arg[mt]);
-        } else if (j == NF && NT > 0) {
-#pragma unroll
-            for (int s = 0; s < NT; ++s)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) T.arg[mt] = MFMA16(Z.zt[s], y.v[mt][s], T.arg[mt]);
-        }
-    };
-    auto gemm_step = [&](const ZRegs<KS>& Z, ArgTile<MT>& T, int j) __attribute__((always_inline)) {
-        const YFrag y = load_ya(j);
-        gemm_mfma(Z, T, y, j);
-    };
+    // dist = 2 (1 - Y.Z) (:447), arg = -dist / sigma (:466)
     auto gemm_end = [&](ArgTile<MT>& T) __attribute__((always_inline)) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const float ni2 = 2.f * nis[16 * mt + c];
             const f32x4 one = (f32x4){1.f, 1.f, 1.f, 1.f};
-            T.arg[mt] = (one - T.arg[mt]) * ni2;                  // dist = 2 (1 - Y.Z) (:447), arg = -dist / sigma (:466)
-        }
-    };
-    auto gemm_tile = [&](const ZRegs<KS>& Z, int slot, ArgTile<MT>& T) __attribute__((always_inline)) {
-        gemm_begin(Z, slot, T);
-#pragma unroll
-        for (int j = 0; j < GSTEPS; ++j) {
-            gemm_step(Z, T, j);
-            __builtin_amdgcn_sched_barrier(0);   // keep the centroid fragments of one column block live at a time
-        }
-        gemm_end(T);
-    };
-    // next round's centroid numerators (harmony.py:443): out[cluster][pc] += R_new^T . Z_cos over the tile
-    f32x4 yacc[MT][NTD];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NTD; ++nt) yacc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    struct ZFrag { float v[NTD]; };
-    auto load_zb = [&](int slot, int r) __attribute__((always_inline)) {
-        const float* zt = zt_wave + (size_t)slot * 16 * LDT + (size_t)(4 * q + r) * LDT + c;
-        ZFrag z;
-#pragma unroll
-        for (int nt = 0; nt < NTD; ++nt) z.v[nt] = zt[16 * nt];
-        return z;
-    };
-    auto ynext_mfma = [&](const f32x4 (&Rn)[MT], const ZFrag& z, int r) __attribute__((always_inline)) {
-#pragma unroll
-        for (int nt = 0; nt < NTD; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) yacc[mt][nt] = MFMA16(Rn[mt][r], z.v[nt], yacc[mt][nt]);
-    };
-    auto ynext_step = [&](const f32x4 (&Rn)[MT], int slot, int r) __attribute__((always_inline)) {
-        const ZFrag z = load_zb(slot, r);
-        ynext_mfma(Rn, z, r);
-    };
-    auto ynext_tile = [&](const f32x4 (&Rn)[MT], int slot) __attribute__((always_inline)) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            ynext_step(Rn, slot, r);
-            __builtin_amdgcn_sched_barrier(0);
+            T.arg[mt] = (one - T.arg[mt]) * ni2;
         }
     };
     // per-(group, cluster) sums a wave carries over the tiles of one group run; lane (c, q) holds the
     // share of its four cells.  flush: reduce over q, one fp64 LDS atomic per (group, cluster).
     auto flush_run = [&](float (&sum)[MT], int grp, double sign) {
+        float v[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const float v = wave_sum_q(sum[mt]);
-            if (q == 0 && v != 0.f) atomicAdd(&Sd[(size_t)grp * K16 + 16 * mt + c], sign * (double)v);
+            v[mt] = wave_sum_q_swap(sum[mt]);
             sum[mt] = 0.f;
+        }
+        if (q == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) atomicAdd(&Sd[(size_t)grp * K16 + 16 * mt + c], sign * (double)v[mt]);
         }
     };
     float gsum[MT], rsum[MT];
@@ -357,16 +289,16 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(SweepArgs a) {
     for (int mt = 0; mt < MT; ++mt) gsum[mt] = rsum[mt] = 0.f;
     double km_acc = 0.0, ent_acc = 0.0;
 
-    // table-dependent half of a tile: exp, penalty, renormalisation, R rows, block sums, objective terms.
+    // ---- table-dependent half of a tile, cut into pieces of about three VALU instructions ----------------
     // With ex = exp(arg), e1 = sum ex (:467-468), t = ex * ratio^theta (:500) and U = sum t:
     //   R = (t / e1) / max(U / e1, 1e-8) = t / max(U, 1e-8 e1)                         (:501-503)
     //   sum R dist          = -scl sum t sigma arg,                  scl = 1 / max(U, 1e-8 e1)   (:399, dist = -arg sigma)
     //   sum sigma R log R   =  scl [sum t sigma arg + sum t sigma log(ratio^theta) - log(max(U, 1e-8 e1)) sum t sigma]   (:402)
-    // ONE exp per entry; t replaces arg in place.
+    // ONE exp per entry.  Cell r of the lane: 5 pieces per cluster tile, then FIN_TAIL closing pieces.
     const int trash_row = (int)a.n_cells;                   // K16 floats behind the last row
     const bool last_col_ok = 16 * (MT - 1) + c < a.Kp;      // cluster tiles before the last lie below K <= Kp entirely
-    struct FinishTables { float pw[MT], lp[MT], sg[MT]; };
-    auto finish_begin = [&](const ArgTile<MT>& T, FinishTables& F) __attribute__((always_inline)) {
+    constexpr int FIN_TAIL = 9 + MT, NPART = 5 * MT, NVALU = NPART + FIN_TAIL;
+    auto finish_begin = [&](const ArgTile<MT>& T, FinishTables<MT>& F) __attribute__((always_inline)) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             F.pw[mt] = rpT[(size_t)T.grp * K16 + 16 * mt + c];
@@ -374,57 +306,18 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(SweepArgs a) {
             F.sg[mt] = sig[16 * mt + c];
         }
     };
-    auto finish_step = [&](const ArgTile<MT>& T, const FinishTables& F, f32x4 (&Rn)[MT], int r) __attribute__((always_inline)) {
-        float e1 = 0.f, us = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const float arg = T.arg[mt][r];
-            const float ex = fast_exp_finite(arg);           // :467
-            e1 += ex;
-            const float t = ex * F.pw[mt];                   // :500 (the 1/e1 of :468 cancels, see above)
-            const float ts = t * F.sg[mt];
-            us += t;
-            a1 = fmaf(ts, arg, a1);
-            a2 = fmaf(ts, F.lp[mt], a2);
-            a3 += ts;
-            Rn[mt][r] = t;
-        }
-        e1 = row16_sum(e1);                                  // column sum of :468
-        us = row16_sum(us);
-        const float den = fmaxf(us, 1e-8f * e1);             // e1 * max(sum R_new, 1e-8)   (:501-502)
-        const int cell = T.cell4[r];
-        const float scl = (cell >= 0) ? __builtin_amdgcn_rcpf(den) : 0.f;   // v_rcp_f32 (1 ulp); dead entries (list padding) contribute exact zeros
-        km_acc -= (double)(scl * a1);
-        const float lden = __builtin_amdgcn_logf(den) * 0.693147182464599609375f;   // den >= 1e-26: a normal number
-        ent_acc += (double)(scl * (a1 + a2 - lden * a3));
-        // unconditional stores: dead entries and the columns beyond Kp of the last cluster tile go to a trash row
-        // behind R (a predicated store would cut the basic block the scheduler interleaves MFMAs and VALU in)
-        const int row_id = (cell >= 0) ? cell : trash_row;
-        float* row = a.R + (size_t)row_id * a.Kp;
-        float* row_last = a.R + (size_t)(last_col_ok ? row_id : trash_row) * a.Kp;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const float rv = Rn[mt][r] * scl;                // :503
-            Rn[mt][r] = rv;
-            if (!(HMX_SABL & 2)) (mt < MT - 1 ? row : row_last)[16 * mt + c] = rv;   // :509 (in place: the order is a list, not a copy)
-        }
-    };
-    // The same finish cut into pieces of about three VALU instructions, for the fused tile below where every piece is
-    // pinned behind one MFMA.  Cell r of the lane: 5 pieces per cluster tile, then FIN_TAIL closing pieces.
-    struct FinishRow { float arg[MT], th[MT], tl[MT], ex[MT], tt[MT], ts[MT]; float e1, us, a1, a2, a3, den, scl, lden, rc, pin; int row_id; };
-    constexpr int FIN_TAIL = 9 + MT;
-    auto fin_part = [&](ArgTile<MT>& T, const FinishTables& F, FinishRow& W, int r, int mt, int p) __attribute__((always_inline)) {
+    auto fin_part = [&](const ArgTile<MT>& T, const FinishTables<MT>& F, FinishRow<MT>& W, int r, int mt, int p) __attribute__((always_inline)) {
         const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f;
         if (p == 0) {
             W.arg[mt] = T.arg[mt][r];
-            W.th[mt] = W.arg[mt] * L2E_HI;
+            W.th[mt] = W.arg[mt] * L2E_HI;                                      // fast_exp_finite, spread over two pieces
             W.tl[mt] = fmaf(W.arg[mt], L2E_LO, fmaf(W.arg[mt], L2E_HI, -W.th[mt]));
         } else if (p == 1) {
             const float pp = __builtin_amdgcn_exp2f(W.th[mt]);
             W.ex[mt] = fmaf(pp, W.tl[mt] * 0.693147182464599609375f, pp);      // :467
         } else if (p == 2) {
             W.e1 += W.ex[mt];
-            W.tt[mt] = W.ex[mt] * F.pw[mt];                                     // :500
+            W.tt[mt] = W.ex[mt] * F.pw[mt];                                     // :500 (the 1/e1 of :468 cancels, see above)
             W.ts[mt] = W.tt[mt] * F.sg[mt];
         } else if (p == 3) {
             W.us += W.tt[mt];
@@ -434,17 +327,17 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(SweepArgs a) {
             W.a3 += W.ts[mt];
         }
     };
-    auto fin_tail = [&](const ArgTile<MT>& T, FinishRow& W, f32x4 (&Rn)[MT], int r, int u) __attribute__((always_inline)) {
+    auto fin_tail = [&](const ArgTile<MT>& T, FinishRow<MT>& W, float (&bsum)[MT], int r, int u) __attribute__((always_inline)) {
         if (u == 0) { W.e1 += DPP_F(W.e1, 0xB1); W.us += DPP_F(W.us, 0xB1); }            // row16_sum, one step per piece
         else if (u == 1) { W.e1 += DPP_F(W.e1, 0x4E); W.us += DPP_F(W.us, 0x4E); }
         else if (u == 2) { W.e1 += DPP_F(W.e1, 0x141); W.us += DPP_F(W.us, 0x141); }
-        else if (u == 3) { W.e1 += DPP_F(W.e1, 0x140); W.us += DPP_F(W.us, 0x140); }
+        else if (u == 3) { W.e1 += DPP_F(W.e1, 0x140); W.us += DPP_F(W.us, 0x140); }    // column sums of :468 and :501
         else if (u == 4) {
-            W.den = fmaxf(W.us, 1e-8f * W.e1);                                  // :501-502
-            W.rc = __builtin_amdgcn_rcpf(W.den);
+            W.den = fmaxf(W.us, 1e-8f * W.e1);                                  // e1 * max(sum R_new, 1e-8)   (:501-502)
+            W.rc = __builtin_amdgcn_rcpf(W.den);                                // v_rcp_f32 (1 ulp)
         } else if (u == 5) {
-            W.scl = (T.cell4[r] >= 0) ? W.rc : 0.f;
-            W.lden = __builtin_amdgcn_logf(W.den) * 0.693147182464599609375f;
+            W.scl = (T.cell4[r] >= 0) ? W.rc : 0.f;                             // dead entries (list padding) contribute exact zeros
+            W.lden = __builtin_amdgcn_logf(W.den) * 0.693147182464599609375f;   // den >= 1e-26: a normal number
         } else if (u == 6) {
             km_acc -= (double)(W.scl * W.a1);
         } else if (u == 7) {
@@ -452,74 +345,43 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(SweepArgs a) {
         } else if (u == 8) {
             W.row_id = (T.cell4[r] >= 0) ? T.cell4[r] : trash_row;
         } else {
+            // unconditional stores: dead entries and the columns beyond Kp of the last cluster tile go to a trash row
+            // behind R (a predicated store would cut the stream into exec-masked blocks)
             const int mt = u - 9;
             const float rv = W.tt[mt] * W.scl;                                  // :503
             W.tt[mt] = rv;
-            Rn[mt][r] = rv;
+            bsum[mt] += rv;                                                     // :506-507
             const int rid = (mt < MT - 1 || last_col_ok) ? W.row_id : trash_row;
-            a.R[(size_t)rid * a.Kp + 16 * mt + c] = rv;                         // :509
+            if (!(HMX_SABL & 2)) a.R[(size_t)rid * a.Kp + 16 * mt + c] = rv;    // :509 (in place: the order is a list, not a copy)
         }
     };
-    // the register a piece starts from / ends in (what the order pins hold on to)
-    auto fin_in = [&](ArgTile<MT>& T, FinishRow& W, int r, int k) -> float& {
-        if (k < 5 * MT) {
-            const int mt = k / 5, p = k % 5;
-            return p == 0 ? W.pin : p == 1 ? W.th[mt] : p == 2 ? W.ex[mt] : p == 3 ? W.tt[mt] : W.ts[mt];
-        }
-        const int u = k - 5 * MT;
-        return u < 4 ? W.e1 : u == 4 ? W.us : u == 5 ? W.rc : u == 6 ? W.scl : u == 7 ? W.lden : u == 8 ? W.scl : W.tt[u - 9 < MT ? u - 9 : 0];
-    };
-    auto fin_out = [&](FinishRow& W, int k) -> float& {
-        if (k < 5 * MT) {
-            const int mt = k / 5, p = k % 5;
-            return p == 0 ? W.tl[mt] : p == 1 ? W.ex[mt] : p == 2 ? W.ts[mt] : p == 3 ? W.a2 : W.a3;
-        }
-        const int u = k - 5 * MT;
-        return u < 4 ? W.us : u == 4 ? W.rc : u == 5 ? W.lden : u == 6 ? W.a1 : u == 7 ? W.a2 : u == 8 ? W.scl : W.tt[u - 9 < MT ? u - 9 : 0];
-    };
-    auto finish_end = [&](const ArgTile<MT>& T, const f32x4 (&Rn)[MT]) __attribute__((always_inline)) {
-        if (T.grp != gsum_grp) {
-            if (gsum_grp >= 0) flush_run(gsum, gsum_grp, 1.0);
-            gsum_grp = T.grp;
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) gsum[mt] += (Rn[mt][0] + Rn[mt][1]) + (Rn[mt][2] + Rn[mt][3]);   // :506-507
-    };
-    auto finish_tile = [&](const ArgTile<MT>& T, f32x4 (&Rn)[MT]) __attribute__((always_inline)) {
-        FinishTables F;
-        finish_begin(T, F);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            finish_step(T, F, Rn, r);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        finish_end(T, Rn);
-    };
-    // old assignments of a tile of the NEXT block: column sums only (:491-492)
-    struct RemIds { int cell16; i32x4 cell4; int grp; bool valid; };
+
+    // ---- old assignments of a tile of the NEXT block: column sums only (:491-492) ---------------------------
+    struct RemIds { int cell16; i32x4 cell4; bool valid; };
     auto rem_ids = [&](int j, bool valid) {
         RemIds t;
         t.valid = valid;
         t.cell16 = valid ? a.cells[(size_t)j * 16 + c] : -1;
         t.cell4 = valid ? *reinterpret_cast<const i32x4*>(a.cells + (size_t)j * 16 + 4 * q) : (i32x4){-1, -1, -1, -1};
-        t.grp = valid ? a.tile_grp[j] : 0;
         return t;
     };
     // The tile's 16 rows travel global -> LDS directly (global_load_lds: no destination registers -- held in VGPRs across
-    // the MFMA phase they were spilled one by one, each spill waiting for its load).  Instruction k moves cluster tile k
-    // (16 columns = 64 bytes) of all 16 rows: lane l brings the 16-byte piece l % 4 of row l / 4 and it lands at byte
-    // 16 (64 k + l) of the wave's landing zone, i.e. the zone is laid out [cluster tile][row][16 columns].  One row
-    // address per lane serves all instructions; pieces beyond Kp re-read the row's first piece (masked out when the
-    // sums are formed).
+    // a tile they are spilled one by one, each spill waiting for its load).  Instruction k moves cluster tile k (16 columns
+    // = 64 bytes) of all 16 rows: lane l brings the 16-byte piece l % 4 of row l / 4 and it lands at byte 16 (64 k + l) of
+    // the wave's landing zone, i.e. the zone is laid out [cluster tile][row][16 columns].  Pieces beyond Kp re-read the
+    // row's first piece (masked out when the sums are formed).  No instruction offset: it would move the LDS address too.
     float* rem_wave = remtile + (size_t)wv * 4 * MT * 64;
     const bool last_piece_ok = 16 * (MT - 1) + 4 * (lane & 3) < a.Kp;
-    auto rem_issue = [&](const RemIds& t) {
-        if (HMX_SABL & 1) return;
+    // lane l's source address: piece l % 4 of the row of list entry l / 4 (formed when the ids have landed for certain,
+    // behind a full wait, so that no wait for them stands between a tile's row stores and the next loads)
+    auto rem_source = [&](const RemIds& t) {
         const int cell = __shfl(t.cell16, lane >> 2, 64);
-        const float* src = a.R + (size_t)(cell >= 0 ? cell : 0) * a.Kp + 4 * (lane & 3);
+        return a.R + (size_t)(cell >= 0 ? cell : 0) * a.Kp + 4 * (lane & 3);
+    };
+    auto rem_issue = [&](const float* src) {
+        if (HMX_SABL & 1) return;
         static_for<MT>([&](auto kc) __attribute__((always_inline)) {
             constexpr int k = decltype(kc)::value;
-            // (no instruction offset: it would move the LDS address along with the global one)
             const float* sk = (k < MT - 1 || last_piece_ok) ? src + 16 * k : src;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sk,
                                              (__attribute__((address_space(3))) void*)(rem_wave + 256 * k), 16, 0, 0);
@@ -527,26 +389,33 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(SweepArgs a) {
     };
     auto rem_consume = [&](const RemIds& t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the rows have landed (nothing else orders an LDS read behind an LDS-DMA)
-        if (t.grp != rsum_grp) {
+        const int grp = group_of(t.cell4[0]);
+        if (grp != rsum_grp) {
             if (rsum_grp >= 0) flush_run(rsum, rsum_grp, -1.0);
-            rsum_grp = t.grp;
+            rsum_grp = grp;
         }
+        // all 4 MT reads first, unconditionally (written as a select they become 28 exec-masked read + wait pairs)
+        float v[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[mt][r] = (HMX_SABL & 1) ? 0.f : rem_wave[(16 * mt + 4 * q + r) * 16 + c];
+                asm("" : "+v"(v[mt][r]));
+            }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const bool col_ok = 16 * mt + c < a.K;
             float s = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = (HMX_SABL & 1) ? 0.f : rem_wave[(16 * mt + 4 * q + r) * 16 + c];
-                s += (col_ok && t.cell4[r] >= 0) ? v : 0.f;
-            }
+            for (int r = 0; r < 4; ++r) s += (col_ok && t.cell4[r] >= 0) ? v[mt][r] : 0.f;
             rsum[mt] += s;
         }
     };
 
     // ---- hand-off machinery ----------------------------------------------------------------------------
     bool failed = false;
-    // add this workgroup's share of hand-off p to the slot tables, then arrive (all four waves call this)
+    // add this workgroup's share of hand-off p to the slot tables, then arrive (all waves call this)
     auto publish = [&](int p) {
         if (gsum_grp >= 0) flush_run(gsum, gsum_grp, 1.0);
         if (rsum_grp >= 0) flush_run(rsum, rsum_grp, -1.0);
@@ -657,64 +526,57 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(SweepArgs a) {
         wg_barrier_lds();
     };
 
-    // ---- the wave's tile stream: iterator three tiles ahead of the tile being finished ------------------
+    // ---- the wave's tile stream: an iterator running ahead of the tile being finished ---------------------
     int la_b = 0, la_i = 0, la_n = chunk_count(0), la_j0 = chunk_first(0);
-    auto la_settle = [&]() {   // skip blocks in which this wave has no (more) tiles
+    auto la_next = [&]() {   // next tile index of this wave's stream (blocks in which it has no tile are skipped), or -1
         while (la_b < a.nblk && la_i >= la_n) {
             ++la_b;
             la_i = 0;
             la_n = chunk_count(la_b);   // entry nblk: 0
             la_j0 = chunk_first(la_b);
         }
-    };
-    auto la_next_ids = [&]() {
-        la_settle();
-        const bool valid = la_b < a.nblk;
-        TileIds<MT> t = load_ids(valid ? la_j0 + la_i : 0, valid);
+        const int j = la_b < a.nblk ? la_j0 + la_i : -1;
         ++la_i;
-        return t;
+        return j;
     };
 
-    // ---- MFMA phase of a tile: distance product of the NEXT tile and Y_next of the tile just finished, as one stream.
-    // Slot order inside each of 4 groups of 8 MT slots: even slots = distance product (cluster tile idx / 4, k-step idx % 4
-    // of the group's 16 columns; a tail group: one k-step per cluster tile), odd slots = Y_next (PC tile idx / MT, cluster
-    // tile idx % MT): two MFMAs on one accumulator are always >= 2 slots apart.  An operand fragment (16 bytes of Y per
-    // cluster tile, one float of the Z tile per PC tile) serves consecutive slots and is read from LDS one fragment ahead
-    // of its first use.  The order is pinned with empty-asm register ties (TIE_*): with one wave per SIMD nobody else
-    // fills the pipe while this wave waits for an operand, and the compiler's own schedule (read, wait, four dependent
-    // MFMAs, read, ...) ran at a quarter of the MFMA rate.
-    auto mfma_phase = [&](const ZRegs<KS>& Zr, ArgTile<MT>& Tn, int slot_n, const f32x4 (&Rp)[MT], int slot_p) __attribute__((always_inline)) {
-        gemm_begin(Zr, slot_n, Tn);          // the rows go to the LDS ring; the A fragments below are read back from there
-        // LDS addresses = one lane-dependent base per operand kind + a compile-time offset (the instruction's immediate);
-        // a pin holds on to a COPY of the base: pinning the sum would keep every one of the ~40 sums in a register
+    // ---- one tile: finish of tile s || distance product of tile s+1 || loads of what comes after ------------------
+    // MFMA slots: group g (16 columns of the rows, or the tail k-steps) x cluster tile x k-step, cluster-tile-major, so that
+    // a centroid fragment (16 bytes of Y per cluster tile and group) serves consecutive MFMAs and is read from LDS one
+    // fragment ahead; an MFMA sits in every other slot of a group (two MFMAs on one accumulator are >= 2 slots apart),
+    // every slot carries one piece of the finish of cell g.  `side(S)`: hook for the loads, behind the MFMA of slot S.
+    constexpr int SLOTS = (2 * 4 * MT > NVALU) ? 2 * 4 * MT : NVALU;   // slots of a group
+    auto tile_stream = [&](const ArgTile<MT>& Tf, const FinishTables<MT>& F, float (&bsum)[MT], const ZRegs<KS>& Zr, ArgTile<MT>& Tn,
+                           auto&& side) __attribute__((always_inline)) {
         const int ya_base = c * LDY + 4 * q, yat_base = c * LDY + q;
-        const int zn_base = (slot_n * 16 + c) * LDT + 4 * q, znt_base = (slot_n * 16 + c) * LDT + q;
-        const int z_base = (slot_p * 16 + 4 * q) * LDT + c;
-        f32x4 ya_cur = ld4(Ys + ya_base), ya_nxt = ya_cur;
-        f32x4 za_cur = (f32x4){0.f, 0.f, 0.f, 0.f}, za_nxt;
-        if constexpr (NF > 0) za_cur = ld4(zt_wave + zn_base);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) Tn.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 ya_cur = (f32x4){0.f, 0.f, 0.f, 0.f}, ya_nxt;
+        if constexpr (NF > 0) ya_cur = ld4(Ys + ya_base);
         else
-            static_for<NT>([&](auto sc) __attribute__((always_inline)) { za_cur[decltype(sc)::value] = zt_wave[znt_base + 4 * decltype(sc)::value]; });
-        za_nxt = za_cur;
-        float zb_cur = zt_wave[z_base], zb_nxt = zb_cur;
-        constexpr int SLOTS = 2 * 4 * MT;
+            static_for<NT>([&](auto sc) __attribute__((always_inline)) { ya_cur[decltype(sc)::value] = Ys[yat_base + 4 * decltype(sc)::value]; });
+        ya_nxt = ya_cur;
         static_for<4>([&](auto gc) __attribute__((always_inline)) {
             constexpr int g = decltype(gc)::value;
             constexpr bool g_full = g < NF, g_tail = (g == NF && NT > 0);
             constexpr int per_mt = g_full ? 4 : (NT > 0 ? NT : 1);
+            FinishRow<MT> W;
+            W.e1 = W.us = W.a1 = W.a2 = W.a3 = 0.f;
+            W.pin = 0.f;
             static_for<SLOTS>([&](auto kc) __attribute__((always_inline)) {
                 constexpr int k = decltype(kc)::value;
                 constexpr int idx = k >> 1;
                 constexpr int g_mt = idx / per_mt, g_i = idx % per_mt;
-                constexpr bool is_gemm = (k & 1) == 0 && (g_full || g_tail) && g_mt < MT;
-                constexpr bool is_yn = (k & 1) == 1 && idx < NTD * MT;
+                constexpr bool is_gemm = (k & 1) == 0 && (g_full || g_tail) && g_mt < MT && !(HMX_SABL & 4);
                 if constexpr (is_gemm) {
-                    Tn.arg[g_mt] = MFMA16(za_cur[g_i], ya_cur[g_i], Tn.arg[g_mt]);
+                    if constexpr (g_full) Tn.arg[g_mt] = MFMA16(Zr.zp[g_full ? g : 0][g_i], ya_cur[g_i], Tn.arg[g_mt]);
+                    else Tn.arg[g_mt] = MFMA16(Zr.zt[g_i < NT ? g_i : 0], ya_cur[g_i], Tn.arg[g_mt]);
                     if constexpr (g_i == 0) {
                         // after the first use of a fragment, read the one after it (next cluster tile, or tile 0 of the next group)
                         constexpr int n_mt = g_mt + 1 < MT ? g_mt + 1 : 0;
                         constexpr int n_g = g_mt + 1 < MT ? g : g + 1;
                         if constexpr (n_g < GSTEPS) {
+                            // (the pin holds on to a COPY of the lane's base address; the rest is the instruction's immediate)
                             int bs = n_g < NF ? ya_base : yat_base;
                             TIE_ACC(Tn.arg[g_mt], bs);
                             if constexpr (n_g < NF) ya_nxt = ld4(Ys + bs + (16 * n_mt * LDY + 16 * n_g));
@@ -725,90 +587,67 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(SweepArgs a) {
                                 });
                         }
                     }
-                    if constexpr (g_mt == 0 && g_i == per_mt - 1 && g + 1 < GSTEPS) {
-                        // the next group's A fragment (this tile's own rows, 16 columns on), once per group
-                        int bs = g + 1 < NF ? zn_base : znt_base;
-                        TIE_ACC(Tn.arg[g_mt], bs);
-                        if constexpr (g + 1 < NF) za_nxt = ld4(zt_wave + bs + 16 * (g + 1));
-                        else
-                            static_for<NT>([&](auto sc) __attribute__((always_inline)) {
-                                constexpr int sx = decltype(sc)::value;
-                                za_nxt[sx] = zt_wave[bs + (16 * NF + 4 * sx)];
-                            });
-                    }
-                    // pin the next slot's MFMA behind this one (through its B operand)
-                    TIE_ACC(Tn.arg[g_mt], zb_cur);
-                    if constexpr (g_i == per_mt - 1) ya_cur = ya_nxt;
-                    if constexpr (g_mt == MT - 1 && g_i == per_mt - 1) za_cur = za_nxt;
-                } else if constexpr (is_yn) {
-                    yacc[idx % MT][idx / MT] = MFMA16(Rp[idx % MT][g], zb_cur, yacc[idx % MT][idx / MT]);
-                    if constexpr (idx % MT == 0) {
-                        constexpr int n_nt = idx / MT + 1 < NTD ? idx / MT + 1 : 0;
-                        constexpr int n_r = idx / MT + 1 < NTD ? g : g + 1;
-                        if constexpr (n_r < 4) {
-                            int bs = z_base;
-                            TIE_ACC(yacc[idx % MT][idx / MT], bs);
-                            zb_nxt = zt_wave[bs + (n_r * LDT + 16 * n_nt)];
-                        }
-                    }
-                    TIE_ACC(yacc[idx % MT][idx / MT], ya_cur);
-                    if constexpr (idx % MT == MT - 1) zb_cur = zb_nxt;
+                    side(std::integral_constant<int, g * SLOTS + k>{}, Tn.arg[g_mt]);
                 }
+                // one piece of the finish of cell g, pinned behind this slot's MFMA; the next MFMA is pinned behind the piece
+                if constexpr (k < NVALU) {
+                    if constexpr (is_gemm) TIE_ACC(Tn.arg[g_mt], fin_in<MT>(W, k));
+                    if constexpr (k < NPART) fin_part(Tf, F, W, g, k / 5, k % 5);
+                    else fin_tail(Tf, W, bsum, g, k - NPART);
+                    if constexpr (is_gemm && g_i == per_mt - 1) TIE_VV(fin_out<MT>(W, k), ya_nxt);
+                    else if constexpr (is_gemm) TIE_VV(fin_out<MT>(W, k), ya_cur);
+                }
+                if constexpr (is_gemm && g_i == per_mt - 1) ya_cur = ya_nxt;
             });
         });
         gemm_end(Tn);
     };
 
-    // ---- the wave's tile stream --------------------------------------------------------------------------------
-    // Tile s is being finished; its successor's rows (s+1) are in flight in zq with its list entries in nx_*; of tile s+2
-    // the entry every lane needs for its row address (c16_2) is known.  Only these few ids are kept in registers.
-    auto la_next = [&]() {   // next tile index of this wave's stream, or -1
-        la_settle();
-        const int j = la_b < a.nblk ? la_j0 + la_i : -1;
-        ++la_i;
-        return j;
-    };
-    auto cell_of = [&](int j) { return j >= 0 ? a.cells[(size_t)j * 16 + c] : -1; };
-    auto issue_rows = [&](int cell16, ZRegs<KS>& Z) {
-        const float* zr = a.Zcos + (size_t)(cell16 >= 0 ? cell16 : 0) * LDZ;
-#pragma unroll
-        for (int j = 0; j < NF; ++j) Z.zp[j] = ld4(zr + 16 * j + 4 * q);
-#pragma unroll
-        for (int s2 = 0; s2 < NT; ++s2) Z.zt[s2] = zr[16 * NF + 4 * s2 + q];
-    };
     // ---- prologue: hand-off 0 = minus the old sums of block 0; first tiles start travelling ---------------
+    // Tile s is being finished (cur); its successor's rows (s+1) are in flight in zq with its list entries in nx_*; of
+    // tile s+2 the row address every lane starts from (zrow_2) is known.
     const int j_0 = la_next(), j_1 = la_next();
     int j_2 = la_next();
     ZRegs<KS> z_a, zq;
-    issue_rows(cell_of(j_0), z_a);
-    issue_rows(cell_of(j_1), zq);
-    int c16_2 = cell_of(j_2);
+    issue_rows(row_of(cell_of(j_0)), z_a);
+    issue_rows(row_of(cell_of(j_1)), zq);
+    const float* zrow_2 = row_of(cell_of(j_2));
     ArgTile<MT> cur;
-    cur.valid = j_0 >= 0;
-    cur.cell4 = cur.valid ? *reinterpret_cast<const i32x4*>(a.cells + (size_t)j_0 * 16 + 4 * q) : (i32x4){-1, -1, -1, -1};
-    cur.grp = cur.valid ? a.tile_grp[j_0] : 0;
-    cur.slot = 0;
-    bool nx_valid = j_1 >= 0;
-    i32x4 nx_cell4 = nx_valid ? *reinterpret_cast<const i32x4*>(a.cells + (size_t)j_1 * 16 + 4 * q) : (i32x4){-1, -1, -1, -1};
-    int nx_grp = nx_valid ? a.tile_grp[j_1] : 0;
+    cur.cell4 = j_0 >= 0 ? *reinterpret_cast<const i32x4*>(a.cells + (size_t)j_0 * 16 + 4 * q) : (i32x4){-1, -1, -1, -1};
+    cur.grp = group_of(cur.cell4[0]);
+    i32x4 nx_cell4 = j_1 >= 0 ? *reinterpret_cast<const i32x4*>(a.cells + (size_t)j_1 * 16 + 4 * q) : (i32x4){-1, -1, -1, -1};
+    int nx_grp = group_of(nx_cell4[0]);
     // old assignments of a chunk without anything to hide behind (prologue; chunks that outlast the previous block's tiles)
     auto rem_chunk = [&](RemIds t, int j0, int u, int n) {
         for (; u < n; ++u) {
-            rem_issue(t);
+            rem_issue(rem_source(t));
             const RemIds tn = rem_ids(j0 + u + 1, u + 1 < n);
             rem_consume(t);
             t = tn;
         }
     };
     rem_chunk(rem_ids(chunk_first(0), chunk_count(0) > 0), chunk_first(0), 0, chunk_count(0));
-    // the removal sums of block p are gathered between hand-off p-1 and hand-off p, one tile per MFMA phase
+    // the removal sums of block p are gathered between hand-off p-1 and hand-off p, one tile per tile finished
     int rn = chunk_count(1), rj0 = chunk_first(1), ru = 0;
     RemIds rid = rem_ids(rj0, rn > 0);
+    const float* rsrc = rem_source(rid);
     publish(0);
-    int n_done = 0;   // tiles whose distance product has been issued: ring slot of tile s = s % RING
-    if (cur.valid) {
-        gemm_tile(z_a, 0, cur);
-        n_done = 1;
+    {   // distance product of the wave's first tile, plain (once per sweep)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) cur.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f32x4 ya = ld4(Ys + (size_t)(16 * mt + c) * LDY + 16 * j + 4 * q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cur.arg[mt] = MFMA16(z_a.zp[j][i], ya[i], cur.arg[mt]);
+            }
+#pragma unroll
+        for (int s = 0; s < NT; ++s)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) cur.arg[mt] = MFMA16(z_a.zt[s], Ys[(size_t)(16 * mt + c) * LDY + 16 * NF + 4 * s + q], cur.arg[mt]);
+        gemm_end(cur);
     }
 
     for (int b = 0; b < a.nblk; ++b) {
@@ -828,68 +667,117 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(SweepArgs a) {
             publish(b + 1);
             SSTAMP(5);
             rn = n2; rj0 = j2; ru = 0; rid = rid2;
+            rsrc = rem_source(rid);
         };
         for (int i = 0; i < n; ++i) {
-            f32x4 Rn[MT];
-            finish_tile(cur, Rn);
-            if (i == 0) SSTAMP(3);
-            if (i == n - 1) end_block();
-            // -- table-independent: rows of tile s+2, list entries of s+2 / s+3, distance product of tile s+1, Y_next of
-            //    tile s, old assignments of one tile of the block after this one (after the next one, behind end_block)
             ZRegs<KS> zn;
-            issue_rows(c16_2, zn);
             const bool n2_valid = j_2 >= 0;
-            const i32x4 n2_cell4 = n2_valid ? *reinterpret_cast<const i32x4*>(a.cells + (size_t)j_2 * 16 + 4 * q) : (i32x4){-1, -1, -1, -1};
-            const int n2_grp = n2_valid ? a.tile_grp[j_2] : 0;
-            const int j_3 = la_next();
-            const int c16_3 = cell_of(j_3);
+            i32x4 n2_cell4 = (i32x4){-1, -1, -1, -1};
+            int j_3 = -1, c16_3 = -1;
             const bool rem_now = ru < rn;
             RemIds rid_next = rid;
-            if (rem_now) {
-                rem_issue(rid);
-                rid_next = rem_ids(rj0 + ru + 1, ru + 1 < rn);
+            ArgTile<MT> nxt;
+            FinishTables<MT> F;
+            finish_begin(cur, F);
+            if (cur.grp != gsum_grp) {
+                if (gsum_grp >= 0) flush_run(gsum, gsum_grp, 1.0);
+                gsum_grp = cur.grp;
             }
-            const int slot_p = cur.slot;
-            if (nx_valid) {
-                const int slot_n = n_done % SWEEP_RING;
-                if (!(HMX_SABL & 4)) mfma_phase(zq, cur, slot_n, Rn, slot_p);   // cur becomes tile s+1: its old contents are spent
-                else {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) cur.arg[mt] = Rn[mt] * -3.f;
+            // the loads of what comes after ride behind the first MFMAs (nothing of this tile depends on them)
+            auto side = [&](auto Sc, f32x4& acc) __attribute__((always_inline)) {
+                constexpr int S = decltype(Sc)::value;
+                if constexpr (S == 0) {
+                    TIE_ACC(acc, zrow_2);
+                    issue_rows(zrow_2, zn);
+                } else if constexpr (S == 2) {
+                    const int* p4 = a.cells + (size_t)(n2_valid ? j_2 : 0) * 16 + 4 * q;
+                    TIE_ACC(acc, p4);
+                    const i32x4 v4 = *reinterpret_cast<const i32x4*>(p4);
+                    n2_cell4 = n2_valid ? v4 : (i32x4){-1, -1, -1, -1};
+                } else if constexpr (S == 4) {
+                    TIE_ACC(acc, rsrc);
+                    if (rem_now) rem_issue(rsrc);
+                } else if constexpr (S == 6) {
+                    j_3 = la_next();
+                    const int* p1 = a.cells + (size_t)(j_3 >= 0 ? j_3 : 0) * 16 + c;
+                    TIE_ACC(acc, p1);
+                    const int v1 = *p1;
+                    c16_3 = j_3 >= 0 ? v1 : -1;
+                } else if constexpr (S == 8) {
+                    if (rem_now) rid_next = rem_ids(rj0 + ru + 1, ru + 1 < rn);
                 }
-                cur.slot = slot_n;
-                ++n_done;
-            } else {
-                ynext_tile(Rn, slot_p);     // the wave's last tile
-            }
-            cur.valid = nx_valid;
-            cur.cell4 = nx_cell4;
-            cur.grp = nx_grp;
+            };
+#ifdef HMX_TIED_STREAM
+            tile_stream(cur, F, gsum, zq, nxt, side);
+#else
+            // plain order, scheduled by the compiler: loads, finish of tile s (28 independent entries: plenty of ILP),
+            // distance product of tile s+1; the partner wave of the SIMD fills the gaps
+            side(std::integral_constant<int, 0>{}, cur.arg[0]);
+            side(std::integral_constant<int, 2>{}, cur.arg[0]);
+            side(std::integral_constant<int, 4>{}, cur.arg[0]);
+            side(std::integral_constant<int, 6>{}, cur.arg[0]);
+            side(std::integral_constant<int, 8>{}, cur.arg[0]);
+            static_for<4>([&](auto gc) __attribute__((always_inline)) {
+                constexpr int g = decltype(gc)::value;
+                FinishRow<MT> W;
+                W.e1 = W.us = W.a1 = W.a2 = W.a3 = 0.f;
+                W.pin = 0.f;
+                static_for<NVALU>([&](auto kc) __attribute__((always_inline)) {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (k < NPART) fin_part(cur, F, W, g, k / 5, k % 5);
+                    else fin_tail(cur, W, gsum, g, k - NPART);
+                });
+            });
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) nxt.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            static_for<GSTEPS>([&](auto gc) __attribute__((always_inline)) {
+                constexpr int g = decltype(gc)::value;
+                f32x4 ya[MT];
+                if constexpr (g < NF) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) ya[mt] = ld4(Ys + (size_t)(16 * mt + c) * LDY + 16 * g + 4 * q);
+#pragma unroll
+                    for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) nxt.arg[mt] = MFMA16(zq.zp[g < NF ? g : 0][i2], ya[mt][i2], nxt.arg[mt]);
+                } else {
+#pragma unroll
+                    for (int s2 = 0; s2 < NT; ++s2) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) ya[mt][s2] = Ys[(size_t)(16 * mt + c) * LDY + 16 * NF + 4 * s2 + q];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) nxt.arg[mt] = MFMA16(zq.zt[s2], ya[mt][s2], nxt.arg[mt]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            gemm_end(nxt);
+#endif
+            if (i == 0) SSTAMP(3);
             if (rem_now) {
                 rem_consume(rid);
                 rid = rid_next;
                 ++ru;
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            nx_valid = n2_valid;
+            // everything requested in the stream has landed: the addresses the next tile starts from are formed here,
+            // not behind its row stores
+            if (i == n - 1) end_block();
+            else rsrc = rem_source(rid);
+            zrow_2 = row_of(c16_3);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) cur.arg[mt] = nxt.arg[mt];
+            cur.cell4 = nx_cell4;
+            cur.grp = nx_grp;
             nx_cell4 = n2_cell4;
-            nx_grp = n2_grp;
+            nx_grp = group_of(n2_cell4[0]);
             zq = zn;
             j_2 = j_3;
-            c16_2 = c16_3;
         }
         if (n == 0) end_block();   // no tile of this block here: the hand-offs still take place
         SSTAMP(6);
-    }
-
-    // ---- next round's centroid numerators: one slab per wave, fragment order (k_rtz2_reduce's layout) ----
-    {
-        float* slab = a.yslab + ((size_t)wg * SWEEP_WAVES + wv) * (MT * NTD * 256);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NTD; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) slab[((mt * NTD + nt) * 4 + r) * 64 + lane] = yacc[mt][nt][r];
     }
 
     // ---- objective partial sums (:399, :402) ----------------------------------------------------
@@ -946,18 +834,16 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(SweepArgs a) {
 
 // ---- host side ---------------------------------------------------------------------------------------
 static int sweep_ks(int d) { return d <= 32 ? 8 : d <= 52 ? 13 : d <= 64 ? 16 : 0; }
-int sweep_row_floats(int d) { return d <= 32 ? 32 : d <= 64 ? 64 : 0; }
-int sweep_slab_floats(int mt, int d) { return mt * (sweep_row_floats(d) / 16) * 256; }   // per wave; SWEEP_WAVES waves per workgroup
+int sweep_row_floats(int d) { return 4 * sweep_ks(d); }   // 32 / 52 / 64: the engine's row lengths for d <= 32 / 52 / 64
 int sweep_waves() { return SWEEP_WAVES; }
 
 size_t sweep_lds_bytes(int K16, int d, int G, int B, int V, int nblk) {
     const int ks = sweep_ks(d);
     if (!ks) return (size_t)1 << 30;
-    const int ldy = (ks & 1) ? 4 * ks : 4 * ks + 4, ldt = sweep_row_floats(d) + 4;
+    const int ldy = (ks & 1) ? 4 * ks : 4 * ks + 4;
     const size_t GK = (size_t)G * K16;
-    return ((size_t)K16 * ldy + (size_t)SWEEP_WAVES * SWEEP_RING * 16 * ldt + (size_t)SWEEP_WAVES * 4 * (K16 / 16) * 64 + 2 * (size_t)K16 + 2 * GK +
-            (size_t)K16 * B) * 4 +
-           (2 * GK + K16 + 2 * SWEEP_WAVES) * 8 + (2 * (size_t)B + (size_t)G * V + 2 * (size_t)SWEEP_WAVES * (nblk + 1) + 16) * 4;
+    return ((size_t)K16 * ldy + (size_t)SWEEP_WAVES * 4 * (K16 / 16) * 64 + 2 * (size_t)K16 + 2 * GK + (size_t)K16 * B) * 4 +
+           (2 * GK + K16 + 2 * SWEEP_WAVES) * 8 + (2 * (size_t)B + (size_t)G * V + G + 1 + 2 * (size_t)SWEEP_WAVES * (nblk + 1) + 16) * 4;
 }
 
 template <int MT, int KS>
@@ -989,7 +875,7 @@ static void launch_sweep_ks(const SweepArgs& a, int mt, int wgs, size_t sm, hipS
 // d = PCs; the rows of Z_cos must be sweep_row_floats(d) floats long.  -1: shape not covered.
 int launch_sweep(const SweepArgs& a, int mt, int d, int wgs, hipStream_t s) {
     const size_t sm = sweep_lds_bytes(16 * mt, d, a.G, a.B, a.V, a.nblk);
-    if (mt < 1 || mt > 7 || sm > 156 * 1024 || a.ldz != sweep_row_floats(d)) return -1;
+    if (mt < 1 || mt > 7 || sm > 156 * 1024 || a.ldz != sweep_row_floats(d) || a.G > 64) return -1;
     switch (sweep_ks(d)) {
         case 8: launch_sweep_ks<8>(a, mt, wgs, sm, s); break;
         case 13: launch_sweep_ks<13>(a, mt, wgs, sm, s); break;
