@@ -25,11 +25,11 @@ HMX_ROUND_ALL = 7
 EXPORTS = [
     "hmx_last_error", "hmx_abi_version", "hmx_create", "hmx_destroy", "hmx_upload", "hmx_init_cluster",
     "hmx_cluster_round", "hmx_cluster_round_seeded", "hmx_moe_correct_ridge", "hmx_get", "hmx_set", "hmx_sync", "hmx_device_ptr",
-    "hmx_kernel_times", "hmx_enable_timing", "hmx_comm_unique_id", "hmx_comm_init", "hmx_set_host_allreduce",
+    "hmx_kernel_times", "hmx_enable_timing", "hmx_counters", "hmx_comm_unique_id", "hmx_comm_init", "hmx_set_host_allreduce",
     "hmx_kmeans_lloyd", "hmx_kmeans_seed", "hmx_compute_lisi", "hmx_get_rows", "hmx_set_ranks", "hmx_peer_export", "hmx_peer_attach", "hmx_peer_selftest", "hmx_peer_enable",
 ]
 HMX_PEER_HANDLE_BYTES = 64
-HMX_ABI_VERSION = 3
+HMX_ABI_VERSION = 4
 HMX_UNIQUE_ID_BYTES = 128
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
 
@@ -87,6 +87,7 @@ def load():
     lib.hmx_sync.argtypes = [vp]
     lib.hmx_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.hmx_kernel_times.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_char_p)]
+    lib.hmx_counters.argtypes = [vp, vp]
     lib.hmx_enable_timing.argtypes = [vp, C.c_int]
     for name in EXPORTS:
         if name not in ("hmx_last_error", "hmx_destroy"):
@@ -297,6 +298,12 @@ class Engine:
 
     def enable_timing(self, on=True):
         _check(self._lib.hmx_enable_timing(self._h, int(on)))
+
+    def counters(self):
+        """dict of the engine's event counters (hmx_counters)."""
+        buf = np.zeros(4, np.int64)
+        _check(self._lib.hmx_counters(self._h, _ptr(buf)))
+        return {"collectives": int(buf[0]), "sweep_fallbacks": int(buf[1]), "seeded_rounds": int(buf[2])}
 
     def kernel_times(self):
         """{family: (total_ms, launches)} since timing was enabled."""

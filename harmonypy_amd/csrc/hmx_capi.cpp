@@ -344,7 +344,7 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
     if (const char* pl = getenv("HMX_PREFETCH_LISTS")) e->prefetch_lists = atoi(pl) != 0;
     if (const char* rm = getenv("HMX_ROUND_MODE")) e->round_mode = (std::string(rm) == "blocks") ? 0 : 1;
     if (const char* sw = getenv("HMX_SWEEP")) e->sweep_kernel = atoi(sw) != 0;
-    if (const char* sl = getenv("HMX_SPIN_LIMIT")) e->spin_limit = (unsigned)std::max(1L, atol(sl));
+    if (const char* sl = getenv("HMX_SPIN_LIMIT")) e->spin_limit = (unsigned)std::max(0L, atol(sl));   // 0: every wait of the persistent kernels gives up at once (tests)
     int rc = 0;
     do {
         if ((rc = use_device(e))) break;
@@ -729,6 +729,22 @@ static int centroid_pass(hmx_engine* e) {
     return 0;
 }
 
+// A grid-wide wait of a persistent sweep kernel gave up (workgroups not co-resident, a peer rank far behind).  R holds
+// new rows for the blocks that were finished and old ones for the rest -- every row still a distribution -- but the O
+// the kernel carried is void: take O from R again; the caller then repeats the round block by block (bounded kernels,
+// one collective per block).  Every rank comes here together: a rank that timed out poisons its objective sums with
+// NaN, which every rank sees after the all-reduce of those sums.
+static int sweep_timed_out(hmx_engine* e) {
+    int rc;
+    const size_t GK = (size_t)e->G * e->K16;
+    if (e->n_sweep_fallbacks++ == 0)
+        fprintf(stderr, "[hmx] rank %d: a grid-wide wait of the sweep kernel timed out; the round is repeated with one launch per "
+                        "block (HMX_ROUND_MODE=blocks avoids the persistent kernel altogether)\n", e->rank);
+    HIP_TRY(hipMemsetAsync(e->Ogrp.p, 0, GK * sizeof(double), e->stream));
+    launch_group_sums(e->R.p, e->Kp, e->K, e->K16, e->s_cells.p, e->s_tile_grp.p, e->n_s_tiles, e->Ogrp.p, e->stream);
+    return sum_over_ranks(e, e->Ogrp.p, GK);
+}
+
 static bool sweep_shape_ok(const hmx_engine* e) {
     return e->mt <= 7 && sweep_row_floats(e->d) == e->dp &&
            sweep_lds_bytes(e->K16, e->d, e->G, e->B, e->V, e->nblk) <= 156 * 1024;
@@ -820,25 +836,19 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
     int rc;
     const size_t GK = (size_t)e->G * e->K16;
     const bool persistent = (flags & HMX_ROUND_UPDATE_R) && e->round_mode == 1 && (!sharded(e) || e->peers_enabled);
-    bool side_work_done = false;
     if (persistent && e->sweep_kernel && sweep_shape_ok(e)) {
         rc = round_sweep(e, flags, tiles_upper, obj_out, before_sweep);
         if (rc <= 0) return rc;
-        // A grid-wide wait gave up (workgroups not co-resident, a peer rank far behind).  R holds new rows for the
-        // blocks that were finished and old ones for the rest -- every row still a distribution -- but the O the
-        // kernel carried is void: take O from R again and repeat the round block by block (bounded kernels, one
-        // collective per block).  Every rank takes this branch together (see the NaN above).
-        if (e->n_sweep_fallbacks++ == 0)
-            fprintf(stderr, "[hmx] k_sweep: a grid-wide wait timed out; this round is repeated with one launch per block "
-                            "(HMX_ROUND_MODE=blocks avoids the persistent kernel altogether)\n");
-        HIP_TRY(hipMemsetAsync(e->Ogrp.p, 0, GK * sizeof(double), e->stream));
-        launch_group_sums(e->R.p, e->Kp, e->K, e->K16, e->s_cells.p, e->s_tile_grp.p, e->n_s_tiles, e->Ogrp.p, e->stream);
-        if ((rc = sum_over_ranks(e, e->Ogrp.p, GK))) return rc;
-        side_work_done = true;
+        if ((rc = sweep_timed_out(e))) return rc;
+        const int saved = e->round_mode;
+        e->round_mode = 0;
+        rc = round_body(e, flags, n_tiles_upper, tiles_upper, obj_out, nullptr);
+        e->round_mode = saved;
+        return rc;
     }
     // Sold | Yacc64 | Snew | objacc are neighbours in xch: one fill instead of four
     HIP_TRY(hipMemsetAsync(e->Sold, 0, (size_t)((e->objacc + 2 * HMX_OBJ_SLOTS + 2) - e->Sold) * sizeof(double), e->stream));
-    const bool legacy_persistent = persistent && !side_work_done && !e->sweep_kernel;
+
 
     // ---- pass over the old R: centroid numerators (:443) and per-block removal sums (:491-492)
     int nsub, spw;
@@ -876,9 +886,9 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         Timed t(e, F_RTZ_REDUCE);
         launch_y_normalize_d(e->Yacc64, e->Y.p, e->K, e->K16, e->d, e->ldy, e->stream);  // :444
     }
-    const bool mega = legacy_persistent && e->mt <= 7 && round_row_floats(e->d) == e->dp &&
+    const bool mega = persistent && e->mt <= 7 && round_row_floats(e->d) == e->dp &&
                       round_lds_bytes(e->K16, e->dp, e->G, e->B) <= 150 * 1024;
-    if (!side_work_done && before_sweep && (rc = before_sweep())) return rc;   // side-stream work that should run beside the sweep, not beside the R^T.Z pass
+    if (before_sweep && (rc = before_sweep())) return rc;   // side-stream work that should run beside the sweep, not beside the R^T.Z pass
     if (mega) {
         // the whole sweep in one persistent launch (k_round); closes O, T and the objective itself
         // the slot tables and the two sync words (carved from the same allocation): one fill
@@ -902,7 +912,7 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         ra.obj = e->objacc; ra.group_cols = e->group_cols.p; ra.Pr_b = e->Pr_b.p; ra.theta = e->theta.p;
         ra.counter = e->sync_words.p; ra.error = e->sync_words.p + 1;
         ra.K = e->K; ra.Kp = e->Kp; ra.K16 = e->K16; ra.dp = e->dp; ra.ldy = e->ldy; ra.G = e->G; ra.B = e->B; ra.V = e->V;
-        ra.nblk = e->nblk;
+        ra.nblk = e->nblk; ra.spin_limit = e->spin_limit;
         if (multi) {
             ra.peer_box = e->peer_dev.p; ra.my_box = e->box; ra.n_ranks = e->n_ranks; ra.rank = e->rank;
             ra.epoch = e->round_epoch;
@@ -955,7 +965,8 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         }
 #endif
         HIP_TRY(hipMemcpyAsync(e->sync_host, e->sync_words.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
-        // the two objective sums (:399, :402) of this rank's cells; the cross-entropy term was formed from job-wide tables
+        // the two objective sums (:399, :402) of this rank's cells; the cross-entropy term was formed from job-wide tables.
+        // A rank whose wait timed out poisons its sums with NaN: every rank then sees the failure in this all-reduce.
         if (multi && (rc = sum_over_ranks(e, e->objacc, 2 * HMX_OBJ_SLOTS))) return rc;
     } else if (flags & HMX_ROUND_UPDATE_R) {
         for (int b = 0; b < e->nblk; ++b) {
@@ -991,9 +1002,13 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         launch_block_table(ta, e->K16, e->stream);
     }
     rc = read_objective(e, obj_out);
-    if (rc == 0 && mega && e->sync_host[1] != 0) {
+    if (rc == 0 && mega && (e->sync_host[1] != 0 || obj_out[0] != obj_out[0] || obj_out[1] != obj_out[1])) {
         e->sync_host[1] = 0;
-        return fail(HMX_ERR_STATE, "k_round: a grid-wide wait timed out (workgroups not co-resident?); set HMX_ROUND_MODE=blocks");
+        if ((rc = sweep_timed_out(e))) return rc;
+        const int saved = e->round_mode;
+        e->round_mode = 0;
+        rc = round_body(e, flags, n_tiles_upper, tiles_upper, obj_out, nullptr);
+        e->round_mode = saved;
     }
     return rc;
 }
@@ -1400,6 +1415,15 @@ int hmx_device_ptr(hmx_engine* e, int which, void** d_ptr, size_t* bytes) {
     size_t need; int rows, cols, ld, elem, rc;
     if ((rc = locate(e, which, d_ptr, &need, &rows, &cols, &ld, &elem))) return rc;
     *bytes = (size_t)rows * ld * elem;
+    return HMX_OK;
+}
+
+int hmx_counters(hmx_engine* e, int64_t out[4]) {
+    if (!e || !out) return fail(HMX_ERR_ARG, "null argument");
+    out[0] = e->n_collectives;
+    out[1] = e->n_sweep_fallbacks;
+    out[2] = (int64_t)e->seeded_rounds;
+    out[3] = 0;
     return HMX_OK;
 }
 

@@ -54,6 +54,7 @@ struct RoundArgs {
     double* const* peer_box;   // n_ranks box base pointers (own box included), device array
     double* my_box;
     unsigned long long epoch;  // flag value of block b in this launch = epoch + b + 1
+    unsigned spin_limit;       // polls a wait may take before it gives up
     int n_ranks, rank;
     int K, Kp, K16, dp, ldy, ldy_lds, G, B, V, nblk;
 };

@@ -908,7 +908,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                 unsigned spins = 0;
                 while (ld_agent(a.counter) < want) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 24)) { gfail = true; break; }
+                    if (++spins > a.spin_limit) { gfail = true; break; }
                 }
             }
             __syncthreads();
@@ -925,7 +925,10 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                 st_sys(reinterpret_cast<unsigned long long*>(a.peer_box[tid] + box_flags(a.n_ranks, GK)) + (size_t)(b & 1) * a.n_ranks + a.rank,
                        a.epoch + (unsigned long long)b + 1ull);
         }
-        if (gfail && tid == 0) atomicExch(a.error, 1u);
+        if (gfail && tid == 0) {
+            atomicExch(a.error, 1u);
+            atomicAdd(&a.obj[0], __builtin_nan(""));   // every rank sees the failure in the all-reduce of the objective sums
+        }
         return;
     }
 
@@ -1005,11 +1008,12 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         // ---- wait until every workgroup has added its sums of block b-1 ---------------------
         if (b > 0 && wv == 0) {
             unsigned spins = 0;
+            if (a.spin_limit == 0) failed = true;   // test knob: give up without looking
             if (!multi) {
                 const unsigned want = (unsigned)b * (unsigned)nwg;
                 while (ld_agent(a.counter) < want) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 24)) { failed = true; break; }
+                    if (++spins > a.spin_limit) { failed = true; break; }
                 }
             } else {   // every rank's total of block b-1 has landed in this rank's box
                 const unsigned long long want = a.epoch + (unsigned long long)b;
@@ -1018,7 +1022,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                     const bool ok = lane >= a.n_ranks || ld_sys(fl + lane) >= want;
                     if (__all(ok)) break;
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 24)) { failed = true; break; }
+                    if (++spins > a.spin_limit) { failed = true; break; }
                 }
             }
 #ifdef HMX_ROUND_PROF
@@ -1160,7 +1164,10 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         for (int w = 0; w < ROUND_WAVES; ++w) v += objw[2 * w + tid];
         if (v != 0.0) atomicAdd(&a.obj[2 * (wg & (HMX_OBJ_SLOTS - 1)) + tid], v);
     }
-    if (failed && tid == 0) atomicExch(a.error, 1u);
+    if (failed && tid == 0) {
+        atomicExch(a.error, 1u);
+        atomicAdd(&a.obj[0], __builtin_nan(""));
+    }
     if (wg != 0) return;
 
     // ---- workgroup 0 closes the sweep: O, cluster mass, cross-entropy term (:405-411) -----------
@@ -1170,7 +1177,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             const unsigned want = (unsigned)a.nblk * (unsigned)nwg;
             while (ld_agent(a.counter) < want) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 24)) { if (lane == 0) atomicExch(a.error, 1u); break; }
+                if (++spins > a.spin_limit) { if (lane == 0) { atomicExch(a.error, 1u); atomicAdd(&a.obj[0], __builtin_nan("")); } break; }
             }
         } else {
             const unsigned long long want = a.epoch + (unsigned long long)a.nblk;
@@ -1179,7 +1186,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                 const bool ok = lane >= a.n_ranks || ld_sys(fl + lane) >= want;
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1u << 24)) { if (lane == 0) atomicExch(a.error, 1u); break; }
+                if (++spins > a.spin_limit) { if (lane == 0) { atomicExch(a.error, 1u); atomicAdd(&a.obj[0], __builtin_nan("")); } break; }
             }
         }
     }

@@ -194,7 +194,10 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(SweepArgs a) {
                 st_sys(reinterpret_cast<unsigned long long*>(a.peer_box[tid] + box_flags(a.n_ranks, GK)) + (size_t)(p & 1) * a.n_ranks + a.rank,
                        a.epoch + (unsigned long long)p + 1ull);
         }
-        if (gfail && tid == 0) atomicExch(a.error, 1u);
+        if (gfail && tid == 0) {
+            atomicExch(a.error, 1u);
+            atomicAdd(&a.obj[0], __builtin_nan(""));   // every rank sees the failure in the all-reduce of the objective sums
+        }
         return;
     }
 
@@ -434,9 +437,10 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(SweepArgs a) {
     auto wait_handoff = [&](int p) {
         if (wv == 0) {
             unsigned spins = 0;
+            if (a.spin_limit == 0) failed = true;   // test knob: give up without looking
             if (!multi) {
                 const unsigned want = (unsigned)(p + 1) * (unsigned)nwg;
-                while (ld_agent(a.counter) < want) {
+                while (!failed && ld_agent(a.counter) < want) {
                     __builtin_amdgcn_s_sleep(1);
                     if (failed || ++spins > a.spin_limit) { failed = true; break; }
                 }
@@ -707,9 +711,9 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(SweepArgs a) {
                     if (rem_now) rid_next = rem_ids(rj0 + ru + 1, ru + 1 < rn);
                 }
             };
-#ifdef HMX_TIED_STREAM
+#ifndef HMX_PLAIN_STREAM
             tile_stream(cur, F, gsum, zq, nxt, side);
-#else
+#else   /* timing experiments only: 707 us per sweep at C3 against 658 for the pinned stream */
             // plain order, scheduled by the compiler: loads, finish of tile s (28 independent entries: plenty of ILP),
             // distance product of tile s+1; the partner wave of the SIMD fills the gaps
             side(std::integral_constant<int, 0>{}, cur.arg[0]);
@@ -794,14 +798,20 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(SweepArgs a) {
         if (v != 0.0) atomicAdd(&a.obj[2 * (wg & (HMX_OBJ_SLOTS - 1)) + tid], v);
     }
     if (wg != 0) {
-        if (failed && tid == 0) atomicExch(a.error, 1u);
+        if (failed && tid == 0) {
+            atomicExch(a.error, 1u);
+            atomicAdd(&a.obj[0], __builtin_nan(""));
+        }
         return;
     }
 
     // ---- workgroup 0 closes the sweep: O, cluster mass, cross-entropy term (:405-411) -----------
     wait_handoff(a.nblk);
     apply_handoff(a.nblk);
-    if (failed && tid == 0) atomicExch(a.error, 1u);
+    if (failed && tid == 0) {
+        atomicExch(a.error, 1u);
+        atomicAdd(&a.obj[0], __builtin_nan(""));
+    }
     for (int i = tid; i < GK; i += SWEEP_THREADS) a.O_out[i] = Ocur[i];
     double part = 0.0;
     for (int i = tid; i < K16 * a.B; i += SWEEP_THREADS) {

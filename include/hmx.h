@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HMX_ABI_VERSION 3
+#define HMX_ABI_VERSION 4
 #define HMX_TILE 16 /* cells per tile */
 /* limits of this build, checked by hmx_create (the reference has none: harmony.py:123-124 caps only the default K) */
 #define HMX_MAX_CLUSTERS 208
@@ -221,6 +221,11 @@ int hmx_device_ptr(hmx_engine* e, int which, void** d_ptr, size_t* bytes);
  * the engine's stream.  names_out receives a static NUL-separated list. */
 int hmx_kernel_times(hmx_engine* e, double* ms_out, int n, const char** names_out);
 int hmx_enable_timing(hmx_engine* e, int on);
+
+/* Event counters of the engine since hmx_create: out[0] collectives issued (sharded jobs), out[1] rounds whose
+ * persistent sweep kernel gave up on a grid-wide wait and were repeated block by block (harmony.py:464-513 has no
+ * counterpart: it runs the blocks one torch call at a time), out[2] rounds with a device-side update order, out[3] 0. */
+int hmx_counters(hmx_engine* e, int64_t out[4]);
 
 #ifdef __cplusplus
 }

@@ -362,6 +362,51 @@ def test_bench_path_parity_c5_shape(monkeypatch):
 
 
 # ------------------------------------------------------------------------------------------
+# the two persistent sweep kernels: opt-in k_sweep, and what happens when a grid-wide wait gives up
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["pbmc_default", "pbmc_two_vars", "pbmc_theta_tau", "synth_small_default"])
+def test_k_sweep_path_vs_reference_golden(case, monkeypatch):
+    """HMX_SWEEP=1 (hmx_sweep.hip: removal sums formed inside the sweep, old R rows through LDS-DMA) replays the
+    reference's schedule to the same 1e-4 as the default k_round path."""
+    monkeypatch.setenv("HMX_SWEEP", "1")
+    data, meta, vars_use, kw, g = load_case(case)
+    rounds = [int(r) for r in g["kmeans_rounds"]]
+    ho = _run_engine(data, meta, vars_use, Y0=g["Y0"], forced_rounds=rounds, **kw)
+    rel_f, max_rel = assert_z_close(ho.Z_corr, g["Z_corr"])
+    print(f"{case} (k_sweep): relF={rel_f:.2e} max={max_rel:.2e}")
+    np.testing.assert_allclose(ho.objective_kmeans, g["objective_kmeans"], rtol=2e-5)
+    np.testing.assert_allclose(ho.O, g["O"], rtol=3e-4, atol=3e-4)
+
+
+@pytest.mark.parametrize("sweep", ["0", "1"])
+def test_sweep_timeout_falls_back_to_blocks(sweep, monkeypatch, capfd):
+    """HMX_SPIN_LIMIT=0 makes every grid-wide wait of the persistent kernel give up at once: the engine must notice,
+    take O from R again and repeat the round with one bounded launch per block -- the run finishes, the state stays
+    consistent (rows of R are distributions, O = R Phi^T exactly although it was rebuilt mid-round, unit rows),
+    and the embedding still lands where the undisturbed run does (cells of the blocks finished before the
+    time-out were updated twice in that round, so not to 1e-4)."""
+    from scipy.stats import pearsonr
+    data, meta, vars_use, kw, g = load_case("pbmc_default")
+    monkeypatch.setenv("HMX_SWEEP", sweep)
+    monkeypatch.setenv("HMX_SPIN_LIMIT", "0")
+    ho = _run_engine(data, meta, vars_use, Y0=g["Y0"], **dict(kw, max_iter_harmony=3))
+    cnt = ho._engine.counters()
+    assert cnt["sweep_fallbacks"] >= 1, cnt
+    assert "timed out" in capfd.readouterr().err
+    R = ho.R
+    np.testing.assert_allclose(R.sum(axis=1), 1.0, atol=3e-6)
+    Phi = ho.Phi
+    np.testing.assert_allclose(ho.O, R.T.astype(np.float64) @ Phi, rtol=2e-5, atol=1e-4)
+    np.testing.assert_allclose(np.linalg.norm(ho.Z_cos, axis=1), 1.0, atol=3e-6)
+    assert np.isfinite(ho.objective_kmeans).all()
+    monkeypatch.delenv("HMX_SPIN_LIMIT")
+    ok = _run_engine(data, meta, vars_use, Y0=g["Y0"], **dict(kw, max_iter_harmony=3))    # the undisturbed run
+    assert ok._engine.counters()["sweep_fallbacks"] == 0
+    cors = [pearsonr(ho.Z_corr[:, j], ok.Z_corr[:, j])[0] for j in range(ho.d)]
+    assert min(cors) > 0.99, min(cors)
+
+
+# ------------------------------------------------------------------------------------------
 # device-side update order (hmx_cluster_round_seeded)
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,B,bs", [(3500, 3, 0.05), (1237, 4, 0.07), (37, 2, 0.05), (100003, 5, 0.05)])
