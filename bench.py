@@ -50,6 +50,7 @@ CONFIGS = {
 }
 CONFIG_INDEX = {"c2": 1, "c3": 2, "c4": 3, "c5": 4, "c4x1": 3}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense (= the f32 vector rate)
 
 
 def synthetic_dataset(N, d, B, K, seed=0, cell_seed=None):
@@ -88,16 +89,64 @@ def quick_centroids(Z, K, seed=0, sample=50_000):
     return np.asarray(km.cluster_centers_.T, dtype=np.float32)  # d x K
 
 
-def cpu_baseline(d, B, K, rounds, sample_cells, seed=1):
-    """Oracle (NumPy port of the reference's CPU path) on a bounded sample; one iteration."""
-    from oracle.harmony_oracle import OracleHarmony, prepare_inputs
+def _reference_baseline(ref_path, Z, meta, K, rounds, Y0):
+    """One Harmony iteration (`rounds` k-means rounds + ridge) of the reference itself, device='cpu', timed around its
+    own harmonize() (harmony.py:419-435); the sklearn fit is replaced by the prepared centroids."""
+    import logging
+    sys.path.insert(0, ref_path)
+    import harmonypy as hm
+    import harmonypy.harmony as hh
+    import torch
+    logging.getLogger("harmonypy").setLevel(logging.WARNING)
+
+    class FixedKMeans:
+        def __init__(self, *a, **k):
+            pass
+
+        def fit(self, X):
+            self.cluster_centers_ = Y0.T.astype(np.float64)
+            return self
+    timing = {}
+    orig = hh.Harmony.harmonize
+
+    def timed(self, *a, **k):
+        t0 = time.perf_counter()
+        r = orig(self, *a, **k)
+        timing["dt"] = time.perf_counter() - t0
+        return r
+    hh.KMeans, hh.Harmony.harmonize = FixedKMeans, timed
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
+        hm.run_harmony(Z, meta, ["batch"], nclust=K, max_iter_harmony=1, max_iter_kmeans=rounds, epsilon_cluster=0.0,
+                       epsilon_harmony=-1e30, verbose=False, random_state=0, device="cpu")
+    finally:
+        hh.Harmony.harmonize = orig
+    return timing["dt"], int(torch.get_num_threads())
+
+
+def cpu_baseline(d, B, K, rounds, sample_cells, seed=1):
+    """The reference's CPU path on a bounded sample of the workload, one Harmony iteration.
+
+    kind "reference": harmonypy itself (`run_harmony(..., device='cpu')`, harmony.py:49) when the environment variable
+    HMX_REFERENCE_PATH names a checkout of it (the build container: /root/reference; a GPU box has none).
+    kind "port": the NumPy oracle, a restatement of the same torch-CPU arithmetic, on min(32, cpus) BLAS threads; its
+    rate relative to the reference's on the same sample and cores is kept in profiles/r02_cpu_baseline_calibration.json
+    (measured where both run)."""
     Z, meta = synthetic_dataset(sample_cells, d, B, K, seed=seed)
     Y0 = quick_centroids(Z, K, seed=seed)
+    what = f"{sample_cells} cells x {d} PCs, {B} batches, K={K}: 1 iteration = {rounds} rounds + ridge"
+    ref_path = os.environ.get("HMX_REFERENCE_PATH")
+    if ref_path and os.path.isdir(os.path.join(ref_path, "harmonypy")):
+        dt, threads = _reference_baseline(ref_path, Z, meta, K, rounds, Y0)
+        return {"value": sample_cells / dt, "unit": "cells/sec/Harmony-iteration", "cores": threads, "kind": "reference",
+                "sample": f"{what} in {dt:.1f} s (harmonypy at {ref_path}, device='cpu', torch threads={threads}, "
+                          f"host has {os.cpu_count()} cpus)"}
+    from oracle.harmony_oracle import OracleHarmony, prepare_inputs
+    threads = min(32, os.cpu_count() or 1)
+    try:
+        from threadpoolctl import threadpool_limits
+        limit = threadpool_limits(limits=threads)
+    except Exception:
+        limit = None
     p = prepare_inputs(Z, meta, ["batch"], nclust=K)
     rng = np.random.default_rng(seed)
     oo = OracleHarmony(p["Z"], p["phi"], p["Pr_b"], p["sigma"], p["theta"], p["lamb"], K=K, run=False,
@@ -108,10 +157,84 @@ def cpu_baseline(d, B, K, rounds, sample_cells, seed=1):
     oo.moe_correct_ridge()
     oo.check_convergence(1)
     dt = time.perf_counter() - t0
-    return {"value": sample_cells / dt, "unit": "cells/sec/Harmony-iteration", "cores": int(threads),
-            "kind": "port",
-            "sample": f"{sample_cells} cells x {d} PCs, {B} batches, K={K}: 1 iteration = {rounds} rounds + ridge "
-                      f"in {dt:.1f} s (NumPy oracle, BLAS threads={threads}, host has {os.cpu_count()} cpus)"}
+    if limit is not None:
+        limit.restore_original_limits()
+    cal = None
+    try:
+        cal = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_baseline_calibration.json")))
+    except Exception:
+        pass
+    out = {"value": sample_cells / dt, "unit": "cells/sec/Harmony-iteration", "cores": int(threads), "kind": "port",
+           "sample": f"{what} in {dt:.1f} s (NumPy oracle: no harmonypy checkout on this box (HMX_REFERENCE_PATH), "
+                     f"BLAS threads={threads}, host has {os.cpu_count()} cpus)"}
+    if cal:
+        out["reference_over_port"] = cal.get("reference_over_port")
+        out["calibration"] = "profiles/r02_cpu_baseline_calibration.json"
+    return out
+
+
+def newest_pmc(engine_version):
+    """HBM bytes per launch of the round kernels from the committed rocprofv3 --pmc passes (scripts/gpu_pmc.sh), only if they
+    were collected on the kernel set that is running: (kernels dict, file name) or (None, reason)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c3_pmc_hbm.json")), reverse=True)
+    for f in files:
+        try:
+            pm = json.load(open(f))
+        except Exception:
+            continue
+        if pm.get("engine_version") == engine_version:
+            return pm["kernels"], os.path.relpath(f, ROOT)
+    return None, (f"no profiles/*_c3_pmc_hbm.json carries engine_version {engine_version}"
+                  + (f" (newest: {os.path.basename(files[0])})" if files else ""))
+
+
+def roofline_block(config, N, d, B, K, ktimes, steps, rounds, wide):
+    """`roofline` of the dominant kernel of the configuration + per-family kernel milliseconds.
+
+    C2 / C3 / C4 (K <= 112, d <= 64): k_round, one persistent launch per update_R sweep (or k_sweep under HMX_SWEEP=1):
+    HBM-bound, algorithmic bytes per cell 4d + 4K + 4 (Z_cos row, R row, list entry).
+    C5 (wide shapes): k_assign_wide, one launch per update block: f32-MFMA-bound, 2 d K flop per cell."""
+    import harmonypy_amd
+    tot, cnt = ktimes.get("assign_block", (0.0, 0))
+    per_launch_ms = tot / max(cnt, 1)
+    n_rounds = steps * rounds
+    sweep = cnt <= n_rounds          # one launch per update_R sweep; else one launch per block
+    cells_per_launch = N if sweep else N / 20.0
+    fam_ms = {k: round(v[0], 3) for k, v in ktimes.items()}
+    t_round_kernels = sum(ktimes[k][0] for k in ("assign_block", "rtz_round", "rtz_reduce", "block_table") if k in ktimes) / max(n_rounds, 1)
+    if wide:
+        flops = cells_per_launch * 2.0 * d * K
+        achieved = flops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "k_assign_wide (one launch per update block; K > 112 or d > 64)",
+                "achieved": achieved, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TF,
+                "traffic": None, "traffic_source": "not collected for this configuration",
+                "avg_launch_us": per_launch_ms * 1e3, "launches": cnt, "algorithmic_flops_per_launch": flops}
+    else:
+        alg_bytes = cells_per_launch * (4 * d + 4 * K + 4)
+        achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        sweep_name = "k_sweep" if os.environ.get("HMX_SWEEP", "0") not in ("0", "") else "k_round"
+        kernel = (f"{sweep_name} (one persistent launch per update_R sweep: all 20 blocks)" if sweep
+                  else "k_assign_lds (one launch per update block)")
+        traffic, traffic_src = None, None
+        if sweep and config == "c3":
+            pm, src = newest_pmc(harmonypy_amd.ENGINE_VERSION)
+            traffic_src = src
+            if pm is not None:
+                for name, rec in pm.items():
+                    if name.startswith("void " + sweep_name):
+                        traffic = rec["hbm_bytes_corrected"]
+        roof = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_us": per_launch_ms * 1e3, "launches": cnt, "algorithmic_bytes_per_launch": alg_bytes}
+    round_bytes = N * (4 * d + 8 * K + 8)
+    roof["round"] = {
+        "algorithmic_bytes": round_bytes, "kernel_ms_per_round": t_round_kernels,
+        "frac_of_hbm_peak": (round_bytes / (t_round_kernels * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_round_kernels > 0 else 0.0,
+        "mfma_flops": N * 4 * d * K,
+        "frac_of_f32_mfma_peak": (N * 4 * d * K / (t_round_kernels * 1e-3) / (F32_MFMA_PEAK_TF * 1e12)) if t_round_kernels > 0 else 0.0}
+    roof["engine_version"] = harmonypy_amd.ENGINE_VERSION
+    return roof, fam_ms
 
 
 def side_config(name, rounds, steps, warmup, device):
@@ -147,12 +270,17 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--rounds", type=int, default=10, help="k-means rounds per Harmony iteration")
     ap.add_argument("--cpu-sample", type=int, default=200_000, help="cells of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-only", action="store_true", help="print only the cpu_baseline object (no GPU needed)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-lisi", action="store_true", help="skip the LISI of the embedding before / after the run to convergence")
     ap.add_argument("--lisi-cells", type=int, default=1_000_000, help="cells of the LISI measurement (evenly spaced subsample above that)")
     ap.add_argument("--no-convergence", action="store_true", help="skip the untimed end-to-end run to convergence")
     args = ap.parse_args()
 
+    if args.cpu_only:
+        N0, d0, B0, K0 = CONFIGS[args.config]
+        print(json.dumps(cpu_baseline(d0, B0, K0, args.rounds, min(args.cpu_sample, N0))))
+        return
     # stdout carries exactly one JSON line: libraries that print banners through C stdio (RCCL's
     # version banner, for one) are sent to stderr for the whole run
     sys.stdout.flush()
@@ -225,6 +353,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ktimes = ho._engine.kernel_times() if timing else {}
+    ho_wide = ho._wide_shape()
+    counters = ho._engine.counters()
     if timing:
         ho._engine.enable_timing(False)
 
@@ -282,39 +412,13 @@ def main():
             "setup_s": t_setup,
         },
     }
+    # the grid-wide waits of the sweep kernel on this rank (the hop every block pays; across ranks when sharded): how often
+    # a poll found the hand-off incomplete (each followed by ~64 shader cycles of sleep) -- rank 0's view, for diagnosis
+    out["sweep_waits"] = {"waits": counters["sweep_waits"], "incomplete_polls_mean": counters["sweep_wait_polls"] / max(counters["sweep_waits"], 1),
+                          "incomplete_polls_max": counters["sweep_wait_polls_max"], "fallback_rounds": counters["sweep_fallbacks"],
+                          "collectives": counters["collectives"]}
     if timing:
-        tot, cnt = ktimes.get("assign_block", (0.0, 0))
-        per_launch_ms = tot / max(cnt, 1)
-        n_rounds = args.steps * args.rounds
-        sweep = cnt <= n_rounds          # k_round: one launch per update_R sweep; else one launch per block
-        cells_per_launch = N if sweep else N / 20.0
-        alg_bytes = cells_per_launch * (4 * d + 4 * K + 4)
-        achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
-        kernel = ("k_round (one persistent launch per update_R sweep: all 20 blocks)" if sweep
-                  else "k_assign_lds (one launch per update block)")
-        traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_v6_c3_pmc_hbm.json")
-        if sweep and args.config == "c3" and os.path.exists(pmc_file):
-            # HBM bytes per launch from the rocprofv3 --pmc passes of this configuration (FETCH_SIZE doubled
-            # for gfx950's half-counted 16-byte streams + WRITE_SIZE; scripts/gpu_pmc.sh), not re-collected here
-            pm = json.load(open(pmc_file))["kernels"]
-            for name, rec in pm.items():
-                if name.startswith("void k_round"):
-                    traffic, traffic_src = rec["hbm_bytes_corrected"], "profiles/r01_v6_c3_pmc_hbm.json"
-        out["roofline"] = {"bound": "hbm", "kernel": kernel, "achieved": achieved,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                           "traffic_source": traffic_src,
-                           "avg_launch_us": per_launch_ms * 1e3, "launches": cnt,
-                           "algorithmic_bytes_per_launch": alg_bytes}
-        round_bytes = N * (4 * d + 8 * K + 8)
-        fam_ms = {k: round(v[0], 3) for k, v in ktimes.items()}
-        t_round_kernels = sum(ktimes[k][0] for k in ("assign_block", "rtz_round", "rtz_reduce", "block_table")) / max(n_rounds, 1)
-        out["roofline"]["round"] = {
-            "algorithmic_bytes": round_bytes, "kernel_ms_per_round": t_round_kernels,
-            "frac_of_hbm_peak": (round_bytes / (t_round_kernels * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_round_kernels > 0 else 0.0,
-            "mfma_flops": N * 4 * d * K,
-            "frac_of_f32_mfma_peak": (N * 4 * d * K / (t_round_kernels * 1e-3) / 157.3e12) if t_round_kernels > 0 else 0.0}
-        out["kernel_ms_total"] = fam_ms
+        out["roofline"], out["kernel_ms_total"] = roofline_block(args.config, N, d, B, K, ktimes, args.steps, args.rounds, ho_wide)
     if conv is not None:
         out["convergence"] = conv
     if conv is not None and world == 1 and not args.no_lisi:
@@ -335,6 +439,10 @@ def main():
         # latency-bound (its working set lives in the L3; 20 sequential hand-offs per round), so the headline
         # figure is quoted on configs[2], the roofline point
         out["configs_1"] = side_config("c2", args.rounds, steps=10, warmup=2, device=f"cuda:{local_rank}")
+        # all 10M cells of BASELINE configs[3] on this ONE GPU, and the per-GPU shard of configs[4] (wide-PC regime)
+        del Z, meta
+        out["configs_3_on_one_gpu"] = side_config("c4x1", args.rounds, steps=2, warmup=1, device=f"cuda:{local_rank}")
+        out["configs_4_shard"] = side_config("c5", args.rounds, steps=2, warmup=1, device=f"cuda:{local_rank}")
     if args.cpu_sample > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(d, B, K, args.rounds, min(args.cpu_sample, N))
     os.write(json_fd, (json.dumps(out) + "\n").encode())

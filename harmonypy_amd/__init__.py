@@ -10,5 +10,8 @@ from .harmony import Harmony, run_harmony, BatchCodes  # noqa: F401
 from .dist import Shard  # noqa: F401
 from .lisi import compute_lisi  # noqa: F401
 
-__version__ = "0.1.0"
-__all__ = ["Harmony", "run_harmony", "BatchCodes", "Shard", "compute_lisi", "__version__"]
+__version__ = "0.2.0"
+# version of the kernel set: profiles/*_pmc_hbm.json name the one their counters were collected on, and bench.py only
+# quotes counter-derived traffic for the version it is running
+ENGINE_VERSION = "r02-v10"
+__all__ = ["Harmony", "run_harmony", "BatchCodes", "Shard", "compute_lisi", "__version__", "ENGINE_VERSION"]

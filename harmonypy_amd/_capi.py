@@ -301,9 +301,10 @@ class Engine:
 
     def counters(self):
         """dict of the engine's event counters (hmx_counters)."""
-        buf = np.zeros(4, np.int64)
+        buf = np.zeros(8, np.int64)
         _check(self._lib.hmx_counters(self._h, _ptr(buf)))
-        return {"collectives": int(buf[0]), "sweep_fallbacks": int(buf[1]), "seeded_rounds": int(buf[2])}
+        return {"collectives": int(buf[0]), "sweep_fallbacks": int(buf[1]), "seeded_rounds": int(buf[2]),
+                "sweep_waits": int(buf[4]), "sweep_wait_polls": int(buf[5]), "sweep_wait_polls_max": int(buf[6])}
 
     def kernel_times(self):
         """{family: (total_ms, launches)} since timing was enabled."""

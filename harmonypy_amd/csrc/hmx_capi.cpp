@@ -109,6 +109,7 @@ struct hmx_engine {
     int sweep_kernel = 0;        // 0: k_round + R^T.Z pass with the removal sums (faster at C3: DESIGN.md §3), 1: k_sweep (hmx_sweep.hip; HMX_SWEEP=1)
     unsigned spin_limit = 1u << 24;  // polls a grid-wide wait may take (HMX_SPIN_LIMIT; tests shrink it to force the fall-back)
     long n_sweep_fallbacks = 0;  // rounds repeated through the per-block path after a wait timed out
+    DevBuf<unsigned long long> wait_stats;   // {waits, incomplete polls, most polls of one wait} of the sweep kernels' grid-wide waits
     DevBuf<double> xch;
     double *Sold = nullptr, *Yacc64 = nullptr, *Snew = nullptr, *objacc = nullptr, *Sr = nullptr, *Oxr = nullptr;
     double* obj_host = nullptr;  // pinned
@@ -375,7 +376,8 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
             e->Sr = e->objacc + n_obj;
             e->Oxr = e->Sr + GK * e->ldy;
         }
-        if ((rc = e->Sslots.reserve(GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 1))) break;
+        if ((rc = e->Sslots.reserve(GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 1)) || (rc = e->wait_stats.reserve(4))) break;
+        (void)hipMemsetAsync(e->wait_stats.p, 0, 4 * sizeof(unsigned long long), e->stream);
         e->sync_words.p = reinterpret_cast<unsigned*>(e->Sslots.p + GK * (e->nblk + 1) * HMX_ROUND_SLOTS);   // borrowed tail
         e->sync_words.n = 2;
         if (hipHostMalloc(reinterpret_cast<void**>(&e->sync_host), 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
@@ -418,7 +420,7 @@ void hmx_destroy(hmx_engine* e) {
     e->task_t0.release(); e->task_t1.release();
     e->task_grp.release(); e->gstart.release(); e->chunk_tab.release(); e->run_count.release(); e->run_start.release();
     e->Ogrp.release(); e->Tmass.release(); e->Ohist.release(); e->xch.release(); e->scratch.release();
-    e->global_id.release(); e->sync_words.p = nullptr; e->sync_words.n = 0; e->Sslots.release(); e->km_hn.release(); e->km_sums.release();
+    e->global_id.release(); e->wait_stats.release(); e->sync_words.p = nullptr; e->sync_words.n = 0; e->Sslots.release(); e->km_hn.release(); e->km_sums.release();
     if (e->sync_host) (void)hipHostFree(e->sync_host);
     comm_release(e);
     peer_release(e);
@@ -784,7 +786,7 @@ static int round_sweep(hmx_engine* e, int flags, const std::vector<int>& tiles_u
         sa.cells = e->lists[e->cur].cells.p; sa.blk_start = e->lists[e->cur].blk_start.p; sa.gstart = e->gstart.p;
         sa.O_start = e->Ogrp.p; sa.D_slots = e->Sslots.p; sa.O_out = e->Ogrp.p; sa.T_out = e->Tmass.p;
         sa.obj = e->objacc; sa.group_cols = e->group_cols.p; sa.Pr_b = e->Pr_b.p; sa.theta = e->theta.p;
-        sa.counter = e->sync_words.p; sa.error = e->sync_words.p + 1;
+        sa.counter = e->sync_words.p; sa.error = e->sync_words.p + 1; sa.wait_stats = e->wait_stats.p;
         sa.spin_limit = e->spin_limit; sa.n_cells = e->N;
         sa.K = e->K; sa.Kp = e->Kp; sa.K16 = e->K16; sa.ldz = e->dp; sa.ldy = e->ldy; sa.G = e->G; sa.B = e->B; sa.V = e->V;
         sa.nblk = e->nblk; sa.n_ranks = 1;
@@ -910,7 +912,7 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         ra.cells = e->lists[e->cur].cells.p; ra.tile_grp = e->lists[e->cur].tile_grp.p; ra.blk_start = e->lists[e->cur].blk_start.p;
         ra.O_start = e->Ogrp.p; ra.S_old = e->Sold; ra.S_new = e->Sslots.p; ra.O_out = e->Ogrp.p; ra.T_out = e->Tmass.p;
         ra.obj = e->objacc; ra.group_cols = e->group_cols.p; ra.Pr_b = e->Pr_b.p; ra.theta = e->theta.p;
-        ra.counter = e->sync_words.p; ra.error = e->sync_words.p + 1;
+        ra.counter = e->sync_words.p; ra.error = e->sync_words.p + 1; ra.wait_stats = e->wait_stats.p;
         ra.K = e->K; ra.Kp = e->Kp; ra.K16 = e->K16; ra.dp = e->dp; ra.ldy = e->ldy; ra.G = e->G; ra.B = e->B; ra.V = e->V;
         ra.nblk = e->nblk; ra.spin_limit = e->spin_limit;
         if (multi) {
@@ -1418,12 +1420,21 @@ int hmx_device_ptr(hmx_engine* e, int which, void** d_ptr, size_t* bytes) {
     return HMX_OK;
 }
 
-int hmx_counters(hmx_engine* e, int64_t out[4]) {
+int hmx_counters(hmx_engine* e, int64_t out[8]) {
     if (!e || !out) return fail(HMX_ERR_ARG, "null argument");
+    int rc;
+    if ((rc = use_device(e))) return rc;
+    unsigned long long ws[4] = {0, 0, 0, 0};
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(ws, e->wait_stats.p, sizeof ws, hipMemcpyDeviceToHost));
     out[0] = e->n_collectives;
     out[1] = e->n_sweep_fallbacks;
     out[2] = (int64_t)e->seeded_rounds;
     out[3] = 0;
+    out[4] = (int64_t)ws[0];
+    out[5] = (int64_t)ws[1];
+    out[6] = (int64_t)ws[2];
+    out[7] = 0;
     return HMX_OK;
 }
 

@@ -49,6 +49,7 @@ struct RoundArgs {
     const float* theta;
     unsigned* counter;       // arrivals (zeroed by the caller)
     unsigned* error;         // set to 1 when a wait gave up (zeroed by the caller)
+    unsigned long long* wait_stats;   // {waits, polls that found the hand-off incomplete, most polls of one wait}: accumulated
     unsigned long long* prof;  // HMX_ROUND_PROF builds: wgs x nblk x 8 time stamps (or null)
     // cells sharded over ranks: the block sums travel through peer boxes (null / 1: single engine)
     double* const* peer_box;   // n_ranks box base pointers (own box included), device array
@@ -79,6 +80,7 @@ struct SweepArgs {
     const float* theta;
     unsigned* counter;       // arrivals (zeroed by the caller)
     unsigned* error;         // set to 1 when a wait gave up (zeroed by the caller)
+    unsigned long long* wait_stats;   // {waits, polls that found the hand-off incomplete, most polls of one wait}: accumulated
     // cells sharded over ranks: the hand-off tables travel through peer boxes (null / 1: single engine)
     double* const* peer_box;   // n_ranks box base pointers (own box included), device array
     double* my_box;

@@ -960,6 +960,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     int cell2[ROUND_TPW], grp2[ROUND_TPW];   // ids of block b+2's tiles (travelling)
     double km_acc = 0.0, ent_acc = 0.0;
     bool failed = false;
+    unsigned ws_n = 0, ws_sum = 0, ws_max = 0;   // this workgroup's grid-wide waits (wave 0)
     // tiles 2p, 2p+1 of a block go to workgroup p % nwg, wave (p / nwg) % WAVES (pass p / nwg / WAVES)
     const int j_first = ROUND_TPW * (wg + nwg * wv);
     const int j_slot = ROUND_TPW * nwg * ROUND_WAVES;
@@ -1025,6 +1026,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                     if (++spins > a.spin_limit) { failed = true; break; }
                 }
             }
+            ws_n += 1; ws_sum += spins; ws_max = max(ws_max, spins);
 #ifdef HMX_ROUND_PROF
             if (tid == 0 && a.prof) a.prof[((size_t)wg * a.nblk + b) * 16 + 10] = spins;
 #endif
@@ -1151,6 +1153,11 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         RSTAMP(5);
     }
 
+    if (tid == 0 && a.wait_stats) {
+        atomicAdd(a.wait_stats, (unsigned long long)ws_n);
+        atomicAdd(a.wait_stats + 1, (unsigned long long)ws_sum);
+        atomicMax(a.wait_stats + 2, (unsigned long long)ws_max);
+    }
     // ---- objective partial sums (:399, :402) ----------------------------------------------------
     km_acc = wave_sum_all(km_acc);
     ent_acc = wave_sum_all(ent_acc);

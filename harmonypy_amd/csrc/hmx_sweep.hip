@@ -418,6 +418,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(SweepArgs a) {
 
     // ---- hand-off machinery ----------------------------------------------------------------------------
     bool failed = false;
+    unsigned ws_n = 0, ws_sum = 0, ws_max = 0;   // this workgroup's grid-wide waits (wave 0)
     // add this workgroup's share of hand-off p to the slot tables, then arrive (all waves call this)
     auto publish = [&](int p) {
         if (gsum_grp >= 0) flush_run(gsum, gsum_grp, 1.0);
@@ -454,6 +455,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(SweepArgs a) {
                     if (failed || ++spins > a.spin_limit) { failed = true; break; }
                 }
             }
+            ws_n += 1; ws_sum += spins; ws_max = max(ws_max, spins);
         }
         wg_barrier_lds();
     };
@@ -784,6 +786,11 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(SweepArgs a) {
         SSTAMP(6);
     }
 
+    if (tid == 0 && a.wait_stats) {
+        atomicAdd(a.wait_stats, (unsigned long long)ws_n);
+        atomicAdd(a.wait_stats + 1, (unsigned long long)ws_sum);
+        atomicMax(a.wait_stats + 2, (unsigned long long)ws_max);
+    }
     // ---- objective partial sums (:399, :402) ----------------------------------------------------
     km_acc = wave_sum_all(km_acc);
     ent_acc = wave_sum_all(ent_acc);
