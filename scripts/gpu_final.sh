@@ -2,7 +2,7 @@
 # Round-end evidence: GPU parity suite, smoke(), default bench line, rocprofv3 kernel stats of the same command.
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 > gpurun_out/pytest_gpu.log
+timeout 1500 python -m pytest tests -m gpu -x -q -rP 2>&1 | grep -E "passed|failed|error|same schedule|diverged|bench path|2 shards|k_sweep\)|1 vs 2" | tail -60 > gpurun_out/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1
 timeout 600 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
 rm -rf gpurun_out/prof
@@ -12,13 +12,13 @@ tail -3 gpurun_out/pytest_gpu.log; tail -2 gpurun_out/smoke.log
 python - <<'PY'
 import json, csv, glob
 d = json.loads(open("gpurun_out/bench_default.json").read().splitlines()[0])
-print(round(d["value"] / 1e6, 2), "M cells/s/it", d["ms_per_step"], d["roofline"], d["cpu_baseline"], d.get("lisi"), d["convergence"]["wall_s"])
+print(round(d["value"] / 1e6, 2), "M cells/s/it", d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["traffic"], d["cpu_baseline"]["value"], d.get("lisi", {}).get("seconds"), d["convergence"]["wall_s"])
 f = glob.glob("gpurun_out/prof/**/*kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 with open("gpurun_out/kernel_stats_summary.txt", "w") as out:
-    out.write("# rocprofv3 --kernel-trace --stats -- python bench.py --cpu-sample 0 --no-roofline  (default: C3, 5 steps of 10 rounds + ridge; run to convergence; LISI of 1M cells before/after)\n")
+    out.write("# rocprofv3 --kernel-trace --stats -- python bench.py --cpu-sample 0 --no-roofline  (default: C3, 5 steps of 10 rounds + ridge; run to convergence; LISI of 1M cells before/after; side configurations C2, 10M cells on one GPU, wide shard)\n")
     out.write(f"{'kernel':72s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>7s}\n")
     for r in rows[:45]:
         out.write(f"{r['Name'][:72]:72s} {r['Calls']:>6s} {float(r['TotalDurationNs'])/1e6:10.2f} {float(r['AverageNs'])/1e3:10.1f} {float(r['Percentage']):7.2f}\n")
-print(open("gpurun_out/kernel_stats_summary.txt").read()[:1800])
+print(open("gpurun_out/kernel_stats_summary.txt").read()[:2200])
 PY
