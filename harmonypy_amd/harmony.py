@@ -436,6 +436,9 @@ class Harmony:
             mode = "torch" if self.N_global <= AUTO_DEVICE_ORDER_CELLS else "device"
         self.update_order = mode
         self._seed = int(random_state) if random_state is not None else 0
+        if verbose and mode == "device":
+            logger.info("  update order: keyed bijection on the device (a different random stream than the reference's "
+                        "torch.randperm; HMX_UPDATE_ORDER=torch replays the reference's)")
 
         # where the wall-clock of the constructor went (seconds per phase); read by bench.py
         self.timing = {}
@@ -630,7 +633,8 @@ class Harmony:
         the host instead -- seconds, where fitting all cells on the host takes minutes (160 s for
         1.25M cells x 200 PCs, K=200)."""
         if self.verbose:
-            logger.info("Computing initial centroids: k-means++ seeding on a subsample, Lloyd iterations on the GPU...")
+            logger.info("Computing initial centroids: k-means++ seeding on a subsample, Lloyd iterations on the GPU "
+                        "(not sklearn's fit on all cells: HMX_KMEANS=host selects that)...")
         n = max(1, int(round(KMEANS_SEED_CELLS * self.N / self.N_global)))
         # evenly spaced over the group-sorted cells: every batch group in proportion
         take = np.linspace(0, self.N - 1, min(n, self.N)).astype(np.int64)

@@ -37,6 +37,9 @@ def compute_lisi(
     ``return_neighbors=True`` also returns the ``3*perplexity - 1`` nearest neighbours of every cell
     (distances, indices), nearest first -- what the reference gets from ``knn.kneighbors`` after
     dropping the first column (lisi.py:55-60).
+
+    Limit of this build: ``3 * perplexity <= 120`` neighbours (perplexity <= 40; the reference takes any): a larger
+    value raises ``ValueError``.
     """
     if isinstance(label_colnames, str):
         label_colnames = [label_colnames]
@@ -65,7 +68,7 @@ def compute_lisi(
                               float(perplexity), _capi._ptr(out), _capi._ptr(kd), _capi._ptr(ki))
     if rc < 0:
         msg = lib.hmx_last_error().decode(errors="replace")
-        if "n_neighbors" in msg:
-            raise ValueError(msg)                                               # what sklearn raises for the reference
+        if "n_neighbors" in msg or msg.startswith("perplexity"):
+            raise ValueError(msg)                                               # what sklearn raises for the reference / this build's limit
         raise _capi.HmxError(f"libhmx: {msg} (code {rc})")
     return (out, kd, ki) if return_neighbors else out

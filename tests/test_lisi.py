@@ -86,3 +86,13 @@ def test_device_lisi_errors():
         hm.compute_lisi(X, meta, ["a"], 5, device="cpu")
     assert hm.compute_lisi(X, meta, ["a"], 5).shape == (50, 1)
     np.testing.assert_allclose(hm.compute_lisi(X, meta, ["a"], 5), 1.0)  # one category: LISI = 1
+
+
+def test_perplexity_beyond_the_build_limit_is_a_value_error():
+    """3 * perplexity > 120 neighbours: refused with ValueError before any device work (lisi.py:53 takes any)."""
+    import pandas as pd
+    import harmonypy_amd
+    X = np.random.default_rng(0).normal(size=(500, 5))
+    meta = pd.DataFrame({"b": np.arange(500) % 3})
+    with pytest.raises(ValueError, match="perplexity"):
+        harmonypy_amd.compute_lisi(X, meta, ["b"], perplexity=41)
