@@ -1060,6 +1060,22 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         wg_barrier_lds();
         RSTAMP(6);
         // ---- cluster mass, then ratio ** theta per (batch, cluster)  (:491, 495-499) ----------
+        if (a.V == 1) {
+            // one batch variable (group g is batch g): mass, ratio, power and log in one pass over the table entries
+            for (int i = tid; i < GK; i += ROUND_THREADS) {
+                const int g = i / K16, k = i - g * K16;
+                double t = 0.0;
+                for (int gg = 0; gg < a.G; ++gg) t += Ocur[(size_t)gg * K16 + k];
+                const float O = (float)Ocur[i];
+                const float E = (float)t * prb[g];                          // :491 (E kept as mass T)
+                const float oe = fmaxf(O + E, 1e-8f);                       // :495-496
+                const float ratio = fminf(fmaxf(E / oe, 1e-8f), 1.0f);      // :497-498
+                const float rp = pow_unit(ratio, tht[g]);                   // :499
+                rpT[i] = rp;
+                lrpT[i] = __builtin_amdgcn_logf(rp) * 0.693147182464599609375f;   // v_log_f32 (log2, 1 ulp) * ln 2
+            }
+            RSTAMP(7);
+        } else {
         for (int k = tid; k < K16; k += ROUND_THREADS) {
             double t = 0.0;
             for (int g = 0; g < a.G; ++g) t += Ocur[(size_t)g * K16 + k];
@@ -1068,16 +1084,11 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         wg_barrier_lds();
         for (int i = tid; i < K16 * a.B; i += ROUND_THREADS) {
             const int bb = i / K16, k = i - bb * K16;
-            double Ob;
-            if (a.V == 1) {
-                Ob = Ocur[(size_t)bgrp[bb] * K16 + k];
-            } else {
-                Ob = 0.0;
-                for (int g = 0; g < a.G; ++g) {
-                    bool has = false;
-                    for (int v = 0; v < a.V; ++v) has |= gcol[g * a.V + v] == bb;
-                    if (has) Ob += Ocur[(size_t)g * K16 + k];
-                }
+            double Ob = 0.0;
+            for (int g = 0; g < a.G; ++g) {
+                bool has = false;
+                for (int v = 0; v < a.V; ++v) has |= gcol[g * a.V + v] == bb;
+                if (has) Ob += Ocur[(size_t)g * K16 + k];
             }
             const float O = (float)Ob;
             const float E = (float)Tm[k] * prb[bb];                     // :491 (E kept as mass T)
@@ -1093,6 +1104,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             for (int v = 0; v < a.V; ++v) s += rpc[(size_t)gcol[g * a.V + v] * K16 + k];
             rpT[i] = s;                                                 // (ratio_pow @ Phi) for the cells of group g
             lrpT[i] = __builtin_amdgcn_logf(s) * 0.693147182464599609375f;   // v_log_f32 (log2, 1 ulp) * ln 2
+        }
         }
         wg_barrier_lds();
         RSTAMP(2);

@@ -55,7 +55,7 @@ def test_device_lisi_matches_reference(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,d,perp,seed", [(1000, 2, 30, 0), (5000, 50, 30, 1), (777, 20, 10, 2), (4099, 64, 42, 3),
+@pytest.mark.parametrize("n,d,perp,seed", [(1000, 2, 30, 0), (5000, 50, 30, 1), (777, 20, 10, 2), (4099, 64, 40, 3),
                                           (1500, 100, 30, 4), (1200, 200, 20, 5), (91, 3, 30, 6)])
 def test_device_neighbours_are_exact(n, d, perp, seed):
     """Neighbour sets, order and distances against the float64 brute-force search of the oracle."""
