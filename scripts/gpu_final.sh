@@ -7,6 +7,19 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 timeout 600 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
 rm -rf gpurun_out/prof
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o r --output-format csv -- python bench.py --cpu-sample 0 --no-roofline > gpurun_out/bench_prof.json 2> gpurun_out/bench_prof.err
+python - <<'PY'
+# per-kernel averages split by grid size (the side configurations launch the same templates on other grids)
+import csv, glob, collections
+agg = collections.defaultdict(list)
+for f in glob.glob("gpurun_out/prof/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        wg = int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))
+        agg[(r["Kernel_Name"][:56], wg)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+with open("gpurun_out/kernel_stats_by_grid.txt", "w") as out:
+    out.write(f"{'kernel':56s} {'workgroups':>10s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s}\n")
+    for (k, wg), v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:40]:
+        out.write(f"{k:56s} {wg:10d} {len(v):6d} {sum(v)/1e3:10.2f} {sum(v)/len(v):10.1f}\n")
+PY
 find gpurun_out/prof -name '*kernel_trace.csv' -size +8M -delete
 tail -3 gpurun_out/pytest_gpu.log; tail -2 gpurun_out/smoke.log
 python - <<'PY'
@@ -20,5 +33,5 @@ with open("gpurun_out/kernel_stats_summary.txt", "w") as out:
     out.write(f"{'kernel':72s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>7s}\n")
     for r in rows[:45]:
         out.write(f"{r['Name'][:72]:72s} {r['Calls']:>6s} {float(r['TotalDurationNs'])/1e6:10.2f} {float(r['AverageNs'])/1e3:10.1f} {float(r['Percentage']):7.2f}\n")
-print(open("gpurun_out/kernel_stats_summary.txt").read()[:2200])
+print(open("gpurun_out/kernel_stats_by_grid.txt").read()[:2400])
 PY
