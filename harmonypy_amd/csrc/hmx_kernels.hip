@@ -537,6 +537,10 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES, 4) void k_assign_lds(AssignArgs 
 #else
 #define RSTAMP(slot) do { } while (0)
 #endif
+// s_waitcnt vmcnt(0) as the builtin (gfx9 encoding: vmcnt 0, expcnt 7, lgkmcnt 15), so that the compiler's own wait
+// insertion knows nothing is outstanding afterwards; as inline assembly it is invisible to it and every later
+// wait it computes assumes the older operations are still in flight
+#define WAIT_VMEM_ALL() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); } while (0)
 #define ROUND_WAVES 8   /* 2 waves per SIMD: 256 registers per lane, two tiles in flight per wave */
 #define ROUND_TPW 2     /* tiles a wave carries across the hand-off */
 #define ROUND_THREADS (64 * ROUND_WAVES)
@@ -598,6 +602,17 @@ __device__ __forceinline__ void round_compute(const float* Ys, const float* nis,
         const f32x4 one = (f32x4){1.f, 1.f, 1.f, 1.f};
         T.arg[mt] = (2.f * (one - T.arg[mt])) * ni;          // dist = 2 (1 - Y.Z) (:447), arg = -dist / sigma (:466)
     }
+}
+
+// a tile's Z_cos fragments from its landing zone in LDS (16 rows x 4 KS floats, row-major)
+template <int KS>
+__device__ __forceinline__ void round_rows_from_lds(const float* zt, int c16, int q, RoundZ<KS>& Z) {
+    constexpr int NF = KS / 4, NT = KS % 4;
+    const float* zr = zt + c16 * (4 * KS);
+#pragma unroll
+    for (int j = 0; j < NF; ++j) Z.zp[j] = ld4(zr + 16 * j + 4 * q);
+#pragma unroll
+    for (int s = 0; s < NT; ++s) Z.zt[s] = zr[16 * NF + 4 * s + q];
 }
 
 // table-dependent half: exp, penalty, renormalisation, R row, block sums, objective terms.
@@ -874,7 +889,11 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     const int GK = a.G * K16;
     const int LDY = a.ldy_lds;
     float* Ys0 = reinterpret_cast<float*>(smem);                         // K16 x LDY
-    float* sig0 = Ys0 + (size_t)K16 * LDY;                               // K16
+    // landing zones of the waves' Z_cos rows (global -> LDS directly): waves x ROUND_TPW tiles x 16 rows x dp floats,
+    // 16-byte aligned (LDY is a multiple of 4); a plain offset from the LDS base: a pointer rebuilt from an integer
+    // would turn every read of the zones into a flat load, which waits on the memory counter as well
+    float* zbuf = Ys0 + (size_t)K16 * LDY;
+    float* sig0 = zbuf + (size_t)ROUND_WAVES * ROUND_TPW * 16 * (4 * KS);   // K16
     float* nis0 = sig0 + K16;                                            // K16  -1/sigma (-1e30 for pads)
     float* sig = sig0;
     float* nis = nis0;
@@ -891,9 +910,10 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     int* bgrp = gcol + a.G * a.V;                                        // B: the group holding batch b (V == 1)
     int* bs = bgrp + a.B;                                                // nblk + 3 tile offsets (two sentinels)
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
-    const int c16 = lane & 15, q = lane >> 4;
+    int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the wave's landing zones and roles are wave-uniform
+    int lane = tid & 63;
+    int c16 = lane & 15, q = lane >> 4;   // (refreshed per block, see the sweep loop)
     const bool multi = a.n_ranks > 1;
     const int wg = blockIdx.x, nwg = multi ? gridDim.x - 1 : gridDim.x;   // compute workgroups
     unsigned long long* my_flags = multi ? reinterpret_cast<unsigned long long*>(a.my_box + box_flags(a.n_ranks, GK)) : nullptr;
@@ -919,7 +939,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                 for (int s = 0; s < HMX_ROUND_SLOTS; ++s) v += ld_agent(sn + (size_t)s * GK);
                 for (int r = 0; r < a.n_ranks; ++r) st_sys(a.peer_box[r] + box_data(a.n_ranks, GK, b & 1, a.rank) + i, v);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            WAIT_VMEM_ALL();
             __syncthreads();
             if (tid < a.n_ranks)
                 st_sys(reinterpret_cast<unsigned long long*>(a.peer_box[tid] + box_flags(a.n_ranks, GK)) + (size_t)(b & 1) * a.n_ranks + a.rank,
@@ -955,9 +975,12 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     (void)NF; (void)NT;
 
     RoundTile<MT> T[ROUND_TPW];
-    RoundZ<KS> Z[ROUND_TPW];
+    float* zb[ROUND_TPW];
+#pragma unroll
+    for (int u = 0; u < ROUND_TPW; ++u) zb[u] = zbuf + (size_t)(wv * ROUND_TPW + u) * 16 * (4 * KS);
     int cell1[ROUND_TPW], grp1[ROUND_TPW];   // ids of block b+1's tiles (landed)
-    int cell2[ROUND_TPW], grp2[ROUND_TPW];   // ids of block b+2's tiles (travelling)
+    int cell2[ROUND_TPW], grp2[ROUND_TPW];   // ids of block b+2's tiles (travelling: raw loads, untouched until they are shifted in)
+    bool valid2[ROUND_TPW];
     double km_acc = 0.0, ent_acc = 0.0;
     bool failed = false;
     unsigned ws_n = 0, ws_sum = 0, ws_max = 0;   // this workgroup's grid-wide waits (wave 0)
@@ -972,6 +995,32 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         grp = valid ? a.tile_grp[t0 + j] : 0;
     };
 
+    // A tile's 16 Z_cos rows travel global -> LDS directly (no destination registers: held in VGPRs across the finishing
+    // pass they push it into scratch, and every scratch reload waits for ALL outstanding memory operations of the wave).
+    // The landing zone is linear in 16-byte pieces: lane l of instruction i brings piece (64 i + l) % KS of row
+    // (64 i + l) / KS, so the zone is the tile row-major.  Dead rows (list padding) read cell 0's row.
+    auto issue_rows = [&](int cell_c16, float* dst) {
+        constexpr int NCH = 16 * KS, NIT = (NCH + 63) / 64;
+        const float* src[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {   // all source addresses first: one wait for the id exchange, not one per request
+            const int idx = 64 * it + lane;
+            const int row = idx / KS, piece = idx - row * KS;
+            const int cell = __shfl(cell_c16, row & 15, 64);   // the rows' ids sit in lanes 0..15
+            src[it] = a.Zcos + (size_t)(cell >= 0 ? cell : 0) * (4 * KS) + 4 * piece;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            // Issued as inline assembly on purpose: after the builtin the compiler waits for vmcnt(0) before the next
+            // LDS read of ANY address (it cannot tell the landing zone from the centroid table), i.e. for the rows.
+            // The waits it computes for its own loads stay correct: memory operations return in order.
+            const unsigned zone = __builtin_amdgcn_readfirstlane(
+                (unsigned)(size_t)(__attribute__((address_space(3))) void*)(dst + 256 * it));
+            if (64 * (it + 1) <= NCH || 64 * it + lane < NCH)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                             :: "v"(src[it]), "s"(zone) : "memory", "m0");
+        }
+    };
     const float* Ys = Ys0;
     // ---- prologue: block 0 computed, block 1's ids landed ---------------------------------------
 #pragma unroll
@@ -979,13 +1028,47 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         load_ids(0, u, T[u].cell, T[u].grp);
         load_ids(1, u, cell1[u], grp1[u]);
     }
+    // tile step shared by the prologue and the sweep: fragments of the landed rows into registers, the landing zones
+    // handed to the rows of the block after (ids in cell1; ids of the block after that requested too), then the distance
+    // GEMM.  The requests are issued here because this is where they are free -- the SIMD's matrix pipe is the bound of
+    // this phase, the partner wave's MFMAs cover them -- and far from the hand-off: a wave's memory operations return
+    // in order, so a request in flight in front of the poll or of the hand-off's loads would be waited for by them.
+    // By the next poll these rows have had a whole distance GEMM to land; they are used a block later.
+    auto tile_step = [&](int blk_ids) {
+        RoundZ<KS> Zf[ROUND_TPW];
 #pragma unroll
-    for (int u = 0; u < ROUND_TPW; ++u) round_issue_z<KS>(a.Zcos, T[u].cell, q, Z[u]);
+        for (int u = 0; u < ROUND_TPW; ++u) round_rows_from_lds<KS>(zb[u], c16, q, Zf[u]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zones are read before they are handed on
+        auto request = [&]() {
 #pragma unroll
-    for (int u = 0; u < ROUND_TPW; ++u) {
-        round_compute<MT, KS>(Ys, nis, LDY, c16, q, Z[u], T[u]);
+        for (int u = 0; u < ROUND_TPW; ++u) {
+            issue_rows(cell1[u], zb[u]);
+            // ids of the block after: clamped loads, the "no such tile" case applied when they are shifted in -- a
+            // predicated load or a select here would be waited for at once, and with it every row request above
+            const int j = j_first + u;
+            const int t0 = bs[blk_ids], t1 = bs[blk_ids + 1];
+            valid2[u] = j < t1 - t0;
+            const int tl = min(t0 + j, bs[a.nblk] - 1);
+            cell2[u] = a.cells[(size_t)tl * 16 + c16];
+            grp2[u] = a.tile_grp[tl];
+        }
+        };
+        // the two waves of a SIMD stagger the request code: one issues it while the other's first tile keeps the pipe busy
+        static_assert(ROUND_TPW == 2, "tile_step is written for two tiles per wave");
+        const bool second = wv >= ROUND_WAVES / 2;
+        if (!second) request();
         __builtin_amdgcn_sched_barrier(0);
-    }
+        round_compute<MT, KS>(Ys, nis, LDY, c16, q, Zf[0], T[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (second) request();
+        __builtin_amdgcn_sched_barrier(0);
+        round_compute<MT, KS>(Ys, nis, LDY, c16, q, Zf[1], T[1]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll
+    for (int u = 0; u < ROUND_TPW; ++u) issue_rows(T[u].cell, zb[u]);
+    WAIT_VMEM_ALL();   // landed (nothing else orders an LDS read behind an LDS-DMA)
+    tile_step(2);
 
     for (int b = 0; b < a.nblk; ++b) {
         const int tb = bs[b], ntl = bs[b + 1] - tb;
@@ -996,15 +1079,11 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             Ys = Ys0 + zero;
             sig = sig0 + zero;
             nis = nis0 + zero;
+            // likewise the lane's own coordinates: everything derived from them (table and row addresses, list
+            // positions) is recomputed per block instead of being kept -- in scratch -- across the sweep
+            asm volatile("" : "+v"(tid), "+v"(lane), "+v"(c16), "+v"(q));
         }
         RSTAMP(0);
-        // ---- operands of the following blocks start travelling: Z_cos rows of block b+1 (ids known),
-        //      ids of block b+2.  Nothing below waits for them before round_compute.
-#pragma unroll
-        for (int u = 0; u < ROUND_TPW; ++u) {
-            round_issue_z<KS>(a.Zcos, cell1[u], q, Z[u]);
-            load_ids(b + 2, u, cell2[u], grp2[u]);
-        }
         RSTAMP(8);
         // ---- wait until every workgroup has added its sums of block b-1 ---------------------
         if (b > 0 && wv == 0) {
@@ -1035,27 +1114,37 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         wg_barrier_lds();
         RSTAMP(1);
         // ---- O without this block, with the previous block's new sums (:491-492, 506-507) ---
-        for (int i = tid; i < GK; i += ROUND_THREADS) {
-            double add[8];
+        for (int base = tid; base < GK; base += 2 * ROUND_THREADS) {   // two entries per thread and trip, all loads in flight together
+            double add[2][8], so[2];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) add[s] = 0.0;
-            if (b > 0 && !(HMX_RABL & 8)) {
-                if (!multi) {
-                    const double* sn = a.S_new + (size_t)(b - 1) * HMX_ROUND_SLOTS * GK + i;
+            for (int n = 0; n < 2; ++n) {
+                const int i = min(base + n * ROUND_THREADS, GK - 1);    // clamped, not predicated
 #pragma unroll
-                    for (int s = 0; s < HMX_ROUND_SLOTS; ++s) add[s] = ld_agent(sn + (size_t)s * GK);   // independent loads
-                } else {
-                    const double* bx = a.my_box + box_data(a.n_ranks, GK, (b - 1) & 1, 0) + i;
+                for (int s = 0; s < 8; ++s) add[n][s] = 0.0;
+                so[n] = a.S_old[(size_t)b * GK + i];
+                if (b > 0 && !(HMX_RABL & 8)) {
+                    if (!multi) {
+                        const double* sn = a.S_new + (size_t)(b - 1) * HMX_ROUND_SLOTS * GK + i;
 #pragma unroll
-                    for (int s = 0; s < 8; ++s)
-                        if (s < a.n_ranks) add[s] = ld_sys(bx + (size_t)s * GK);
+                        for (int s = 0; s < HMX_ROUND_SLOTS; ++s) add[n][s] = ld_agent(sn + (size_t)s * GK);   // independent loads
+                    } else {
+                        const double* bx = a.my_box + box_data(a.n_ranks, GK, (b - 1) & 1, 0) + i;
+#pragma unroll
+                        for (int s = 0; s < 8; ++s) add[n][s] = ld_sys(bx + (size_t)min(s, a.n_ranks - 1) * GK);
+                    }
                 }
             }
-            double o = Ocur[i] - a.S_old[(size_t)b * GK + i];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) o += add[s];
-            Ocur[i] = o;
-            Sd[i] = 0.0;
+            for (int n = 0; n < 2; ++n) {
+                const int i = base + n * ROUND_THREADS;
+                if (i < GK) {
+                    double o = Ocur[i] - so[n];
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) o += (!multi || s < a.n_ranks) ? add[n][s] : 0.0;
+                    Ocur[i] = o;
+                    Sd[i] = 0.0;
+                }
+            }
         }
         wg_barrier_lds();
         RSTAMP(6);
@@ -1143,7 +1232,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                 if (v != 0.0) atomicAdd(dst + i, v);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the sums are performed (and the next operands landed)
+        WAIT_VMEM_ALL();   // the sums are performed (and the next operands landed)
         wg_barrier_lds();
         if (tid == 0) __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         RSTAMP(4);
@@ -1152,16 +1241,10 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         for (int u = 0; u < ROUND_TPW; ++u) {
             T[u].cell = cell1[u];
             T[u].grp = grp1[u];
-            cell1[u] = cell2[u];
-            grp1[u] = grp2[u];
+            cell1[u] = valid2[u] ? cell2[u] : -1;
+            grp1[u] = valid2[u] ? grp2[u] : 0;
         }
-        if (b + 1 < a.nblk) {
-#pragma unroll
-            for (int u = 0; u < ROUND_TPW; ++u) {
-                round_compute<MT, KS>(Ys, nis, LDY, c16, q, Z[u], T[u]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+        if (b + 1 < a.nblk) tile_step(b + 3);   // rows landed: vmcnt(0) above
         RSTAMP(5);
     }
 
@@ -3012,7 +3095,7 @@ size_t round_lds_bytes(int K16, int dp, int G, int B) {
     const size_t GK = (size_t)G * K16;
     // sigma, -1/sigma, rp, lrp, rpc | O, S, T, objective scratch (fp64) | Pr_b, theta, group_cols (V <= 8), bgrp, block offsets
     return ((size_t)K16 * lds_ldy(dp) + 2 * (size_t)K16 + 2 * GK + (size_t)K16 * B) * 4 + (2 * GK + K16 + 2 * ROUND_WAVES) * 8 +
-           (3 * (size_t)B + (size_t)G * 8 + 64) * 4;
+           (3 * (size_t)B + (size_t)G * 8 + 64) * 4 + 16 + (size_t)ROUND_WAVES * ROUND_TPW * 16 * dp * 4;
 }
 
 size_t peer_box_doubles(int n_ranks, size_t GK) { return box_flags(n_ranks, GK) + 2 * (size_t)n_ranks + 2 * (size_t)n_ranks + 8; }
