@@ -376,7 +376,7 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
             e->Sr = e->objacc + n_obj;
             e->Oxr = e->Sr + GK * e->ldy;
         }
-        if ((rc = e->Sslots.reserve(GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 1)) || (rc = e->wait_stats.reserve(4))) break;
+        if ((rc = e->Sslots.reserve(GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 1 + 128)) || (rc = e->wait_stats.reserve(4))) break;   // + slack: the per-round fill is rounded up to 1 KB
         (void)hipMemsetAsync(e->wait_stats.p, 0, 4 * sizeof(unsigned long long), e->stream);
         e->sync_words.p = reinterpret_cast<unsigned*>(e->Sslots.p + GK * (e->nblk + 1) * HMX_ROUND_SLOTS);   // borrowed tail
         e->sync_words.n = 2;
@@ -896,7 +896,8 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
     if (mega) {
         // the whole sweep in one persistent launch (k_round); closes O, T and the objective itself
         // the slot tables and the two sync words (carved from the same allocation): one fill
-        HIP_TRY(hipMemsetAsync(e->Sslots.p, 0, (GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 1) * sizeof(double), e->stream));
+        // (size rounded up to 1 KB inside the allocation: an odd size makes the runtime launch a second fill kernel for the tail)
+        HIP_TRY(hipMemsetAsync(e->Sslots.p, 0, (((GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 1) * sizeof(double) + 1023) / 1024) * 1024, e->stream));
         int max_upper = 0;
         for (int b = 0; b < e->nblk; ++b) max_upper = std::max(max_upper, tiles_upper[b]);
         const bool multi = e->peers_enabled && e->n_ranks > 1;
@@ -968,9 +969,9 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
             fprintf(stderr, "[k_round prof] whole sweep mean %.0f ticks over %d workgroups\n", tot / wgs, wgs);
         }
 #endif
-        HIP_TRY(hipMemcpyAsync(e->sync_host, e->sync_words.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
         // the two objective sums (:399, :402) of this rank's cells; the cross-entropy term was formed from job-wide tables.
-        // A rank whose wait timed out poisons its sums with NaN: every rank then sees the failure in this all-reduce.
+        // A rank whose wait timed out poisons its sums with NaN: every rank then sees the failure in this all-reduce --
+        // and so does the host, in the objective it reads anyway (no separate copy of the error word).
         if (multi && (rc = sum_over_ranks(e, e->objacc, 2 * HMX_OBJ_SLOTS))) return rc;
     } else if (flags & HMX_ROUND_UPDATE_R) {
         for (int b = 0; b < e->nblk; ++b) {
