@@ -13,5 +13,5 @@ from .lisi import compute_lisi  # noqa: F401
 __version__ = "0.2.0"
 # version of the kernel set: profiles/*_pmc_hbm.json name the one their counters were collected on, and bench.py only
 # quotes counter-derived traffic for the version it is running
-ENGINE_VERSION = "r02-v12"
+ENGINE_VERSION = "r02-v13"
 __all__ = ["Harmony", "run_harmony", "BatchCodes", "Shard", "compute_lisi", "__version__", "ENGINE_VERSION"]

@@ -891,7 +891,7 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         launch_y_normalize_d(e->Yacc64, e->Y.p, e->K, e->K16, e->d, e->ldy, e->stream);  // :444
     }
     const bool mega = persistent && e->mt <= 7 && round_row_floats(e->d) == e->dp &&
-                      round_lds_bytes(e->K16, e->dp, e->G, e->B) <= 150 * 1024;
+                      round_lds_bytes(e->K16, e->dp, e->G, e->B, e->V) <= HMX_ROUND_LDS_LIMIT;
     if (before_sweep && (rc = before_sweep())) return rc;   // side-stream work that should run beside the sweep, not beside the R^T.Z pass
     if (mega) {
         // the whole sweep in one persistent launch (k_round); closes O, T and the objective itself

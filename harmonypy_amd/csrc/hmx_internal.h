@@ -172,7 +172,9 @@ size_t sweep_lds_bytes(int K16, int d, int G, int B, int V, int nblk);
 int sweep_row_floats(int d);
 int sweep_waves();
 int launch_sweep(const SweepArgs& a, int mt, int d, int wgs, hipStream_t s);
-size_t round_lds_bytes(int K16, int dp, int G, int B);
+size_t round_lds_bytes(int K16, int dp, int G, int B, int V);
+// k_round has no static LDS and one workgroup per CU: everything the CU has (160 KB), less a small margin
+#define HMX_ROUND_LDS_LIMIT (size_t)(159 * 1024)
 int round_row_floats(int d);
 int launch_round(const RoundArgs& a, int mt, int wgs, hipStream_t s);
 size_t peer_box_doubles(int n_ranks, size_t GK);

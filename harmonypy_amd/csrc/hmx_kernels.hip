@@ -899,8 +899,8 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     float* nis = nis0;
     float* rpT = nis + K16;                                              // G x K16
     float* lrpT = rpT + GK;                                              // G x K16
-    float* rpc = lrpT + GK;                                              // B x K16 powered ratios
-    double* Ocur = reinterpret_cast<double*>(rpc + (size_t)K16 * a.B);   // G x K16 (all offsets so far are even)
+    float* rpc = lrpT + GK;                                              // B x K16 powered ratios (several batch variables only)
+    double* Ocur = reinterpret_cast<double*>(rpc + (a.V == 1 ? 0 : (size_t)K16 * a.B));   // G x K16 (all offsets so far are even)
     double* Sd = Ocur + GK;                                              // G x K16 this block's new sums
     double* Tm = Sd + GK;                                                // K16 cluster mass
     double* objw = Tm + K16;                                             // waves x 2
@@ -3091,10 +3091,10 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
     return 0;
 }
 
-size_t round_lds_bytes(int K16, int dp, int G, int B) {
+size_t round_lds_bytes(int K16, int dp, int G, int B, int V) {
     const size_t GK = (size_t)G * K16;
-    // sigma, -1/sigma, rp, lrp, rpc | O, S, T, objective scratch (fp64) | Pr_b, theta, group_cols (V <= 8), bgrp, block offsets
-    return ((size_t)K16 * lds_ldy(dp) + 2 * (size_t)K16 + 2 * GK + (size_t)K16 * B) * 4 + (2 * GK + K16 + 2 * ROUND_WAVES) * 8 +
+    // sigma, -1/sigma, rp, lrp, rpc (V > 1) | O, S, T, objective scratch (fp64) | Pr_b, theta, group_cols (V <= 8), bgrp, block offsets | landing zones
+    return ((size_t)K16 * lds_ldy(dp) + 2 * (size_t)K16 + 2 * GK + (V == 1 ? 0 : (size_t)K16 * B)) * 4 + (2 * GK + K16 + 2 * ROUND_WAVES) * 8 +
            (3 * (size_t)B + (size_t)G * 8 + 64) * 4 + 16 + (size_t)ROUND_WAVES * ROUND_TPW * 16 * dp * 4;
 }
 
@@ -3186,8 +3186,8 @@ static void launch_round_ks(const RoundArgs& a, int mt, int wgs, size_t sm, hipS
 int launch_round(const RoundArgs& a_in, int mt, int wgs, hipStream_t s) {
     RoundArgs a = a_in;
     a.ldy_lds = lds_ldy(a.dp);
-    const size_t sm = round_lds_bytes(a.K16, a.dp, a.G, a.B);
-    if (mt < 1 || mt > 7 || sm > 150 * 1024) return -1;
+    const size_t sm = round_lds_bytes(a.K16, a.dp, a.G, a.B, a.V);
+    if (mt < 1 || mt > 7 || sm > HMX_ROUND_LDS_LIMIT) return -1;
     switch (a.dp) {
         case 32: launch_round_ks<8>(a, mt, wgs, sm, s); break;
         case 52: launch_round_ks<13>(a, mt, wgs, sm, s); break;
