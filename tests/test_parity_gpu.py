@@ -350,6 +350,14 @@ def test_bench_path_parity_c3_shape(monkeypatch):
     _bench_path_case(150_000, 50, 8, 100, monkeypatch, ridge_dtype=np.float64)
 
 
+def test_bench_path_parity_many_batches(monkeypatch):
+    """30 batch groups at K=100, d=50: the most the one-launch sweep serves (its LDS tables grow with the group
+    count: 161 KB of the CU's 160 KiB here); same checks as the C3 shape, and the persistent
+    kernel -- not the per-block fall-back -- must have run."""
+    ho = _bench_path_case(40_000, 50, 30, 100, monkeypatch, ridge_dtype=np.float64, rounds=(3, 3))
+    assert ho._engine.counters()["sweep_waits"] > 0
+
+
 def test_bench_path_parity_c5_shape(monkeypatch):
     """BASELINE configs[4]'s exact shape (d=200, K=200, 32 batches: the wide kernels) at 40k cells,
     seeded device-order rounds vs the oracle: objectives 2e-5, R 1e-4 (plain fp32 arithmetic), Z_corr
