@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             const int j = j_first + u;
             const int t0 = bs[blk_ids], t1 = bs[blk_ids + 1];
             valid2[u] = j < t1 - t0;
-            const int tl = min(t0 + j, bs[a.nblk] - 1);
+            const int tl = max(min(t0 + j, bs[a.nblk] - 1), 0);   // (a shard may hold no tile at all)
             cell2[u] = a.cells[(size_t)tl * 16 + c16];
             grp2[u] = a.tile_grp[tl];
         }
