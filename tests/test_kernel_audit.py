@@ -1,0 +1,71 @@
+"""Static audit of the device code in libhmx.so (no GPU needed): the hot kernels must not spill vector registers
+(a scratch reload is followed by `s_waitcnt vmcnt(0)`: it drains every load in flight), must not use scratch at all,
+and the persistent sweep must keep its LDS pointers in their address space (flat loads wait on the memory counter
+too) and fetch its rows through the LDS-DMA path.  See DESIGN.md section 3 ("three traps") and scripts/kernel_audit.py."""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import kernel_audit  # noqa: E402
+
+LIB = os.path.join(ROOT, "harmonypy_amd", "libhmx.so")
+pytestmark = pytest.mark.skipif(not (kernel_audit.tools_available() and os.path.exists(LIB)),
+                                reason="needs the ROCm LLVM tools and a built libhmx.so")
+
+# kernels known to spill today (vector registers spilled): the wide / generic fall-back kernels, next round's work.
+# The numbers are ceilings: getting better passes, getting worse fails.
+KNOWN_SPILLS = {
+    "_Z10k_rtz_wideILi13EEv7RtzArgs": 8,
+    "_Z12k_assign_ldsILi7ELb1EEv10AssignArgs": 5,
+    "_Z13k_assign_wideILi13ELb1EEv10AssignArgs": 2,
+    "_Z5k_rtzILi7ELi4EEv7RtzArgs": 4,
+    "_ZN12_GLOBAL__N_110k_lisi_knnILi4ELi4EEEv11LisiKnnArgs": 3,      # the 50-PC LISI search
+    "_Z7k_sweepILi7ELi13EEv9SweepArgs": 24,                           # the one-pass study kernel (HMX_SWEEP=1)
+    "_Z7k_sweepILi7ELi16EEv9SweepArgs": 26,
+    "_Z7k_sweepILi7ELi8EEv9SweepArgs": 2,
+}
+
+
+@pytest.fixture(scope="module")
+def rows():
+    return kernel_audit.audit(LIB)
+
+
+def test_every_kernel_is_listed_with_its_resources(rows):
+    names = {r["name"] for r in rows}
+    assert len(rows) > 100 and any("k_round" in n for n in names) and any("k_lisi_knn" in n for n in names)
+    for r in rows:
+        assert 0 < r["vgpr_count"] <= 512, r["name"]
+        if "k_roundILi" in r["name"]:
+            assert r["vgpr_count"] <= 256, r["name"]          # 512-thread workgroups: at most 256 per lane
+
+
+def test_hot_kernels_do_not_spill(rows):
+    hot = re.compile(r"k_round|k_rtz2|k_ridge_apply2|k_lisi_finish|k_kmeans_step")
+    checked = 0
+    for r in rows:
+        if not hot.search(r["name"]):
+            continue
+        checked += 1
+        assert r["vgpr_spill_count"] == 0, f"{r['name']}: {r['vgpr_spill_count']} spilled VGPRs"
+        assert r["private_segment_fixed_size"] == 0 and r.get("scratch", 0) == 0, f"{r['name']} uses scratch"
+    assert checked >= 21 + 7   # 21 k_round instances, the k_rtz2 family, ...
+
+
+def test_no_new_spills_elsewhere(rows):
+    for r in rows:
+        allowed = KNOWN_SPILLS.get(r["name"], 0)
+        assert r["vgpr_spill_count"] <= allowed, f"{r['name']}: {r['vgpr_spill_count']} spilled VGPRs (allowed {allowed})"
+
+
+def test_sweep_kernel_keeps_lds_pointers_and_uses_lds_dma(rows):
+    for r in rows:
+        if "k_roundILi" not in r["name"]:
+            continue
+        assert r["lds_dma"] >= 16, f"{r['name']}: rows must travel global -> LDS directly"
+        assert r["flat"] <= 2, f"{r['name']}: {r['flat']} flat memory operations (an LDS pointer lost its address space?)"
+        assert r["mfma"] > 0
