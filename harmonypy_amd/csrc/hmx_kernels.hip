@@ -515,9 +515,15 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES, 4) void k_assign_lds(AssignArgs 
 // harmony.py:447, 466-468) does not depend on that table.  So:
 //   * one workgroup of 8 waves per CU stays resident for the whole sweep; Y, sigma live in LDS;
 //   * block b's tiles are dealt round-robin over the workgroups, two tiles per wave; the
-//     table-independent half of a tile ("pre": gather, MFMA, exp-sum; the exponent arguments
-//     stay in 4*MT registers per tile) runs BEFORE the wave waits for block b-1 to complete,
-//     i.e. it overlaps the grid-wide hand-off;
+//     table-independent half of a tile ("pre": distance MFMAs; the exponent arguments stay in
+//     4*MT registers per tile) runs BEFORE the wave waits for block b-1 to complete, i.e. it
+//     overlaps the grid-wide hand-off;
+//   * the tiles' Z_cos rows travel global -> LDS directly (landing zones, no destination
+//     registers), requested a block ahead from inside the "pre" phase (tile_step): anything in
+//     flight in front of the poll or of the hand-off's loads would be waited for by them, and
+//     rows held in registers across "post" put the kernel into scratch;
+//   * a wave's own coordinates (lane, c16, q, tid) are refreshed through an empty asm at the top
+//     of every block, so nothing derived from them is hoisted out of the sweep and spilled;
 //   * hand-off: every workgroup adds its block sums to one of HMX_ROUND_SLOTS fp64 tables with
 //     agent-scope atomics, drains them (s_waitcnt vmcnt(0)), and one lane bumps an arrival
 //     counter; consumers poll the counter with relaxed agent-scope loads and read the tables
