@@ -783,8 +783,10 @@ __global__ __launch_bounds__(64 * WIDE_WAVES, 2) void k_assign_wide(AssignArgs a
     float* sig = nis + K16;                                              // K16
     double* Sd = reinterpret_cast<double*>(sig + K16);                   // G x K16 block sums (when they fit)
     double* objw = Sd + (a.tables_in_lds ? (size_t)a.G * K16 : 0);       // waves x 2
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int c16 = lane & 15, q = lane >> 4;
+    int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar
+    int lane = tid & 63;
+    int c16 = lane & 15, q = lane >> 4;                         // (refreshed per pass, see the loop)
     const int nkb = a.dp >> 4;
     const int GK = a.G * K16;
     const int tile_begin = a.blk_start ? a.blk_start[a.blk] : a.tile_begin;
@@ -804,6 +806,9 @@ __global__ __launch_bounds__(64 * WIDE_WAVES, 2) void k_assign_wide(AssignArgs a
     double km_acc = 0.0, ent_acc = 0.0;
     int stage = 0;
     for (int base = blockIdx.x * WIDE_WAVES; base < ntiles; base += gridDim.x * WIDE_WAVES) {   // workgroup-uniform trip count
+        // the lane's coordinates pass through an empty asm once per pass: what is derived from them (staging and fragment
+        // addresses) is recomputed instead of being kept -- partly in scratch -- across the passes
+        asm volatile("" : "+v"(tid), "+v"(lane), "+v"(c16), "+v"(q));
         const int t = tile_begin + base + wv;
         const bool has = base + wv < ntiles;
         RoundTile<MT> T;
@@ -1721,8 +1726,10 @@ __global__ __launch_bounds__(512, 2) void k_rtz_wide(RtzArgs a) {
     float* lds = reinterpret_cast<float*>(smem);
     const int LDR = a.ldr, LDZ = a.ldz;
     const int tile_floats = 16 * (LDR + LDZ);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int c16 = lane & 15, q = lane >> 4;
+    const int tid = threadIdx.x;
+    int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the wave's column blocks are wave-uniform
+    int c16 = lane & 15, q = lane >> 4;                         // (refreshed per tile, see the loop)
     const int wg = blockIdx.x;
 
     int t0, t1;
@@ -1836,6 +1843,10 @@ __global__ __launch_bounds__(512, 2) void k_rtz_wide(RtzArgs a) {
     }
     for (int t = t0; t < t1; ++t) {
         const int buf = (t - t0) & 1;
+        // the lane's coordinates pass through an empty asm once per tile: the fragment addresses derived from them are
+        // recomputed instead of being kept across the loop (MT = 13: 8 of them were spilled, every reload an
+        // s_waitcnt vmcnt(0) in front of the loads in flight; scripts/kernel_audit.py)
+        asm volatile("" : "+v"(lane), "+v"(c16), "+v"(q));
         __syncthreads();          // tile t is complete in lds[buf]; nobody reads lds[buf ^ 1] any more
         stash(buf ^ 1, v[0]);     // tile t+1 (its loads were issued RTZ_DEPTH iterations ago)
 #pragma unroll
