@@ -10,8 +10,15 @@ from .harmony import Harmony, run_harmony, BatchCodes  # noqa: F401
 from .dist import Shard  # noqa: F401
 from .lisi import compute_lisi  # noqa: F401
 
-__version__ = "0.2.0"
-# version of the kernel set: profiles/*_pmc_hbm.json name the one their counters were collected on, and bench.py only
-# quotes counter-derived traffic for the version it is running
-ENGINE_VERSION = "r02-v13"
-__all__ = ["Harmony", "run_harmony", "BatchCodes", "Shard", "compute_lisi", "__version__", "ENGINE_VERSION"]
+__version__ = "0.3.0"
+
+
+def engine_version() -> str:
+    """Identity of the kernel set in the loaded libhmx.so: the build id ``_build.py`` computed from csrc/ and hmx.h
+    (``hmx_build_id()``).  profiles/*_pmc_hbm.json name the build their counters were collected on and bench.py only
+    quotes counter-derived traffic for the build that is running -- nothing here is maintained by hand."""
+    from . import _capi
+    return _capi.build_id()
+
+
+__all__ = ["Harmony", "run_harmony", "BatchCodes", "Shard", "compute_lisi", "__version__", "engine_version"]

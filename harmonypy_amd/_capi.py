@@ -26,10 +26,10 @@ EXPORTS = [
     "hmx_last_error", "hmx_abi_version", "hmx_create", "hmx_destroy", "hmx_upload", "hmx_init_cluster",
     "hmx_cluster_round", "hmx_cluster_round_seeded", "hmx_moe_correct_ridge", "hmx_get", "hmx_set", "hmx_sync", "hmx_device_ptr",
     "hmx_kernel_times", "hmx_enable_timing", "hmx_counters", "hmx_comm_unique_id", "hmx_comm_init", "hmx_set_host_allreduce",
-    "hmx_kmeans_lloyd", "hmx_kmeans_seed", "hmx_compute_lisi", "hmx_get_rows", "hmx_set_ranks", "hmx_peer_export", "hmx_peer_attach", "hmx_peer_selftest", "hmx_peer_enable",
+    "hmx_build_id", "hmx_has_sweep_kernel", "hmx_cluster", "hmx_kmeans_lloyd", "hmx_kmeans_seed", "hmx_compute_lisi", "hmx_get_rows", "hmx_set_ranks", "hmx_peer_export", "hmx_peer_attach", "hmx_peer_selftest", "hmx_peer_enable",
 ]
 HMX_PEER_HANDLE_BYTES = 64
-HMX_ABI_VERSION = 4
+HMX_ABI_VERSION = 5
 HMX_UNIQUE_ID_BYTES = 128
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
 
@@ -80,6 +80,9 @@ def load():
     lib.hmx_kmeans_lloyd.argtypes = [vp, vp, C.c_int, vp]
     lib.hmx_cluster_round.argtypes = [vp, C.c_int, vp, i64, vp, i32, vp, vp]
     lib.hmx_cluster_round_seeded.argtypes = [vp, C.c_int, C.c_uint64, i64, vp]
+    lib.hmx_cluster.argtypes = [vp, C.c_uint64, i64, C.c_int, C.c_int, C.c_int, C.c_double, vp, vp]
+    lib.hmx_build_id.argtypes = []
+    lib.hmx_has_sweep_kernel.argtypes = []
     lib.hmx_moe_correct_ridge.argtypes = [vp]
     lib.hmx_get.argtypes = [vp, C.c_int, vp, C.c_size_t]
     lib.hmx_set.argtypes = [vp, C.c_int, vp, C.c_size_t]
@@ -90,10 +93,21 @@ def load():
     lib.hmx_counters.argtypes = [vp, vp]
     lib.hmx_enable_timing.argtypes = [vp, C.c_int]
     for name in EXPORTS:
-        if name not in ("hmx_last_error", "hmx_destroy"):
+        if name not in ("hmx_last_error", "hmx_destroy", "hmx_build_id"):
             getattr(lib, name).restype = C.c_int
+    lib.hmx_build_id.restype = C.c_char_p
     _lib = lib
     return lib
+
+
+def build_id() -> str:
+    """Identity of the kernel set in the loaded library (hash of csrc/ and hmx.h taken at build time)."""
+    return load().hmx_build_id().decode()
+
+
+def has_sweep_kernel() -> bool:
+    """Whether the library carries the opt-in study kernel k_sweep (``python -m harmonypy_amd._build -DHMX_WITH_SWEEP``)."""
+    return bool(load().hmx_has_sweep_kernel())
 
 
 def _check(rc):
@@ -237,6 +251,17 @@ class Engine:
         out = np.zeros(4, np.float64)
         _check(self._lib.hmx_cluster_round_seeded(self._h, flags, int(seed) & (2**64 - 1), int(cells_per_block), _ptr(out)))
         return out
+
+    def cluster(self, seed, cells_per_block, max_rounds, forced_rounds=None, window=3, epsilon=1e-5):
+        """All rounds of one ``cluster()`` call on the device-side update order (hmx_cluster): returns the
+        (rounds x 4) objective terms of the rounds that ran."""
+        n = int(max_rounds if forced_rounds is None else forced_rounds)
+        out = np.zeros((max(n, 1), 4), np.float64)
+        done = C.c_int32(0)
+        _check(self._lib.hmx_cluster(self._h, int(seed) & (2**64 - 1), int(cells_per_block), int(max_rounds),
+                                     -1 if forced_rounds is None else int(forced_rounds), int(window), float(epsilon),
+                                     _ptr(out), C.byref(done)))
+        return out[:done.value]
 
     def moe_correct_ridge(self):
         _check(self._lib.hmx_moe_correct_ridge(self._h))

@@ -133,6 +133,13 @@ struct hmx_engine {
     int round_wgs_cap = 0;               // HMX_ROUND_WGS: cap of the sweep grid (tests with several engines on one GPU)
     int n_s_tiles = 0, ntasks = 0;
     std::vector<int> h_task_grp;
+    // the R^T.Z pass in storage order (k_rtz3): group-pure tasks over the static tiles, block ids in static tile order
+    int rtz_kernel = 3;                  // HMX_RTZ=2: the list-order kernel k_rtz2 everywhere (A/B timing, fall-back)
+    bool static_contig = false;          // every static tile holds consecutive cells (what harmonypy_amd builds)
+    int ntasks3 = 0;
+    DevBuf<int> t3_t0, t3_t1, t3_c0, t3_cend, t3_grp, s_tile_start;
+    DevBuf<unsigned char> tile_blk[2], tile_blk_zero;
+    DevBuf<double> Osave;                // O at the start of the round in flight (exact replay after a time-out)
 
     struct Span { hipEvent_t a, b; int fam; };
     std::vector<Span> spans;
@@ -345,6 +352,14 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
     if (const char* pl = getenv("HMX_PREFETCH_LISTS")) e->prefetch_lists = atoi(pl) != 0;
     if (const char* rm = getenv("HMX_ROUND_MODE")) e->round_mode = (std::string(rm) == "blocks") ? 0 : 1;
     if (const char* sw = getenv("HMX_SWEEP")) e->sweep_kernel = atoi(sw) != 0;
+#ifndef HMX_WITH_SWEEP
+    if (e->sweep_kernel) {
+        delete e;
+        return fail(HMX_ERR_ARG, "HMX_SWEEP=1 asks for the study kernel k_sweep, which this library was built without "
+                                 "(python -m harmonypy_amd._build -DHMX_WITH_SWEEP)");
+    }
+#endif
+    if (const char* rk = getenv("HMX_RTZ")) e->rtz_kernel = atoi(rk) == 2 ? 2 : 3;
     if (const char* sl = getenv("HMX_SPIN_LIMIT")) e->spin_limit = (unsigned)std::max(0L, atol(sl));   // 0: every wait of the persistent kernels gives up at once (tests)
     int rc = 0;
     do {
@@ -357,8 +372,9 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
         if (se != hipSuccess) { rc = fail(HMX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se)); break; }
         const size_t N = (size_t)e->N, GK = (size_t)e->G * e->K16;
         // R: + a trash row behind the last cell for k_sweep's unconditional stores
-        if ((rc = e->Zorig.reserve(N * e->dp)) || (rc = e->Zcos.reserve(N * e->dp)) || (rc = e->Zcorr.reserve(N * e->dp)) ||
-            (rc = e->R.reserve(N * e->Kp + e->K16 + 64)) || (rc = e->Y.reserve((size_t)e->K16 * e->ldy)) ||
+        // + 16 rows of slack behind Z_orig / Z_cos / R: the streaming pass (k_rtz3) fetches whole 16-cell tiles
+        if ((rc = e->Zorig.reserve((N + 16) * e->dp)) || (rc = e->Zcos.reserve((N + 16) * e->dp)) || (rc = e->Zcorr.reserve(N * e->dp)) ||
+            (rc = e->R.reserve((N + 16) * e->Kp + e->K16 + 64)) || (rc = e->Osave.reserve(GK)) || (rc = e->Y.reserve((size_t)e->K16 * e->ldy)) ||
             (rc = e->Yacc.reserve((size_t)e->K16 * e->ldy)) || (rc = e->sigma.reserve(e->K16)) ||
             (rc = e->theta.reserve(e->B)) || (rc = e->Pr_b.reserve(e->B)) || (rc = e->lamb.reserve(e->B + 1)) ||
             (rc = e->rp.reserve(GK)) || (rc = e->lrp.reserve(GK)) || (rc = e->group_cols.reserve((size_t)e->G * e->V)) ||
@@ -418,6 +434,8 @@ void hmx_destroy(hmx_engine* e) {
     if (e->stream2) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamDestroy(e->stream2); }
     if (e->pre_event) (void)hipEventDestroy(e->pre_event);
     e->task_t0.release(); e->task_t1.release();
+    e->t3_t0.release(); e->t3_t1.release(); e->t3_c0.release(); e->t3_cend.release(); e->t3_grp.release(); e->s_tile_start.release();
+    e->tile_blk[0].release(); e->tile_blk[1].release(); e->tile_blk_zero.release(); e->Osave.release();
     e->task_grp.release(); e->gstart.release(); e->chunk_tab.release(); e->run_count.release(); e->run_start.release();
     e->Ogrp.release(); e->Tmass.release(); e->Ohist.release(); e->xch.release(); e->scratch.release();
     e->global_id.release(); e->wait_stats.release(); e->sync_words.p = nullptr; e->sync_words.n = 0; e->Sslots.release(); e->km_hn.release(); e->km_sums.release();
@@ -524,6 +542,71 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
     HIP_TRY(hipMemcpyAsync(e->task_t0.p, t0.data(), t0.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(e->task_t1.p, t1.data(), t1.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(e->task_grp.p, tg.data(), tg.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    {   // the streaming R^T.Z pass (k_rtz3) needs consecutive cells in every static tile -- what harmonypy_amd's layout is
+        bool contig = true;
+        std::vector<int> tstart(e->G + 1, 0);
+        for (int t = 0; t < n_static_tiles && contig; ++t) {
+            const int32_t* c = static_cells + (size_t)t * HMX_TILE;
+            int n = 0;
+            while (n < HMX_TILE && c[n] >= 0) ++n;
+            if (n == 0) { contig = false; break; }
+            for (int i = 0; i < HMX_TILE; ++i)
+                if (c[i] != (i < n ? c[0] + i : -1)) contig = false;
+            // a tile that is not full is the last of its group; a group's tiles continue each other's cells
+            const bool last_of_group = t + 1 == n_static_tiles || static_tile_group[t + 1] != static_tile_group[t];
+            if (!last_of_group && (n < HMX_TILE || static_cells[(size_t)(t + 1) * HMX_TILE] != c[0] + HMX_TILE)) contig = false;
+        }
+        for (int t = 0; t < n_static_tiles; ++t) tstart[static_tile_group[t] + 1]++;
+        for (int g = 0; g < e->G; ++g) tstart[g + 1] += tstart[g];
+        // groups without cells have no tile; a group's first tile starts at the group's first cell
+        std::vector<int> gs2(e->G + 1, 0);
+        {
+            std::vector<int> gcount(e->G, 0);
+            for (int t = 0; t < n_static_tiles; ++t)
+                for (int i = 0; i < HMX_TILE; ++i)
+                    if (static_cells[(size_t)t * HMX_TILE + i] >= 0) gcount[static_tile_group[t]]++;
+            for (int g = 0; g < e->G; ++g) gs2[g + 1] = gs2[g] + gcount[g];
+        }
+        for (int g = 0; g < e->G && contig; ++g)
+            if (tstart[g + 1] > tstart[g] && static_cells[(size_t)tstart[g] * HMX_TILE] != gs2[g]) contig = false;
+        e->static_contig = contig;
+        e->ntasks3 = 0;
+        if (contig) {
+            std::vector<int> a0, a1, ac0, acend, ag;
+            const int target = std::max(1, 2 * e->n_cus - e->G);
+            const int CH3 = std::max(16, std::min(256, (n_static_tiles + target - 1) / target));
+            for (int g = 0; g < e->G; ++g) {
+                const int ts = tstart[g], te = tstart[g + 1];
+                if (te <= ts) continue;
+                const int m = (te - ts + CH3 - 1) / CH3, per = (te - ts + m - 1) / m;
+                for (int i = ts; i < te; i += per) {
+                    a0.push_back(i); a1.push_back(std::min(i + per, te)); ag.push_back(g);
+                    ac0.push_back(gs2[g] + (i - ts) * HMX_TILE); acend.push_back(gs2[g + 1]);
+                }
+            }
+            e->ntasks3 = (int)a0.size();
+            const size_t nt3 = a0.size();
+            if ((rc = e->t3_t0.reserve(nt3)) || (rc = e->t3_t1.reserve(nt3)) || (rc = e->t3_c0.reserve(nt3)) || (rc = e->t3_cend.reserve(nt3)) ||
+                (rc = e->t3_grp.reserve(nt3)) || (rc = e->s_tile_start.reserve(e->G + 1)) ||
+                (rc = e->tile_blk[0].reserve((size_t)n_static_tiles * HMX_TILE)) || (rc = e->tile_blk[1].reserve((size_t)n_static_tiles * HMX_TILE)) ||
+                (rc = e->tile_blk_zero.reserve((size_t)n_static_tiles * HMX_TILE)))
+                return rc;
+            HIP_TRY(hipMemcpyAsync(e->t3_t0.p, a0.data(), nt3 * sizeof(int), hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(hipMemcpyAsync(e->t3_t1.p, a1.data(), nt3 * sizeof(int), hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(hipMemcpyAsync(e->t3_c0.p, ac0.data(), nt3 * sizeof(int), hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(hipMemcpyAsync(e->t3_cend.p, acend.data(), nt3 * sizeof(int), hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(hipMemcpyAsync(e->t3_grp.p, ag.data(), nt3 * sizeof(int), hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(hipMemcpyAsync(e->s_tile_start.p, tstart.data(), tstart.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(hipMemsetAsync(e->tile_blk[0].p, 255, (size_t)n_static_tiles * HMX_TILE, e->stream));   // 255: no block (static padding)
+            HIP_TRY(hipMemsetAsync(e->tile_blk[1].p, 255, (size_t)n_static_tiles * HMX_TILE, e->stream));
+            HIP_TRY(hipMemsetAsync(e->tile_blk_zero.p, 0, (size_t)n_static_tiles * HMX_TILE, e->stream));
+            // the slack rows are read (and discarded) by the last tile of the last group: keep them finite
+            HIP_TRY(hipMemsetAsync(e->R.p + (size_t)e->N * e->Kp, 0, (size_t)16 * e->Kp * sizeof(float), e->stream));
+            HIP_TRY(hipMemsetAsync(e->Zorig.p + (size_t)e->N * e->dp, 0, (size_t)16 * e->dp * sizeof(float), e->stream));
+            HIP_TRY(hipMemsetAsync(e->Zcos.p + (size_t)e->N * e->dp, 0, (size_t)16 * e->dp * sizeof(float), e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+        }
+    }
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipGetLastError());
     e->uploaded = true;
@@ -701,9 +784,49 @@ int hmx_init_cluster(hmx_engine* e, const float* Y0, double obj_out[4]) {
     return read_objective(e, obj_out);
 }
 
+static bool use_rtz3(const hmx_engine* e) {
+    return e->rtz_kernel == 3 && e->static_contig && e->ntasks3 > 0 && rtz3_ok(e->mt, e->dp, e->nblk, e->G);
+}
+
+// What the sweep kernel needs done before it starts, folded into k_rtz3_finish when a single engine runs the fused
+// path: the slot tables + sync words and the objective accumulators zeroed, O at the start of the round kept aside.
+struct Rtz3Duties { bool on = false; };
+
+// The R^T.Z pass in storage order (k_rtz3 + k_rtz3_finish).
+//   mode 0: Z_cos; block ids `tile_blk` with `nblk_cols` one-hot columns -> Yacc64 (centroid numerators, :443),
+//           Sold (removal sums of every block, :491-492) and, with `normalize`, Y (:444);
+//   mode 1: Z_orig, all ids 0 -> Sr (ridge right-hand sides, :556-563), Oxr (exact O, :550).
+static int rtz3_pass(hmx_engine* e, int mode, const unsigned char* tile_blk, int nblk_cols, bool normalize, bool duties) {
+    int rc;
+    if ((rc = e->slab.reserve((size_t)e->ntasks3 * rtz3_slab_floats(e->mt, e->dp, nblk_cols)))) return rc;
+    {
+        Timed t(e, mode == 1 ? F_RIDGE_STATS : F_RTZ_ROUND);
+        Rtz3Args r{};
+        r.R = e->R.p; r.Z = mode == 1 ? e->Zorig.p : e->Zcos.p; r.tile_blk = tile_blk;
+        r.task_t0 = e->t3_t0.p; r.task_t1 = e->t3_t1.p; r.task_c0 = e->t3_c0.p; r.task_cend = e->t3_cend.p;
+        r.slab = e->slab.p; r.ntasks = e->ntasks3; r.Kp = e->Kp;
+        if (launch_rtz3(r, e->mt, e->dp, nblk_cols, e->stream)) return fail(HMX_ERR_ARG, "unsupported shape for k_rtz3");
+    }
+    Timed t(e, mode == 1 ? F_RIDGE_STATS : F_RTZ_REDUCE);
+    const size_t GK = (size_t)e->G * e->K16;
+    Rtz3FinishArgs f{};
+    f.slab = e->slab.p; f.task_grp = e->t3_grp.p; f.ntasks = e->ntasks3;
+    f.MT = e->mt; f.KS = e->dp / 4; f.NTB = rtz3_ntb(e->dp, nblk_cols);
+    f.K = e->K; f.K16 = e->K16; f.d = e->d; f.ld = e->ldy; f.G = e->G; f.nblk = nblk_cols; f.mode = mode;
+    f.Ysum = e->Yacc64; f.Yout = normalize ? e->Y.p : nullptr; f.Sold = e->Sold; f.Sr = e->Sr; f.Oxr = e->Oxr;
+    if (duties) {
+        f.zero_p = e->Sslots.p; f.zero_n = GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 1;   // slot tables + the two sync words
+        f.zero2_p = e->objacc; f.zero2_n = 2 * HMX_OBJ_SLOTS + 2;
+        f.copy_src = e->Ogrp.p; f.copy_dst = e->Osave.p; f.copy_n = (int)GK;
+    }
+    launch_rtz3_finish(f, e->stream);
+    return 0;
+}
+
 // Centroid numerators sum_cells R (x) Z_cos (harmony.py:443) of this rank's cells into Yacc64, by a pass over the
-// static list (k_rtz2 without the removal sums: those are formed inside k_sweep).
+// static list (no removal sums: k_sweep forms those itself).
 static int centroid_pass(hmx_engine* e) {
+    if (use_rtz3(e)) return rtz3_pass(e, 0, e->tile_blk_zero.p, 1, false, false);
     int rc, nsub, spw;
     rtz_geometry(e->mt, e->ntd, &nsub, &spw);
     const bool rtz2 = rtz2_ok(e->mt, e->dp);
@@ -733,29 +856,38 @@ static int centroid_pass(hmx_engine* e) {
     return 0;
 }
 
-// A grid-wide wait of a persistent sweep kernel gave up (workgroups not co-resident, a peer rank far behind).  R holds
-// new rows for the blocks that were finished and old ones for the rest -- every row still a distribution -- but the O
-// the kernel carried is void: take O from R again; the caller then repeats the round block by block (bounded kernels,
-// one collective per block).  Every rank comes here together: a rank that timed out poisons its objective sums with
-// NaN, which every rank sees after the all-reduce of those sums.
-static int sweep_timed_out(hmx_engine* e) {
-    int rc;
-    const size_t GK = (size_t)e->G * e->K16;
+static void note_sweep_timeout(hmx_engine* e) {
     if (e->n_sweep_fallbacks++ == 0)
         fprintf(stderr, "[hmx] rank %d: a grid-wide wait of the sweep kernel timed out; the round is repeated with one launch per "
                         "block (HMX_ROUND_MODE=blocks avoids the persistent kernel altogether)\n", e->rank);
+    if (e->n_sweep_fallbacks == 2 && e->round_mode == 1) {
+        // every time-out costs the whole spin budget of the launch: a GPU that cannot keep the grid resident will not
+        // start to.  All ranks count the same fall-backs (the failure travels in the all-reduced objective block).
+        e->round_mode = 0;
+        fprintf(stderr, "[hmx] rank %d: second time-out: this engine stays on the per-block path\n", e->rank);
+    }
+}
+
+#ifdef HMX_WITH_SWEEP
+// (k_sweep, the opt-in study kernel) A grid-wide wait gave up.  k_sweep forms the removal sums inside the launch, so
+// nothing of the failed round can be replayed exactly: take O from R again (every row is still a distribution); the
+// caller then repeats the round block by block.  Every rank comes here together: a rank that timed out poisons its
+// objective sums with NaN, which every rank sees after the all-reduce of those sums.
+static int sweep_timed_out(hmx_engine* e) {
+    const size_t GK = (size_t)e->G * e->K16;
+    note_sweep_timeout(e);
     HIP_TRY(hipMemsetAsync(e->Ogrp.p, 0, GK * sizeof(double), e->stream));
     launch_group_sums(e->R.p, e->Kp, e->K, e->K16, e->s_cells.p, e->s_tile_grp.p, e->n_s_tiles, e->Ogrp.p, e->stream);
     return sum_over_ranks(e, e->Ogrp.p, GK);
 }
 
 static bool sweep_shape_ok(const hmx_engine* e) {
-    return e->mt <= 7 && sweep_row_floats(e->d) == e->dp &&
+    return e->mt <= 7 && e->G <= 64 && sweep_row_floats(e->d) == e->dp &&
            sweep_lds_bytes(e->K16, e->d, e->G, e->B, e->V, e->nblk) <= 156 * 1024;
 }
 
-// One k-means round on k_sweep (hmx_sweep.hip): centroids from a pass over R (k_rtz2 without the removal sums) ->
-// ONE persistent launch (update_R over all blocks with the removal sums formed inside, objective).
+// One k-means round on k_sweep (hmx_sweep.hip): centroids from a pass over R -> ONE persistent launch (update_R over
+// all blocks with the removal sums formed inside, objective).
 // Returns 1 when a grid-wide wait of the kernel timed out on any rank (the caller repeats the round block by block).
 static int round_sweep(hmx_engine* e, int flags, const std::vector<int>& tiles_upper, double obj_out[4],
                        const std::function<int()>& before_sweep) {
@@ -769,13 +901,10 @@ static int round_sweep(hmx_engine* e, int flags, const std::vector<int>& tiles_u
         launch_y_normalize_d(e->Yacc64, e->Y.p, e->K, e->K16, e->d, e->ldy, e->stream);  // :444
     }
     if (before_sweep && (rc = before_sweep())) return rc;   // side-stream work that should run beside the sweep
-    // the hand-off tables and the two sync words (carved from the same allocation): one fill
     HIP_TRY(hipMemsetAsync(e->Sslots.p, 0, (GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 1) * sizeof(double), e->stream));
     int max_upper = 0;
     for (int b = 0; b < e->nblk; ++b) max_upper = std::max(max_upper, tiles_upper[b]);
     const bool multi = e->peers_enabled && e->n_ranks > 1;
-    // one workgroup of 8 waves per CU; a few CUs stay free for the second stream (next round's lists) and the
-    // gateway workgroup.  Smallest grid that reaches the lowest tiles-per-wave count of the largest block.
     const int waves = sweep_waves();
     int wgs_max = std::max(1, e->n_cus - (multi ? 1 : 0) - (e->prefetch_lists ? 12 : 0));
     if (e->round_wgs_cap > 0) wgs_max = std::min(wgs_max, e->round_wgs_cap);
@@ -797,49 +926,63 @@ static int round_sweep(hmx_engine* e, int flags, const std::vector<int>& tiles_u
             sa.epoch = e->round_epoch;
             e->round_epoch += 64;
         }
-#ifdef HMX_SWEEP_PROF
-        static DevBuf<unsigned long long> prof;
-        static int prof_rounds = 0;
-        if (prof.reserve((size_t)wgs * e->nblk * 16)) return -1;
-        sa.prof = prof.p;
-#endif
         if (launch_sweep(sa, e->mt, e->d, multi ? wgs + 1 : wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported shape for k_sweep");
-#ifdef HMX_SWEEP_PROF
-        if (++prof_rounds == 25) {   // one round in steady state: phase durations (shader cycles) of wave 0 over workgroups and blocks
-            std::vector<unsigned long long> h((size_t)wgs * e->nblk * 16);
-            (void)hipStreamSynchronize(e->stream);
-            (void)hipMemcpy(h.data(), prof.p, h.size() * 8, hipMemcpyDeviceToHost);
-            auto mean = [&](int from, int to) {
-                double sum = 0;
-                for (int w = 0; w < wgs; ++w)
-                    for (int b = 0; b < e->nblk; ++b) sum += (double)(h[((size_t)w * e->nblk + b) * 16 + to] - h[((size_t)w * e->nblk + b) * 16 + from]);
-                return sum / (wgs * e->nblk);
-            };
-            fprintf(stderr, "[k_sweep prof] wait %.0f | apply+table %.0f | first tile stream %.0f | other tiles, old-R tail %.0f | publish %.0f | after publish %.0f\n",
-                    mean(0, 1), mean(1, 2), mean(2, 3), mean(3, 4), mean(4, 5), mean(5, 6));
-            double tot = 0;
-            for (int w = 0; w < wgs; ++w) tot += (double)(h[((size_t)w * e->nblk + e->nblk - 1) * 16 + 6] - h[(size_t)w * e->nblk * 16]);
-            fprintf(stderr, "[k_sweep prof] block loop mean %.0f cycles over %d workgroups\n", tot / wgs, wgs);
-        }
-#endif
     }
-    HIP_TRY(hipMemcpyAsync(e->sync_host, e->sync_words.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
-    // the two objective sums (:399, :402) of this rank's cells; the cross-entropy term was formed from job-wide tables.
-    // A rank whose wait timed out poisons its sums with NaN: every rank then sees the failure in the very same all-reduce.
     if (sharded(e) && (rc = sum_over_ranks(e, e->objacc, 2 * HMX_OBJ_SLOTS))) return rc;
     if ((rc = read_objective(e, obj_out))) return rc;
-    const bool timed_out = e->sync_host[1] != 0 || obj_out[0] != obj_out[0] || obj_out[1] != obj_out[1];
-    e->sync_host[1] = 0;
-    return timed_out ? 1 : 0;
+    return (obj_out[0] != obj_out[0] || obj_out[1] != obj_out[1]) ? 1 : 0;
+}
+#endif
+
+// update_R block by block (harmony.py:476-507): per block the diversity table (k_block_table), the assignment of the
+// block's tiles (bounded launch) and the block's new sums over all ranks; closes O, T and the cross-entropy term.
+// Needs Sold (removal sums) and Y of this round; Snew and objacc zeroed by the caller.
+static int blocks_loop(hmx_engine* e, int flags, const std::vector<int>& tiles_upper) {
+    int rc;
+    const size_t GK = (size_t)e->G * e->K16;
+    for (int b = 0; b < e->nblk; ++b) {
+        {
+            Timed t(e, F_BLOCK_TABLE);
+            TableArgs ta = table_args(e);
+            ta.O_prev = (b == 0) ? e->Ogrp.p : e->Ohist.p + GK * (b - 1);
+            ta.S_add = (b == 0) ? nullptr : e->Snew + GK * (b - 1);
+            ta.S_sub = e->Sold + GK * b;
+            ta.O_out = e->Ohist.p + GK * b;
+            ta.rp = e->rp.p; ta.lrp = e->lrp.p;
+            launch_block_table(ta, e->K16, e->stream);
+        }
+        if (tiles_upper[b] > 0) {
+            Timed t(e, F_ASSIGN_BLOCK);
+            AssignArgs a = assign_args(e);
+            a.cells = e->lists[e->cur].cells.p; a.tile_grp = e->lists[e->cur].tile_grp.p; a.S_out = e->Snew + GK * b;
+            a.blk_start = e->lists[e->cur].blk_start.p; a.blk = b;
+            a.tile_begin = 0; a.tile_end = tiles_upper[b];
+            if (launch_assign(a, true, e->max_wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported cluster count");
+        }
+        // the block's new sums (:506-507) over all ranks; the last block takes the two objective
+        // sums (:399, :402) along: objacc follows Snew in xch
+        const bool last = b == e->nblk - 1;
+        if ((rc = sum_over_ranks(e, e->Snew + GK * b, GK + (last ? 2 * HMX_OBJ_SLOTS : 0)))) return rc;
+    }
+    Timed t(e, F_BLOCK_TABLE);
+    TableArgs ta = table_args(e);  // close the round: O, T state and the cross-entropy term
+    ta.O_prev = e->Ohist.p + GK * (e->nblk - 1);
+    ta.S_add = e->Snew + GK * (e->nblk - 1);
+    ta.O_out = e->Ogrp.p; ta.T_out = e->Tmass.p;
+    if (flags & HMX_ROUND_OBJECTIVE) ta.obj_cross = e->objacc + 2 * HMX_OBJ_SLOTS;
+    launch_block_table(ta, e->K16, e->stream);
+    return 0;
 }
 
-// Kernel sequence of one round; the lists (cells, tile groups, block_tile_start) are already in
-// device memory.  tiles_upper[b] bounds the tile count of block b (grid sizing only).
+// Kernel sequence of one round; the lists (cells, tile groups, block_tile_start) and, for the streaming R^T.Z pass, the
+// block ids in static tile order (tile_blk) are already in device memory.  tiles_upper[b] bounds the tile count of block b
+// (grid sizing only).
 static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::vector<int>& tiles_upper, double obj_out[4],
                       const std::function<int()>& before_sweep = nullptr) {
     int rc;
     const size_t GK = (size_t)e->G * e->K16;
     const bool persistent = (flags & HMX_ROUND_UPDATE_R) && e->round_mode == 1 && (!sharded(e) || e->peers_enabled);
+#ifdef HMX_WITH_SWEEP
     if (persistent && e->sweep_kernel && sweep_shape_ok(e)) {
         rc = round_sweep(e, flags, tiles_upper, obj_out, before_sweep);
         if (rc <= 0) return rc;
@@ -847,175 +990,163 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         const int saved = e->round_mode;
         e->round_mode = 0;
         rc = round_body(e, flags, n_tiles_upper, tiles_upper, obj_out, nullptr);
-        e->round_mode = saved;
+        e->round_mode = e->round_mode == 0 && e->n_sweep_fallbacks >= 2 ? 0 : saved;
         return rc;
     }
-    // Sold | Yacc64 | Snew | objacc are neighbours in xch: one fill instead of four
-    HIP_TRY(hipMemsetAsync(e->Sold, 0, (size_t)((e->objacc + 2 * HMX_OBJ_SLOTS + 2) - e->Sold) * sizeof(double), e->stream));
-
-
-    // ---- pass over the old R: centroid numerators (:443) and per-block removal sums (:491-492)
-    int nsub, spw;
-    rtz_geometry(e->mt, e->ntd, &nsub, &spw);
-    const bool rtz2 = rtz2_ok(e->mt, e->dp) && e->round_mode == 1;
-    const bool rtzw = !rtz2 && rtz_wide_ok(e->mt, e->dp);
-    int wgs = rtz2 ? std::min(e->rtz_wgs_per_cu * e->n_cus, std::max(1, (n_tiles_upper + 7) / 8))
-              : rtzw ? std::min(e->n_cus, std::max(1, (n_tiles_upper + 7) / 8))
-                     : std::min(256, std::max(1, (n_tiles_upper + 31) / 32));
-    if ((rc = e->slab.reserve(rtz2 ? (size_t)wgs * rtz2_slab_floats(e->mt, e->dp)
-                              : rtzw ? (size_t)wgs * rtz_wide_slab_floats(e->mt, e->dp) : (size_t)wgs * 4 * spw)))
-        return rc;
-    {
-        Timed t(e, F_RTZ_ROUND);
-        RtzArgs r{};
-        r.R = e->R.p; r.Z = e->Zcos.p; r.cells = e->lists[e->cur].cells.p; r.tile_grp = e->lists[e->cur].tile_grp.p; r.blk_start = e->lists[e->cur].blk_start.p;
-        r.S_out = e->Sold; r.slab = e->slab.p; r.n_tiles = n_tiles_upper; r.nblk = e->nblk;
-        r.K = e->K; r.Kp = e->Kp; r.K16 = e->K16; r.G = e->G; r.mt = e->mt; r.dp = e->dp; r.ntd = e->ntd;
-        if (rtz2) launch_rtz2(r, wgs, e->stream);
-#ifdef RTZ_PROF
-        if (rtz2) { static int calls = 0; if (++calls % 40 == 0) rtz_prof_dump(); }
 #endif
-        else if (rtzw) launch_rtz_wide(r, wgs, e->stream);
-        else launch_rtz(r, wgs, e->stream);
-    }
-    if (flags & HMX_ROUND_CENTROIDS) {
-        Timed t(e, F_RTZ_REDUCE);
-        if (rtz2) launch_rtz2_reduce(e->slab.p, wgs, e->mt, e->dp, e->K16, e->ldy, e->Yacc64, nullptr, e->stream);
-        else if (rtzw) launch_rtz_wide_reduce(e->slab.p, wgs, e->mt, e->dp, e->K16, e->ldy, e->Yacc64, nullptr, e->stream);
-        else launch_rtz_reduce(e->slab.p, wgs * 4, e->mt, e->ntd, e->K16, e->ldy, e->Yacc64, nullptr, e->stream);
-    }
-    // removal sums of every block and the centroid numerators: one collective (neighbours in xch)
-    if ((rc = sum_over_ranks(e, e->Sold, GK * e->nblk + ((flags & HMX_ROUND_CENTROIDS) ? (size_t)e->K16 * e->ldy : 0)))) return rc;
-    if (flags & HMX_ROUND_CENTROIDS) {
-        Timed t(e, F_RTZ_REDUCE);
-        launch_y_normalize_d(e->Yacc64, e->Y.p, e->K, e->K16, e->d, e->ldy, e->stream);  // :444
-    }
     const bool mega = persistent && e->mt <= 7 && round_row_floats(e->d) == e->dp &&
                       round_lds_bytes(e->K16, e->dp, e->G, e->B, e->V) <= HMX_ROUND_LDS_LIMIT;
+    const bool r3 = use_rtz3(e);
+    // a single engine on the persistent sweep: k_rtz3_finish normalises the centroids itself (no collective is due in
+    // between) and does the sweep kernel's fills -- three launches per round
+    const bool fused = r3 && mega && !sharded(e);
+    if (!fused)   // Sold | Yacc64 | Snew | objacc are neighbours in xch: one fill instead of four
+        HIP_TRY(hipMemsetAsync(e->Sold, 0, (size_t)((e->objacc + 2 * HMX_OBJ_SLOTS + 2) - e->Sold) * sizeof(double), e->stream));
+
+    // ---- pass over the old R: centroid numerators (:443) and per-block removal sums (:491-492)
+    if (r3) {
+        const bool upd = (flags & HMX_ROUND_UPDATE_R) != 0;
+        if ((rc = rtz3_pass(e, 0, upd ? e->tile_blk[e->cur].p : e->tile_blk_zero.p, upd ? e->nblk : 1,
+                            fused && (flags & HMX_ROUND_CENTROIDS), fused)))
+            return rc;
+    } else {
+        int nsub, spw;
+        rtz_geometry(e->mt, e->ntd, &nsub, &spw);
+        const bool rtz2 = rtz2_ok(e->mt, e->dp) && e->round_mode == 1;
+        const bool rtzw = !rtz2 && rtz_wide_ok(e->mt, e->dp);
+        int wgs = rtz2 ? std::min(e->rtz_wgs_per_cu * e->n_cus, std::max(1, (n_tiles_upper + 7) / 8))
+                  : rtzw ? std::min(e->n_cus, std::max(1, (n_tiles_upper + 7) / 8))
+                         : std::min(256, std::max(1, (n_tiles_upper + 31) / 32));
+        if ((rc = e->slab.reserve(rtz2 ? (size_t)wgs * rtz2_slab_floats(e->mt, e->dp)
+                                  : rtzw ? (size_t)wgs * rtz_wide_slab_floats(e->mt, e->dp) : (size_t)wgs * 4 * spw)))
+            return rc;
+        {
+            Timed t(e, F_RTZ_ROUND);
+            RtzArgs r{};
+            r.R = e->R.p; r.Z = e->Zcos.p; r.cells = e->lists[e->cur].cells.p; r.tile_grp = e->lists[e->cur].tile_grp.p; r.blk_start = e->lists[e->cur].blk_start.p;
+            r.S_out = e->Sold; r.slab = e->slab.p; r.n_tiles = n_tiles_upper; r.nblk = e->nblk;
+            r.K = e->K; r.Kp = e->Kp; r.K16 = e->K16; r.G = e->G; r.mt = e->mt; r.dp = e->dp; r.ntd = e->ntd;
+            if (rtz2) launch_rtz2(r, wgs, e->stream);
+#ifdef RTZ_PROF
+            if (rtz2) { static int calls = 0; if (++calls % 40 == 0) rtz_prof_dump(); }
+#endif
+            else if (rtzw) launch_rtz_wide(r, wgs, e->stream);
+            else launch_rtz(r, wgs, e->stream);
+        }
+        if (flags & HMX_ROUND_CENTROIDS) {
+            Timed t(e, F_RTZ_REDUCE);
+            if (rtz2) launch_rtz2_reduce(e->slab.p, wgs, e->mt, e->dp, e->K16, e->ldy, e->Yacc64, nullptr, e->stream);
+            else if (rtzw) launch_rtz_wide_reduce(e->slab.p, wgs, e->mt, e->dp, e->K16, e->ldy, e->Yacc64, nullptr, e->stream);
+            else launch_rtz_reduce(e->slab.p, wgs * 4, e->mt, e->ntd, e->K16, e->ldy, e->Yacc64, nullptr, e->stream);
+        }
+    }
+    if (!fused) {
+        // removal sums of every block and the centroid numerators: one collective (neighbours in xch)
+        if ((rc = sum_over_ranks(e, e->Sold, GK * e->nblk + ((flags & HMX_ROUND_CENTROIDS) ? (size_t)e->K16 * e->ldy : 0)))) return rc;
+        if (flags & HMX_ROUND_CENTROIDS) {
+            Timed t(e, F_RTZ_REDUCE);
+            launch_y_normalize_d(e->Yacc64, e->Y.p, e->K, e->K16, e->d, e->ldy, e->stream);  // :444
+        }
+    }
     if (before_sweep && (rc = before_sweep())) return rc;   // side-stream work that should run beside the sweep, not beside the R^T.Z pass
     if (mega) {
         // the whole sweep in one persistent launch (k_round); closes O, T and the objective itself
-        // the slot tables and the two sync words (carved from the same allocation): one fill
-        // (size rounded up to 1 KB inside the allocation: an odd size makes the runtime launch a second fill kernel for the tail)
-        HIP_TRY(hipMemsetAsync(e->Sslots.p, 0, (((GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 1) * sizeof(double) + 1023) / 1024) * 1024, e->stream));
+        if (!fused) {
+            // the slot tables and the two sync words (carved from the same allocation): one fill (size rounded up to 1 KB
+            // inside the allocation: an odd size makes the runtime launch a second fill kernel for the tail); O at the
+            // start of the round is kept for an exact replay
+            HIP_TRY(hipMemsetAsync(e->Sslots.p, 0, (((GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 1) * sizeof(double) + 1023) / 1024) * 1024, e->stream));
+            HIP_TRY(hipMemcpyAsync(e->Osave.p, e->Ogrp.p, GK * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+        }
         int max_upper = 0;
         for (int b = 0; b < e->nblk; ++b) max_upper = std::max(max_upper, tiles_upper[b]);
         const bool multi = e->peers_enabled && e->n_ranks > 1;
         int wgs = std::min(e->n_cus - (multi ? 1 : 0), std::max(1, (max_upper + 13) / 14));   // ~14 of a workgroup's 16 tile slots: 224 of 256 CUs at C3, the rest serve the second stream
-        if (multi) {
-            // every rank must size its grid from its own share, but a rank whose share is small must not
-            // starve the others: the grid only decides how this rank's tiles are dealt out
-            if (e->round_wgs_cap > 0) wgs = std::min(wgs, e->round_wgs_cap);
-        } else if (e->round_wgs_cap > 0) {
-            wgs = std::min(wgs, e->round_wgs_cap);
-        }
-        Timed t(e, F_ASSIGN_BLOCK);
-        RoundArgs ra{};
-        ra.Zcos = e->Zcos.p; ra.Y = e->Y.p; ra.sigma = e->sigma.p; ra.R = e->R.p;
-        ra.cells = e->lists[e->cur].cells.p; ra.tile_grp = e->lists[e->cur].tile_grp.p; ra.blk_start = e->lists[e->cur].blk_start.p;
-        ra.O_start = e->Ogrp.p; ra.S_old = e->Sold; ra.S_new = e->Sslots.p; ra.O_out = e->Ogrp.p; ra.T_out = e->Tmass.p;
-        ra.obj = e->objacc; ra.group_cols = e->group_cols.p; ra.Pr_b = e->Pr_b.p; ra.theta = e->theta.p;
-        ra.counter = e->sync_words.p; ra.error = e->sync_words.p + 1; ra.wait_stats = e->wait_stats.p;
-        ra.K = e->K; ra.Kp = e->Kp; ra.K16 = e->K16; ra.dp = e->dp; ra.ldy = e->ldy; ra.G = e->G; ra.B = e->B; ra.V = e->V;
-        ra.nblk = e->nblk; ra.spin_limit = e->spin_limit;
-        if (multi) {
-            ra.peer_box = e->peer_dev.p; ra.my_box = e->box; ra.n_ranks = e->n_ranks; ra.rank = e->rank;
-            ra.epoch = e->round_epoch;
-            e->round_epoch += 64;
-        }
+        // (sharded: every rank sizes its grid from its own share; the grid only decides how this rank's tiles are dealt out)
+        if (e->round_wgs_cap > 0) wgs = std::min(wgs, e->round_wgs_cap);
+        {
+            Timed t(e, F_ASSIGN_BLOCK);
+            RoundArgs ra{};
+            ra.Zcos = e->Zcos.p; ra.Y = e->Y.p; ra.sigma = e->sigma.p; ra.R = e->R.p;
+            ra.cells = e->lists[e->cur].cells.p; ra.tile_grp = e->lists[e->cur].tile_grp.p; ra.blk_start = e->lists[e->cur].blk_start.p;
+            ra.O_start = e->Ogrp.p; ra.S_old = e->Sold; ra.S_new = e->Sslots.p; ra.O_out = e->Ogrp.p; ra.T_out = e->Tmass.p;
+            ra.obj = e->objacc; ra.group_cols = e->group_cols.p; ra.Pr_b = e->Pr_b.p; ra.theta = e->theta.p;
+            ra.counter = e->sync_words.p; ra.error = e->sync_words.p + 1; ra.wait_stats = e->wait_stats.p;
+            ra.K = e->K; ra.Kp = e->Kp; ra.K16 = e->K16; ra.dp = e->dp; ra.ldy = e->ldy; ra.G = e->G; ra.B = e->B; ra.V = e->V;
+            ra.nblk = e->nblk; ra.spin_limit = e->spin_limit;
+            if (multi) {
+                ra.peer_box = e->peer_dev.p; ra.my_box = e->box; ra.n_ranks = e->n_ranks; ra.rank = e->rank;
+                ra.epoch = e->round_epoch;
+                e->round_epoch += 64;
+            }
 #ifdef HMX_ROUND_PROF
-        static DevBuf<unsigned long long> prof;
-        static int prof_rounds = 0;
-        if (prof.reserve((size_t)wgs * e->nblk * 16)) return -1;
-        ra.prof = prof.p;
+            static DevBuf<unsigned long long> prof;
+            static int prof_rounds = 0;
+            if (prof.reserve((size_t)wgs * e->nblk * 16)) return -1;
+            ra.prof = prof.p;
 #endif
-        if (launch_round(ra, e->mt, multi ? wgs + 1 : wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported shape for k_round");
+            if (launch_round(ra, e->mt, multi ? wgs + 1 : wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported shape for k_round");
 #ifdef HMX_ROUND_PROF
-        if (++prof_rounds == 25) {   // one round in steady state: phase durations over workgroups and blocks
-            std::vector<unsigned long long> h((size_t)wgs * e->nblk * 16);
-            (void)hipStreamSynchronize(e->stream);
-            (void)hipMemcpy(h.data(), prof.p, h.size() * 8, hipMemcpyDeviceToHost);
-            const char* names[5] = {"wait", "table", "post", "flush+arrive", "pre(next)"};
-            for (int ph = 0; ph < 5; ++ph) {
-                double sum = 0, mx = 0;
-                for (int w = 0; w < wgs; ++w)
-                    for (int b = 0; b < e->nblk; ++b) {
-                        const double dtk = (double)(h[((size_t)w * e->nblk + b) * 16 + ph + 1] - h[((size_t)w * e->nblk + b) * 16 + ph]);
-                        sum += dtk; mx = std::max(mx, dtk);
-                    }
-                fprintf(stderr, "[k_round prof] %-14s mean %.0f ticks  max %.0f\n", names[ph], sum / (wgs * e->nblk), mx);
+            if (++prof_rounds == 25) {   // one round in steady state: phase durations over workgroups and blocks
+                std::vector<unsigned long long> h((size_t)wgs * e->nblk * 16);
+                (void)hipStreamSynchronize(e->stream);
+                (void)hipMemcpy(h.data(), prof.p, h.size() * 8, hipMemcpyDeviceToHost);
+                const char* names[5] = {"wait", "table", "post", "flush+arrive", "pre(next)"};
+                for (int ph = 0; ph < 5; ++ph) {
+                    double sum = 0, mx = 0;
+                    for (int w = 0; w < wgs; ++w)
+                        for (int b = 0; b < e->nblk; ++b) {
+                            const double dtk = (double)(h[((size_t)w * e->nblk + b) * 16 + ph + 1] - h[((size_t)w * e->nblk + b) * 16 + ph]);
+                            sum += dtk; mx = std::max(mx, dtk);
+                        }
+                    fprintf(stderr, "[k_round prof] %-14s mean %.0f ticks  max %.0f\n", names[ph], sum / (wgs * e->nblk), mx);
+                }
+                double tot = 0;
+                for (int w = 0; w < wgs; ++w) tot += (double)(h[((size_t)w * e->nblk + e->nblk - 1) * 16 + 5] - h[(size_t)w * e->nblk * 16]);
+                {
+                    double s1 = 0, s2 = 0, s3 = 0;
+                    for (int w = 0; w < wgs; ++w)
+                        for (int b = 0; b < e->nblk; ++b) {
+                            const unsigned long long* r = &h[((size_t)w * e->nblk + b) * 16];
+                            s1 += (double)(r[6] - r[1]); s2 += (double)(r[7] - r[6]); s3 += (double)(r[2] - r[7]);
+                        }
+                    fprintf(stderr, "[k_round prof] table split: O update %.0f, pow %.0f, rp/log %.0f\n", s1 / (wgs * e->nblk), s2 / (wgs * e->nblk), s3 / (wgs * e->nblk));
+                }
+                {
+                    double s1 = 0, s2 = 0, s3 = 0, sp = 0;
+                    for (int w = 0; w < wgs; ++w)
+                        for (int b = 1; b < e->nblk; ++b) {
+                            const unsigned long long* r = &h[((size_t)w * e->nblk + b) * 16];
+                            s1 += (double)(r[8] - r[0]); s2 += (double)(r[9] - r[8]); s3 += (double)(r[1] - r[9]); sp += (double)r[10];
+                        }
+                    const double n = (double)wgs * (e->nblk - 1);
+                    fprintf(stderr, "[k_round prof] wait split: gather issue %.0f, poll %.0f (%.1f spins), syncthreads %.0f\n", s1 / n, s2 / n, sp / n, s3 / n);
+                }
+                fprintf(stderr, "[k_round prof] whole sweep mean %.0f ticks over %d workgroups\n", tot / wgs, wgs);
             }
-            double tot = 0;
-            for (int w = 0; w < wgs; ++w) tot += (double)(h[((size_t)w * e->nblk + e->nblk - 1) * 16 + 5] - h[(size_t)w * e->nblk * 16]);
-            {
-                double s1 = 0, s2 = 0, s3 = 0;
-                for (int w = 0; w < wgs; ++w)
-                    for (int b = 0; b < e->nblk; ++b) {
-                        const unsigned long long* r = &h[((size_t)w * e->nblk + b) * 16];
-                        s1 += (double)(r[6] - r[1]); s2 += (double)(r[7] - r[6]); s3 += (double)(r[2] - r[7]);
-                    }
-                fprintf(stderr, "[k_round prof] table split: O update %.0f, pow %.0f, rp/log %.0f\n", s1 / (wgs * e->nblk), s2 / (wgs * e->nblk), s3 / (wgs * e->nblk));
-            }
-            {
-                double s1 = 0, s2 = 0, s3 = 0, sp = 0;
-                for (int w = 0; w < wgs; ++w)
-                    for (int b = 1; b < e->nblk; ++b) {
-                        const unsigned long long* r = &h[((size_t)w * e->nblk + b) * 16];
-                        s1 += (double)(r[8] - r[0]); s2 += (double)(r[9] - r[8]); s3 += (double)(r[1] - r[9]); sp += (double)r[10];
-                    }
-                const double n = (double)wgs * (e->nblk - 1);
-                fprintf(stderr, "[k_round prof] wait split: gather issue %.0f, poll %.0f (%.1f spins), syncthreads %.0f\n", s1 / n, s2 / n, sp / n, s3 / n);
-            }
-            fprintf(stderr, "[k_round prof] whole sweep mean %.0f ticks over %d workgroups\n", tot / wgs, wgs);
-        }
 #endif
-        // the two objective sums (:399, :402) of this rank's cells; the cross-entropy term was formed from job-wide tables.
-        // A rank whose wait timed out poisons its sums with NaN: every rank then sees the failure in this all-reduce --
-        // and so does the host, in the objective it reads anyway (no separate copy of the error word).
-        if (multi && (rc = sum_over_ranks(e, e->objacc, 2 * HMX_OBJ_SLOTS))) return rc;
-    } else if (flags & HMX_ROUND_UPDATE_R) {
-        for (int b = 0; b < e->nblk; ++b) {
-            {
-                Timed t(e, F_BLOCK_TABLE);
-                TableArgs ta = table_args(e);
-                ta.O_prev = (b == 0) ? e->Ogrp.p : e->Ohist.p + GK * (b - 1);
-                ta.S_add = (b == 0) ? nullptr : e->Snew + GK * (b - 1);
-                ta.S_sub = e->Sold + GK * b;
-                ta.O_out = e->Ohist.p + GK * b;
-                ta.rp = e->rp.p; ta.lrp = e->lrp.p;
-                launch_block_table(ta, e->K16, e->stream);
-            }
-            if (tiles_upper[b] > 0) {
-                Timed t(e, F_ASSIGN_BLOCK);
-                AssignArgs a = assign_args(e);
-                a.cells = e->lists[e->cur].cells.p; a.tile_grp = e->lists[e->cur].tile_grp.p; a.S_out = e->Snew + GK * b;
-                a.blk_start = e->lists[e->cur].blk_start.p; a.blk = b;
-                a.tile_begin = 0; a.tile_end = tiles_upper[b];
-                if (launch_assign(a, true, e->max_wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported cluster count");
-            }
-            // the block's new sums (:506-507) over all ranks; the last block takes the two objective
-            // sums (:399, :402) along: objacc follows Snew in xch
-            const bool last = b == e->nblk - 1;
-            if ((rc = sum_over_ranks(e, e->Snew + GK * b, GK + (last ? 2 * HMX_OBJ_SLOTS : 0)))) return rc;
         }
-        Timed t(e, F_BLOCK_TABLE);
-        TableArgs ta = table_args(e);  // close the round: O, T state and the cross-entropy term
-        ta.O_prev = e->Ohist.p + GK * (e->nblk - 1);
-        ta.S_add = e->Snew + GK * (e->nblk - 1);
-        ta.O_out = e->Ogrp.p; ta.T_out = e->Tmass.p;
-        if (flags & HMX_ROUND_OBJECTIVE) ta.obj_cross = e->objacc + 2 * HMX_OBJ_SLOTS;
-        launch_block_table(ta, e->K16, e->stream);
+        // objacc = [2 x SLOTS partial sums of (:399, :402) | cross-entropy term (:405-411) | number of workgroups whose
+        // grid-wide wait gave up].  Sharded: one all-reduce of the whole block -- the cross term was formed from job-wide
+        // tables and is contributed by rank 0 only, and every rank learns of a time-out on ANY rank at the same point.
+        if (multi && (rc = sum_over_ranks(e, e->objacc, 2 * HMX_OBJ_SLOTS + 2))) return rc;
+        if ((rc = read_objective(e, obj_out))) return rc;
+        if (e->obj_host[2 * HMX_OBJ_SLOTS + 1] != 0.0) {
+            // EXACT replay, block by block, from the round's own start: O as it was (Osave), the removal sums and centroids
+            // the failed launch used (Sold, Y: untouched by it), the round's own lists.  Rows the failed launch already
+            // replaced are computed again -- a new row depends on Z_cos, Y and its block's table, never on the old row.
+            note_sweep_timeout(e);
+            HIP_TRY(hipMemcpyAsync(e->Ogrp.p, e->Osave.p, GK * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+            HIP_TRY(hipMemsetAsync(e->Snew, 0, (size_t)((e->objacc + 2 * HMX_OBJ_SLOTS + 2) - e->Snew) * sizeof(double), e->stream));
+            if ((rc = blocks_loop(e, flags, tiles_upper))) return rc;
+            return read_objective(e, obj_out);
+        }
+        return 0;
     }
-    rc = read_objective(e, obj_out);
-    if (rc == 0 && mega && (e->sync_host[1] != 0 || obj_out[0] != obj_out[0] || obj_out[1] != obj_out[1])) {
-        e->sync_host[1] = 0;
-        if ((rc = sweep_timed_out(e))) return rc;
-        const int saved = e->round_mode;
-        e->round_mode = 0;
-        rc = round_body(e, flags, n_tiles_upper, tiles_upper, obj_out, nullptr);
-        e->round_mode = saved;
+    if (flags & HMX_ROUND_UPDATE_R) {
+        if ((rc = blocks_loop(e, flags, tiles_upper))) return rc;
     }
-    return rc;
+    return read_objective(e, obj_out);
 }
 
 static int check_round_flags(hmx_engine* e, int flags, double* obj_out) {
@@ -1025,6 +1156,13 @@ static int check_round_flags(hmx_engine* e, int flags, double* obj_out) {
         return fail(HMX_ERR_ARG, "HMX_ROUND_OBJECTIVE needs HMX_ROUND_UPDATE_R in this build");
     if (!(flags & (HMX_ROUND_CENTROIDS | HMX_ROUND_UPDATE_R))) return fail(HMX_ERR_ARG, "nothing to do");
     return 0;
+}
+
+// block ids in static tile order for the streaming R^T.Z pass, from the lists `which` (on stream s, behind their build)
+static void build_tile_blocks(hmx_engine* e, int which, int64_t n_pos_upper, hipStream_t s) {
+    if (!use_rtz3(e)) return;
+    launch_tile_blocks(e->lists[which].cells.p, e->lists[which].tile_grp.p, e->lists[which].blk_start.p, e->nblk, n_pos_upper,
+                       e->gstart.p, e->s_tile_start.p, e->tile_blk[which].p, s);
 }
 
 int hmx_cluster_round(hmx_engine* e, int flags, const int32_t* cells, int64_t n_pos, const int32_t* tile_group,
@@ -1060,14 +1198,14 @@ int hmx_cluster_round(hmx_engine* e, int flags, const int32_t* cells, int64_t n_
     HIP_TRY(hipMemcpyAsync(e->lists[e->cur].tile_grp.p, tile_group, n_tiles * sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(e->lists[e->cur].blk_start.p, block_tile_start, (e->nblk + 1) * sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));  // host lists are borrowed for the call only
+    if (flags & HMX_ROUND_UPDATE_R) build_tile_blocks(e, e->cur, n_pos, e->stream);
     return round_body(e, flags, n_tiles, upper, obj_out);
 }
 
-int hmx_cluster_round_seeded(hmx_engine* e, int flags, uint64_t seed, int64_t cells_per_block, double obj_out[4]) {
+// One round whose update order comes from the keyed bijection (seed, round counter): lists built on the device, the
+// next round's lists prepared on the second stream beside the sweep kernel.
+static int seeded_round(hmx_engine* e, int flags, uint64_t seed, int64_t cells_per_block, double obj_out[4]) {
     int rc;
-    if ((rc = check_round_flags(e, flags, obj_out))) return rc;
-    if (cells_per_block < 0 || cells_per_block * (e->nblk - 1) > e->Ng) return fail(HMX_ERR_ARG, "cells_per_block out of range");
-    if ((rc = use_device(e))) return rc;
     const int nkeys = e->nblk * e->G;
     const int nchunks = order_chunks(e->N);
     const size_t pos_cap = (size_t)e->N + (size_t)nkeys * (HMX_TILE - 1) + HMX_TILE;
@@ -1092,6 +1230,7 @@ int hmx_cluster_round_seeded(hmx_engine* e, int flags, uint64_t seed, int64_t ce
         o.gstart = e->gstart.p; o.chunk_tab = e->chunk_tab.p; o.run_count = e->run_count.p; o.run_start = e->run_start.p;
         o.blk_start = e->lists[which].blk_start.p; o.cells = e->lists[which].cells.p; o.tile_grp = e->lists[which].tile_grp.p;
         launch_order(o, s);
+        build_tile_blocks(e, which, (int64_t)pos_cap, s);
     };
     const uint64_t counter = e->seeded_rounds++;
     if (e->pre_valid && e->pre_seed == seed && e->pre_counter == counter && e->pre_cpb == cells_per_block) {
@@ -1124,7 +1263,7 @@ int hmx_cluster_round_seeded(hmx_engine* e, int flags, uint64_t seed, int64_t ce
             upper[b] = size_b > 0 ? (int)((size_b + HMX_TILE - 1) / HMX_TILE) + e->G : 0;
             total += upper[b];
         }
-    } else if (e->peers_enabled && e->round_mode == 1 && ((e->sweep_kernel && sweep_shape_ok(e)) || (e->mt <= 7 && round_row_floats(e->d) == e->dp))) {
+    } else if (e->peers_enabled && e->round_mode == 1 && e->mt <= 7 && round_row_floats(e->d) == e->dp) {
         // a shard holds a random share of every block.  The sweep kernel and the R^T.Z pass read the
         // tile offsets on the device and cope with any grid, so a generous estimate (mean + 8 sigma
         // of a hypergeometric share) sizes the grids without a host round trip
@@ -1144,6 +1283,65 @@ int hmx_cluster_round_seeded(hmx_engine* e, int flags, uint64_t seed, int64_t ce
         total = bs[e->nblk];
     }
     return round_body(e, flags, total, upper, obj_out, prefetch);
+}
+
+int hmx_cluster_round_seeded(hmx_engine* e, int flags, uint64_t seed, int64_t cells_per_block, double obj_out[4]) {
+    int rc;
+    if ((rc = check_round_flags(e, flags, obj_out))) return rc;
+    if (cells_per_block < 0 || cells_per_block * (e->nblk - 1) > e->Ng) return fail(HMX_ERR_ARG, "cells_per_block out of range");
+    if ((rc = use_device(e))) return rc;
+    return seeded_round(e, flags, seed, cells_per_block, obj_out);
+}
+
+// harmony.py:437-462, the rounds of ONE cluster() call without leaving the library: rounds of hmx_cluster_round_seeded
+// with flags HMX_ROUND_ALL; after round i > window (0-based, :455) the windowed test of check_convergence(0)
+// (:517-523) on objective = (sum of the three terms) * 2000 / N_global (:412-416) -- the same double arithmetic on the
+// same fp32-rounded terms Python would do -- ends the call.  forced_rounds >= 0 runs exactly that many rounds.
+int hmx_cluster(hmx_engine* e, uint64_t seed, int64_t cells_per_block, int max_rounds, int forced_rounds, int window,
+                double epsilon, double* obj_out, int32_t* rounds_out) {
+    int rc;
+    double probe[4];
+    if (!rounds_out) return fail(HMX_ERR_ARG, "null argument");
+    if ((rc = check_round_flags(e, HMX_ROUND_ALL, obj_out ? obj_out : probe))) return rc;
+    if (!obj_out) return fail(HMX_ERR_ARG, "null argument");
+    if (cells_per_block < 0 || cells_per_block * (e->nblk - 1) > e->Ng) return fail(HMX_ERR_ARG, "cells_per_block out of range");
+    if (window < 1 || max_rounds < 0) return fail(HMX_ERR_ARG, "window must be >= 1, max_rounds >= 0");
+    if ((rc = use_device(e))) return rc;
+    const int n = forced_rounds >= 0 ? forced_rounds : max_rounds;
+    const double norm_const = 2000.0 / (double)e->Ng;               // :412
+    std::vector<double> hist;
+    hist.reserve(n);
+    *rounds_out = 0;
+    for (int i = 0; i < n; ++i) {
+        double* o = obj_out + 4 * (size_t)i;
+        if ((rc = seeded_round(e, HMX_ROUND_ALL, seed, cells_per_block, o))) return rc;
+        hist.push_back((o[0] + o[1] + o[2]) * norm_const);          // :413
+        *rounds_out = i + 1;
+        if (forced_rounds < 0 && i > window) {                      // :455-458
+            double obj_old = 0.0, obj_new = 0.0;                    // :519-522, summed left to right like Python's sum()
+            const size_t m = hist.size();
+            for (int j = 0; j < window; ++j) obj_old += hist[m - window - 1 + j];
+            for (int j = 0; j < window; ++j) obj_new += hist[m - window + j];
+            if (std::fabs(obj_old - obj_new) / std::fabs(obj_old) < epsilon) break;
+        }
+    }
+    return HMX_OK;
+}
+
+const char* hmx_build_id(void) {
+#ifdef HMX_BUILD_ID
+    return HMX_BUILD_ID;
+#else
+    return "unknown";
+#endif
+}
+
+int hmx_has_sweep_kernel(void) {
+#ifdef HMX_WITH_SWEEP
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 int hmx_comm_unique_id(void* out_id) {
@@ -1269,6 +1467,10 @@ int hmx_moe_correct_ridge(hmx_engine* e) {
     if ((rc = e->slab.reserve((size_t)std::max(e->ntasks, 1) * (rtz2 ? rtz2_slab_floats(e->mt, e->dp)
                                                                      : rtzw ? rtz_wide_slab_floats(e->mt, e->dp) : spw))))
         return rc;
+    if (use_rtz3(e)) {
+        // the streaming pass: Sr and Oxr are written whole by k_rtz3_finish (no fills)
+        if ((rc = rtz3_pass(e, 1, e->tile_blk_zero.p, 1, false, false))) return rc;
+    } else {
     HIP_TRY(hipMemsetAsync(e->Sr, 0, GK * e->ldy * sizeof(double), e->stream));
     HIP_TRY(hipMemsetAsync(e->Oxr, 0, GK * sizeof(double), e->stream));
     {
@@ -1288,6 +1490,7 @@ int hmx_moe_correct_ridge(hmx_engine* e) {
             launch_rtz(r, (e->ntasks + 3) / 4, e->stream);
             launch_rtz_reduce(e->slab.p, e->ntasks, e->mt, e->ntd, e->K16, e->ldy, e->Sr, e->task_grp.p, e->stream);
         }
+    }
     }
     if ((rc = sum_over_ranks(e, e->Sr, GK * e->ldy + GK))) return rc;   // Sr and Oxr are neighbours
     {

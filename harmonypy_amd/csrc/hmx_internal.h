@@ -108,6 +108,44 @@ struct RtzArgs {
     int ldr, ldz;          // k_rtz2: LDS row strides (set by the launcher)
 };
 
+// The R^T.Z pass in storage order (k_rtz3, hmx_rtz3.hip): tasks are runs of static tiles of ONE group.
+struct Rtz3Args {
+    const float* R;            // N x Kp (+ 16 rows of slack)
+    const float* Z;            // N x dp (+ 16 rows of slack): Z_cos (k-means round) or Z_orig (ridge)
+    const unsigned char* tile_blk;   // n_static_tiles x 16 block ids in static tile order (all 0: column 0 = plain column sums)
+    const int* task_t0;        // static tile range of a task
+    const int* task_t1;
+    const int* task_c0;        // first cell of tile task_t0 (the cells of a group's tiles are consecutive)
+    const int* task_cend;      // first cell behind the task's group
+    float* slab;               // ntasks x MT x NT x 256 accumulators in fragment order
+    int ntasks, Kp;
+};
+struct Rtz3FinishArgs {
+    const float* slab;
+    const int* task_grp;
+    int ntasks, MT, KS, NTB, K, K16, d, ld, G, nblk;
+    int mode;                  // 0: k-means round (Ysum, Sold, optional Yout), 1: ridge (Sr, Oxr)
+    double* Ysum;              // K16 x ld
+    float* Yout;               // K16 x ld unit rows, or null (a collective comes first)
+    double* Sold;              // nblk x G x K16
+    double* Sr;                // G x K16 x ld
+    double* Oxr;               // G x K16
+    double* zero_p;            // fill duties for the sweep kernel (or null): slot tables + sync words, objective accumulators
+    size_t zero_n;
+    double* zero2_p;
+    size_t zero2_n;
+    const double* copy_src;    // copy duty: O at the start of the round, kept for an exact replay (or null)
+    double* copy_dst;
+    int copy_n;
+};
+bool rtz3_ok(int mt, int dp, int nblk, int G);
+int rtz3_ntb(int dp, int nblk);
+int rtz3_slab_floats(int mt, int dp, int nblk);
+int launch_rtz3(const Rtz3Args& a, int mt, int dp, int nblk, hipStream_t s);
+void launch_rtz3_finish(const Rtz3FinishArgs& a, hipStream_t s);
+void launch_tile_blocks(const int* cells, const int* tile_grp, const int* blk_start, int nblk, int64_t n_pos_upper, const int* gstart,
+                        const int* s_tile_start, unsigned char* tile_blk, hipStream_t s);
+
 struct TableArgs {
     const double* O_prev;  // G x K16
     const double* S_add;   // G x K16 or null

@@ -934,7 +934,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         //      rank's total into every rank's box (xGMI peer writes), then raise this rank's flag there.
         bool gfail = false;
         for (int b = 0; b < a.nblk; ++b) {
-            if (wv == 0) {
+            if (wv == 0 && !gfail) {
                 const unsigned want = (unsigned)(b + 1) * (unsigned)nwg;
                 unsigned spins = 0;
                 while (ld_agent(a.counter) < want) {
@@ -958,7 +958,8 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         }
         if (gfail && tid == 0) {
             atomicExch(a.error, 1u);
-            atomicAdd(&a.obj[0], __builtin_nan(""));   // every rank sees the failure in the all-reduce of the objective sums
+            atomicAdd(&a.obj[0], __builtin_nan(""));
+            atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS + 1], 1.0);   // every rank sees the count of failures in the all-reduce of the objective block
         }
         return;
     }
@@ -1097,10 +1098,11 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         RSTAMP(0);
         RSTAMP(8);
         // ---- wait until every workgroup has added its sums of block b-1 ---------------------
-        if (b > 0 && wv == 0) {
+        if (b > 0 && wv == 0 && !failed) {   // (a wait that gave up is not repeated block after block: the launch is lost)
             unsigned spins = 0;
             if (a.spin_limit == 0) failed = true;   // test knob: give up without looking
-            if (!multi) {
+            if (failed) {
+            } else if (!multi) {
                 const unsigned want = (unsigned)b * (unsigned)nwg;
                 while (ld_agent(a.counter) < want) {
                     __builtin_amdgcn_s_sleep(1);
@@ -1280,6 +1282,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     if (failed && tid == 0) {
         atomicExch(a.error, 1u);
         atomicAdd(&a.obj[0], __builtin_nan(""));
+        atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS + 1], 1.0);   // the host (every rank's, after the all-reduce) replays the round block by block
     }
     if (wg != 0) return;
 
@@ -1290,7 +1293,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             const unsigned want = (unsigned)a.nblk * (unsigned)nwg;
             while (ld_agent(a.counter) < want) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > a.spin_limit) { if (lane == 0) { atomicExch(a.error, 1u); atomicAdd(&a.obj[0], __builtin_nan("")); } break; }
+                if (++spins > a.spin_limit) { if (lane == 0) { atomicExch(a.error, 1u); atomicAdd(&a.obj[0], __builtin_nan("")); atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS + 1], 1.0); } break; }
             }
         } else {
             const unsigned long long want = a.epoch + (unsigned long long)a.nblk;
@@ -1299,7 +1302,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                 const bool ok = lane >= a.n_ranks || ld_sys(fl + lane) >= want;
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > a.spin_limit) { if (lane == 0) { atomicExch(a.error, 1u); atomicAdd(&a.obj[0], __builtin_nan("")); } break; }
+                if (++spins > a.spin_limit) { if (lane == 0) { atomicExch(a.error, 1u); atomicAdd(&a.obj[0], __builtin_nan("")); atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS + 1], 1.0); } break; }
             }
         }
     }
@@ -1342,7 +1345,9 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     if (tid == 0) {
         double v = 0.0;
         for (int w = 0; w < ROUND_WAVES; ++w) v += objw[w];
-        atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS], v);
+        // sharded: the term comes from job-wide tables, identical on every rank, and the objective block is summed over
+        // the ranks as a whole (it carries the failure count too): rank 0 contributes it
+        if (!multi || a.rank == 0) atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS], v);
     }
 }
 

@@ -1,0 +1,350 @@
+// hmx_rtz3.hip -- the R^T.Z pass as a STREAMING kernel (gfx950): centroid numerators Z_cos R^T (harmony.py:443), the removal
+// sums of every update block R_blk Phi_blk^T (harmony.py:491-492) and the ridge statistics Phi_Rk Z_orig^T with the exact
+// O (harmony.py:550, 556-563), all from ONE pass over R and Z in storage order.
+//
+// Why another kernel (k_rtz2, hmx_kernels.hip, walks the round's block-major list): gathering rows of 400 / 208 bytes in a
+// random order fetches 1.38x the algorithmic bytes (whole 128-byte lines), and its four waves share every tile through
+// LDS with a workgroup barrier per tile and ~150 bookkeeping instructions beside 28 MFMAs.  Here:
+//   * cells are read in storage order (group-sorted, rows contiguous): every byte fetched is used;
+//   * a WAVE is the unit: it owns whole 16-cell tiles, brings them global -> LDS with `global_load_lds_dwordx4`
+//     (1 KB per instruction, no destination registers), double buffered in its private LDS region, and multiplies a tile
+//     with all MT x NT output tiles in its own accumulators -- no workgroup barrier, no ids, no shuffles in the loop;
+//   * block membership does not decide the ORDER any more; it rides in the product: the B operand is the Z tile
+//     (PC columns) extended by one-hot columns "cell is in block j", so the MFMAs deliver sum_{cells in block j} R[cell][k]
+//     next to the centroid numerators.  16 bytes of block ids per tile (static tile order, written once per round by
+//     k_tile_blocks from the round's lists) travel with the tile.  With all ids 0 column 0 is the plain column sum of R:
+//     the exact O of the ridge step.
+//
+// MFMA fragment conventions (hmx_device.h); index maps chosen so that a lane's operands are 16-byte LDS reads:
+//   k index (ks, q)      <-> cell 4q + ks of the tile             (a lane's four block ids are one dword)
+//   A row m = c16, tile mt: cluster 64h + 4 c16 + j for mt = 4h + j in the full groups of four tiles,
+//                           cluster 64H + r c16 + j for the r = MT % 4 remaining tiles (H = MT / 4)
+//   B col n = c16, tile nt < 4: column 4 c16 + nt of [Z row (dp floats) | one-hot of blocks 0 .. 63-dp]
+//                  tile nt >= 4: one-hot of block (64 - dp) + 16 (nt - 4) + c16
+// k_rtz3_finish undoes the maps when it sums the per-task slabs in fp64.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "hmx_internal.h"
+#include "hmx_device.h"
+
+namespace {
+
+// one 1 KB piece global -> LDS: lane l brings 16 bytes from `src` to LDS byte address `zone` + 16 l.  Inline assembly on
+// purpose: the builtin makes the compiler drain vmcnt before any later LDS read.
+__device__ __forceinline__ void dma16(const void* src, unsigned zone) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(zone) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) const void*)p);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {   // gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+
+}  // namespace
+
+#define RTZ3_WAVES 4
+
+template <int MT, int KS, int NTB>
+__global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
+    constexpr int NT = 4 + NTB, DP = 4 * KS;
+    constexpr int NR = MT, NZ = (KS + 3) / 4, NI = NR + NZ + 1;   // VMEM operations per tile: R pieces, Z pieces, block ids
+    constexpr int H = MT / 4, REM = MT % 4;
+    static_assert(KS <= 16 && NI < 60, "shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* lds = reinterpret_cast<float*>(smem);
+    const int Kp = a.Kp;
+    const int buf_floats = 16 * (Kp + DP) + 4;                     // R tile | Z tile | 16 block-id bytes
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, c16 = lane & 15, q = lane >> 4;
+    const int task = blockIdx.x;
+    const int t0 = a.task_t0[task], t1 = a.task_t1[task];
+    const int c_first = a.task_c0[task], c_end = a.task_cend[task];
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // tiles of this wave: t0 + wv + RTZ3_WAVES i
+    const int n_mine = (t1 - t0 - wv + RTZ3_WAVES - 1) / RTZ3_WAVES;
+    auto issue = [&](int i) {                                       // tile i of this wave -> buffer i & 1
+        const int t = t0 + wv + RTZ3_WAVES * i;
+        const int c0 = c_first + 16 * (t - t0);
+        float* buf = lds + (size_t)(2 * wv + (i & 1)) * buf_floats;
+        const char* rs = reinterpret_cast<const char*>(a.R + (size_t)c0 * Kp) + 16 * lane;
+        const char* zs = reinterpret_cast<const char*>(a.Z + (size_t)c0 * DP) + 16 * lane;
+#pragma unroll
+        for (int it = 0; it < NR; ++it) {
+            const unsigned zone = lds_addr(reinterpret_cast<const char*>(buf) + 1024 * it);
+            if (it + 1 < NR || 1024 * it + 16 * lane < 64 * Kp) dma16(rs + 1024 * it, zone);
+        }
+#pragma unroll
+        for (int it = 0; it < NZ; ++it) {
+            const unsigned zone = lds_addr(reinterpret_cast<const char*>(buf + 16 * Kp) + 1024 * it);
+            if (1024 * (it + 1) <= 64 * DP || 1024 * it + 16 * lane < 64 * DP) dma16(zs + 1024 * it, zone);
+        }
+        const unsigned zone = lds_addr(buf + 16 * (Kp + DP));
+        if (lane == 0) dma16(a.tile_blk + (size_t)16 * t, zone);
+    };
+    if (n_mine > 0) issue(0);
+    if (n_mine > 1) issue(1);
+
+    for (int i = 0; i < n_mine; ++i) {
+        // tile i has landed: the only younger operations are the NI of tile i+1 (memory operations complete in order)
+        asm volatile("" ::: "memory");
+        if (i + 1 < n_mine) wait_vmcnt<NI>(); else wait_vmcnt<0>();
+        asm volatile("" ::: "memory");
+        const int t = t0 + wv + RTZ3_WAVES * i;
+        const int c0 = c_first + 16 * (t - t0);
+        float* Rt = lds + (size_t)(2 * wv + (i & 1)) * buf_floats;
+        float* Zt = Rt + 16 * Kp;
+        const int n_live = min(16, c_end - c0);                     // wave-uniform; < 16 only in a group's last tile
+        if (n_live < 16) {
+            // rows past the group's end hold other cells (or the slack behind the array): they count for nothing
+            for (int j = n_live * Kp + lane; j < 16 * Kp; j += 64) Rt[j] = 0.f;
+            for (int j = n_live * DP + lane; j < 16 * DP; j += 64) Zt[j] = 0.f;
+        }
+        const unsigned bw = reinterpret_cast<const unsigned*>(Zt + 16 * DP)[q];   // block ids of cells 4q .. 4q+3
+        float afr[4][MT];
+        f32x4 zfr[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float* rr = Rt + (size_t)(4 * q + ks) * Kp;
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const f32x4 v = ld4(rr + 64 * h + 4 * c16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) afr[ks][4 * h + j] = v[j];
+            }
+#pragma unroll
+            for (int j = 0; j < REM; ++j) afr[ks][4 * H + j] = rr[64 * H + REM * c16 + j];
+            zfr[ks] = ld4(Zt + (size_t)(4 * q + ks) * DP + 4 * min(c16, KS - 1));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the buffer is in registers: hand it to tile i+2
+        if (i + 2 < n_mine) issue(i + 2);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int bid = (bw >> (8 * ks)) & 255;
+            float bfr[NT];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bfr[nt] = (c16 < KS) ? zfr[ks][nt] : ((bid == 4 * c16 + nt - DP) ? 1.f : 0.f);
+#pragma unroll
+            for (int e = 0; e < NTB; ++e) bfr[4 + e] = (bid == (64 - DP) + 16 * e + c16) ? 1.f : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA16(afr[ks][mt], bfr[nt], acc[mt][nt]);
+        }
+    }
+
+    // ---- the four waves' accumulators meet in LDS (fragment order), one slab per task goes out -------------------------
+    __syncthreads();                                                // every wave is done with its buffers (all requests landed)
+    constexpr int PER = MT * NT * 256;
+#pragma unroll 1
+    for (int w = 0; w < RTZ3_WAVES; ++w) {
+        if (wv == w) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* p = lds + ((mt * NT + nt) * 4 + r) * 64 + lane;
+                        *p = (w == 0) ? acc[mt][nt][r] : *p + acc[mt][nt][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float* slab = a.slab + (size_t)task * PER;
+    for (int j = tid; j < PER / 4; j += 64 * RTZ3_WAVES) st4(slab + 4 * j, ld4(lds + 4 * j));
+}
+
+// ------------------------------------------------------------------------------------------
+// k_rtz3_finish: the per-task slabs summed in fp64, one workgroup per cluster k; undoes the index maps of k_rtz3.
+//   mode 0 (k-means round): Ysum[k][pc] over all tasks (the centroid numerators, :443), Sold[blk][g][k] over the tasks of
+//          group g (the removal sums, :491-492); with Yout the row is normalised on the spot (:444) -- no collective
+//          is due in between on a single engine -- and the workgroups share the fills the sweep kernel needs.
+//   mode 1 (ridge): Sr[g][k][pc] (:556-563) and the exact Oxr[g][k] (:550) over the tasks of group g.
+// ------------------------------------------------------------------------------------------
+#define RTZ3_FIN_THREADS 1024   /* many short chains of dependent-free loads: the slab reads are latency-bound */
+__global__ __launch_bounds__(RTZ3_FIN_THREADS) void k_rtz3_finish(Rtz3FinishArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* tab = reinterpret_cast<double*>(smem);                  // G x NV
+    const int NT = 4 + a.NTB, NV = 16 * NT, DP = 4 * a.KS;
+    const int k = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < a.G * NV; i += RTZ3_FIN_THREADS) tab[i] = 0.0;
+    if (a.zero_p) {                                                 // fill duty: this workgroup's slice
+        const size_t per = (a.zero_n + gridDim.x - 1) / gridDim.x;
+        const size_t z0 = (size_t)k * per, z1 = min(z0 + per, a.zero_n);
+        for (size_t i = z0 + tid; i < z1; i += RTZ3_FIN_THREADS) a.zero_p[i] = 0.0;
+    }
+    if (a.zero2_p)
+        for (size_t i = (size_t)k * RTZ3_FIN_THREADS + tid; i < a.zero2_n; i += (size_t)gridDim.x * RTZ3_FIN_THREADS) a.zero2_p[i] = 0.0;
+    if (a.copy_dst)
+        for (int i = k * RTZ3_FIN_THREADS + tid; i < a.copy_n; i += gridDim.x * RTZ3_FIN_THREADS) a.copy_dst[i] = a.copy_src[i];
+    __syncthreads();
+    // where cluster k sits in a slab: tile mt, row m of the tile
+    const int Hq = a.MT / 4, rem = a.MT % 4;
+    int mt, m;
+    if (k < 64 * Hq) { mt = 4 * (k / 64) + (k & 3); m = (k & 63) >> 2; }
+    else { const int x = k - 64 * Hq; m = x / rem; mt = 4 * Hq + x % rem; }
+    const int per = a.MT * NT * 256;
+    const int nslice = RTZ3_FIN_THREADS / NV;
+    const int v = tid % NV, sl = tid / NV;                          // value (nt, n) of the row, slice of the tasks
+    if (sl < nslice) {
+        const int nt = v >> 4, n = v & 15;
+        const size_t off = (size_t)((mt * NT + nt) * 4 + (m & 3)) * 64 + 16 * (m >> 2) + n;
+        int g = -1;
+        double acc = 0.0;
+        for (int w = sl; w < a.ntasks; w += nslice) {
+            const int gw = a.task_grp[w];
+            if (gw != g) {
+                if (g >= 0 && acc != 0.0) atomicAdd(&tab[g * NV + v], acc);
+                g = gw;
+                acc = 0.0;
+            }
+            acc += (double)a.slab[(size_t)w * per + off];
+        }
+        if (g >= 0 && acc != 0.0) atomicAdd(&tab[g * NV + v], acc);
+    }
+    __syncthreads();
+    auto col_pc = [&](int pc) { return 16 * (pc & 3) + (pc >> 2); };
+    auto col_blk = [&](int j) {
+        if (j < 64 - DP) { const int c = DP + j; return 16 * (c & 3) + (c >> 2); }
+        const int x = j - (64 - DP);
+        return 16 * (4 + x / 16) + (x & 15);
+    };
+    if (a.mode == 1) {
+        for (int i = tid; i < a.G * a.ld; i += RTZ3_FIN_THREADS) {
+            const int g = i / a.ld, j = i - g * a.ld;
+            a.Sr[((size_t)g * a.K16 + k) * a.ld + j] = (k < a.K && j < a.d) ? tab[g * NV + col_pc(j)] : 0.0;
+        }
+        for (int g = tid; g < a.G; g += RTZ3_FIN_THREADS) a.Oxr[(size_t)g * a.K16 + k] = (k < a.K) ? tab[g * NV + col_blk(0)] : 0.0;
+        return;
+    }
+    for (int i = tid; i < a.nblk * a.G; i += RTZ3_FIN_THREADS) {
+        const int b = i / a.G, g = i - b * a.G;
+        a.Sold[((size_t)b * a.G + g) * a.K16 + k] = (k < a.K) ? tab[g * NV + col_blk(b)] : 0.0;
+    }
+    if (tid < 64) {                                                 // one wave: the row's numerators, then (:444) its unit form
+        const int lane = tid;
+        float vals[4];
+        float ss = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = lane + 64 * u;
+            double s = 0.0;
+            if (k < a.K && j < a.d)
+                for (int g = 0; g < a.G; ++g) s += tab[g * NV + col_pc(j)];
+            if (j < a.ld) a.Ysum[(size_t)k * a.ld + j] = s;
+            vals[u] = (float)s;                                     // fp64 sums are rounded to fp32 first (:443)
+            ss += vals[u] * vals[u];
+        }
+        if (a.Yout) {
+            for (int msk = 32; msk >= 1; msk >>= 1) ss += __shfl_xor(ss, msk, 64);
+            const float nrm = sqrtf(ss);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = lane + 64 * u;
+                if (j < a.ld) a.Yout[(size_t)k * a.ld + j] = (k < a.K && j < a.d) ? vals[u] / nrm : 0.f;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_tile_blocks: block id of every cell in STATIC tile order (16 bytes per static tile), from a round's block-major list
+// (cells, tile groups, block tile offsets: built on the host from torch.randperm or on the device from the keyed
+// bijection, harmony.py:471-484).  Static position of internal cell c of group g: 16 * s_tile_start[g] + (c - gstart[g]).
+// Positions of the static padding are never written (they stay 255: no block); k_rtz3 zeroes those rows anyway.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tile_blocks(const int* __restrict__ cells, const int* __restrict__ tile_grp,
+                                                     const int* __restrict__ blk_start, int nblk, const int* __restrict__ gstart,
+                                                     const int* __restrict__ s_tile_start, unsigned char* __restrict__ tile_blk) {
+    __shared__ int bs[64 + 2];
+    for (int i = threadIdx.x; i <= nblk; i += 256) bs[i] = blk_start[i];
+    __syncthreads();
+    const int n_pos = 16 * bs[nblk];
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < n_pos; p += gridDim.x * 256) {
+        const int c = cells[p];
+        if (c < 0) continue;
+        const int t = p >> 4;
+        int b = 0;
+        while (b + 1 < nblk && t >= bs[b + 1]) ++b;
+        const int g = tile_grp[t];
+        tile_blk[(size_t)16 * s_tile_start[g] + (c - gstart[g])] = (unsigned char)b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+int rtz3_ntb(int dp, int nblk) { return std::max(0, (nblk - (64 - dp) + 15) / 16); }
+bool rtz3_ok(int mt, int dp, int nblk, int G) {
+    return mt >= 1 && mt <= 7 && (dp == 32 || dp == 52 || dp == 64) && rtz3_ntb(dp, nblk) <= 2 && G <= 64 && nblk <= 64;
+}
+int rtz3_slab_floats(int mt, int dp, int nblk) { return mt * (4 + rtz3_ntb(dp, nblk)) * 256; }
+size_t rtz3_lds_bytes(int Kp, int dp) { return (size_t)2 * RTZ3_WAVES * (16 * (Kp + dp) + 4) * sizeof(float); }
+
+template <int MT, int KS, int NTB>
+static void launch_rtz3_t(const Rtz3Args& a, size_t sm, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rtz3<MT, KS, NTB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_rtz3<MT, KS, NTB>), dim3(a.ntasks), dim3(64 * RTZ3_WAVES), sm, s, a);
+}
+template <int KS, int NTB>
+static void launch_rtz3_m(const Rtz3Args& a, int mt, size_t sm, hipStream_t s) {
+    switch (mt) {
+        case 1: launch_rtz3_t<1, KS, NTB>(a, sm, s); break;
+        case 2: launch_rtz3_t<2, KS, NTB>(a, sm, s); break;
+        case 3: launch_rtz3_t<3, KS, NTB>(a, sm, s); break;
+        case 4: launch_rtz3_t<4, KS, NTB>(a, sm, s); break;
+        case 5: launch_rtz3_t<5, KS, NTB>(a, sm, s); break;
+        case 6: launch_rtz3_t<6, KS, NTB>(a, sm, s); break;
+        default: launch_rtz3_t<7, KS, NTB>(a, sm, s); break;
+    }
+}
+template <int KS>
+static void launch_rtz3_k(const Rtz3Args& a, int mt, int ntb, size_t sm, hipStream_t s) {
+    switch (ntb) {
+        case 0: launch_rtz3_m<KS, 0>(a, mt, sm, s); break;
+        case 1: launch_rtz3_m<KS, 1>(a, mt, sm, s); break;
+        default: launch_rtz3_m<KS, 2>(a, mt, sm, s); break;
+    }
+}
+
+// `nblk` decides the one-hot columns (1 for the ridge / centroid-only passes: column 0 = the plain column sums)
+int launch_rtz3(const Rtz3Args& a, int mt, int dp, int nblk, hipStream_t s) {
+    if (!rtz3_ok(mt, dp, nblk, 1) || a.ntasks <= 0) return -1;
+    const int ntb = rtz3_ntb(dp, nblk);
+    const size_t sm = std::max(rtz3_lds_bytes(a.Kp, dp), (size_t)rtz3_slab_floats(mt, dp, nblk) * sizeof(float));
+    switch (dp) {
+        case 32: launch_rtz3_k<8>(a, mt, ntb, sm, s); break;
+        case 52: launch_rtz3_k<13>(a, mt, ntb, sm, s); break;
+        default: launch_rtz3_k<16>(a, mt, ntb, sm, s); break;
+    }
+    return 0;
+}
+
+void launch_rtz3_finish(const Rtz3FinishArgs& a, hipStream_t s) {
+    const size_t sm = (size_t)a.G * 16 * (4 + a.NTB) * sizeof(double);
+    hipLaunchKernelGGL(k_rtz3_finish, dim3(a.K16), dim3(RTZ3_FIN_THREADS), sm, s, a);
+}
+
+void launch_tile_blocks(const int* cells, const int* tile_grp, const int* blk_start, int nblk, int64_t n_pos_upper, const int* gstart,
+                        const int* s_tile_start, unsigned char* tile_blk, hipStream_t s) {
+    const int wgs = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (n_pos_upper + 1023) / 1024));
+    hipLaunchKernelGGL(k_tile_blocks, dim3(wgs), dim3(256), 0, s, cells, tile_grp, blk_start, nblk, gstart, s_tile_start, tile_blk);
+}

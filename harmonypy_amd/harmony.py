@@ -715,6 +715,17 @@ class Harmony:
         """``_rounds`` (keyword only, not in the reference): run exactly that many rounds."""
         rounds = 0
         forced = _rounds if _rounds is not None else (self._schedule.pop(0) if self._schedule else None)
+        if self.update_order == "device":
+            # device-side update order: all rounds of this call inside the library (hmx_cluster) -- the same rounds, the
+            # same test on the same numbers (harmony.py:455-458, 517-523), no trip through Python between rounds
+            terms = self._engine.cluster(self._seed, self._cells_per_block, self.max_iter_kmeans, forced,
+                                         self.window_size, self.epsilon_kmeans)
+            for t in terms:
+                self._pending_objective = t
+                self.compute_objective()                                         # :453
+            self.kmeans_rounds.append(len(terms))
+            self.objective_harmony.append(self.objective_kmeans[-1])
+            return
         for i in range(self.max_iter_kmeans if forced is None else forced):
             self._round(_capi.HMX_ROUND_ALL)                                     # :443-450
             self.compute_objective()                                             # :453

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HMX_ABI_VERSION 4
+#define HMX_ABI_VERSION 5
 #define HMX_TILE 16 /* cells per tile */
 /* limits of this build, checked by hmx_create (the reference has none: harmony.py:123-124 caps only the default K) */
 #define HMX_MAX_CLUSTERS 208
@@ -83,6 +83,11 @@ typedef struct hmx_engine hmx_engine;
 
 const char* hmx_last_error(void);
 int hmx_abi_version(void);
+/* Identity of the kernel set in this library: 12 hex digits of the SHA-256 over csrc/ and this header, computed by
+ * harmonypy_amd/_build.py at build time.  Profiles and counter files name the build they were collected on. */
+const char* hmx_build_id(void);
+/* 1 when the library was built with the opt-in one-pass study kernel k_sweep (-DHMX_WITH_SWEEP). */
+int hmx_has_sweep_kernel(void);
 
 /* Allocate the device state of one `Harmony` object (harmony.py:230-278, 357-364). */
 int hmx_create(const hmx_config* cfg, hmx_engine** out);
@@ -93,6 +98,9 @@ void hmx_destroy(hmx_engine* e);
  * so that Z travels in the caller's order and is regrouped on the device; NULL = Z is
  * already in internal order.  static_cells/static_tile_group: the
  * group-sorted identity list padded to tiles (n_static_pos = 16*n_static_tiles).
+ * One batch variable (n_vars == 1): group g IS batch g -- n_groups == n_batches and group_cols[g] == g are
+ * required (the closed-form ridge solve and the sweep kernel's tables index by it): batch levels that
+ * hold no cell must be dropped by the caller (harmony.py:134 counts the levels present, too).
  * group_cols: G x V Phi-row indices of every group.  lamb: B+1 floats, ignored
  * when lambda_estimation.  Pr_b (harmony.py:170) is the batch proportion over the
  * whole job.  global_id: for every internal cell its index in [0, n_cells_global)
@@ -186,6 +194,7 @@ int hmx_kmeans_lloyd(hmx_engine* e, const float* centers_in, int n_iter, float* 
 #define HMX_ROUND_CENTROIDS 1 /* harmony.py:443-447 */
 #define HMX_ROUND_UPDATE_R 2  /* harmony.py:450, 464-513 */
 #define HMX_ROUND_OBJECTIVE 4 /* harmony.py:453, 394-417 */
+#define HMX_ROUND_ALL 7       /* the reference's round: all three */
 int hmx_cluster_round(hmx_engine* e, int flags, const int32_t* cells, int64_t n_pos,
                       const int32_t* tile_group, int32_t n_tiles, const int32_t* block_tile_start,
                       double obj_out[4]);
@@ -200,6 +209,16 @@ int hmx_cluster_round(hmx_engine* e, int flags, const int32_t* cells, int64_t n_
  * (the reference itself changes stream between its 'cpu' and 'cuda' devices). */
 int hmx_cluster_round_seeded(hmx_engine* e, int flags, uint64_t seed, int64_t cells_per_block,
                              double obj_out[4]);
+
+/* harmony.py:437-462: ALL rounds of one cluster() call, update order as in hmx_cluster_round_seeded, without a trip
+ * through the caller between rounds.  Round i (0-based) is followed, when i > window (harmony.py:455), by the windowed
+ * test of check_convergence(0) (harmony.py:517-523) on objective_i = (sum of the three terms) * 2000 / n_cells_global
+ * (harmony.py:412-413) -- the double arithmetic Python does on the same fp32-rounded terms; the call ends when the
+ * relative change of the window sums is below `epsilon` or after max_rounds rounds.  forced_rounds >= 0 runs exactly
+ * that many rounds instead (no test).  obj_out: 4 doubles per round run (as hmx_cluster_round: the three terms, 0),
+ * room for max(max_rounds, forced_rounds) rounds; *rounds_out: rounds run (harmony.py:460 kmeans_rounds entry). */
+int hmx_cluster(hmx_engine* e, uint64_t seed, int64_t cells_per_block, int max_rounds, int forced_rounds, int window,
+                double epsilon, double* obj_out, int32_t* rounds_out);
 
 /* harmony.py:535-569. */
 int hmx_moe_correct_ridge(hmx_engine* e);

@@ -1,9 +1,9 @@
 """ASan + UBSan build of the C-ABI host code, exercised without a GPU: the C99 client and the ABI error
 paths run against a library compiled with -fsanitize=address,undefined (host code only: -fno-gpu-sanitize).
 
-Slow to build (~2 min), so the test only runs when the sanitized library exists (HMX_ASAN_LIB, or
-build_abl/libhmx_asan.so -- `python -m harmonypy_amd._build -o build_abl/libhmx_asan.so -fsanitize=address,undefined
--fno-gpu-sanitize -g`) or when HMX_BUILD_ASAN=1 asks for it to be built."""
+The sanitized library (build/libhmx_asan.so) is rebuilt whenever its stamp does not carry the build id of the current
+sources (`_build.build_sanitized`: only hmx_capi.cpp is recompiled, the kernel objects are shared with libhmx.so) -- a
+stale library is never tested, a missing compiler fails the test instead of skipping it."""
 import glob
 import os
 import shutil
@@ -14,7 +14,7 @@ import pytest
 
 from conftest import ROOT
 
-ASAN_LIB = os.environ.get("HMX_ASAN_LIB") or os.path.join(ROOT, "build_abl", "libhmx_asan.so")
+ASAN_LIB = os.path.join(ROOT, "build", "libhmx_asan.so")
 
 
 def _runtime():
@@ -24,14 +24,13 @@ def _runtime():
 
 @pytest.fixture(scope="module")
 def asan_lib():
-    if not os.path.exists(ASAN_LIB):
-        if os.environ.get("HMX_BUILD_ASAN") != "1":
-            pytest.skip("no sanitized library (set HMX_BUILD_ASAN=1 to build it: ~2 minutes)")
-        subprocess.run([sys.executable, "-m", "harmonypy_amd._build", "-o", ASAN_LIB, "-fsanitize=address,undefined",
-                        "-fno-gpu-sanitize", "-g", "-fno-omit-frame-pointer"], check=True, cwd=ROOT)
-    if _runtime() is None:
-        pytest.skip("clang's ASan runtime not found")
-    return ASAN_LIB
+    from harmonypy_amd import _build
+    _build.build(verbose=False)                 # the kernel objects the sanitized library shares
+    lib = _build.build_sanitized(ASAN_LIB)
+    with open(lib + ".buildid") as f:
+        assert f.read().strip() == _build.build_id(_build.ASAN_FLAGS), "sanitized library is stale"
+    assert _runtime() is not None, "clang's ASan runtime not found under /opt/rocm/lib/llvm"
+    return lib
 
 
 def _env():
