@@ -2,7 +2,8 @@
 """bench.py -- throughput of the Harmony iteration engine on MI355X.
 
     python bench.py --gpus 1 --steps K --warmup W            (defaults finish in ~2-3 minutes)
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...                             (launches its own N ranks, one per GPU, over RCCL)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W   (the driver's form)
 
 Metric (BASELINE.json): cells/sec/Harmony-iteration = cells x iterations / T_harmonize, inputs
 resident in HBM when the timed region starts.  A *step* is one Harmony iteration
@@ -14,7 +15,11 @@ device inside the timed region.
 
 Workload at --gpus 1: BASELINE.json configs[2] (C3, the roofline point): synthetic 1M cells x
 50 PCs, 8 batches, K=100.  `--config c2` selects configs[1] (69k x 50, 4 batches, K=30).
-With N > 1 ranks every GPU holds one such shard (weak scaling).
+With N > 1 ranks the default is the job BASELINE.json names for several GPUs: configs[3], 10M cells x 50 PCs,
+16 batches, K=100, cells sharded evenly over the N ranks (STRONG scaling: 10M / N cells per GPU; its one-GPU point
+is the `configs_3_on_one_gpu` entry of the default line); `--config c5` shards configs[4] (10M x 200 PCs, K=200) the
+same way, `--config c3` keeps 1M cells per GPU (weak scaling).  A run that cannot bring up N ranks on N devices
+exits non-zero instead of reporting fewer GPUs.
 
 One JSON line on stdout (rank 0).  Besides the contract fields:
   roofline     -- the dominant kernel (k_round, one persistent launch per update_R sweep):
@@ -49,6 +54,29 @@ CONFIGS = {
     "c4x1": (10_000_000, 50, 16, 100),
 }
 CONFIG_INDEX = {"c2": 1, "c3": 2, "c4": 3, "c5": 4, "c4x1": 3}
+# cells of the whole job of the configurations BASELINE.json defines over several GPUs (sharded evenly: strong scaling)
+JOB_CELLS = {"c4": 10_000_000, "c5": 10_000_000}
+
+
+def self_launch(args_list, n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script through torch.distributed.run
+    (one process per GPU, rendezvous on 127.0.0.1) and hand their exit status on.  Returns the command (for tests)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(args_list)
+
+
+def resolve_workload(config, gpus):
+    """(config name, cells of this job per GPU, scaling) for `--config` (None = default) on `gpus` ranks."""
+    if config is None:
+        config = "c3" if gpus == 1 else "c4"
+    if gpus > 1 and config in JOB_CELLS:
+        return config, JOB_CELLS[config] // gpus, "strong"
+    return config, CONFIGS[config][0], "weak"
+
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense (= the f32 vector rate)
 
@@ -135,13 +163,29 @@ def cpu_baseline(d, B, K, rounds, sample_cells, seed=1):
     Y0 = quick_centroids(Z, K, seed=seed)
     what = f"{sample_cells} cells x {d} PCs, {B} batches, K={K}: 1 iteration = {rounds} rounds + ridge"
     ref_path = os.environ.get("HMX_REFERENCE_PATH")
-    if ref_path and os.path.isdir(os.path.join(ref_path, "harmonypy")):
+    if not (ref_path and os.path.isdir(os.path.join(ref_path, "harmonypy"))):
+        ref_path = None
+        try:   # an installed harmonypy (site-packages) serves as well as a checkout
+            import importlib.util
+            spec = importlib.util.find_spec("harmonypy")
+            if spec is not None and spec.origin and "harmonypy_amd" not in spec.origin:
+                ref_path = os.path.dirname(os.path.dirname(spec.origin))
+        except Exception:
+            ref_path = None
+    if ref_path:
         dt, threads = _reference_baseline(ref_path, Z, meta, K, rounds, Y0)
         return {"value": sample_cells / dt, "unit": "cells/sec/Harmony-iteration", "cores": threads, "kind": "reference",
                 "sample": f"{what} in {dt:.1f} s (harmonypy at {ref_path}, device='cpu', torch threads={threads}, "
                           f"host has {os.cpu_count()} cpus)"}
     from oracle.harmony_oracle import OracleHarmony, prepare_inputs
-    threads = min(32, os.cpu_count() or 1)
+    cal = None
+    try:
+        cal = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_baseline_calibration.json")))
+    except Exception:
+        pass
+    # the thread count the reference/port ratio was measured at (8), so that the ratio applies to this very run
+    cal_threads = int(cal["samples"]["200000"]["port"]["cores"]) if cal else 8
+    threads = min(cal_threads, os.cpu_count() or 1)
     try:
         from threadpoolctl import threadpool_limits
         limit = threadpool_limits(limits=threads)
@@ -159,17 +203,13 @@ def cpu_baseline(d, B, K, rounds, sample_cells, seed=1):
     dt = time.perf_counter() - t0
     if limit is not None:
         limit.restore_original_limits()
-    cal = None
-    try:
-        cal = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_baseline_calibration.json")))
-    except Exception:
-        pass
     out = {"value": sample_cells / dt, "unit": "cells/sec/Harmony-iteration", "cores": int(threads), "kind": "port",
-           "sample": f"{what} in {dt:.1f} s (NumPy oracle: no harmonypy checkout on this box (HMX_REFERENCE_PATH), "
+           "sample": f"{what} in {dt:.1f} s (NumPy oracle: no harmonypy on this box (HMX_REFERENCE_PATH, site-packages), "
                      f"BLAS threads={threads}, host has {os.cpu_count()} cpus)"}
     if cal:
         out["reference_over_port"] = cal.get("reference_over_port")
-        out["calibration"] = "profiles/r02_cpu_baseline_calibration.json"
+        out["value_reference_equivalent"] = out["value"] * cal.get("reference_over_port", 1.0)
+        out["calibration"] = "profiles/r02_cpu_baseline_calibration.json (harmonypy itself vs this port, same sample, same 8 threads)"
     return out
 
 
@@ -218,7 +258,7 @@ def roofline_block(config, N, d, B, K, ktimes, steps, rounds, wide):
                   else "k_assign_lds (one launch per update block)")
         traffic, traffic_src = None, None
         if sweep and config == "c3":
-            pm, src = newest_pmc(harmonypy_amd.ENGINE_VERSION)
+            pm, src = newest_pmc(harmonypy_amd.engine_version())
             traffic_src = src
             if pm is not None:
                 for name, rec in pm.items():
@@ -233,7 +273,7 @@ def roofline_block(config, N, d, B, K, ktimes, steps, rounds, wide):
         "frac_of_hbm_peak": (round_bytes / (t_round_kernels * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_round_kernels > 0 else 0.0,
         "mfma_flops": N * 4 * d * K,
         "frac_of_f32_mfma_peak": (N * 4 * d * K / (t_round_kernels * 1e-3) / (F32_MFMA_PEAK_TF * 1e12)) if t_round_kernels > 0 else 0.0}
-    roof["engine_version"] = harmonypy_amd.ENGINE_VERSION
+    roof["engine_version"] = harmonypy_amd.engine_version()
     return roof, fam_ms
 
 
@@ -267,7 +307,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="default: c3 on one GPU; c4 = BASELINE configs[3] (10M cells sharded over the ranks) on several")
     ap.add_argument("--rounds", type=int, default=10, help="k-means rounds per Harmony iteration")
     ap.add_argument("--cpu-sample", type=int, default=200_000, help="cells of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-only", action="store_true", help="print only the cpu_baseline object (no GPU needed)")
@@ -276,11 +317,17 @@ def main():
     ap.add_argument("--lisi-cells", type=int, default=1_000_000, help="cells of the LISI measurement (evenly spaced subsample above that)")
     ap.add_argument("--no-convergence", action="store_true", help="skip the untimed end-to-end run to convergence")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
 
     if args.cpu_only:
-        N0, d0, B0, K0 = CONFIGS[args.config]
+        N0, d0, B0, K0 = CONFIGS[args.config or "c3"]
         print(json.dumps(cpu_baseline(d0, B0, K0, args.rounds, min(args.cpu_sample, N0))))
-        return
+        return 0
+    # --gpus N from a plain command line: start the N ranks ourselves (one process per GPU)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import subprocess
+        return subprocess.call(self_launch(sys.argv[1:], args.gpus))
     # stdout carries exactly one JSON line: libraries that print banners through C stdio (RCCL's
     # version banner, for one) are sent to stderr for the whole run
     sys.stdout.flush()
@@ -291,28 +338,37 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a figure for a different GPU count", file=sys.stderr)
+        return 2
     import torch
+    backend = os.environ.get("HMX_BENCH_BACKEND", "nccl")   # gloo: several ranks on one GPU (tests of the sharded path)
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1 or (backend == "nccl" and n_dev < world):
+        print(f"bench.py: {world} rank(s) need {world} GPU(s), {n_dev} visible", file=sys.stderr)
+        return 3
     dist = None
     shard = None
     if world > 1 or os.environ.get("HMX_BENCH_FORCE_SHARD"):
         import torch.distributed as dist
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)   # several ranks on one GPU only happen in tests
+        local_rank = local_rank % n_dev   # several ranks on one GPU only happen in tests
         torch.cuda.set_device(local_rank)
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29512")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(os.environ.get("HMX_BENCH_BACKEND", "nccl"))   # gloo: several ranks on one GPU (testing)
+        dist.init_process_group(backend)
 
-    N, d, B, K = CONFIGS[args.config]
+    config, N, scaling = resolve_workload(args.config, world)
+    _, d, B, K = CONFIGS[config]
+    if os.environ.get("HMX_BENCH_CELLS"):                   # tests: a smaller job, same shape
+        N = int(os.environ["HMX_BENCH_CELLS"])
     os.environ["HMX_UPDATE_ORDER"] = "device"
     import harmonypy_amd
     from harmonypy_amd import harmony as H
 
-    # every rank holds one shard of N cells of ONE job of world*N cells (weak scaling): the same
-    # cell types and batch effects on every rank (seed 0), different cells (cell_seed = rank)
+    # every rank holds one shard of N cells of ONE job of world*N cells: the same cell types and batch effects on
+    # every rank (seed 0), different cells (cell_seed = rank)
     Z, meta = synthetic_dataset(N, d, B, K, seed=0, cell_seed=rank)
     Y0 = quick_centroids(Z, K, seed=0) if rank == 0 else None
     if dist is not None:
@@ -357,12 +413,21 @@ def main():
     counters = ho._engine.counters()
     if timing:
         ho._engine.enable_timing(False)
+    transport = str(getattr(ho, "transport", None))
+    # every rank's view of the sharded path, for diagnosis of a scaling run: transport, whether the in-kernel peer
+    # exchange passed its self-test there, the hops of the sweep kernel's grid-wide waits, collectives issued
+    per_rank = None
+    if shard is not None:
+        mine = {"rank": rank, "device": local_rank, "transport": transport, "peer_exchange": bool(getattr(shard, "peer_exchange", False)),
+                "sweep_waits": counters["sweep_waits"], "incomplete_polls": counters["sweep_wait_polls"],
+                "incomplete_polls_max": counters["sweep_wait_polls_max"], "fallback_rounds": counters["sweep_fallbacks"],
+                "collectives": counters["collectives"], "timed_s": dt}
+        per_rank = shard.allgather_object(mine)
 
     # ---- second figure of BASELINE.json's metric: wall-clock to convergence of a default run_harmony on the
     #      same cells (its own initialisation: k-means++ seeds on a subsample + Lloyd iterations on the GPU,
     #      natural round / iteration counts), outside the timed region of `value`
     conv = None
-    transport = str(getattr(ho, "transport", None))
     if not args.no_convergence:
         del ho
         fence_t = time.perf_counter()
@@ -389,16 +454,18 @@ def main():
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
-        return
+        return 0
     ms_per_step = 1e3 * dt / args.steps
     value = N * world * args.steps / dt
+    job = (f"BASELINE configs[{CONFIG_INDEX[config]}] ({config.upper()}): " +
+           (f"{N * world} cells x {d} PCs, {B} batches, K={K} sharded over {world} GPUs ({N} cells per GPU)" if scaling == "strong"
+            else f"{N} cells x {d} PCs, {B} batches, K={K} per GPU"))
     out = {
         "metric": "cells/sec/Harmony-iteration", "value": value, "unit": "cells/sec/Harmony-iteration",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": f"BASELINE configs[{CONFIG_INDEX[args.config]}] ({args.config.upper()}): "
-                        f"{N} cells x {d} PCs, {B} batches, K={K} per GPU; step = 1 Harmony iteration = "
+            "workload": f"{job}; step = 1 Harmony iteration = "
                         f"{args.rounds} k-means rounds (block_size 0.05 -> 20 blocks) + 1 ridge correction",
             "cells_per_gpu": N, "pcs": d, "batches": B, "clusters": K, "rounds_per_iteration": args.rounds,
             "update_order": "device (keyed bijection, generated inside the timed region)",
@@ -417,8 +484,15 @@ def main():
     out["sweep_waits"] = {"waits": counters["sweep_waits"], "incomplete_polls_mean": counters["sweep_wait_polls"] / max(counters["sweep_waits"], 1),
                           "incomplete_polls_max": counters["sweep_wait_polls_max"], "fallback_rounds": counters["sweep_fallbacks"],
                           "collectives": counters["collectives"]}
+    if per_rank is not None:
+        polls = [r["incomplete_polls"] / max(r["sweep_waits"], 1) for r in per_rank]
+        out["ranks"] = {"per_rank": per_rank,
+                        "incomplete_polls_mean": {"min": min(polls), "mean": sum(polls) / len(polls), "max": max(polls)},
+                        "peer_exchange_on_all": all(r["peer_exchange"] for r in per_rank),
+                        "transports": sorted(set(r["transport"] for r in per_rank)),
+                        "collectives_per_rank": sorted(set(r["collectives"] for r in per_rank))}
     if timing:
-        out["roofline"], out["kernel_ms_total"] = roofline_block(args.config, N, d, B, K, ktimes, args.steps, args.rounds, ho_wide)
+        out["roofline"], out["kernel_ms_total"] = roofline_block(config, N, d, B, K, ktimes, args.steps, args.rounds, ho_wide)
     if conv is not None:
         out["convergence"] = conv
     if conv is not None and world == 1 and not args.no_lisi:
@@ -434,12 +508,13 @@ def main():
         out["lisi"] = {"cells": int(len(take)), "pcs": d, "perplexity": 30, "seconds": t_l, "cells_per_sec": len(take) / t_l,
                        "batches": B, "batch_lisi_before": float(before.mean()), "batch_lisi_after": float(after.mean()),
                        "note": "host float64 input to host output, exact neighbours; not part of `value`"}
-    if world == 1 and args.config == "c3" and not args.no_convergence:
+    if world == 1 and config == "c3" and not args.no_convergence:
         # BASELINE configs[1] (69k cells x 50 PCs, 4 batches, K=30) measured the same way, for reference: it is
         # latency-bound (its working set lives in the L3; 20 sequential hand-offs per round), so the headline
         # figure is quoted on configs[2], the roofline point
         out["configs_1"] = side_config("c2", args.rounds, steps=10, warmup=2, device=f"cuda:{local_rank}")
-        # all 10M cells of BASELINE configs[3] on this ONE GPU, and the per-GPU shard of configs[4] (wide-PC regime)
+        # all 10M cells of BASELINE configs[3] on this ONE GPU (the N=1 point of the strong-scaling curve `--gpus N`
+        # measures), and the per-GPU shard of configs[4] on 8 GPUs (wide-PC regime)
         del Z, meta
         out["configs_3_on_one_gpu"] = side_config("c4x1", args.rounds, steps=2, warmup=1, device=f"cuda:{local_rank}")
         out["configs_4_shard"] = side_config("c5", args.rounds, steps=2, warmup=1, device=f"cuda:{local_rank}")
@@ -449,7 +524,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

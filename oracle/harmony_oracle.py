@@ -337,11 +337,14 @@ class OracleHarmony:
             cov = (Phi_Rk @ Phi_moe.T + np.diag(lam.astype(T))).astype(T)   # :550
             inv_cov = np.linalg.inv(cov).astype(T)                       # :553
             Z_tmp = Z_orig * Rk                                          # :556
-            W = inv_cov[:, 0:1] @ Z_tmp.sum(axis=1, dtype=T, keepdims=True).T   # :559
+            # The row sums over N are accumulated in float64 and rounded once to the working type: torch's sum kernels
+            # are that accurate, NumPy's float32 row sums are not -- at BASELINE configs[4]'s shape (signed PCs, heavy
+            # cancellation) they alone moved Z_corr by 1.2e-4 away from the reference, which sits 3.6e-6 from its own
+            # float64 evaluation there (tests/golden/ridge_conditioning.json, tests/test_large_golden.py).
+            W = inv_cov[:, 0:1] @ Z_tmp.sum(axis=1, dtype=np.float64, keepdims=True).astype(T).T   # :559
             for b in range(self.B):                                      # :561-563
-                # C-contiguous gather so the row sums are pairwise like torch's
                 cols = np.ascontiguousarray(Z_tmp[:, self.batch_index[b]])
-                part = cols.sum(axis=1, dtype=T, keepdims=True)
+                part = cols.sum(axis=1, dtype=np.float64, keepdims=True).astype(T)
                 W = W + inv_cov[:, b + 1:b + 2] @ part.T
             W[0, :] = 0                                                  # :565
             self.W_all[k] = W

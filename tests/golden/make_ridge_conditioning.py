@@ -119,7 +119,8 @@ def case(label, name=None, **shape):
     _, Zr64_8 = run(8, ridge64=True, **shape)
     if name:
         N = R1.shape[0]
-        rows = np.linspace(0, N - 1, min(SAMPLE_ROWS, N)).astype(np.int64)
+        n_rows = SAMPLE_ROWS if R1.shape[1] * Z1.shape[1] <= 5000 else 800      # keeps every file near 2 MB
+        rows = np.linspace(0, N - 1, min(n_rows, N)).astype(np.int64)
         np.savez_compressed(
             os.path.join(HERE, f"large_{name}.npz"),
             shape=np.array([shape.get("N", 69_000), shape.get("d", 50), shape.get("B", 4), shape.get("K", 30),

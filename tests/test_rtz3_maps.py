@@ -1,0 +1,120 @@
+"""Index maps of the streaming R^T.Z pass (csrc/hmx_rtz3.hip), replayed in NumPy -- no GPU.
+
+k_rtz3 permutes the MFMA row / column / k indices so that a lane's operands are 16-byte LDS reads, and k_rtz3_finish
+undoes the permutation when it sums the slabs.  This test transcribes both sides' index arithmetic (lane by lane, with
+the fragment conventions of v_mfma_f32_16x16x4_f32 from hmx_device.h) and checks that, for every shape family the
+launcher instantiates, the round trip delivers  Y[k][pc] = sum_cells R[cell][k] Z[cell][pc]  and
+S[blk][k] = sum_{cells in blk} R[cell][k]  -- a slip in either map shows up here before it costs GPU minutes."""
+import numpy as np
+import pytest
+
+
+def mfma16(a_lane, b_lane, acc):
+    """v_mfma_f32_16x16x4_f32: a_lane[l] = A[i = l & 15][k = l >> 4], b_lane[l] = B[k = l >> 4][j = l & 15],
+    acc[l][r] = D[row = 4 (l >> 4) + r][col = l & 15]."""
+    A = np.zeros((16, 4))
+    B = np.zeros((4, 16))
+    for l in range(64):
+        A[l & 15, l >> 4] = a_lane[l]
+        B[l >> 4, l & 15] = b_lane[l]
+    D = A @ B
+    for l in range(64):
+        for r in range(4):
+            acc[l, r] += D[4 * (l >> 4) + r, l & 15]
+
+
+def kernel_tile(Rt, Zt, blk, MT, KS, NTB, acc):
+    """One 16-cell tile through k_rtz3's fragment construction (Rt: 16 x Kp, Zt: 16 x 4KS, blk: 16 block ids)."""
+    NT, DP = 4 + NTB, 4 * KS
+    H, REM = MT // 4, MT % 4
+    Kp = Rt.shape[1]
+    flatR = np.concatenate([Rt.ravel(), Zt.ravel()])        # a read past a row's end continues into what follows it
+    for ks in range(4):
+        afr = np.zeros((MT, 64))
+        bfr = np.zeros((NT, 64))
+        for lane in range(64):
+            c16, q = lane & 15, lane >> 4
+            cell = 4 * q + ks
+            base = cell * Kp
+            for h in range(H):
+                for j in range(4):
+                    afr[4 * h + j, lane] = flatR[base + 64 * h + 4 * c16 + j]
+            for j in range(REM):
+                afr[4 * H + j, lane] = flatR[base + 64 * H + REM * c16 + j]
+            z = Zt[cell, 4 * min(c16, KS - 1): 4 * min(c16, KS - 1) + 4]
+            bid = int(blk[4 * q + ks])
+            for nt in range(4):
+                bfr[nt, lane] = z[nt] if c16 < KS else (1.0 if bid == 4 * c16 + nt - DP else 0.0)
+            for e in range(NTB):
+                bfr[4 + e, lane] = 1.0 if bid == (64 - DP) + 16 * e + c16 else 0.0
+        for mt in range(MT):
+            for nt in range(NT):
+                mfma16(afr[mt], bfr[nt], acc[mt][nt])
+
+
+def finish(slab, MT, KS, NTB, K, d, nblk):
+    """k_rtz3_finish's read-out of one slab [mt][nt][r][lane]."""
+    NT, DP = 4 + NTB, 4 * KS
+    Hq, rem = MT // 4, MT % 4
+
+    def col_pc(pc):
+        return 16 * (pc & 3) + (pc >> 2)
+
+    def col_blk(j):
+        if j < 64 - DP:
+            c = DP + j
+            return 16 * (c & 3) + (c >> 2)
+        x = j - (64 - DP)
+        return 16 * (4 + x // 16) + (x & 15)
+    Y = np.zeros((K, d))
+    S = np.zeros((nblk, K))
+    for k in range(K):
+        if k < 64 * Hq:
+            mt, m = 4 * (k // 64) + (k & 3), (k & 63) >> 2
+        else:
+            x = k - 64 * Hq
+            m, mt = x // rem, 4 * Hq + x % rem
+
+        def val(v):
+            nt, n = v >> 4, v & 15
+            return slab[((mt * NT + nt) * 4 + (m & 3)) * 64 + 16 * (m >> 2) + n]
+        for pc in range(d):
+            Y[k, pc] = val(col_pc(pc))
+        for b in range(nblk):
+            S[b, k] = val(col_blk(b))
+    return Y, S
+
+
+@pytest.mark.parametrize("K,d,nblk", [(100, 50, 20), (30, 50, 20), (100, 30, 20), (64, 64, 20), (17, 33, 8), (112, 52, 44),
+                                      (5, 3, 1), (48, 64, 32), (100, 50, 1)])
+def test_rtz3_round_trip(K, d, nblk):
+    rng = np.random.default_rng(K * 1000 + d)
+    Kp, MT = (K + 3) & ~3, (K + 15) // 16
+    dp = 32 if d <= 32 else 52 if d <= 52 else 64
+    KS = dp // 4
+    NTB = max(0, (nblk - (64 - dp) + 15) // 16)
+    assert NTB <= 2
+    NT = 4 + NTB
+    n_tiles = 3
+    R = rng.random((16 * n_tiles, Kp))
+    R[:, K:] = 0.0
+    Z = rng.normal(size=(16 * n_tiles, dp))
+    Z[:, d:] = 0.0
+    blk = rng.integers(0, nblk, size=16 * n_tiles)
+    blk[5] = 255                                             # a padding position: no block
+    acc = [[np.zeros((64, 4)) for _ in range(NT)] for _ in range(MT)]
+    for t in range(n_tiles):
+        kernel_tile(R[16 * t:16 * t + 16], Z[16 * t:16 * t + 16], blk[16 * t:16 * t + 16], MT, KS, NTB, acc)
+    slab = np.zeros(MT * NT * 256)
+    for mt in range(MT):
+        for nt in range(NT):
+            for r in range(4):
+                for lane in range(64):
+                    slab[((mt * NT + nt) * 4 + r) * 64 + lane] = acc[mt][nt][lane, r]
+    Y, S = finish(slab, MT, KS, NTB, K, d, nblk)
+    np.testing.assert_allclose(Y, R[:, :K].T @ Z[:, :d], rtol=1e-12, atol=1e-12)
+    S_ref = np.zeros((nblk, K))
+    for i in range(16 * n_tiles):
+        if blk[i] < nblk:
+            S_ref[blk[i]] += R[i, :K]
+    np.testing.assert_allclose(S, S_ref, rtol=1e-12, atol=1e-12)

@@ -84,9 +84,10 @@ def test_sharded_device_kmeans_and_device_order(tmp_path, monkeypatch):
 
 def test_two_shards_survive_a_sweep_timeout(tmp_path, monkeypatch):
     """Two engines, peer exchange inside the persistent kernel, and HMX_SPIN_LIMIT=0: every wait for the other rank's
-    flags gives up.  Both ranks must notice together (the failing rank poisons its objective sums, which every rank
-    sees after the all-reduce), rebuild O, repeat the round with one launch + one collective per block and end with
-    the same tables and history on both ranks."""
+    flags gives up.  Both ranks must notice together (the objective block carries the count of failed waits and is
+    all-reduced as a whole), replay the round EXACTLY with one launch + one collective per block (from the round's own
+    start: saved O, the removal sums and centroids already summed over the ranks) and end with the same tables and
+    history on both ranks -- and with the reference's Z_corr within 1e-4."""
     monkeypatch.setenv("HMX_PEER_EXCHANGE", "1")
     monkeypatch.setenv("HMX_SPIN_LIMIT", "0")
     case = "pbmc_short"
@@ -98,5 +99,27 @@ def test_two_shards_survive_a_sweep_timeout(tmp_path, monkeypatch):
     for key in ("O", "E", "Y", "objective_kmeans"):
         np.testing.assert_array_equal(res[0][key], res[1][key])
     Z = np.concatenate([r["Z_corr"] for r in res], axis=0)
-    rel_f, _ = z_errors(Z, g["Z_corr"])
-    assert rel_f < 5e-2, rel_f      # a degraded round updates some blocks twice: close to, not equal to, the reference
+    rel_f, max_rel = assert_z_close(Z, g["Z_corr"])
+    print(f"2 shards, every sweep timed out: relF={rel_f:.2e} max={max_rel:.2e}")
+    np.testing.assert_allclose(res[0]["objective_kmeans"], g["objective_kmeans"], rtol=2e-5)
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` from a plain command line starts two ranks itself (torch.distributed.run, one process
+    per GPU; here gloo + two engines on the one GPU of the box) and reports n_gpus = 2, strong scaling of a configs[3]
+    shaped job, with every rank's transport / peer-exchange / wait statistics in the line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HMX_BENCH_BACKEND="gloo", HMX_ROUND_WGS="100", HMX_BENCH_CELLS="60000")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--cpu-sample", "0", "--no-convergence"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["cells_total"] == 120000
+    assert len(line["ranks"]["per_rank"]) == 2 and line["ranks"]["transports"] == ["host+peer"]
+    assert line["ranks"]["peer_exchange_on_all"] and line["value"] > 0
