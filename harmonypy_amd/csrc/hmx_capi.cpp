@@ -42,6 +42,8 @@ int fail(int code, const char* fmt, ...) {
             return fail(HMX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
+#define HMX_DEFER_MAX 8   /* rounds of one cluster() call whose objective may be read back late (no decision hangs on them) */
+
 enum Family { F_ASSIGN_BLOCK = 0, F_ASSIGN_INIT, F_RTZ_ROUND, F_RTZ_REDUCE, F_BLOCK_TABLE, F_RIDGE_STATS, F_RIDGE_SOLVE, F_RIDGE_APPLY, F_COUNT };
 const char* kFamilyNames = "assign_block\0assign_init\0rtz_round\0rtz_reduce\0block_table\0ridge_stats\0ridge_solve\0ridge_apply\0";
 
@@ -113,6 +115,9 @@ struct hmx_engine {
     DevBuf<double> xch;
     double *Sold = nullptr, *Yacc64 = nullptr, *Snew = nullptr, *objacc = nullptr, *Sr = nullptr, *Oxr = nullptr;
     double* obj_host = nullptr;  // pinned
+    double* obj_defer = nullptr; // pinned: objective blocks of rounds whose read-back was deferred (hmx_cluster)
+    hipEvent_t sync_event = nullptr;
+    long clean_sweeps = 0;       // persistent sweeps that were read back at once and had no time-out
     // transport for sharded jobs (null / 1 = single engine)
     void* nccl_comm = nullptr;
     int n_ranks = 1, rank = 0;
@@ -276,17 +281,37 @@ void drain_spans(hmx_engine* e) {
     e->spans.clear();
 }
 
-int read_objective(hmx_engine* e, double out[4]) {
-    const int n = 2 * HMX_OBJ_SLOTS + 2;
-    HIP_TRY(hipMemcpyAsync(e->obj_host, e->objacc, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+// Wait for the engine's stream.  The wake-up of a blocking synchronise costs 15-25 us -- on a 500 us round that is worth
+// a short spin on an event first (the round trip sits on the critical path of every round that ends in a decision).
+int wait_stream(hmx_engine* e) {
+    if (e->sync_event && hipEventRecord(e->sync_event, e->stream) == hipSuccess) {
+        for (int spin = 0; spin < 200000; ++spin) {
+            const hipError_t q = hipEventQuery(e->sync_event);
+            if (q == hipSuccess) return 0;
+            if (q != hipErrorNotReady) break;
+        }
+        (void)hipGetLastError();   // hipErrorNotReady is sticky in hipGetLastError
+    }
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+void fold_objective(const double* host, double out[4]) {
     double km = 0.0, ent = 0.0;
-    for (int i = 0; i < HMX_OBJ_SLOTS; ++i) { km += e->obj_host[2 * i]; ent += e->obj_host[2 * i + 1]; }
+    for (int i = 0; i < HMX_OBJ_SLOTS; ++i) { km += host[2 * i]; ent += host[2 * i + 1]; }
     out[0] = (double)(float)km;  // `.item()` of an fp32 tensor
     out[1] = (double)(float)ent;
-    out[2] = (double)(float)e->obj_host[2 * HMX_OBJ_SLOTS];
+    out[2] = (double)(float)host[2 * HMX_OBJ_SLOTS];
     out[3] = 0.0;
+}
+
+int read_objective(hmx_engine* e, double out[4]) {
+    const int n = 2 * HMX_OBJ_SLOTS + 2;
+    int rc;
+    HIP_TRY(hipMemcpyAsync(e->obj_host, e->objacc, n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    if ((rc = wait_stream(e))) return rc;
+    HIP_TRY(hipGetLastError());
+    fold_objective(e->obj_host, out);
     return 0;
 }
 
@@ -404,6 +429,9 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
         if (e->V > 1 && (rc = e->scratch.reserve((size_t)e->K16 * (e->B + 1) * (e->B + 1 + e->d)))) break;
         hipError_t pe = hipHostMalloc(reinterpret_cast<void**>(&e->obj_host), (2 * HMX_OBJ_SLOTS + 2) * sizeof(double), hipHostMallocDefault);
         if (pe != hipSuccess) { rc = fail(HMX_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(pe)); break; }
+        pe = hipHostMalloc(reinterpret_cast<void**>(&e->obj_defer), (size_t)HMX_DEFER_MAX * (2 * HMX_OBJ_SLOTS + 2) * sizeof(double), hipHostMallocDefault);
+        if (pe != hipSuccess) { rc = fail(HMX_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(pe)); break; }
+        (void)hipEventCreateWithFlags(&e->sync_event, hipEventDisableTiming);
         (void)hipMemsetAsync(e->R.p, 0, N * e->Kp * sizeof(float), e->stream);
         (void)hipMemsetAsync(e->Ogrp.p, 0, GK * sizeof(double), e->stream);
         (void)hipMemsetAsync(e->Tmass.p, 0, e->K16 * sizeof(double), e->stream);
@@ -444,6 +472,8 @@ void hmx_destroy(hmx_engine* e) {
     peer_release(e);
     if (e->stage_host) (void)hipHostFree(e->stage_host);
     if (e->obj_host) (void)hipHostFree(e->obj_host);
+    if (e->obj_defer) (void)hipHostFree(e->obj_defer);
+    if (e->sync_event) (void)hipEventDestroy(e->sync_event);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -978,7 +1008,7 @@ static int blocks_loop(hmx_engine* e, int flags, const std::vector<int>& tiles_u
 // block ids in static tile order (tile_blk) are already in device memory.  tiles_upper[b] bounds the tile count of block b
 // (grid sizing only).
 static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::vector<int>& tiles_upper, double obj_out[4],
-                      const std::function<int()>& before_sweep = nullptr) {
+                      const std::function<int()>& before_sweep = nullptr, double* defer_slot = nullptr) {
     int rc;
     const size_t GK = (size_t)e->G * e->K16;
     const bool persistent = (flags & HMX_ROUND_UPDATE_R) && e->round_mode == 1 && (!sharded(e) || e->peers_enabled);
@@ -989,7 +1019,7 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         if ((rc = sweep_timed_out(e))) return rc;
         const int saved = e->round_mode;
         e->round_mode = 0;
-        rc = round_body(e, flags, n_tiles_upper, tiles_upper, obj_out, nullptr);
+        rc = round_body(e, flags, n_tiles_upper, tiles_upper, obj_out, nullptr, nullptr);
         e->round_mode = e->round_mode == 0 && e->n_sweep_fallbacks >= 2 ? 0 : saved;
         return rc;
     }
@@ -1130,7 +1160,15 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         // grid-wide wait gave up].  Sharded: one all-reduce of the whole block -- the cross term was formed from job-wide
         // tables and is contributed by rank 0 only, and every rank learns of a time-out on ANY rank at the same point.
         if (multi && (rc = sum_over_ranks(e, e->objacc, 2 * HMX_OBJ_SLOTS + 2))) return rc;
+        if (defer_slot && fused && e->clean_sweeps > 0) {
+            // nothing hangs on this round's objective yet (hmx_cluster): its block travels to the host behind the sweep
+            // and is looked at with the next round that needs a decision.  Only on an engine whose sweeps have been seen
+            // to complete -- the way a grid-wide wait fails on a single engine (workgroups not co-resident) shows at once.
+            HIP_TRY(hipMemcpyAsync(defer_slot, e->objacc, (2 * HMX_OBJ_SLOTS + 2) * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+            return 1;   // deferred
+        }
         if ((rc = read_objective(e, obj_out))) return rc;
+        if (e->obj_host[2 * HMX_OBJ_SLOTS + 1] == 0.0) e->clean_sweeps++;
         if (e->obj_host[2 * HMX_OBJ_SLOTS + 1] != 0.0) {
             // EXACT replay, block by block, from the round's own start: O as it was (Osave), the removal sums and centroids
             // the failed launch used (Sold, Y: untouched by it), the round's own lists.  Rows the failed launch already
@@ -1204,7 +1242,7 @@ int hmx_cluster_round(hmx_engine* e, int flags, const int32_t* cells, int64_t n_
 
 // One round whose update order comes from the keyed bijection (seed, round counter): lists built on the device, the
 // next round's lists prepared on the second stream beside the sweep kernel.
-static int seeded_round(hmx_engine* e, int flags, uint64_t seed, int64_t cells_per_block, double obj_out[4]) {
+static int seeded_round(hmx_engine* e, int flags, uint64_t seed, int64_t cells_per_block, double obj_out[4], double* defer_slot = nullptr) {
     int rc;
     const int nkeys = e->nblk * e->G;
     const int nchunks = order_chunks(e->N);
@@ -1229,8 +1267,8 @@ static int seeded_round(hmx_engine* e, int flags, uint64_t seed, int64_t cells_p
         o.key0 = (uint32_t)z; o.key1 = (uint32_t)(z >> 32) | 1u;
         o.gstart = e->gstart.p; o.chunk_tab = e->chunk_tab.p; o.run_count = e->run_count.p; o.run_start = e->run_start.p;
         o.blk_start = e->lists[which].blk_start.p; o.cells = e->lists[which].cells.p; o.tile_grp = e->lists[which].tile_grp.p;
+        if (use_rtz3(e)) { o.tile_blk = e->tile_blk[which].p; o.s_tile_start = e->s_tile_start.p; }   // block ids in static tile order, by the way
         launch_order(o, s);
-        build_tile_blocks(e, which, (int64_t)pos_cap, s);
     };
     const uint64_t counter = e->seeded_rounds++;
     if (e->pre_valid && e->pre_seed == seed && e->pre_counter == counter && e->pre_cpb == cells_per_block) {
@@ -1282,7 +1320,7 @@ static int seeded_round(hmx_engine* e, int flags, uint64_t seed, int64_t cells_p
         for (int b = 0; b < e->nblk; ++b) upper[b] = bs[b + 1] - bs[b];
         total = bs[e->nblk];
     }
-    return round_body(e, flags, total, upper, obj_out, prefetch);
+    return round_body(e, flags, total, upper, obj_out, prefetch, defer_slot);
 }
 
 int hmx_cluster_round_seeded(hmx_engine* e, int flags, uint64_t seed, int64_t cells_per_block, double obj_out[4]) {
@@ -1312,12 +1350,42 @@ int hmx_cluster(hmx_engine* e, uint64_t seed, int64_t cells_per_block, int max_r
     std::vector<double> hist;
     hist.reserve(n);
     *rounds_out = 0;
+    // Rounds i <= window never end in a decision (harmony.py:455): their objective blocks follow the sweep to the host and
+    // are folded when round window + 1 (or the last round) is read -- the history is the same, the host round trip is paid
+    // only where the algorithm needs it.  A run of forced rounds is treated like a natural one: from round window + 1 on
+    // every round is read back before the next starts, as the test of harmony.py:517-523 would require.
+    int first_pending = 0, n_pending = 0;
+    auto resolve = [&]() -> int {   // the deferred blocks have landed (the stream was waited for since)
+        for (int j = 0; j < n_pending; ++j) {
+            const double* blk = e->obj_defer + (size_t)j * (2 * HMX_OBJ_SLOTS + 2);
+            if (blk[2 * HMX_OBJ_SLOTS + 1] != 0.0)
+                return fail(HMX_ERR_STATE, "a grid-wide wait of the sweep kernel timed out in round %d of this call, whose objective "
+                                           "was read late: the assignment is void (HMX_ROUND_MODE=blocks avoids the persistent kernel)",
+                            first_pending + j);
+            fold_objective(blk, obj_out + 4 * (size_t)(first_pending + j));
+        }
+        n_pending = 0;
+        return 0;
+    };
     for (int i = 0; i < n; ++i) {
         double* o = obj_out + 4 * (size_t)i;
-        if ((rc = seeded_round(e, HMX_ROUND_ALL, seed, cells_per_block, o))) return rc;
-        hist.push_back((o[0] + o[1] + o[2]) * norm_const);          // :413
+        const bool decision = i > window;
+        const bool may_defer = !decision && i + 1 < n && n_pending < HMX_DEFER_MAX;
+        rc = seeded_round(e, HMX_ROUND_ALL, seed, cells_per_block, o,
+                          may_defer ? e->obj_defer + (size_t)n_pending * (2 * HMX_OBJ_SLOTS + 2) : nullptr);
+        if (rc < 0) return rc;
+        if (rc == 1) {                                              // deferred
+            if (n_pending == 0) first_pending = i;
+            ++n_pending;
+            continue;
+        }
+        if ((rc = resolve())) return rc;                            // this round was read back: everything older has landed
+        for (size_t j = hist.size(); j <= (size_t)i; ++j) {
+            const double* oj = obj_out + 4 * j;
+            hist.push_back((oj[0] + oj[1] + oj[2]) * norm_const);   // :413
+        }
         *rounds_out = i + 1;
-        if (forced_rounds < 0 && i > window) {                      // :455-458
+        if (forced_rounds < 0 && decision) {                        // :455-458
             double obj_old = 0.0, obj_new = 0.0;                    // :519-522, summed left to right like Python's sum()
             const size_t m = hist.size();
             for (int j = 0; j < window; ++j) obj_old += hist[m - window - 1 + j];
@@ -1325,6 +1393,10 @@ int hmx_cluster(hmx_engine* e, uint64_t seed, int64_t cells_per_block, int max_r
             if (std::fabs(obj_old - obj_new) / std::fabs(obj_old) < epsilon) break;
         }
     }
+    if (n_pending > 0) {                                            // (cannot happen: the last round is always read back)
+        if ((rc = wait_stream(e)) || (rc = resolve())) return rc;
+    }
+    *rounds_out = (int)std::max<size_t>(hist.size(), (size_t)*rounds_out);
     return HMX_OK;
 }
 

@@ -204,6 +204,10 @@ struct OrderArgs {
     int* blk_start;        // nblk+1 (tiles)
     int* cells;            // padded list
     int* tile_grp;
+    // for the streaming R^T.Z pass (k_rtz3): every cell's block id in STATIC tile order, written by the histogram pass
+    // (position of internal cell c of group g: 16 * s_tile_start[g] + c - gstart[g]); null = not wanted
+    unsigned char* tile_blk;
+    const int* s_tile_start;
 };
 
 size_t sweep_lds_bytes(int K16, int d, int G, int B, int V, int nblk);

@@ -713,9 +713,12 @@ __device__ __forceinline__ void round_post_pass1(const float* sig, const float* 
 // second pass for the two tiles a wave carries: R rows out, sums over the 16 cells of a tile into
 // the block's (group, cluster) table.  Tiles of one group (the usual case: a wave's tiles are
 // neighbours in the block's group-sorted list) share one cross-lane reduction.
+#ifndef HMX_ROUND_SUMS
+#define HMX_ROUND_SUMS 0   /* 1 (experiment): a wave's block sums go to its own fp32 slots in LDS (plain stores), summed at publish time, instead of fp64 LDS atomics on shared addresses */
+#endif
 template <int MT>
 __device__ __forceinline__ void round_post_pass2(float* R, int Kp, double* Sd, int c16, int q, const RoundTile<MT>& T0,
-                                                 float scl0, bool has1, const RoundTile<MT>& T1, float scl1) {
+                                                 float scl0, bool has1, const RoundTile<MT>& T1, float scl1, float* slot0 = nullptr, float* slot1 = nullptr) {
     constexpr int K16 = 16 * MT;
     const bool live0 = T0.cell >= 0, live1 = has1 && T1.cell >= 0;
     float* row0 = R + (size_t)(live0 ? T0.cell : 0) * Kp;
@@ -740,8 +743,11 @@ __device__ __forceinline__ void round_post_pass2(float* R, int Kp, double* Sd, i
 #pragma unroll
             for (int r = 0; r < 4; ++r) ss[r] = row16_sum(sm[r]);      // (:506-507)
             if (c16 == 0) {
+                if (HMX_ROUND_SUMS && slot0) st4(slot0 + col, ss);
+                else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) atomicAdd(sd0 + col + r, (double)ss[r]);
+                }
             }
         } else {
             f32x4 s0, s1;
@@ -751,10 +757,15 @@ __device__ __forceinline__ void round_post_pass2(float* R, int Kp, double* Sd, i
                 s1[r] = row16_sum(rv1[r]);
             }
             if (c16 == 0) {
+                if (HMX_ROUND_SUMS && slot0) {
+                    st4(slot0 + col, s0);
+                    if (has1) st4(slot1 + col, s1);
+                } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     atomicAdd(sd0 + col + r, (double)s0[r]);
                     if (has1) atomicAdd(sd1 + col + r, (double)s1[r]);
+                }
                 }
             }
         }
@@ -920,6 +931,12 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     int* gcol = reinterpret_cast<int*>(tht + a.B);                       // G x V
     int* bgrp = gcol + a.G * a.V;                                        // B: the group holding batch b (V == 1)
     int* bs = bgrp + a.B;                                                // nblk + 3 tile offsets (two sentinels)
+#if HMX_ROUND_SUMS
+    // waves x tiles x K16 block sums of the wave's tiles, 16-byte aligned as an OFFSET from the LDS base (a pointer rebuilt
+    // from an integer would lose its address space)
+    float* Sw = Ys0 + (((reinterpret_cast<float*>(bs + a.nblk + 3) - Ys0) + 3) & ~(ptrdiff_t)3);
+    int* Sg = reinterpret_cast<int*>(Sw + ROUND_WAVES * ROUND_TPW * K16); // their groups (-1: no tile)
+#endif
 
     int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the wave's landing zones and roles are wave-uniform
@@ -1218,7 +1235,18 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             if (has1) round_post_pass1<MT>(sig, rpT, lrpT, q, T[1], scl1, km_acc, ent_acc);
             __builtin_amdgcn_sched_barrier(0);
+#if HMX_ROUND_SUMS
+            round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T[0], scl0, has1, T[1], scl1, Sw + (size_t)(wv * ROUND_TPW) * K16, Sw + (size_t)(wv * ROUND_TPW + 1) * K16);
+            if (lane == 0) {
+                Sg[wv * ROUND_TPW] = T[0].grp;
+                Sg[wv * ROUND_TPW + 1] = (has1 && T[1].grp != T[0].grp) ? T[1].grp : -1;
+            }
+        } else if (lane == 0) {
+            Sg[wv * ROUND_TPW] = -1;
+            Sg[wv * ROUND_TPW + 1] = -1;
+#else
             round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T[0], scl0, has1, T[1], scl1);
+#endif
         }
         for (int j = j_first + j_slot; j < ntl; j += j_slot) {   // blocks larger than the grid carries
 #pragma unroll 1
@@ -1241,7 +1269,13 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         {
             double* dst = a.S_new + ((size_t)b * HMX_ROUND_SLOTS + (wg % HMX_ROUND_SLOTS)) * GK;
             for (int i = tid; i < GK; i += ROUND_THREADS) {
-                const double v = Sd[i];
+                double v = Sd[i];
+#if HMX_ROUND_SUMS
+                const int g = i / K16, k = i - g * K16;
+#pragma unroll
+                for (int sl = 0; sl < ROUND_WAVES * ROUND_TPW; ++sl)
+                    if (Sg[sl] == g) v += (double)Sw[sl * K16 + k];
+#endif
                 if (v != 0.0) atomicAdd(dst + i, v);
             }
         }
@@ -2770,7 +2804,11 @@ __global__ __launch_bounds__(64) void k_order_pass(OrderArgs a) {
             const uint32_t gid = a.global_id ? (uint32_t)a.global_id[cell] : (uint32_t)cell;
             const int64_t p = feistel_position(gid, (uint32_t)a.Ng, a.half_bits, a.key0, a.key1);
             const int b = (a.cpb > 0) ? (int)min((int64_t)(p / a.cpb), (int64_t)(a.nblk - 1)) : a.nblk - 1;
-            key = b * a.G + group_of_cell(a.gstart, a.G, cell);
+            const int g = group_of_cell(a.gstart, a.G, cell);
+            key = b * a.G + g;
+            // the histogram pass walks the cells in storage order: the block ids the streaming R^T.Z pass wants
+            // (static tile order) are consecutive bytes here -- no scatter from the list
+            if (MODE == 0 && a.tile_blk) a.tile_blk[(size_t)16 * a.s_tile_start[g] + (cell - a.gstart[g])] = (unsigned char)b;
         }
         if (MODE == 0) {                      // a histogram needs no order
             if (live) atomicAdd(&cnt[key], 1);
@@ -3117,7 +3155,11 @@ size_t round_lds_bytes(int K16, int dp, int G, int B, int V) {
     const size_t GK = (size_t)G * K16;
     // sigma, -1/sigma, rp, lrp, rpc (V > 1) | O, S, T, objective scratch (fp64) | Pr_b, theta, group_cols (V <= 8), bgrp, block offsets | landing zones
     return ((size_t)K16 * lds_ldy(dp) + 2 * (size_t)K16 + 2 * GK + (V == 1 ? 0 : (size_t)K16 * B)) * 4 + (2 * GK + K16 + 2 * ROUND_WAVES) * 8 +
-           (3 * (size_t)B + (size_t)G * 8 + 64) * 4 + 16 + (size_t)ROUND_WAVES * ROUND_TPW * 16 * dp * 4;
+           (3 * (size_t)B + (size_t)G * 8 + 64) * 4 + 16 + (size_t)ROUND_WAVES * ROUND_TPW * 16 * dp * 4
+#if HMX_ROUND_SUMS
+           + 64 + (size_t)ROUND_WAVES * ROUND_TPW * (K16 + 1) * 4
+#endif
+        ;
 }
 
 size_t peer_box_doubles(int n_ranks, size_t GK) { return box_flags(n_ranks, GK) + 2 * (size_t)n_ranks + 2 * (size_t)n_ranks + 8; }

@@ -26,16 +26,20 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "hmx_internal.h"
 #include "hmx_device.h"
 
 namespace {
 
-// one 1 KB piece global -> LDS: lane l brings 16 bytes from `src` to LDS byte address `zone` + 16 l.  Inline assembly on
-// purpose: the builtin makes the compiler drain vmcnt before any later LDS read.
-__device__ __forceinline__ void dma16(const void* src, unsigned zone) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(zone) : "memory", "m0");
+// one 1 KB piece global -> LDS: lane l brings the 16 bytes at `base` + `voff` (= 16 l) to LDS byte address `zone` + 16 l.
+// `base` is wave-uniform and travels in scalar registers (the SADDR form of the instruction): the stream's addresses cost
+// no vector registers, however far ahead the compiler forms them.  Inline assembly on purpose: the
+// builtin makes the compiler drain vmcnt before any later LDS read.
+__device__ __forceinline__ void dma16(const void* base, unsigned voff, unsigned zone) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(zone) : "memory", "m0");
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) const void*)p);
@@ -64,6 +68,7 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, c16 = lane & 15, q = lane >> 4;
+    const int lane16 = 16 * lane;
     const int task = blockIdx.x;
     const int t0 = a.task_t0[task], t1 = a.task_t1[task];
     const int c_first = a.task_c0[task], c_end = a.task_cend[task];
@@ -76,28 +81,56 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
 
     // tiles of this wave: t0 + wv + RTZ3_WAVES i
     const int n_mine = (t1 - t0 - wv + RTZ3_WAVES - 1) / RTZ3_WAVES;
-    auto issue = [&](int i) {                                       // tile i of this wave -> buffer i & 1
-        const int t = t0 + wv + RTZ3_WAVES * i;
-        const int c0 = c_first + 16 * (t - t0);
-        float* buf = lds + (size_t)(2 * wv + (i & 1)) * buf_floats;
-        const char* rs = reinterpret_cast<const char*>(a.R + (size_t)c0 * Kp) + 16 * lane;
-        const char* zs = reinterpret_cast<const char*>(a.Z + (size_t)c0 * DP) + 16 * lane;
-#pragma unroll
-        for (int it = 0; it < NR; ++it) {
-            const unsigned zone = lds_addr(reinterpret_cast<const char*>(buf) + 1024 * it);
-            if (it + 1 < NR || 1024 * it + 16 * lane < 64 * Kp) dma16(rs + 1024 * it, zone);
-        }
-#pragma unroll
-        for (int it = 0; it < NZ; ++it) {
-            const unsigned zone = lds_addr(reinterpret_cast<const char*>(buf + 16 * Kp) + 1024 * it);
-            if (1024 * (it + 1) <= 64 * DP || 1024 * it + 16 * lane < 64 * DP) dma16(zs + 1024 * it, zone);
-        }
-        const unsigned zone = lds_addr(buf + 16 * (Kp + DP));
-        if (lane == 0) dma16(a.tile_blk + (size_t)16 * t, zone);
+    // The three streams of this wave (R rows, Z rows, block ids) as wave-uniform byte pointers to the NEXT tile to request,
+    // advanced by a constant per tile: scalar registers and scalar adds only (a 64-bit product per request would be formed
+    // on the vector unit and kept live across the MFMAs).
+    auto uniform64 = [](unsigned long long v) {
+        return ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
+               (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)v);
     };
-    if (n_mine > 0) issue(0);
-    if (n_mine > 1) issue(1);
+    const int c_mine = c_first + 16 * wv;                           // first cell of this wave's first tile
+    unsigned long long nr = uniform64((unsigned long long)(a.R + (size_t)c_mine * Kp));
+    unsigned long long nz = uniform64((unsigned long long)(a.Z + (size_t)c_mine * DP));
+    unsigned long long nb = uniform64((unsigned long long)(a.tile_blk + (size_t)16 * (t0 + wv)));
+    const unsigned long long step_r = (unsigned long long)__builtin_amdgcn_readfirstlane(RTZ3_WAVES * 64 * Kp);   // 16 rows x 4 B x waves
+    constexpr unsigned long long step_z = (unsigned long long)RTZ3_WAVES * 64 * DP, step_b = 16 * RTZ3_WAVES;
+    const unsigned zone0 = lds_addr(lds + (size_t)(2 * wv) * buf_floats);
+    const unsigned buf_bytes = __builtin_amdgcn_readfirstlane((unsigned)buf_floats * 4u);
+    const unsigned r_bytes = __builtin_amdgcn_readfirstlane(64u * (unsigned)Kp);
+    // piece p of the NI requests that bring the next tile into buffer `par`: R pieces, Z pieces, the block ids
+    auto issue_piece = [&](int par, int p) {
+        const unsigned zb = zone0 + (par ? buf_bytes : 0u);
+        if (p < NR) {
+            if (p + 1 < NR || 1024 * p + lane16 < 64 * Kp) dma16((const void*)(nr + 1024ull * p), lane16, zb + 1024u * p);
+        } else if (p < NR + NZ) {
+            const int it = p - NR;
+            if (1024 * (it + 1) <= 64 * DP || 1024 * it + lane16 < 64 * DP) dma16((const void*)(nz + 1024ull * it), lane16, zb + r_bytes + 1024u * it);
+        } else {
+            if (lane == 0) dma16((const void*)nb, lane16, zb + r_bytes + 64u * DP);
+        }
+    };
+    auto advance = [&]() { nr += step_r; nz += step_z; nb += step_b; };
+    if (n_mine > 0) {
+#pragma unroll
+        for (int p = 0; p < NI; ++p) issue_piece(0, p);
+        advance();
+    }
+    if (n_mine > 1) {
+#pragma unroll
+        for (int p = 0; p < NI; ++p) issue_piece(1, p);
+        advance();
+    }
 
+    // Per tile: all fragments of the tile are read from LDS first (4 k-steps x (MT + 4) registers), which frees the buffer;
+    // the NI requests of tile i+2 then ride BETWEEN the MT x NT x 4 MFMAs of tile i (an LDS-DMA request costs ~60 cycles of
+    // issue among MFMAs, ~100 on its own: the first version issued all of them before the first MFMA and ran at 188 us per
+    // pass at C3 with the matrix pipe 60 % busy).  Reading the next k-step's fragments under the current one's MFMAs as
+    // well was built and dropped: the scheduler then keeps two fragment sets and the request addresses live and spills.
+    constexpr int NMF = 4 * MT * NT;                                // MFMAs of a tile
+    // (six column tiles -- 29 to 44 update blocks -- leave no registers for it: there the requests go out in one piece
+    // before the first MFMA, and the partner wave of the SIMD covers them)
+    constexpr bool INTERLEAVE = NT <= 5;
+    constexpr int GAP = !INTERLEAVE ? NMF + 1 : NMF / NI > 0 ? NMF / NI : 1;   // MFMAs between two requests
     for (int i = 0; i < n_mine; ++i) {
         // tile i has landed: the only younger operations are the NI of tile i+1 (memory operations complete in order)
         asm volatile("" ::: "memory");
@@ -129,8 +162,12 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
             for (int j = 0; j < REM; ++j) afr[ks][4 * H + j] = rr[64 * H + REM * c16 + j];
             zfr[ks] = ld4(Zt + (size_t)(4 * q + ks) * DP + 4 * min(c16, KS - 1));
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the buffer is in registers: hand it to tile i+2
-        if (i + 2 < n_mine) issue(i + 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the buffer is in registers: it may be overwritten
+        const bool more = i + 2 < n_mine;                           // wave-uniform
+        if (!INTERLEAVE && more) {
+#pragma unroll
+            for (int p = 0; p < NI; ++p) issue_piece(i & 1, p);
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int bid = (bw >> (8 * ks)) & 255;
@@ -142,8 +179,22 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA16(afr[ks][mt], bfr[nt], acc[mt][nt]);
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = MFMA16(afr[ks][mt], bfr[nt], acc[mt][nt]);
+                    const int m = (ks * MT + mt) * NT + nt;
+                    if ((m + 1) % GAP == 0 && (m + 1) / GAP - 1 < NI) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more) issue_piece(i & 1, (m + 1) / GAP - 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
         }
+        if (INTERLEAVE && NMF / GAP < NI) {                         // (tiny shapes: fewer MFMAs than requests)
+#pragma unroll
+            for (int p = NMF / GAP; p < NI; ++p)
+                if (more) issue_piece(i & 1, p);
+        }
+        if (more) advance();
     }
 
     // ---- the four waves' accumulators meet in LDS (fragment order), one slab per task goes out -------------------------
@@ -205,14 +256,28 @@ __global__ __launch_bounds__(RTZ3_FIN_THREADS) void k_rtz3_finish(Rtz3FinishArgs
         const size_t off = (size_t)((mt * NT + nt) * 4 + (m & 3)) * 64 + 16 * (m >> 2) + n;
         int g = -1;
         double acc = 0.0;
-        for (int w = sl; w < a.ntasks; w += nslice) {
-            const int gw = a.task_grp[w];
-            if (gw != g) {
-                if (g >= 0 && acc != 0.0) atomicAdd(&tab[g * NV + v], acc);
-                g = gw;
-                acc = 0.0;
+        // the slab reads are latency-bound: eight independent loads in flight per thread (clamped, not predicated: a
+        // select on the loaded value keeps them one batch), then folded in task order (tasks are sorted by group)
+        constexpr int BATCH = 8;
+        for (int w0 = sl; w0 < a.ntasks; w0 += BATCH * nslice) {
+            float val[BATCH];
+            int grp[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int w = min(w0 + u * nslice, a.ntasks - 1);
+                val[u] = a.slab[(size_t)w * per + off];
+                grp[u] = a.task_grp[w];
             }
-            acc += (double)a.slab[(size_t)w * per + off];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                if (w0 + u * nslice >= a.ntasks) break;
+                if (grp[u] != g) {
+                    if (g >= 0 && acc != 0.0) atomicAdd(&tab[g * NV + v], acc);
+                    g = grp[u];
+                    acc = 0.0;
+                }
+                acc += (double)val[u];
+            }
         }
         if (g >= 0 && acc != 0.0) atomicAdd(&tab[g * NV + v], acc);
     }
@@ -301,6 +366,11 @@ static void launch_rtz3_t(const Rtz3Args& a, size_t sm, hipStream_t s) {
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rtz3<MT, KS, NTB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
+        if (getenv("HMX_DEBUG")) {
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_rtz3<MT, KS, NTB>), 64 * RTZ3_WAVES, sm);
+            fprintf(stderr, "[hmx] k_rtz3<%d,%d,%d>: %d tasks, %zu bytes of LDS per workgroup, %d workgroups per CU\n", MT, KS, NTB, a.ntasks, sm, nb);
+        }
     }
     hipLaunchKernelGGL((k_rtz3<MT, KS, NTB>), dim3(a.ntasks), dim3(64 * RTZ3_WAVES), sm, s, a);
 }
