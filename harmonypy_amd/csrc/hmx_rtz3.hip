@@ -85,14 +85,15 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
     // advanced by a constant per tile: scalar registers and scalar adds only (a 64-bit product per request would be formed
     // on the vector unit and kept live across the MFMAs).
     auto uniform64 = [](unsigned long long v) {
-        return ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
-               (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)v);
+        // (the builtin returns a signed int: through `unsigned`, or a low half >= 2^31 sign-extends into the high one)
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
+               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v);
     };
     const int c_mine = c_first + 16 * wv;                           // first cell of this wave's first tile
     unsigned long long nr = uniform64((unsigned long long)(a.R + (size_t)c_mine * Kp));
     unsigned long long nz = uniform64((unsigned long long)(a.Z + (size_t)c_mine * DP));
     unsigned long long nb = uniform64((unsigned long long)(a.tile_blk + (size_t)16 * (t0 + wv)));
-    const unsigned long long step_r = (unsigned long long)__builtin_amdgcn_readfirstlane(RTZ3_WAVES * 64 * Kp);   // 16 rows x 4 B x waves
+    const unsigned long long step_r = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(RTZ3_WAVES * 64 * Kp);   // 16 rows x 4 B x waves
     constexpr unsigned long long step_z = (unsigned long long)RTZ3_WAVES * 64 * DP, step_b = 16 * RTZ3_WAVES;
     const unsigned zone0 = lds_addr(lds + (size_t)(2 * wv) * buf_floats);
     const unsigned buf_bytes = __builtin_amdgcn_readfirstlane((unsigned)buf_floats * 4u);

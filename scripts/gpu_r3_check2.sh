@@ -3,6 +3,9 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 HMX_DEBUG=1 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1; tail -3 gpurun_out/smoke.log
+# gate: the benchmarked shape first -- a fault here ends the script instead of burning the budget on core dumps
+timeout 300 python -m pytest tests/test_parity_gpu.py -m gpu -q -x -k "bench_path_parity_c3 or forced_schedule" > gpurun_out/pytest_gate.log 2>&1 || { tail -20 gpurun_out/pytest_gate.log; echo "GATE FAILED"; exit 1; }
+tail -2 gpurun_out/pytest_gate.log
 timeout 1500 python -m pytest tests -m gpu -q -rP --maxfail=12 > gpurun_out/pytest_gpu_full.log 2>&1
 grep -E "passed|failed|error|FAILED|ERROR|Z_corr vs|time-out replay|2 shards, every|bench path" gpurun_out/pytest_gpu_full.log | tail -30 > gpurun_out/pytest_gpu.log
 tail -16 gpurun_out/pytest_gpu.log
