@@ -54,6 +54,9 @@ __device__ __forceinline__ void wait_vmcnt() {   // gfx9 encoding: vmcnt[3:0] | 
 }  // namespace
 
 #define RTZ3_WAVES 4
+#ifndef HMX_RTZ3_ABL
+#define HMX_RTZ3_ABL 0   /* timing experiments only (results become wrong): 1 no MFMAs (the stream alone), 2 no requests after the prologue (the arithmetic alone) */
+#endif
 
 template <int MT, int KS, int NTB>
 __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
@@ -135,7 +138,11 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
     for (int i = 0; i < n_mine; ++i) {
         // tile i has landed: the only younger operations are the NI of tile i+1 (memory operations complete in order)
         asm volatile("" ::: "memory");
+#if HMX_RTZ3_ABL & 2
+        wait_vmcnt<0>();
+#else
         if (i + 1 < n_mine) wait_vmcnt<NI>(); else wait_vmcnt<0>();
+#endif
         asm volatile("" ::: "memory");
         const int t = t0 + wv + RTZ3_WAVES * i;
         const int c0 = c_first + 16 * (t - t0);
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
             zfr[ks] = ld4(Zt + (size_t)(4 * q + ks) * DP + 4 * min(c16, KS - 1));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the buffer is in registers: it may be overwritten
-        const bool more = i + 2 < n_mine;                           // wave-uniform
+        const bool more = i + 2 < n_mine && !(HMX_RTZ3_ABL & 2);     // wave-uniform
         if (!INTERLEAVE && more) {
 #pragma unroll
             for (int p = 0; p < NI; ++p) issue_piece(i & 1, p);
@@ -181,7 +188,11 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
+#if HMX_RTZ3_ABL & 1
+                    acc[mt][nt][0] += afr[ks][mt] * bfr[nt];
+#else
                     acc[mt][nt] = MFMA16(afr[ks][mt], bfr[nt], acc[mt][nt]);
+#endif
                     const int m = (ks * MT + mt) * NT + nt;
                     if ((m + 1) % GAP == 0 && (m + 1) / GAP - 1 < NI) {
                         __builtin_amdgcn_sched_barrier(0);
