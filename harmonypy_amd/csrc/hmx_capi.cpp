@@ -142,7 +142,7 @@ struct hmx_engine {
     int rtz_kernel = 3;                  // HMX_RTZ=2: the list-order kernel k_rtz2 everywhere (A/B timing, fall-back)
     bool static_contig = false;          // every static tile holds consecutive cells (what harmonypy_amd builds)
     int ntasks3 = 0;
-    DevBuf<int> t3_t0, t3_t1, t3_c0, t3_cend, t3_grp, s_tile_start;
+    DevBuf<int> t3_t0, t3_t1, t3_c0, t3_cend, t3_grp, t3_stride, s_tile_start;
     DevBuf<unsigned char> tile_blk[2], tile_blk_zero;
     DevBuf<double> Osave;                // O at the start of the round in flight (exact replay after a time-out)
 
@@ -462,7 +462,7 @@ void hmx_destroy(hmx_engine* e) {
     if (e->stream2) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamDestroy(e->stream2); }
     if (e->pre_event) (void)hipEventDestroy(e->pre_event);
     e->task_t0.release(); e->task_t1.release();
-    e->t3_t0.release(); e->t3_t1.release(); e->t3_c0.release(); e->t3_cend.release(); e->t3_grp.release(); e->s_tile_start.release();
+    e->t3_t0.release(); e->t3_t1.release(); e->t3_stride.release(); e->t3_c0.release(); e->t3_cend.release(); e->t3_grp.release(); e->s_tile_start.release();
     e->tile_blk[0].release(); e->tile_blk[1].release(); e->tile_blk_zero.release(); e->Osave.release();
     e->task_grp.release(); e->gstart.release(); e->chunk_tab.release(); e->run_count.release(); e->run_start.release();
     e->Ogrp.release(); e->Tmass.release(); e->Ohist.release(); e->xch.release(); e->scratch.release();
@@ -602,21 +602,33 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
         e->static_contig = contig;
         e->ntasks3 = 0;
         if (contig) {
-            std::vector<int> a0, a1, ac0, acend, ag;
+            std::vector<int> a0, a1, ac0, acend, ag, ast;
             const int target = std::max(1, 2 * e->n_cus - e->G);
             const int CH3 = std::max(16, std::min(256, (n_static_tiles + target - 1) / target));
+            // HMX_RTZ3_TASKS=contig: a task is a contiguous run of a group's tiles; default: the m tasks of a group take
+            // neighbouring quads of tiles (task j: tiles ts + 4j + w + 4m i) and sweep the group's rows together
+            const char* tk = getenv("HMX_RTZ3_TASKS");
+            const bool interleave = !(tk && std::string(tk) == "contig");
             for (int g = 0; g < e->G; ++g) {
                 const int ts = tstart[g], te = tstart[g + 1];
                 if (te <= ts) continue;
                 const int m = (te - ts + CH3 - 1) / CH3, per = (te - ts + m - 1) / m;
+                if (interleave) {
+                    const int mm = std::min(m, (te - ts + 3) / 4);       // no task without a tile
+                    for (int j = 0; j < mm; ++j) {
+                        a0.push_back(ts + 4 * j); a1.push_back(te); ag.push_back(g); ast.push_back(4 * mm);
+                        ac0.push_back(gs2[g] + 4 * j * HMX_TILE); acend.push_back(gs2[g + 1]);
+                    }
+                    continue;
+                }
                 for (int i = ts; i < te; i += per) {
-                    a0.push_back(i); a1.push_back(std::min(i + per, te)); ag.push_back(g);
+                    a0.push_back(i); a1.push_back(std::min(i + per, te)); ag.push_back(g); ast.push_back(4);
                     ac0.push_back(gs2[g] + (i - ts) * HMX_TILE); acend.push_back(gs2[g + 1]);
                 }
             }
             e->ntasks3 = (int)a0.size();
             const size_t nt3 = a0.size();
-            if ((rc = e->t3_t0.reserve(nt3)) || (rc = e->t3_t1.reserve(nt3)) || (rc = e->t3_c0.reserve(nt3)) || (rc = e->t3_cend.reserve(nt3)) ||
+            if ((rc = e->t3_t0.reserve(nt3)) || (rc = e->t3_t1.reserve(nt3)) || (rc = e->t3_c0.reserve(nt3)) || (rc = e->t3_cend.reserve(nt3)) || (rc = e->t3_stride.reserve(nt3)) ||
                 (rc = e->t3_grp.reserve(nt3)) || (rc = e->s_tile_start.reserve(e->G + 1)) ||
                 (rc = e->tile_blk[0].reserve((size_t)n_static_tiles * HMX_TILE)) || (rc = e->tile_blk[1].reserve((size_t)n_static_tiles * HMX_TILE)) ||
                 (rc = e->tile_blk_zero.reserve((size_t)n_static_tiles * HMX_TILE)))
@@ -624,6 +636,7 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
             HIP_TRY(hipMemcpyAsync(e->t3_t0.p, a0.data(), nt3 * sizeof(int), hipMemcpyHostToDevice, e->stream));
             HIP_TRY(hipMemcpyAsync(e->t3_t1.p, a1.data(), nt3 * sizeof(int), hipMemcpyHostToDevice, e->stream));
             HIP_TRY(hipMemcpyAsync(e->t3_c0.p, ac0.data(), nt3 * sizeof(int), hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(hipMemcpyAsync(e->t3_stride.p, ast.data(), nt3 * sizeof(int), hipMemcpyHostToDevice, e->stream));
             HIP_TRY(hipMemcpyAsync(e->t3_cend.p, acend.data(), nt3 * sizeof(int), hipMemcpyHostToDevice, e->stream));
             HIP_TRY(hipMemcpyAsync(e->t3_grp.p, ag.data(), nt3 * sizeof(int), hipMemcpyHostToDevice, e->stream));
             HIP_TRY(hipMemcpyAsync(e->s_tile_start.p, tstart.data(), tstart.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
@@ -833,7 +846,7 @@ static int rtz3_pass(hmx_engine* e, int mode, const unsigned char* tile_blk, int
         Timed t(e, mode == 1 ? F_RIDGE_STATS : F_RTZ_ROUND);
         Rtz3Args r{};
         r.R = e->R.p; r.Z = mode == 1 ? e->Zorig.p : e->Zcos.p; r.tile_blk = tile_blk;
-        r.task_t0 = e->t3_t0.p; r.task_t1 = e->t3_t1.p; r.task_c0 = e->t3_c0.p; r.task_cend = e->t3_cend.p;
+        r.task_t0 = e->t3_t0.p; r.task_t1 = e->t3_t1.p; r.task_stride = e->t3_stride.p; r.task_c0 = e->t3_c0.p; r.task_cend = e->t3_cend.p;
         r.slab = e->slab.p; r.ntasks = e->ntasks3; r.Kp = e->Kp;
         if (launch_rtz3(r, e->mt, e->dp, nblk_cols, e->stream)) return fail(HMX_ERR_ARG, "unsupported shape for k_rtz3");
     }

@@ -115,6 +115,7 @@ struct Rtz3Args {
     const unsigned char* tile_blk;   // n_static_tiles x 16 block ids in static tile order (all 0: column 0 = plain column sums)
     const int* task_t0;        // static tile range of a task
     const int* task_t1;
+    const int* task_stride;    // tiles between a wave's consecutive tiles (4: contiguous task; 4 x tasks of the group: interleaved)
     const int* task_c0;        // first cell of tile task_t0 (the cells of a group's tiles are consecutive)
     const int* task_cend;      // first cell behind the task's group
     float* slab;               // ntasks x MT x NT x 256 accumulators in fragment order

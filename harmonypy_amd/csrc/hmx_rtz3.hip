@@ -38,7 +38,13 @@ namespace {
 // `base` is wave-uniform and travels in scalar registers (the SADDR form of the instruction): the stream's addresses cost
 // no vector registers, however far ahead the compiler forms them.  Inline assembly on purpose: the
 // builtin makes the compiler drain vmcnt before any later LDS read.
-__device__ __forceinline__ void dma16(const void* base, unsigned voff, unsigned zone) {
+__device__ __forceinline__ void dma16(const void* base_, unsigned voff, unsigned zone) {
+    // (under register pressure the compiler may park a wave-uniform pointer in vector registers: say it again that it is
+    // uniform -- folded away when the value already sits in scalar registers.  The builtin returns a signed int: through
+    // `unsigned`, or a low half >= 2^31 sign-extends into the high one.)
+    const unsigned long long bits = (unsigned long long)base_;
+    const void* base = (const void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(bits >> 32)) << 32) |
+                                     (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)bits));
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(zone) : "memory", "m0");
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
@@ -75,6 +81,10 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
     const int task = blockIdx.x;
     const int t0 = a.task_t0[task], t1 = a.task_t1[task];
     const int c_first = a.task_c0[task], c_end = a.task_cend[task];
+    // tiles of wave w: t0 + w + stride i (< t1).  stride = RTZ3_WAVES: a task is a contiguous run of tiles; stride = RTZ3_WAVES x
+    // (tasks of the group): the group's tasks take neighbouring quads of tiles and sweep the group's rows together, like a
+    // grid-stride copy (DRAM pages and TLB entries are shared by the whole chip instead of one stream per workgroup)
+    const int stride = __builtin_amdgcn_readfirstlane(a.task_stride[task]);
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -82,8 +92,7 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // tiles of this wave: t0 + wv + RTZ3_WAVES i
-    const int n_mine = (t1 - t0 - wv + RTZ3_WAVES - 1) / RTZ3_WAVES;
+    const int n_mine = (t1 - t0 - wv + stride - 1) / stride;
     // The three streams of this wave (R rows, Z rows, block ids) as wave-uniform byte pointers to the NEXT tile to request,
     // advanced by a constant per tile: scalar registers and scalar adds only (a 64-bit product per request would be formed
     // on the vector unit and kept live across the MFMAs).
@@ -96,8 +105,9 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
     unsigned long long nr = uniform64((unsigned long long)(a.R + (size_t)c_mine * Kp));
     unsigned long long nz = uniform64((unsigned long long)(a.Z + (size_t)c_mine * DP));
     unsigned long long nb = uniform64((unsigned long long)(a.tile_blk + (size_t)16 * (t0 + wv)));
-    const unsigned long long step_r = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(RTZ3_WAVES * 64 * Kp);   // 16 rows x 4 B x waves
-    constexpr unsigned long long step_z = (unsigned long long)RTZ3_WAVES * 64 * DP, step_b = 16 * RTZ3_WAVES;
+    const unsigned long long step_r = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(stride * 64 * Kp);   // 16 rows x 4 B per tile
+    const unsigned long long step_z = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(stride * 64 * DP);
+    const unsigned long long step_b = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(16 * stride);
     const unsigned zone0 = lds_addr(lds + (size_t)(2 * wv) * buf_floats);
     const unsigned buf_bytes = __builtin_amdgcn_readfirstlane((unsigned)buf_floats * 4u);
     const unsigned r_bytes = __builtin_amdgcn_readfirstlane(64u * (unsigned)Kp);
@@ -125,18 +135,115 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
         advance();
     }
 
-    // Per tile: all fragments of the tile are read from LDS first (4 k-steps x (MT + 4) registers), which frees the buffer;
-    // the NI requests of tile i+2 then ride BETWEEN the MT x NT x 4 MFMAs of tile i (an LDS-DMA request costs ~60 cycles of
-    // issue among MFMAs, ~100 on its own: the first version issued all of them before the first MFMA and ran at 188 us per
-    // pass at C3 with the matrix pipe 60 % busy).  Reading the next k-step's fragments under the current one's MFMAs as
-    // well was built and dropped: the scheduler then keeps two fragment sets and the request addresses live and spills.
-    constexpr int NMF = 4 * MT * NT;                                // MFMAs of a tile
-    // (six column tiles -- 29 to 44 update blocks -- leave no registers for it: there the requests go out in one piece
-    // before the first MFMA, and the partner wave of the SIMD covers them)
-    constexpr bool INTERLEAVE = NT <= 5;
-    constexpr int GAP = !INTERLEAVE ? NMF + 1 : NMF / NI > 0 ? NMF / NI : 1;   // MFMAs between two requests
+  if constexpr (NT <= 5) {
+    // The wave's work is one stream of k-steps (4 per tile).  While the MT x NT MFMAs of a k-step are in the matrix pipe the
+    // fragments of the NEXT k-step are read from LDS into the other register set -- across tile boundaries too: under the
+    // last k-step of tile i the wave waits for tile i+1 (requested a whole tile earlier), reads its first fragments, and
+    // then hands tile i's buffer (whose last read has long returned) to tile i+2, the NI requests riding between the MFMAs.
+    // So a wave never has an MFMA-free phase after its prologue.  Why it matters: the two waves of a SIMD start together and
+    // do identical work; with "read all fragments, then 4 x MT x NT MFMAs" they reached their read phases together and the
+    // matrix pipe idled for both (measured: 66 % busy, 172-190 us per pass at C3 with or without the memory traffic).
+    constexpr int NMF = MT * NT;                                    // MFMAs of a k-step
+    constexpr int HEAD = NMF / 3;                                   // MFMAs of the last k-step issued before the wait for the next tile
+    constexpr int GAP = (NMF - HEAD) / NI > 0 ? (NMF - HEAD) / NI : 1;   // MFMAs between two requests
+    float afr[2][MT];
+    f32x4 zfr[2];
+    unsigned bw = 0, bw_next = 0;
+    auto read_frags = [&](const float* Rt, const float* Zt, int ks, int set) {
+        const float* rr = Rt + (size_t)(4 * q + ks) * Kp;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const f32x4 v = ld4(rr + 64 * h + 4 * c16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) afr[set][4 * h + j] = v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < REM; ++j) afr[set][4 * H + j] = rr[64 * H + REM * c16 + j];
+        zfr[set] = ld4(Zt + (size_t)(4 * q + ks) * DP + 4 * min(c16, KS - 1));
+    };
+    // tile i has landed (nothing younger is in flight at the points this is called): rows past the group's end hold other
+    // cells (or the slack behind the array) and count for nothing; then its first fragments and its block ids
+    auto open_tile = [&](int i) {
+        asm volatile("" ::: "memory");
+        wait_vmcnt<0>();
+        asm volatile("" ::: "memory");
+        const int c0 = c_mine + 16 * stride * i;
+        float* Rt = lds + (size_t)(2 * wv + (i & 1)) * buf_floats;
+        float* Zt = Rt + 16 * Kp;
+        const int n_live = min(16, c_end - c0);                     // wave-uniform; < 16 only in a group's last tile
+        if (n_live < 16) {
+            for (int j = n_live * Kp + lane; j < 16 * Kp; j += 64) Rt[j] = 0.f;
+            for (int j = n_live * DP + lane; j < 16 * DP; j += 64) Zt[j] = 0.f;
+        }
+        bw_next = reinterpret_cast<const unsigned*>(Zt + 16 * DP)[q];   // block ids of cells 4q .. 4q+3
+        read_frags(Rt, Zt, 0, 0);
+    };
+    if (n_mine > 0) {
+        if (n_mine > 1) wait_vmcnt<NI>(); else wait_vmcnt<0>();     // tile 0 (tile 1 may still travel)
+        asm volatile("" ::: "memory");
+        const int n_live = min(16, c_end - c_mine);
+        float* Rt = lds + (size_t)(2 * wv) * buf_floats;
+        float* Zt = Rt + 16 * Kp;
+        if (n_live < 16) {
+            for (int j = n_live * Kp + lane; j < 16 * Kp; j += 64) Rt[j] = 0.f;
+            for (int j = n_live * DP + lane; j < 16 * DP; j += 64) Zt[j] = 0.f;
+        }
+        bw_next = reinterpret_cast<const unsigned*>(Zt + 16 * DP)[q];
+        read_frags(Rt, Zt, 0, 0);
+    }
     for (int i = 0; i < n_mine; ++i) {
-        // tile i has landed: the only younger operations are the NI of tile i+1 (memory operations complete in order)
+        float* Rt = lds + (size_t)(2 * wv + (i & 1)) * buf_floats;
+        float* Zt = Rt + 16 * Kp;
+        bw = bw_next;
+        const bool next = i + 1 < n_mine;                           // wave-uniform
+        const bool more = i + 2 < n_mine && !(HMX_RTZ3_ABL & 2);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int set = ks & 1;
+            if (ks < 3) read_frags(Rt, Zt, ks + 1, set ^ 1);
+            const int bid = (bw >> (8 * ks)) & 255;
+            float bfr[NT];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bfr[nt] = (c16 < KS) ? zfr[set][nt] : ((bid == 4 * c16 + nt - DP) ? 1.f : 0.f);
+#pragma unroll
+            for (int e = 0; e < NTB; ++e) bfr[4 + e] = (bid == (64 - DP) + 16 * e + c16) ? 1.f : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+#if HMX_RTZ3_ABL & 1
+                    acc[mt][nt][0] += afr[set][mt] * bfr[nt];
+#else
+                    acc[mt][nt] = MFMA16(afr[set][mt], bfr[nt], acc[mt][nt]);
+#endif
+                    if (ks == 3) {
+                        const int m = mt * NT + nt + 1;             // MFMAs of this k-step issued so far
+                        if (m == HEAD) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (next) open_tile(i + 1);             // (the reads of tile i's buffer returned before this k-step began)
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if (m > HEAD && (m - HEAD) % GAP == 0 && (m - HEAD) / GAP - 1 < NI) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (more) issue_piece(i & 1, (m - HEAD) / GAP - 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+        }
+        if ((NMF - HEAD) / GAP < NI) {                              // (tiny shapes: fewer MFMAs than requests)
+#pragma unroll
+            for (int p = (NMF - HEAD) / GAP; p < NI; ++p)
+                if (more) issue_piece(i & 1, p);
+        }
+        if (more) advance();
+    }
+
+  } else {
+    // Six column tiles (29 to 44 update blocks, or 17+ with 64-float rows): 168 accumulators leave no room for a second
+    // fragment set.  Plain form: wait for the tile, read all its fragments, hand the buffer on, multiply; the partner wave
+    // of the SIMD covers the read phase when it can.
+    for (int i = 0; i < n_mine; ++i) {
         asm volatile("" ::: "memory");
 #if HMX_RTZ3_ABL & 2
         wait_vmcnt<0>();
@@ -144,17 +251,15 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
         if (i + 1 < n_mine) wait_vmcnt<NI>(); else wait_vmcnt<0>();
 #endif
         asm volatile("" ::: "memory");
-        const int t = t0 + wv + RTZ3_WAVES * i;
-        const int c0 = c_first + 16 * (t - t0);
+        const int c0 = c_mine + 16 * stride * i;
         float* Rt = lds + (size_t)(2 * wv + (i & 1)) * buf_floats;
         float* Zt = Rt + 16 * Kp;
-        const int n_live = min(16, c_end - c0);                     // wave-uniform; < 16 only in a group's last tile
+        const int n_live = min(16, c_end - c0);
         if (n_live < 16) {
-            // rows past the group's end hold other cells (or the slack behind the array): they count for nothing
             for (int j = n_live * Kp + lane; j < 16 * Kp; j += 64) Rt[j] = 0.f;
             for (int j = n_live * DP + lane; j < 16 * DP; j += 64) Zt[j] = 0.f;
         }
-        const unsigned bw = reinterpret_cast<const unsigned*>(Zt + 16 * DP)[q];   // block ids of cells 4q .. 4q+3
+        const unsigned bw = reinterpret_cast<const unsigned*>(Zt + 16 * DP)[q];
         float afr[4][MT];
         f32x4 zfr[4];
 #pragma unroll
@@ -171,10 +276,10 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
             zfr[ks] = ld4(Zt + (size_t)(4 * q + ks) * DP + 4 * min(c16, KS - 1));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the buffer is in registers: it may be overwritten
-        const bool more = i + 2 < n_mine && !(HMX_RTZ3_ABL & 2);     // wave-uniform
-        if (!INTERLEAVE && more) {
+        if (i + 2 < n_mine && !(HMX_RTZ3_ABL & 2)) {
 #pragma unroll
             for (int p = 0; p < NI; ++p) issue_piece(i & 1, p);
+            advance();
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -187,27 +292,10 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-#if HMX_RTZ3_ABL & 1
-                    acc[mt][nt][0] += afr[ks][mt] * bfr[nt];
-#else
-                    acc[mt][nt] = MFMA16(afr[ks][mt], bfr[nt], acc[mt][nt]);
-#endif
-                    const int m = (ks * MT + mt) * NT + nt;
-                    if ((m + 1) % GAP == 0 && (m + 1) / GAP - 1 < NI) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (more) issue_piece(i & 1, (m + 1) / GAP - 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA16(afr[ks][mt], bfr[nt], acc[mt][nt]);
         }
-        if (INTERLEAVE && NMF / GAP < NI) {                         // (tiny shapes: fewer MFMAs than requests)
-#pragma unroll
-            for (int p = NMF / GAP; p < NI; ++p)
-                if (more) issue_piece(i & 1, p);
-        }
-        if (more) advance();
     }
+  }
 
     // ---- the four waves' accumulators meet in LDS (fragment order), one slab per task goes out -------------------------
     __syncthreads();                                                // every wave is done with its buffers (all requests landed)
