@@ -45,7 +45,11 @@ __device__ __forceinline__ void dma16(const void* base_, unsigned voff, unsigned
     const unsigned long long bits = (unsigned long long)base_;
     const void* base = (const void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(bits >> 32)) << 32) |
                                      (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)bits));
+#if HMX_RTZ3_NT
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(base), "s"(zone) : "memory", "m0");
+#else
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(zone) : "memory", "m0");
+#endif
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) const void*)p);
@@ -60,6 +64,9 @@ __device__ __forceinline__ void wait_vmcnt() {   // gfx9 encoding: vmcnt[3:0] | 
 }  // namespace
 
 #define RTZ3_WAVES 4
+#ifndef HMX_RTZ3_NT
+#define HMX_RTZ3_NT 1    /* the rows are read once per pass: non-temporal requests (micro-benchmark of this very pattern: 6.2 -> 6.9 TB/s) */
+#endif
 #ifndef HMX_RTZ3_ABL
 #define HMX_RTZ3_ABL 0   /* timing experiments only (results become wrong): 1 no MFMAs (the stream alone), 2 no requests after the prologue (the arithmetic alone) */
 #endif
@@ -144,8 +151,11 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
     // do identical work; with "read all fragments, then 4 x MT x NT MFMAs" they reached their read phases together and the
     // matrix pipe idled for both (measured: 66 % busy, 172-190 us per pass at C3 with or without the memory traffic).
     constexpr int NMF = MT * NT;                                    // MFMAs of a k-step
-    constexpr int HEAD = NMF / 3;                                   // MFMAs of the last k-step issued before the wait for the next tile
-    constexpr int GAP = (NMF - HEAD) / NI > 0 ? (NMF - HEAD) / NI : 1;   // MFMAs between two requests
+    // last k-step of a tile: first the NI requests of tile i+2 (one every GAP MFMAs: tile i's buffer is free, its last
+    // fragments are in registers), THEN the wait for tile i+1 -- two tiles travel while the wave multiplies.  (The other
+    // order -- wait first, request after -- left one tile in flight per wave and the stream at 3.7 TB/s.)
+    constexpr int GAP = NMF >= 3 * NI ? 2 : 1;                      // MFMAs between two requests
+    constexpr int OPEN = NI * GAP + 1 < NMF ? (NI * GAP + 1 > 2 * NMF / 3 ? NI * GAP + 1 : 2 * NMF / 3) : NMF;   // MFMAs issued before the wait
     float afr[2][MT];
     f32x4 zfr[2];
     unsigned bw = 0, bw_next = 0;
@@ -163,9 +173,9 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
     };
     // tile i has landed (nothing younger is in flight at the points this is called): rows past the group's end hold other
     // cells (or the slack behind the array) and count for nothing; then its first fragments and its block ids
-    auto open_tile = [&](int i) {
+    auto open_tile = [&](int i, bool younger) {
         asm volatile("" ::: "memory");
-        wait_vmcnt<0>();
+        if (younger) wait_vmcnt<NI>(); else wait_vmcnt<0>();        // (the requests of tile i+1 may travel on)
         asm volatile("" ::: "memory");
         const int c0 = c_mine + 16 * stride * i;
         float* Rt = lds + (size_t)(2 * wv + (i & 1)) * buf_floats;
@@ -218,23 +228,23 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
 #endif
                     if (ks == 3) {
                         const int m = mt * NT + nt + 1;             // MFMAs of this k-step issued so far
-                        if (m == HEAD) {
+                        if (m % GAP == 0 && m / GAP - 1 < NI && m < OPEN) {
                             __builtin_amdgcn_sched_barrier(0);
-                            if (next) open_tile(i + 1);             // (the reads of tile i's buffer returned before this k-step began)
+                            if (more) issue_piece(i & 1, m / GAP - 1);   // (the reads of tile i's buffer returned before this k-step began)
                             __builtin_amdgcn_sched_barrier(0);
                         }
-                        if (m > HEAD && (m - HEAD) % GAP == 0 && (m - HEAD) / GAP - 1 < NI) {
+                        if (m == OPEN) {
                             __builtin_amdgcn_sched_barrier(0);
-                            if (more) issue_piece(i & 1, (m - HEAD) / GAP - 1);
+                            if ((OPEN - 1) / GAP < NI) {            // (few MFMAs per k-step: the remaining requests go out here)
+#pragma unroll
+                                for (int p = (OPEN - 1) / GAP; p < NI; ++p)
+                                    if (more) issue_piece(i & 1, p);
+                            }
+                            if (next) open_tile(i + 1, more);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
                 }
-        }
-        if ((NMF - HEAD) / GAP < NI) {                              // (tiny shapes: fewer MFMAs than requests)
-#pragma unroll
-            for (int p = (NMF - HEAD) / GAP; p < NI; ++p)
-                if (more) issue_piece(i & 1, p);
         }
         if (more) advance();
     }

@@ -15,6 +15,7 @@ except Exception as e:
 PY
 }
 timeout 200 python bench.py --no-lisi --no-convergence --cpu-sample 0 > gpurun_out/bench_inter.json 2> gpurun_out/bench_inter.err; report inter
+HMX_LIB=$PWD/build/libhmx_nont.so timeout 200 python bench.py --no-lisi --no-convergence --cpu-sample 0 > gpurun_out/bench_nont.json 2> gpurun_out/bench_nont.err; report nont
 HMX_RTZ3_TASKS=contig timeout 200 python bench.py --no-lisi --no-convergence --cpu-sample 0 > gpurun_out/bench_contig.json 2> gpurun_out/bench_contig.err; report contig
 for v in abl1 abl2; do
   HMX_LIB=$PWD/build/libhmx_$v.so timeout 200 python bench.py --no-lisi --no-convergence --cpu-sample 0 --steps 3 > gpurun_out/bench_$v.json 2> gpurun_out/bench_$v.err; report $v
