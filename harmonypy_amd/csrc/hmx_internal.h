@@ -118,7 +118,8 @@ struct Rtz3Args {
     const int* task_stride;    // tiles between a wave's consecutive tiles (4: contiguous task; 4 x tasks of the group: interleaved)
     const int* task_c0;        // first cell of tile task_t0 (the cells of a group's tiles are consecutive)
     const int* task_cend;      // first cell behind the task's group
-    float* slab;               // ntasks x MT x NT x 256 accumulators in fragment order
+    float* slab;               // ntasks x MT x NT x 256 accumulators, [tile][lane][r]
+    unsigned long long* prof;  // -DHMX_RTZ3_PROF builds: ntasks x waves x 8 time stamps (else null)
     int ntasks, Kp;
 };
 struct Rtz3FinishArgs {

@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "hmx_internal.h"
 #include "hmx_device.h"
@@ -71,6 +72,13 @@ __device__ __forceinline__ void wait_vmcnt() {   // gfx9 encoding: vmcnt[3:0] | 
 #define HMX_RTZ3_ABL 0   /* timing experiments only (results become wrong): 1 no MFMAs (the stream alone), 2 no requests after the prologue (the arithmetic alone) */
 #endif
 
+#ifdef HMX_RTZ3_PROF   /* timing experiments only: s_memtime stamps per wave */
+#define R3STAMP(k) do { if (lane == 0 && a.prof) a.prof[((size_t)blockIdx.x * RTZ3_WAVES + wv) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define R3ACC(k, v) do { if (lane == 0 && a.prof) a.prof[((size_t)blockIdx.x * RTZ3_WAVES + wv) * 8 + (k)] += (v); } while (0)
+#else
+#define R3STAMP(k) do { } while (0)
+#define R3ACC(k, v) do { } while (0)
+#endif
 template <int MT, int KS, int NTB>
 __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
     constexpr int NT = 4 + NTB, DP = 4 * KS;
@@ -93,6 +101,7 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
     // grid-stride copy (DRAM pages and TLB entries are shared by the whole chip instead of one stream per workgroup)
     const int stride = __builtin_amdgcn_readfirstlane(a.task_stride[task]);
 
+    R3STAMP(0);
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -175,7 +184,13 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
     // cells (or the slack behind the array) and count for nothing; then its first fragments and its block ids
     auto open_tile = [&](int i, bool younger) {
         asm volatile("" ::: "memory");
+#ifdef HMX_RTZ3_PROF
+        const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
+#endif
         if (younger) wait_vmcnt<NI>(); else wait_vmcnt<0>();        // (the requests of tile i+1 may travel on)
+#ifdef HMX_RTZ3_PROF
+        R3ACC(4, __builtin_amdgcn_s_memtime() - w0_);
+#endif
         asm volatile("" ::: "memory");
         const int c0 = c_mine + 16 * stride * i;
         float* Rt = lds + (size_t)(2 * wv + (i & 1)) * buf_floats;
@@ -201,6 +216,7 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
         bw_next = reinterpret_cast<const unsigned*>(Zt + 16 * DP)[q];
         read_frags(Rt, Zt, 0, 0);
     }
+    R3STAMP(1);
     for (int i = 0; i < n_mine; ++i) {
         float* Rt = lds + (size_t)(2 * wv + (i & 1)) * buf_floats;
         float* Zt = Rt + 16 * Kp;
@@ -307,26 +323,37 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
     }
   }
 
-    // ---- the four waves' accumulators meet in LDS (fragment order), one slab per task goes out -------------------------
+    R3STAMP(2);
+    // ---- the four waves' accumulators meet in the task's slab: [output tile][lane][r], i.e. a lane's four values of a tile
+    //      are 16 contiguous bytes.  Two waves at a time store their accumulators to two LDS regions (ds_write_b128, one per
+    //      tile; one region when the LDS holds only one), then all threads add the regions into the slab (the second pair on
+    //      top of the first: a read-modify-write of the thread's own 16-byte pieces, L2-resident).  No accumulator is read
+    //      back into registers.  (The first version added one wave after the other with 4-byte LDS read-modify-writes:
+    //      48 k cycles per wave, 12 % of the pass.)
     __syncthreads();                                                // every wave is done with its buffers (all requests landed)
     constexpr int PER = MT * NT * 256;
+    const int nreg = (2 * PER <= 2 * RTZ3_WAVES * buf_floats) ? 2 : 1;   // workgroup-uniform
+    float* slab = a.slab + (size_t)task * PER;
 #pragma unroll 1
-    for (int w = 0; w < RTZ3_WAVES; ++w) {
-        if (wv == w) {
+    for (int r0 = 0; r0 < RTZ3_WAVES; r0 += nreg) {
+        if (wv >= r0 && wv < r0 + nreg) {
+            float* reg = lds + (size_t)(wv - r0) * PER + 4 * lane;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float* p = lds + ((mt * NT + nt) * 4 + r) * 64 + lane;
-                        *p = (w == 0) ? acc[mt][nt][r] : *p + acc[mt][nt][r];
-                    }
+                for (int nt = 0; nt < NT; ++nt) st4(reg + (mt * NT + nt) * 256, acc[mt][nt]);
         }
         __syncthreads();
+        for (int j = tid; j < PER / 4; j += 64 * RTZ3_WAVES) {
+            f32x4 v = ld4(lds + 4 * j);
+            if (nreg == 2) v += ld4(lds + PER + 4 * j);
+            if (r0 > 0) v += ld4(slab + 4 * j);
+            st4(slab + 4 * j, v);
+        }
+        __syncthreads();                                            // (the regions are overwritten by the next pair)
     }
-    float* slab = a.slab + (size_t)task * PER;
-    for (int j = tid; j < PER / 4; j += 64 * RTZ3_WAVES) st4(slab + 4 * j, ld4(lds + 4 * j));
+    R3STAMP(3);
+    R3ACC(5, (unsigned long long)n_mine);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -363,7 +390,7 @@ __global__ __launch_bounds__(RTZ3_FIN_THREADS) void k_rtz3_finish(Rtz3FinishArgs
     const int v = tid % NV, sl = tid / NV;                          // value (nt, n) of the row, slice of the tasks
     if (sl < nslice) {
         const int nt = v >> 4, n = v & 15;
-        const size_t off = (size_t)((mt * NT + nt) * 4 + (m & 3)) * 64 + 16 * (m >> 2) + n;
+        const size_t off = (size_t)(mt * NT + nt) * 256 + (size_t)(16 * (m >> 2) + n) * 4 + (m & 3);   // [tile][lane][r]: row m = 4 q + r, column n
         int g = -1;
         double acc = 0.0;
         // the slab reads are latency-bound: eight independent loads in flight per thread (clamped, not predicated: a
@@ -482,6 +509,32 @@ static void launch_rtz3_t(const Rtz3Args& a, size_t sm, hipStream_t s) {
             fprintf(stderr, "[hmx] k_rtz3<%d,%d,%d>: %d tasks, %zu bytes of LDS per workgroup, %d workgroups per CU\n", MT, KS, NTB, a.ntasks, sm, nb);
         }
     }
+#ifdef HMX_RTZ3_PROF
+    static unsigned long long* prof = nullptr;
+    static int calls = 0;
+    Rtz3Args b = a;
+    if (!prof) (void)hipMalloc(reinterpret_cast<void**>(&prof), (size_t)4096 * RTZ3_WAVES * 8 * 8);
+    (void)hipMemsetAsync(prof, 0, (size_t)a.ntasks * RTZ3_WAVES * 8 * 8, s);
+    b.prof = prof;
+    hipLaunchKernelGGL((k_rtz3<MT, KS, NTB>), dim3(a.ntasks), dim3(64 * RTZ3_WAVES), sm, s, b);
+    if (++calls == 30) {
+        std::vector<unsigned long long> h((size_t)a.ntasks * RTZ3_WAVES * 8);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h.data(), prof, h.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long t_min = ~0ull, t_max = 0;
+        double pro = 0, loop = 0, epi = 0, wait = 0, tiles = 0, start_spread_max = 0;
+        const size_t nw = (size_t)a.ntasks * RTZ3_WAVES;
+        for (size_t w = 0; w < nw; ++w) { t_min = std::min(t_min, h[w * 8]); t_max = std::max(t_max, h[w * 8 + 3]); }
+        for (size_t w = 0; w < nw; ++w) {
+            const unsigned long long* r = &h[w * 8];
+            pro += (double)(r[1] - r[0]); loop += (double)(r[2] - r[1]); epi += (double)(r[3] - r[2]); wait += (double)r[4]; tiles += (double)r[5];
+            start_spread_max = std::max(start_spread_max, (double)(r[0] - t_min));
+        }
+        fprintf(stderr, "[k_rtz3 prof] <%d,%d,%d> %d tasks: kernel span %.0f cycles; per wave: prologue %.0f, loop %.0f (%.0f per tile, %.1f tiles), of which waiting for tiles %.0f (%.0f per tile), epilogue %.0f; latest wave start +%.0f\n",
+                MT, KS, NTB, a.ntasks, (double)(t_max - t_min), pro / nw, loop / nw, loop / tiles, tiles / nw, wait / nw, wait / tiles, epi / nw, start_spread_max);
+    }
+    return;
+#endif
     hipLaunchKernelGGL((k_rtz3<MT, KS, NTB>), dim3(a.ntasks), dim3(64 * RTZ3_WAVES), sm, s, a);
 }
 template <int KS, int NTB>

@@ -53,7 +53,7 @@ def kernel_tile(Rt, Zt, blk, MT, KS, NTB, acc):
 
 
 def finish(slab, MT, KS, NTB, K, d, nblk):
-    """k_rtz3_finish's read-out of one slab [mt][nt][r][lane]."""
+    """k_rtz3_finish's read-out of one slab [mt][nt][lane][r]."""
     NT, DP = 4 + NTB, 4 * KS
     Hq, rem = MT // 4, MT % 4
 
@@ -77,7 +77,7 @@ def finish(slab, MT, KS, NTB, K, d, nblk):
 
         def val(v):
             nt, n = v >> 4, v & 15
-            return slab[((mt * NT + nt) * 4 + (m & 3)) * 64 + 16 * (m >> 2) + n]
+            return slab[(mt * NT + nt) * 256 + (16 * (m >> 2) + n) * 4 + (m & 3)]
         for pc in range(d):
             Y[k, pc] = val(col_pc(pc))
         for b in range(nblk):
@@ -110,7 +110,7 @@ def test_rtz3_round_trip(K, d, nblk):
         for nt in range(NT):
             for r in range(4):
                 for lane in range(64):
-                    slab[((mt * NT + nt) * 4 + r) * 64 + lane] = acc[mt][nt][lane, r]
+                    slab[(mt * NT + nt) * 256 + lane * 4 + r] = acc[mt][nt][lane, r]
     Y, S = finish(slab, MT, KS, NTB, K, d, nblk)
     np.testing.assert_allclose(Y, R[:, :K].T @ Z[:, :d], rtol=1e-12, atol=1e-12)
     S_ref = np.zeros((nblk, K))
