@@ -448,8 +448,7 @@ def main():
                 "converged": bool(ho2.check_convergence(1)), "cells_total": N * world,
                 "setup_breakdown_s": {k: round(v, 4) for k, v in ho2.timing.items() if k != "harmonize"},
                 "init": "upload (rows regrouped on the GPU) + k-means++ seeds on a 32k-cell subsample (GPU) + 25 Lloyd "
-                        + ("iterations on that subsample (host, sklearn: K > 112 or d > 64)" if ho2._wide_shape()
-                           else "iterations over all cells (GPU)") + " + init_cluster; not part of `value`"}
+                        "iterations over all cells (GPU) + init_cluster; not part of `value`"}
     if rank != 0:
         if dist is not None:
             dist.barrier()

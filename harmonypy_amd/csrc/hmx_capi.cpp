@@ -609,20 +609,22 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
             // neighbouring quads of tiles (task j: tiles ts + 4j + w + 4m i) and sweep the group's rows together
             const char* tk = getenv("HMX_RTZ3_TASKS");
             const bool interleave = !(tk && std::string(tk) == "contig");
+            // tiles a workgroup takes side by side: k_rtz3's four waves own a tile each, k_rtzw's eight share one
+            const int quad = rtz_wide_ok(e->mt, e->dp) ? 1 : 4;
             for (int g = 0; g < e->G; ++g) {
                 const int ts = tstart[g], te = tstart[g + 1];
                 if (te <= ts) continue;
                 const int m = (te - ts + CH3 - 1) / CH3, per = (te - ts + m - 1) / m;
                 if (interleave) {
-                    const int mm = std::min(m, (te - ts + 3) / 4);       // no task without a tile
+                    const int mm = std::min(m, (te - ts + quad - 1) / quad);       // no task without a tile
                     for (int j = 0; j < mm; ++j) {
-                        a0.push_back(ts + 4 * j); a1.push_back(te); ag.push_back(g); ast.push_back(4 * mm);
-                        ac0.push_back(gs2[g] + 4 * j * HMX_TILE); acend.push_back(gs2[g + 1]);
+                        a0.push_back(ts + quad * j); a1.push_back(te); ag.push_back(g); ast.push_back(quad * mm);
+                        ac0.push_back(gs2[g] + quad * j * HMX_TILE); acend.push_back(gs2[g + 1]);
                     }
                     continue;
                 }
                 for (int i = ts; i < te; i += per) {
-                    a0.push_back(i); a1.push_back(std::min(i + per, te)); ag.push_back(g); ast.push_back(4);
+                    a0.push_back(i); a1.push_back(std::min(i + per, te)); ag.push_back(g); ast.push_back(quad);
                     ac0.push_back(gs2[g] + (i - ts) * HMX_TILE); acend.push_back(gs2[g + 1]);
                 }
             }
@@ -764,11 +766,13 @@ int hmx_kmeans_seed(hmx_engine* e, const float* points, int64_t n_points, uint64
     return HMX_OK;
 }
 
+static int lloyd_wide(hmx_engine* e, const float* centers_in, int n_iter, float* centers_out);
+
 int hmx_kmeans_lloyd(hmx_engine* e, const float* centers_in, int n_iter, float* centers_out) {
     if (!e || !centers_in || !centers_out) return fail(HMX_ERR_ARG, "null argument");
     if (!e->uploaded) return fail(HMX_ERR_STATE, "hmx_upload must come first");
     if (n_iter < 0) return fail(HMX_ERR_ARG, "n_iter must be >= 0");
-    if (e->mt > 7 || e->dp > 64) return fail(HMX_ERR_ARG, "device k-means supports K <= 112 and d <= 64");
+    if (e->mt > 7 || e->dp > 64) return lloyd_wide(e, centers_in, n_iter, centers_out);
     int rc;
     if ((rc = use_device(e))) return rc;
     const size_t nsum = (size_t)e->K16 * (e->d + 1);
@@ -830,6 +834,11 @@ int hmx_init_cluster(hmx_engine* e, const float* Y0, double obj_out[4]) {
 static bool use_rtz3(const hmx_engine* e) {
     return e->rtz_kernel == 3 && e->static_contig && e->ntasks3 > 0 && rtz3_ok(e->mt, e->dp, e->nblk, e->G);
 }
+// the same pass for wide shapes (K > 112 or d > 64): k_rtzw, eight waves sharing every tile
+static bool use_rtzw(const hmx_engine* e) {
+    return e->rtz_kernel == 3 && e->static_contig && e->ntasks3 > 0 && rtzw_ok(e->mt, e->dp, e->d, e->nblk, e->G);
+}
+static bool streaming_rtz(const hmx_engine* e) { return use_rtz3(e) || use_rtzw(e); }
 
 // What the sweep kernel needs done before it starts, folded into k_rtz3_finish when a single engine runs the fused
 // path: the slot tables + sync words and the objective accumulators zeroed, O at the start of the round kept aside.
@@ -838,24 +847,29 @@ struct Rtz3Duties { bool on = false; };
 // The R^T.Z pass in storage order (k_rtz3 + k_rtz3_finish).
 //   mode 0: Z_cos; block ids `tile_blk` with `nblk_cols` one-hot columns -> Yacc64 (centroid numerators, :443),
 //           Sold (removal sums of every block, :491-492) and, with `normalize`, Y (:444);
-//   mode 1: Z_orig, all ids 0 -> Sr (ridge right-hand sides, :556-563), Oxr (exact O, :550).
+//   mode 1: Z_orig, all ids 0 -> Sr (ridge right-hand sides, :556-563), Oxr (exact O, :550);
+//   mode 2: the same statistics of Z_cos (member sums and counts of the device k-means' hard assignment).
 static int rtz3_pass(hmx_engine* e, int mode, const unsigned char* tile_blk, int nblk_cols, bool normalize, bool duties) {
     int rc;
-    if ((rc = e->slab.reserve((size_t)e->ntasks3 * rtz3_slab_floats(e->mt, e->dp, nblk_cols)))) return rc;
+    const bool wide = !use_rtz3(e);
+    if ((rc = e->slab.reserve((size_t)e->ntasks3 * (wide ? rtzw_slab_floats(e->mt, e->dp, e->d, nblk_cols) : rtz3_slab_floats(e->mt, e->dp, nblk_cols)))))
+        return rc;
     {
         Timed t(e, mode == 1 ? F_RIDGE_STATS : F_RTZ_ROUND);
         Rtz3Args r{};
         r.R = e->R.p; r.Z = mode == 1 ? e->Zorig.p : e->Zcos.p; r.tile_blk = tile_blk;
         r.task_t0 = e->t3_t0.p; r.task_t1 = e->t3_t1.p; r.task_stride = e->t3_stride.p; r.task_c0 = e->t3_c0.p; r.task_cend = e->t3_cend.p;
         r.slab = e->slab.p; r.ntasks = e->ntasks3; r.Kp = e->Kp;
-        if (launch_rtz3(r, e->mt, e->dp, nblk_cols, e->stream)) return fail(HMX_ERR_ARG, "unsupported shape for k_rtz3");
+        if (wide ? launch_rtzw(r, e->mt, e->dp, e->d, nblk_cols, e->stream) : launch_rtz3(r, e->mt, e->dp, nblk_cols, e->stream))
+            return fail(HMX_ERR_ARG, "unsupported shape for the streaming R^T.Z pass");
     }
     Timed t(e, mode == 1 ? F_RIDGE_STATS : F_RTZ_REDUCE);
     const size_t GK = (size_t)e->G * e->K16;
     Rtz3FinishArgs f{};
     f.slab = e->slab.p; f.task_grp = e->t3_grp.p; f.ntasks = e->ntasks3;
     f.MT = e->mt; f.KS = e->dp / 4; f.NTB = rtz3_ntb(e->dp, nblk_cols);
-    f.K = e->K; f.K16 = e->K16; f.d = e->d; f.ld = e->ldy; f.G = e->G; f.nblk = nblk_cols; f.mode = mode;
+    f.wide = wide ? 1 : 0; f.NT = wide ? rtzw_nt(e->dp, e->d, nblk_cols) : 4 + f.NTB;
+    f.K = e->K; f.K16 = e->K16; f.d = e->d; f.ld = e->ldy; f.G = e->G; f.nblk = nblk_cols; f.mode = mode == 0 ? 0 : 1;
     f.Ysum = e->Yacc64; f.Yout = normalize ? e->Y.p : nullptr; f.Sold = e->Sold; f.Sr = e->Sr; f.Oxr = e->Oxr;
     if (duties) {
         f.zero_p = e->Sslots.p; f.zero_n = GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 1;   // slot tables + the two sync words
@@ -869,7 +883,7 @@ static int rtz3_pass(hmx_engine* e, int mode, const unsigned char* tile_blk, int
 // Centroid numerators sum_cells R (x) Z_cos (harmony.py:443) of this rank's cells into Yacc64, by a pass over the
 // static list (no removal sums: k_sweep forms those itself).
 static int centroid_pass(hmx_engine* e) {
-    if (use_rtz3(e)) return rtz3_pass(e, 0, e->tile_blk_zero.p, 1, false, false);
+    if (streaming_rtz(e)) return rtz3_pass(e, 0, e->tile_blk_zero.p, 1, false, false);
     int rc, nsub, spw;
     rtz_geometry(e->mt, e->ntd, &nsub, &spw);
     const bool rtz2 = rtz2_ok(e->mt, e->dp);
@@ -897,6 +911,41 @@ static int centroid_pass(hmx_engine* e) {
     else if (rtzw) launch_rtz_wide_reduce(e->slab.p, wgs, e->mt, e->dp, e->K16, e->ldy, e->Yacc64, nullptr, e->stream);
     else launch_rtz_reduce(e->slab.p, wgs * 4, e->mt, e->ntd, e->K16, e->ldy, e->Yacc64, nullptr, e->stream);
     return 0;
+}
+
+// Lloyd iterations for shapes beyond k_kmeans_step (K > 112 or d > 64): per iteration the hard assignment of every cell
+// (k_assign_wide writes a one-hot row of R -- R is free before init_cluster), then the member sums and counts as the
+// R^T.Z statistics of that assignment (the streaming pass over Z_cos, summed over ranks like the ridge statistics).
+static int lloyd_wide(hmx_engine* e, const float* centers_in, int n_iter, float* centers_out) {
+    int rc;
+    if (!streaming_rtz(e)) return fail(HMX_ERR_ARG, "device k-means for K > 112 or d > 64 needs the streaming R^T.Z pass (consecutive cells in every static tile)");
+    if ((rc = use_device(e))) return rc;
+    e->clustered = false;   // R serves as scratch: whatever assignment the engine held is void until hmx_init_cluster runs (again)
+    const size_t nsum = (size_t)e->K16 * (e->d + 1), GK = (size_t)e->G * e->K16;
+    if ((rc = e->km_hn.reserve(e->K16)) || (rc = e->km_sums.reserve(nsum))) return rc;
+    std::vector<float> y((size_t)e->K16 * e->ldy, 0.f);
+    for (int k = 0; k < e->K; ++k) std::memcpy(&y[(size_t)k * e->ldy], centers_in + (size_t)k * e->d, sizeof(float) * e->d);
+    HIP_TRY(hipMemcpyAsync(e->Yacc.p, y.data(), y.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemsetAsync(e->km_sums.p, 0, nsum * sizeof(double), e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    launch_kmeans_update(e->km_sums.p, e->Yacc.p, e->km_hn.p, e->K, e->K16, e->d, e->ldy, e->stream);   // counts 0: norms only
+    for (int it = 0; it < n_iter; ++it) {
+        AssignArgs a = assign_args(e);
+        a.Y = e->Yacc.p; a.hn = e->km_hn.p;
+        a.cells = e->s_cells.p; a.tile_grp = e->s_tile_grp.p; a.S_out = e->Ogrp.p;
+        a.tile_begin = 0; a.tile_end = e->n_s_tiles;
+        if (launch_assign(a, false, e->max_wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported cluster count");
+        if ((rc = rtz3_pass(e, 2, e->tile_blk_zero.p, 1, false, false))) return rc;
+        if ((rc = sum_over_ranks(e, e->Sr, GK * e->ldy + GK))) return rc;   // Sr and Oxr are neighbours
+        launch_kmeans_sums_from_stats(e->Sr, e->Oxr, e->G, e->K16, e->ldy, e->d, e->km_sums.p, e->stream);
+        launch_kmeans_update(e->km_sums.p, e->Yacc.p, e->km_hn.p, e->K, e->K16, e->d, e->ldy, e->stream);
+    }
+    HIP_TRY(hipMemsetAsync(e->R.p, 0, (size_t)e->N * e->Kp * sizeof(float), e->stream));   // leave R as hmx_create made it
+    HIP_TRY(hipMemsetAsync(e->Ogrp.p, 0, GK * sizeof(double), e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy2D(centers_out, (size_t)e->d * 4, e->Yacc.p, (size_t)e->ldy * 4, (size_t)e->d * 4, e->K, hipMemcpyDeviceToHost));
+    return HMX_OK;
 }
 
 static void note_sweep_timeout(hmx_engine* e) {
@@ -1039,7 +1088,7 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
 #endif
     const bool mega = persistent && e->mt <= 7 && round_row_floats(e->d) == e->dp &&
                       round_lds_bytes(e->K16, e->dp, e->G, e->B, e->V) <= HMX_ROUND_LDS_LIMIT;
-    const bool r3 = use_rtz3(e);
+    const bool r3 = streaming_rtz(e);
     // a single engine on the persistent sweep: k_rtz3_finish normalises the centroids itself (no collective is due in
     // between) and does the sweep kernel's fills -- three launches per round
     const bool fused = r3 && mega && !sharded(e);
@@ -1211,7 +1260,7 @@ static int check_round_flags(hmx_engine* e, int flags, double* obj_out) {
 
 // block ids in static tile order for the streaming R^T.Z pass, from the lists `which` (on stream s, behind their build)
 static void build_tile_blocks(hmx_engine* e, int which, int64_t n_pos_upper, hipStream_t s) {
-    if (!use_rtz3(e)) return;
+    if (!streaming_rtz(e)) return;
     launch_tile_blocks(e->lists[which].cells.p, e->lists[which].tile_grp.p, e->lists[which].blk_start.p, e->nblk, n_pos_upper,
                        e->gstart.p, e->s_tile_start.p, e->tile_blk[which].p, s);
 }
@@ -1280,7 +1329,7 @@ static int seeded_round(hmx_engine* e, int flags, uint64_t seed, int64_t cells_p
         o.key0 = (uint32_t)z; o.key1 = (uint32_t)(z >> 32) | 1u;
         o.gstart = e->gstart.p; o.chunk_tab = e->chunk_tab.p; o.run_count = e->run_count.p; o.run_start = e->run_start.p;
         o.blk_start = e->lists[which].blk_start.p; o.cells = e->lists[which].cells.p; o.tile_grp = e->lists[which].tile_grp.p;
-        if (use_rtz3(e)) { o.tile_blk = e->tile_blk[which].p; o.s_tile_start = e->s_tile_start.p; }   // block ids in static tile order, by the way
+        if (streaming_rtz(e)) { o.tile_blk = e->tile_blk[which].p; o.s_tile_start = e->s_tile_start.p; }   // block ids in static tile order, by the way
         launch_order(o, s);
     };
     const uint64_t counter = e->seeded_rounds++;
@@ -1552,7 +1601,7 @@ int hmx_moe_correct_ridge(hmx_engine* e) {
     if ((rc = e->slab.reserve((size_t)std::max(e->ntasks, 1) * (rtz2 ? rtz2_slab_floats(e->mt, e->dp)
                                                                      : rtzw ? rtz_wide_slab_floats(e->mt, e->dp) : spw))))
         return rc;
-    if (use_rtz3(e)) {
+    if (streaming_rtz(e)) {
         // the streaming pass: Sr and Oxr are written whole by k_rtz3_finish (no fills)
         if ((rc = rtz3_pass(e, 1, e->tile_blk_zero.p, 1, false, false))) return rc;
     } else {

@@ -25,6 +25,8 @@ struct AssignArgs {
     int tile_begin, tile_end;  // host-side range (or an upper bound of its length when blk_start)
     int K, Kp, K16, mt, dp, ldy;
     int G, ldy_lds, tables_in_lds, tiles_per_wave, ablate;
+    const float* hn;       // k_assign_wide without penalty only: half squared norms of the centres in Y (+inf for pads) -> HARD
+                           // assignment of the device k-means (a one-hot row of R per cell) instead of the softmax; null otherwise
 };
 
 #define HMX_ROUND_SLOTS 4 /* k_round: a block's new sums are spread over this many fp64 tables */
@@ -121,11 +123,13 @@ struct Rtz3Args {
     float* slab;               // ntasks x MT x NT x 256 accumulators, [tile][lane][r]
     unsigned long long* prof;  // -DHMX_RTZ3_PROF builds: ntasks x waves x 8 time stamps (else null)
     int ntasks, Kp;
+    int dp, d, nt;             // k_rtzw (wide shapes; set by its launcher): row floats of Z, PCs, output column tiles
 };
 struct Rtz3FinishArgs {
     const float* slab;
     const int* task_grp;
     int ntasks, MT, KS, NTB, K, K16, d, ld, G, nblk;
+    int wide, NT;              // k_rtzw's slabs: plain column tiles, NT of them (KS = dp / 4 there too)
     int mode;                  // 0: k-means round (Ysum, Sold, optional Yout), 1: ridge (Sr, Oxr)
     double* Ysum;              // K16 x ld
     float* Yout;               // K16 x ld unit rows, or null (a collective comes first)
@@ -145,6 +149,10 @@ int rtz3_ntb(int dp, int nblk);
 int rtz3_slab_floats(int mt, int dp, int nblk);
 int launch_rtz3(const Rtz3Args& a, int mt, int dp, int nblk, hipStream_t s);
 void launch_rtz3_finish(const Rtz3FinishArgs& a, hipStream_t s);
+bool rtzw_ok(int mt, int dp, int d, int nblk, int G);
+int rtzw_nt(int dp, int d, int nblk);
+int rtzw_slab_floats(int mt, int dp, int d, int nblk);
+int launch_rtzw(const Rtz3Args& a, int mt, int dp, int d, int nblk, hipStream_t s);
 void launch_tile_blocks(const int* cells, const int* tile_grp, const int* blk_start, int nblk, int64_t n_pos_upper, const int* gstart,
                         const int* s_tile_start, unsigned char* tile_blk, hipStream_t s);
 
@@ -276,6 +284,7 @@ int launch_kmeans_step(const float* Zcos, const float* C, const float* hn, const
                        int K16, int dp, int ldy, int wgs, hipStream_t s);
 void launch_kmeans_sums(const float* slab, int wgs, int K16, int dp, int d, double* sums, hipStream_t s);
 void launch_kmeans_update(const double* sums, float* C, float* hn, int K, int K16, int d, int ldy, hipStream_t s);
+void launch_kmeans_sums_from_stats(const double* Sr, const double* Oxr, int G, int K16, int ld, int d, double* sums, hipStream_t s);
 void launch_gather_rows(const float* src, int ld, int cols, const int* rows, int n_rows, float* dst, hipStream_t s);
 void launch_order(const OrderArgs& a, hipStream_t s);
 int order_chunks(int64_t N);

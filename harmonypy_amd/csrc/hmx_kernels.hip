@@ -804,9 +804,10 @@ __global__ __launch_bounds__(64 * WIDE_WAVES, 2) void k_assign_wide(AssignArgs a
     const int tile_end = a.blk_start ? a.blk_start[a.blk + 1] : a.tile_end;
     const int ntiles = tile_end - tile_begin;
 
+    const bool hard = !PENALTY && a.hn != nullptr;              // Lloyd iteration of the device k-means: nearest centre, one-hot row
     for (int i = tid; i < K16; i += 64 * WIDE_WAVES) {
         const float sgm = (i < a.K) ? a.sigma[i] : 0.f;
-        sig[i] = sgm;
+        sig[i] = hard ? a.hn[i] : sgm;                   // (hard: the half squared norms take sigma's place in LDS)
         nis[i] = (i < a.K) ? -1.0f / sgm : -60.f;       // pads: Y row 0 -> dist 2 -> arg -120 -> exp == 0
     }
     if (a.tables_in_lds)
@@ -855,6 +856,38 @@ __global__ __launch_bounds__(64 * WIDE_WAVES, 2) void k_assign_wide(AssignArgs a
                 for (int i = 0; i < 4; ++i) T.arg[mt] = MFMA16(ya[i], b[i], T.arg[mt]);
             }
             stage ^= 1;
+        }
+        if (hard) {
+            // sklearn's Lloyd step (harmony.py:370-372): the nearest centre maximises z.c - |c|^2 / 2; ties go to the smaller index
+            float best = -INFINITY;
+            int bk = 0;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f32x4 h4 = ld4(sig + 16 * mt + 4 * q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sc = T.arg[mt][r] - h4[r];
+                    if (sc > best) { best = sc; bk = 16 * mt + 4 * q + r; }
+                }
+            }
+#pragma unroll
+            for (int m = 16; m <= 32; m <<= 1) {
+                const float ob = __shfl_xor(best, m, 64);
+                const int ok = __shfl_xor(bk, m, 64);
+                if (ob > best || (ob == best && ok < bk)) { best = ob; bk = ok; }
+            }
+            if (has && T.cell >= 0) {
+                float* row = a.R + (size_t)T.cell * a.Kp;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int col = 16 * mt + 4 * q;
+                    f32x4 oh;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) oh[r] = (col + r == bk) ? 1.f : 0.f;
+                    if (col < a.Kp) st4(row + col, oh);
+                }
+            }
+            continue;
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -2628,6 +2661,18 @@ __global__ __launch_bounds__(256) void k_kmeans_sums(const float* __restrict__ s
     }
 }
 
+// member sums and counts of the wide-shape Lloyd step from the R^T.Z statistics of the one-hot assignment
+// (Sr: G x K16 x ld sums per batch group, Oxr: G x K16 member counts per group)
+__global__ __launch_bounds__(256) void k_kmeans_sums_from_stats(const double* __restrict__ Sr, const double* __restrict__ Oxr, int G,
+                                                                int K16, int ld, int d, double* __restrict__ sums /* K16 x (d+1) */) {
+    const int k = blockIdx.x;
+    for (int j = threadIdx.x; j <= d; j += 256) {
+        double s = 0.0;
+        for (int g = 0; g < G; ++g) s += (j < d) ? Sr[((size_t)g * K16 + k) * ld + j] : Oxr[(size_t)g * K16 + k];
+        sums[(size_t)k * (d + 1) + j] = s;
+    }
+}
+
 // new centres from the (job-wide) sums: mean of the members; empty clusters keep their centre
 __global__ __launch_bounds__(64) void k_kmeans_update(const double* __restrict__ sums, float* __restrict__ C, float* __restrict__ hn,
                                                       int K, int d, int ldy) {
@@ -3335,6 +3380,10 @@ int launch_kmeans_step(const float* Zcos, const float* C, const float* hn, const
 
 void launch_kmeans_sums(const float* slab, int wgs, int K16, int dp, int d, double* sums, hipStream_t s) {
     hipLaunchKernelGGL(k_kmeans_sums, dim3(K16), dim3(256), 0, s, slab, wgs, K16, lds_ldy(dp), d, sums);
+}
+
+void launch_kmeans_sums_from_stats(const double* Sr, const double* Oxr, int G, int K16, int ld, int d, double* sums, hipStream_t s) {
+    hipLaunchKernelGGL(k_kmeans_sums_from_stats, dim3(K16), dim3(256), 0, s, Sr, Oxr, G, K16, ld, d, sums);
 }
 
 void launch_kmeans_update(const double* sums, float* C, float* hn, int K, int K16, int d, int ldy, hipStream_t s) {

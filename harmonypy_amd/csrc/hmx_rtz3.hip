@@ -357,6 +357,128 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_rtzw: the same streaming pass for shapes whose output does not fit one wave's registers (K up to 208, d up to 208:
+// BASELINE configs[4], the f32-MFMA-bound regime).  Eight waves share every 16-cell tile: the tile's R rows, Z rows and block
+// ids travel global -> LDS (each wave requests its share of the 1 KB pieces) into a ring of four tile buffers, three tiles
+// ahead; one workgroup barrier per tile says "tile i is complete, nobody reads tile i-1 any more"; wave w owns the column
+// tiles w and w + 8 of the output and ALL MT cluster tiles of them (2 x MT accumulators), so nothing is reduced across
+// waves -- every wave stores its own output tiles.  Cluster rows use k_rtz3's permuted map (16-byte A reads); columns are
+// plain: PC tile nt holds columns 16 nt .., the columns d .. dp-1 the row padding leaves free in the last PC tile carry
+// the first one-hot block columns, whole extra tiles the rest.
+// ------------------------------------------------------------------------------------------
+#define RTZW_WAVES 8
+#define RTZW_NBUF 4
+template <int MT>
+__global__ __launch_bounds__(64 * RTZW_WAVES, 1) void k_rtzw(Rtz3Args a) {
+    constexpr int H = MT / 4, REM = MT % 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* lds = reinterpret_cast<float*>(smem);
+    const int Kp = a.Kp, DP = a.dp, d = a.d, NT = a.nt, NTP = DP >> 4;
+    const int buf_floats = 16 * (Kp + DP) + 4;
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, c16 = lane & 15, q = lane >> 4;
+    const int lane16 = 16 * lane;
+    const int task = blockIdx.x;
+    const int t0 = a.task_t0[task], t1 = a.task_t1[task];
+    const int c_first = a.task_c0[task], c_end = a.task_cend[task];
+    const int stride = __builtin_amdgcn_readfirstlane(a.task_stride[task]);   // tiles between two tiles of this workgroup
+    const int n_tiles = (t1 - t0 + stride - 1) / stride;
+
+    // this wave's output column tiles
+    const int nt0 = wv, nt1 = wv + RTZW_WAVES;
+    const bool has0 = nt0 < NT, has1 = nt1 < NT;                   // wave-uniform
+    f32x4 acc0[MT], acc1[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { acc0[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    // requests: a tile is n_pr pieces of R (64 Kp bytes), n_pz of Z (64 dp bytes) and one of block ids; piece p goes to wave p % 8
+    const int n_pr = (64 * Kp + 1023) / 1024, n_pz = (64 * DP + 1023) / 1024, n_p = n_pr + n_pz + 1;
+    const int npw = (n_p - wv + RTZW_WAVES - 1) / RTZW_WAVES;     // requests of this wave per tile (wave-uniform)
+    auto uniform64 = [](unsigned long long v) {
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
+               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v);
+    };
+    const unsigned zone0 = lds_addr(lds);
+    auto issue = [&](int i) {                                       // this wave's pieces of tile i of the task
+        const int c0 = c_first + 16 * stride * i;
+        const unsigned zb = zone0 + (unsigned)(i % RTZW_NBUF) * (unsigned)buf_floats * 4u;
+        const unsigned long long rs = uniform64((unsigned long long)(a.R + (size_t)c0 * Kp));
+        const unsigned long long zs = uniform64((unsigned long long)(a.Z + (size_t)c0 * DP));
+        const unsigned long long bs = uniform64((unsigned long long)(a.tile_blk + (size_t)16 * (t0 + stride * i)));
+        for (int p = wv; p < n_p; p += RTZW_WAVES) {
+            if (p < n_pr) {
+                if (1024 * p + lane16 < 64 * Kp) dma16((const void*)(rs + 1024ull * p), lane16, zb + 1024u * p);
+            } else if (p < n_pr + n_pz) {
+                const int it = p - n_pr;
+                if (1024 * it + lane16 < 64 * DP) dma16((const void*)(zs + 1024ull * it), lane16, zb + 64u * Kp + 1024u * it);
+            } else {
+                if (lane == 0) dma16((const void*)bs, lane16, zb + 64u * (Kp + DP));
+            }
+        }
+    };
+    for (int i = 0; i < RTZW_NBUF - 1 && i < n_tiles; ++i) issue(i);
+
+    for (int i = 0; i < n_tiles; ++i) {
+        // this wave's pieces of tile i have landed: younger are those of the (up to) two tiles behind it
+        asm volatile("" ::: "memory");
+        const int younger = min(RTZW_NBUF - 2, n_tiles - 1 - i) * npw;       // wave-uniform, one of a few values
+        if (younger >= 8) wait_vmcnt<8>(); else if (younger == 6) wait_vmcnt<6>(); else if (younger == 4) wait_vmcnt<4>();
+        else if (younger == 3) wait_vmcnt<3>(); else if (younger == 2) wait_vmcnt<2>(); else if (younger == 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
+        asm volatile("" ::: "memory");
+        wg_barrier_lds();                                           // tile i is complete; nobody reads tile i-1 any more (the requests in flight keep travelling)
+        if (i + RTZW_NBUF - 1 < n_tiles) issue(i + RTZW_NBUF - 1);  // ... whose buffer goes to tile i+3
+        const int c0 = c_first + 16 * stride * i;
+        float* Rt = lds + (size_t)(i % RTZW_NBUF) * buf_floats;
+        float* Zt = Rt + 16 * Kp;
+        const int n_live = min(16, c_end - c0);                     // workgroup-uniform; < 16 only in a group's last tile
+        const unsigned bw = reinterpret_cast<const unsigned*>(Zt + 16 * DP)[q];   // block ids of cells 4q .. 4q+3
+        const int spare = DP - d;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int cell = 4 * q + ks;
+            const bool live = cell < n_live;                        // rows past the group's end count for nothing
+            const float* rr = Rt + (size_t)cell * Kp;
+            float afr[MT];
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const f32x4 v = ld4(rr + 64 * h + 4 * c16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) afr[4 * h + j] = live ? v[j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < REM; ++j) afr[4 * H + j] = live ? rr[64 * H + REM * c16 + j] : 0.f;
+            const int bid = (bw >> (8 * ks)) & 255;
+            auto bval = [&](int nt) {                               // B operand of column tile nt for this lane's column c16
+                if (nt < NTP) {
+                    const int col = 16 * nt + c16;
+                    const float z = Zt[(size_t)cell * DP + col];
+                    const float zv = live ? z : 0.f;                // (the slack behind the array may hold anything)
+                    return col < d ? zv : ((bid == col - d) ? 1.f : 0.f);
+                }
+                return (bid == spare + 16 * (nt - NTP) + c16) ? 1.f : 0.f;
+            };
+            const float b0 = has0 ? bval(nt0) : 0.f, b1 = has1 ? bval(nt1) : 0.f;
+            if (has0) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc0[mt] = MFMA16(afr[mt], b0, acc0[mt]);
+            }
+            if (has1) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc1[mt] = MFMA16(afr[mt], b1, acc1[mt]);
+            }
+        }
+    }
+    // every wave stores its own output tiles: slab [mt][nt][lane][r]
+    float* slab = a.slab + (size_t)task * ((size_t)MT * NT * 256);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        if (has0) st4(slab + ((size_t)(mt * NT + nt0) * 64 + lane) * 4, acc0[mt]);
+        if (has1) st4(slab + ((size_t)(mt * NT + nt1) * 64 + lane) * 4, acc1[mt]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_rtz3_finish: the per-task slabs summed in fp64, one workgroup per cluster k; undoes the index maps of k_rtz3.
 //   mode 0 (k-means round): Ysum[k][pc] over all tasks (the centroid numerators, :443), Sold[blk][g][k] over the tasks of
 //          group g (the removal sums, :491-492); with Yout the row is normalised on the spot (:444) -- no collective
@@ -367,7 +489,7 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
 __global__ __launch_bounds__(RTZ3_FIN_THREADS) void k_rtz3_finish(Rtz3FinishArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* tab = reinterpret_cast<double*>(smem);                  // G x NV
-    const int NT = 4 + a.NTB, NV = 16 * NT, DP = 4 * a.KS;
+    const int NT = a.wide ? a.NT : 4 + a.NTB, NV = 16 * NT, DP = 4 * a.KS;
     const int k = blockIdx.x, tid = threadIdx.x;
     for (int i = tid; i < a.G * NV; i += RTZ3_FIN_THREADS) tab[i] = 0.0;
     if (a.zero_p) {                                                 // fill duty: this workgroup's slice
@@ -419,8 +541,13 @@ __global__ __launch_bounds__(RTZ3_FIN_THREADS) void k_rtz3_finish(Rtz3FinishArgs
         if (g >= 0 && acc != 0.0) atomicAdd(&tab[g * NV + v], acc);
     }
     __syncthreads();
-    auto col_pc = [&](int pc) { return 16 * (pc & 3) + (pc >> 2); };
+    // column of a PC / of a block's one-hot in the row's NV values (v = 16 nt + n): k_rtz3's permuted tiles, or k_rtzw's plain ones
+    auto col_pc = [&](int pc) { return a.wide ? pc : 16 * (pc & 3) + (pc >> 2); };
     auto col_blk = [&](int j) {
+        if (a.wide) {                                               // spare columns d .. DP-1 of the last PC tile first, then whole tiles
+            const int spare = DP - a.d;
+            return j < spare ? a.d + j : DP + (j - spare);
+        }
         if (j < 64 - DP) { const int c = DP + j; return 16 * (c & 3) + (c >> 2); }
         const int x = j - (64 - DP);
         return 16 * (4 + x / 16) + (x & 15);
@@ -572,8 +699,49 @@ int launch_rtz3(const Rtz3Args& a, int mt, int dp, int nblk, hipStream_t s) {
 }
 
 void launch_rtz3_finish(const Rtz3FinishArgs& a, hipStream_t s) {
-    const size_t sm = (size_t)a.G * 16 * (4 + a.NTB) * sizeof(double);
+    const size_t sm = (size_t)a.G * 16 * (a.wide ? a.NT : 4 + a.NTB) * sizeof(double);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rtz3_finish), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
     hipLaunchKernelGGL(k_rtz3_finish, dim3(a.K16), dim3(RTZ3_FIN_THREADS), sm, s, a);
+}
+
+// ---- wide shapes (k_rtzw)
+int rtzw_nt(int dp, int d, int nblk) { return dp / 16 + std::max(0, (nblk - (dp - d) + 15) / 16); }
+bool rtzw_ok(int mt, int dp, int d, int nblk, int G) {
+    return mt >= 1 && mt <= 13 && dp % 16 == 0 && dp <= 208 && (mt > 7 || dp > 64) && rtzw_nt(dp, d, nblk) <= 2 * RTZW_WAVES &&
+           nblk <= 64 && (size_t)G * 16 * rtzw_nt(dp, d, nblk) * sizeof(double) <= 150 * 1024;
+}
+int rtzw_slab_floats(int mt, int dp, int d, int nblk) { return mt * rtzw_nt(dp, d, nblk) * 256; }
+
+template <int MT>
+static void launch_rtzw_t(const Rtz3Args& a, size_t sm, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rtzw<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_rtzw<MT>), dim3(a.ntasks), dim3(64 * RTZW_WAVES), sm, s, a);
+}
+
+int launch_rtzw(const Rtz3Args& a_in, int mt, int dp, int d, int nblk, hipStream_t s) {
+    if (!rtzw_ok(mt, dp, d, nblk, 1) || a_in.ntasks <= 0) return -1;
+    Rtz3Args a = a_in;
+    a.dp = dp; a.d = d; a.nt = rtzw_nt(dp, d, nblk);
+    const size_t sm = (size_t)RTZW_NBUF * (16 * (a.Kp + dp) + 4) * sizeof(float);
+    if (sm > 160 * 1024) return -1;
+    switch (mt) {
+        case 1: launch_rtzw_t<1>(a, sm, s); break;   case 2: launch_rtzw_t<2>(a, sm, s); break;
+        case 3: launch_rtzw_t<3>(a, sm, s); break;   case 4: launch_rtzw_t<4>(a, sm, s); break;
+        case 5: launch_rtzw_t<5>(a, sm, s); break;   case 6: launch_rtzw_t<6>(a, sm, s); break;
+        case 7: launch_rtzw_t<7>(a, sm, s); break;   case 8: launch_rtzw_t<8>(a, sm, s); break;
+        case 9: launch_rtzw_t<9>(a, sm, s); break;   case 10: launch_rtzw_t<10>(a, sm, s); break;
+        case 11: launch_rtzw_t<11>(a, sm, s); break; case 12: launch_rtzw_t<12>(a, sm, s); break;
+        default: launch_rtzw_t<13>(a, sm, s); break;
+    }
+    return 0;
 }
 
 void launch_tile_blocks(const int* cells, const int* tile_grp, const int* blk_start, int nblk, int64_t n_pos_upper, const int* gstart,

@@ -45,7 +45,7 @@ KMEANS_GATHER_CELLS = 2_000_000
 # Initial centroids (harmony.py:369-373).  "host": the reference's sklearn KMeans call on all cells
 # (bit-identical Y0; 18 s at 1M cells).  "device": k-means++ seeding on a subsample of
 # KMEANS_SEED_CELLS cells (~300 per cluster at K=100), then the 25 Lloyd iterations on the GPU over all cells (all ranks when
-# sharded; for K > 112 or d > 64 the Lloyd iterations run on the subsample with sklearn instead).
+# sharded).
 # "auto": host up to KMEANS_DEVICE_CELLS cells, device above.  Override: HMX_KMEANS.
 KMEANS = "auto"
 KMEANS_DEVICE_CELLS = 200_000
@@ -627,11 +627,7 @@ class Harmony:
         return self.K > 112 or self.d > 64
 
     def _device_kmeans(self, random_state):
-        """k-means++ seeding on a subsample (device), Lloyd iterations over all cells (device).
-
-        Wide shapes (``_wide_shape``): the Lloyd iterations run on the same subsample with sklearn on
-        the host instead -- seconds, where fitting all cells on the host takes minutes (160 s for
-        1.25M cells x 200 PCs, K=200)."""
+        """k-means++ seeding on a subsample (device), Lloyd iterations over all cells (device)."""
         if self.verbose:
             logger.info("Computing initial centroids: k-means++ seeding on a subsample, Lloyd iterations on the GPU "
                         "(not sklearn's fit on all cells: HMX_KMEANS=host selects that)...")
@@ -653,16 +649,12 @@ class Harmony:
             centers, _ = kmeans_plusplus(np.ascontiguousarray(sub, dtype=np.float32), n_clusters=self.K,
                                          random_state=random_state)
             centers = np.asarray(centers, dtype=np.float32)
-        if self._wide_shape() and sub is not None:
-            from sklearn.cluster import KMeans
-            model = KMeans(n_clusters=self.K, init=np.asarray(centers, dtype=np.float64), n_init=1, max_iter=25,
-                           random_state=random_state)
-            centers = np.asarray(model.fit(np.asarray(sub, dtype=np.float64)).cluster_centers_, dtype=np.float32)
         if self.shard is not None:
             centers = self.shard.broadcast_object(centers)
         self._lap("kmeans_seeds")
-        if not self._wide_shape():
-            centers = self._engine.kmeans_lloyd(centers, 25)                     # max_iter=25, harmony.py:371
+        # max_iter=25 (harmony.py:371) Lloyd iterations over ALL cells on the device -- wide shapes (K > 112 or d > 64) too:
+        # hard assignment as a one-hot R, member sums as the R^T.Z statistics of it (hmx_kmeans_lloyd)
+        centers = self._engine.kmeans_lloyd(centers, 25)
         self._lap("kmeans_lloyd")
         if self.verbose:
             logger.info("KMeans initialization complete.")

@@ -182,7 +182,9 @@ int hmx_kmeans_seed(hmx_engine* e, const float* points, int64_t n_points, uint64
  * jobs too large for that the caller seeds on a subsample and lets the engine run the Lloyd
  * iterations over all cells of Z_cos (Euclidean k-means, centroid = mean of its members, empty
  * clusters keep their centre; sums over all ranks when cells are sharded).  centers_in / centers_out:
- * K x d row-major; the result is what hmx_init_cluster takes as Y0. */
+ * K x d row-major; the result is what hmx_init_cluster takes as Y0.  Shapes with K > 112 or d > 64 use R as
+ * scratch (hard assignment as a one-hot R, member sums as the R^T.Z statistics of it): an assignment the engine
+ * held is void afterwards, hmx_init_cluster must follow. */
 int hmx_kmeans_lloyd(hmx_engine* e, const float* centers_in, int n_iter, float* centers_out);
 
 /* One pass of the loop body harmony.py:443-453.

@@ -498,10 +498,11 @@ def test_device_order_gives_equivalent_correction(monkeypatch):
 # ------------------------------------------------------------------------------------------
 # device-side Lloyd iterations of the initial k-means (hmx_kmeans_lloyd)
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("N,d,K", [(5000, 20, 12), (3333, 50, 100), (700, 7, 3)])
+@pytest.mark.parametrize("N,d,K", [(5000, 20, 12), (3333, 50, 100), (700, 7, 3), (2500, 80, 120), (1500, 30, 150), (4000, 200, 200)])
 def test_device_lloyd_matches_numpy_lloyd(N, d, K, monkeypatch):
     """Same seeds, same number of iterations: the GPU's Euclidean Lloyd iterations over Z_cos give
-    the centres of a plain NumPy restatement (argmax of z.c - |c|^2/2, mean of the members)."""
+    the centres of a plain NumPy restatement (argmax of z.c - |c|^2/2, mean of the members) -- the narrow shapes on
+    k_kmeans_step, K > 112 or d > 64 (BASELINE configs[4]'s regime) through the one-hot R and the streaming R^T.Z pass."""
     from harmonypy_amd import harmony as H
     rng = np.random.default_rng(K)
     cent = rng.normal(size=(K, d)) * 4.0
@@ -544,7 +545,7 @@ def test_device_kmeans_initialisation_end_to_end(monkeypatch):
 
 def test_device_kmeans_initialisation_wide_shapes(monkeypatch):
     """K > 112 / d > 64 (BASELINE config 5's regime): HMX_KMEANS=device seeds on the GPU and runs the Lloyd
-    iterations on the subsample instead of fitting all cells on the host; the run ends where the host-initialised
+    iterations over all cells on the GPU as well (no sklearn anywhere); the run ends where the host-initialised
     one does (objective within 2 %, embeddings correlated per PC)."""
     from scipy.stats import pearsonr
     rng = np.random.default_rng(5)
