@@ -419,54 +419,82 @@ __global__ __launch_bounds__(64 * RTZW_WAVES, 1) void k_rtzw(Rtz3Args a) {
     };
     for (int i = 0; i < RTZW_NBUF - 1 && i < n_tiles; ++i) issue(i);
 
-    for (int i = 0; i < n_tiles; ++i) {
-        // this wave's pieces of tile i have landed: younger are those of the (up to) two tiles behind it
+    // One stream of k-steps per wave, as in k_rtz3: the fragments of the next k-step are read while the 2 x MT MFMAs of the
+    // current one are in the matrix pipe; inside the last k-step of tile i the wave waits for its pieces of tile i+1,
+    // meets the others at the barrier ("tile i+1 is complete, nobody reads tile i any more" -- every wave's last reads of
+    // tile i returned before its last k-step began), hands tile i's buffer to tile i+4 and reads tile i+1's first
+    // fragments.  No branches in the stream: a wave without a second (or first) column tile multiplies zeros -- the SIMD
+    // that hosts it is not the busiest one anyway, and straight-line code is what lets the compiler overlap reads and MFMAs.
+    // (First version: barrier, requests, then per k-step "read fragments, multiply" behind `if (has tile)` branches: the
+    // eight waves left every barrier in lock-step and paid every LDS latency together -- 1.43 ms per pass at configs[4],
+    // slower than the kernel it replaces.)
+    float afr[2][MT];
+    float bq[2][2];
+    const int spare = DP - d;
+    auto wait_mine = [&](int i) {                                   // this wave's pieces of tile i have landed
         asm volatile("" ::: "memory");
         const int younger = min(RTZW_NBUF - 2, n_tiles - 1 - i) * npw;       // wave-uniform, one of a few values
         if (younger >= 8) wait_vmcnt<8>(); else if (younger == 6) wait_vmcnt<6>(); else if (younger == 4) wait_vmcnt<4>();
         else if (younger == 3) wait_vmcnt<3>(); else if (younger == 2) wait_vmcnt<2>(); else if (younger == 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
         asm volatile("" ::: "memory");
-        wg_barrier_lds();                                           // tile i is complete; nobody reads tile i-1 any more (the requests in flight keep travelling)
-        if (i + RTZW_NBUF - 1 < n_tiles) issue(i + RTZW_NBUF - 1);  // ... whose buffer goes to tile i+3
+    };
+    auto read_frags = [&](int i, int ks, int set, unsigned bwv) {
         const int c0 = c_first + 16 * stride * i;
-        float* Rt = lds + (size_t)(i % RTZW_NBUF) * buf_floats;
-        float* Zt = Rt + 16 * Kp;
-        const int n_live = min(16, c_end - c0);                     // workgroup-uniform; < 16 only in a group's last tile
-        const unsigned bw = reinterpret_cast<const unsigned*>(Zt + 16 * DP)[q];   // block ids of cells 4q .. 4q+3
-        const int spare = DP - d;
+        const float* Rt = lds + (size_t)(i % RTZW_NBUF) * buf_floats;
+        const float* Zt = Rt + 16 * Kp;
+        const int cell = 4 * q + ks;
+        const bool live = cell < c_end - c0;                        // rows past the group's end count for nothing
+        const float* rr = Rt + (size_t)cell * Kp;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const f32x4 v = ld4(rr + 64 * h + 4 * c16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) afr[set][4 * h + j] = live ? v[j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < REM; ++j) afr[set][4 * H + j] = live ? rr[64 * H + REM * c16 + j] : 0.f;
+        const int bid = (bwv >> (8 * ks)) & 255;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int nt = u ? nt1 : nt0;
+            const int col = 16 * min(nt, NTP - 1) + c16;            // (clamped: a read that is not used stays inside the tile)
+            const float z = Zt[(size_t)cell * DP + col];
+            const float pcv = (col < d) ? (live ? z : 0.f) : ((bid == col - d) ? 1.f : 0.f);   // PC column, or a block column in the row padding
+            const float blv = (bid == spare + 16 * (nt - NTP) + c16) ? 1.f : 0.f;               // a block column of the extra tiles
+            bq[set][u] = (nt >= NT) ? 0.f : (nt < NTP ? pcv : blv);
+        }
+    };
+    unsigned bw = 0, bw_next = 0;
+    if (n_tiles > 0) {
+        wait_mine(0);
+        wg_barrier_lds();
+        if (RTZW_NBUF - 1 < n_tiles) issue(RTZW_NBUF - 1);
+        bw_next = reinterpret_cast<const unsigned*>(lds + 16 * (Kp + DP))[q];
+        read_frags(0, 0, 0, bw_next);
+    }
+    for (int i = 0; i < n_tiles; ++i) {
+        bw = bw_next;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int cell = 4 * q + ks;
-            const bool live = cell < n_live;                        // rows past the group's end count for nothing
-            const float* rr = Rt + (size_t)cell * Kp;
-            float afr[MT];
+            const int set = ks & 1;
+            if (ks < 3) read_frags(i, ks + 1, set ^ 1, bw);
 #pragma unroll
-            for (int h = 0; h < H; ++h) {
-                const f32x4 v = ld4(rr + 64 * h + 4 * c16);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) afr[4 * h + j] = live ? v[j] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < REM; ++j) afr[4 * H + j] = live ? rr[64 * H + REM * c16 + j] : 0.f;
-            const int bid = (bw >> (8 * ks)) & 255;
-            auto bval = [&](int nt) {                               // B operand of column tile nt for this lane's column c16
-                if (nt < NTP) {
-                    const int col = 16 * nt + c16;
-                    const float z = Zt[(size_t)cell * DP + col];
-                    const float zv = live ? z : 0.f;                // (the slack behind the array may hold anything)
-                    return col < d ? zv : ((bid == col - d) ? 1.f : 0.f);
+            for (int mt = 0; mt < MT; ++mt) {
+                acc0[mt] = MFMA16(afr[set][mt], bq[set][0], acc0[mt]);
+                if (ks == 3 && mt == MT / 2) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (i + 1 < n_tiles) {
+                        wait_mine(i + 1);
+                        wg_barrier_lds();                           // tile i+1 is complete; nobody reads tile i any more
+                        if (i + RTZW_NBUF < n_tiles) issue(i + RTZW_NBUF);
+                        bw_next = reinterpret_cast<const unsigned*>(lds + (size_t)((i + 1) % RTZW_NBUF) * buf_floats + 16 * (Kp + DP))[q];
+                        read_frags(i + 1, 0, 0, bw_next);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                return (bid == spare + 16 * (nt - NTP) + c16) ? 1.f : 0.f;
-            };
-            const float b0 = has0 ? bval(nt0) : 0.f, b1 = has1 ? bval(nt1) : 0.f;
-            if (has0) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc0[mt] = MFMA16(afr[mt], b0, acc0[mt]);
             }
-            if (has1) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc1[mt] = MFMA16(afr[mt], b1, acc1[mt]);
-            }
+            for (int mt = 0; mt < MT; ++mt) acc1[mt] = MFMA16(afr[set][mt], bq[set][1], acc1[mt]);
         }
     }
     // every wave stores its own output tiles: slab [mt][nt][lane][r]
