@@ -75,7 +75,11 @@ __device__ __forceinline__ void wait_vmcnt() {   // gfx9 encoding: vmcnt[3:0] | 
 #ifdef HMX_RTZ3_PROF   /* timing experiments only: s_memtime stamps per wave */
 #define R3STAMP(k) do { if (lane == 0 && a.prof) a.prof[((size_t)blockIdx.x * RTZ3_WAVES + wv) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define R3ACC(k, v) do { if (lane == 0 && a.prof) a.prof[((size_t)blockIdx.x * RTZ3_WAVES + wv) * 8 + (k)] += (v); } while (0)
+#define R3STAMP8(k) do { if (lane == 0 && a.prof) a.prof[((size_t)blockIdx.x * 8 + wv) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define R3ACC8(k, v) do { if (lane == 0 && a.prof) a.prof[((size_t)blockIdx.x * 8 + wv) * 8 + (k)] += (v); } while (0)
 #else
+#define R3STAMP8(k) do { } while (0)
+#define R3ACC8(k, v) do { } while (0)
 #define R3STAMP(k) do { } while (0)
 #define R3ACC(k, v) do { } while (0)
 #endif
@@ -417,6 +421,7 @@ __global__ __launch_bounds__(64 * RTZW_WAVES, 1) void k_rtzw(Rtz3Args a) {
             }
         }
     };
+    R3STAMP8(0);
     for (int i = 0; i < RTZW_NBUF - 1 && i < n_tiles; ++i) issue(i);
 
     // One stream of k-steps per wave, as in k_rtz3: the fragments of the next k-step are read while the 2 x MT MFMAs of the
@@ -433,9 +438,20 @@ __global__ __launch_bounds__(64 * RTZW_WAVES, 1) void k_rtzw(Rtz3Args a) {
     const int spare = DP - d;
     auto wait_mine = [&](int i) {                                   // this wave's pieces of tile i have landed
         asm volatile("" ::: "memory");
+#ifdef HMX_RTZ3_PROF
+        const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
+#endif
         const int younger = min(RTZW_NBUF - 2, n_tiles - 1 - i) * npw;       // wave-uniform, one of a few values
         if (younger >= 8) wait_vmcnt<8>(); else if (younger == 6) wait_vmcnt<6>(); else if (younger == 4) wait_vmcnt<4>();
         else if (younger == 3) wait_vmcnt<3>(); else if (younger == 2) wait_vmcnt<2>(); else if (younger == 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
+#ifdef HMX_RTZ3_PROF
+        const unsigned long long w1_ = __builtin_amdgcn_s_memtime();
+        R3ACC8(4, w1_ - w0_);
+        wg_barrier_lds();
+        R3ACC8(6, __builtin_amdgcn_s_memtime() - w1_);
+#else
+        wg_barrier_lds();                                           // ... and everybody's: the tile is complete; nobody reads the tile before it any more
+#endif
         asm volatile("" ::: "memory");
     };
     auto read_frags = [&](int i, int ks, int set, unsigned bwv) {
@@ -443,35 +459,41 @@ __global__ __launch_bounds__(64 * RTZW_WAVES, 1) void k_rtzw(Rtz3Args a) {
         const float* Rt = lds + (size_t)(i % RTZW_NBUF) * buf_floats;
         const float* Zt = Rt + 16 * Kp;
         const int cell = 4 * q + ks;
-        const bool live = cell < c_end - c0;                        // rows past the group's end count for nothing
-        const float* rr = Rt + (size_t)cell * Kp;
+        const bool live = cell < c_end - c0;                        // rows past the group's end count for nothing:
+        const float lm = live ? 1.f : 0.f;                          // as a factor, not a select (a select invites the compiler to
+        const float* rr = Rt + (size_t)cell * Kp;                   // branch around the read and wait for it; the rows are finite)
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             const f32x4 v = ld4(rr + 64 * h + 4 * c16);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) afr[set][4 * h + j] = live ? v[j] : 0.f;
+            for (int j = 0; j < 4; ++j) afr[set][4 * h + j] = v[j] * lm;
         }
 #pragma unroll
-        for (int j = 0; j < REM; ++j) afr[set][4 * H + j] = live ? rr[64 * H + REM * c16 + j] : 0.f;
+        for (int j = 0; j < REM; ++j) afr[set][4 * H + j] = rr[64 * H + REM * c16 + j] * lm;
         const int bid = (bwv >> (8 * ks)) & 255;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
+            // B operand of this wave's column tile u for the lane's column c16: a PC column (Z value), a one-hot block column
+            // in the row padding of the last PC tile or in an extra tile, or nothing.  Written as z * mask + one-hot with the
+            // LDS read unconditional: as nested selects the compiler put the read under exec-mask branches and waited for
+            // it on the spot, eight times per tile (every row in LDS is finite, so z * 0 is 0).
             const int nt = u ? nt1 : nt0;
             const int col = 16 * min(nt, NTP - 1) + c16;            // (clamped: a read that is not used stays inside the tile)
             const float z = Zt[(size_t)cell * DP + col];
-            const float pcv = (col < d) ? (live ? z : 0.f) : ((bid == col - d) ? 1.f : 0.f);   // PC column, or a block column in the row padding
-            const float blv = (bid == spare + 16 * (nt - NTP) + c16) ? 1.f : 0.f;               // a block column of the extra tiles
-            bq[set][u] = (nt >= NT) ? 0.f : (nt < NTP ? pcv : blv);
+            const float m_pc = (nt < NTP && col < d && live) ? 1.f : 0.f;
+            const int blk_col = nt < NTP ? col - d : spare + 16 * (nt - NTP) + c16;   // block whose one-hot column this is (negative: none)
+            const float oh = (nt < NT && blk_col == bid && blk_col >= 0) ? 1.f : 0.f;
+            bq[set][u] = fmaf(z, m_pc, oh);
         }
     };
     unsigned bw = 0, bw_next = 0;
     if (n_tiles > 0) {
         wait_mine(0);
-        wg_barrier_lds();
         if (RTZW_NBUF - 1 < n_tiles) issue(RTZW_NBUF - 1);
         bw_next = reinterpret_cast<const unsigned*>(lds + 16 * (Kp + DP))[q];
         read_frags(0, 0, 0, bw_next);
     }
+    R3STAMP8(1);
     for (int i = 0; i < n_tiles; ++i) {
         bw = bw_next;
 #pragma unroll
@@ -484,8 +506,7 @@ __global__ __launch_bounds__(64 * RTZW_WAVES, 1) void k_rtzw(Rtz3Args a) {
                 if (ks == 3 && mt == MT / 2) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (i + 1 < n_tiles) {
-                        wait_mine(i + 1);
-                        wg_barrier_lds();                           // tile i+1 is complete; nobody reads tile i any more
+                        wait_mine(i + 1);                           // tile i+1 is complete; nobody reads tile i any more
                         if (i + RTZW_NBUF < n_tiles) issue(i + RTZW_NBUF);
                         bw_next = reinterpret_cast<const unsigned*>(lds + (size_t)((i + 1) % RTZW_NBUF) * buf_floats + 16 * (Kp + DP))[q];
                         read_frags(i + 1, 0, 0, bw_next);
@@ -497,6 +518,8 @@ __global__ __launch_bounds__(64 * RTZW_WAVES, 1) void k_rtzw(Rtz3Args a) {
             for (int mt = 0; mt < MT; ++mt) acc1[mt] = MFMA16(afr[set][mt], bq[set][1], acc1[mt]);
         }
     }
+    R3STAMP8(2);
+    R3ACC8(5, (unsigned long long)n_tiles);
     // every wave stores its own output tiles: slab [mt][nt][lane][r]
     float* slab = a.slab + (size_t)task * ((size_t)MT * NT * 256);
 #pragma unroll
@@ -751,6 +774,29 @@ static void launch_rtzw_t(const Rtz3Args& a, size_t sm, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rtzw<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
+#ifdef HMX_RTZ3_PROF
+    static unsigned long long* prof = nullptr;
+    static int calls = 0;
+    Rtz3Args b = a;
+    if (!prof) (void)hipMalloc(reinterpret_cast<void**>(&prof), (size_t)4096 * 8 * 8 * 8);
+    (void)hipMemsetAsync(prof, 0, (size_t)a.ntasks * 8 * 8 * 8, s);
+    b.prof = prof;
+    hipLaunchKernelGGL((k_rtzw<MT>), dim3(a.ntasks), dim3(64 * RTZW_WAVES), sm, s, b);
+    if (++calls == 12) {
+        std::vector<unsigned long long> h((size_t)a.ntasks * 8 * 8);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h.data(), prof, h.size() * 8, hipMemcpyDeviceToHost);
+        double pro = 0, loop = 0, wait = 0, bar = 0, tiles = 0;
+        const size_t nw = (size_t)a.ntasks * 8;
+        for (size_t w = 0; w < nw; ++w) {
+            const unsigned long long* r = &h[w * 8];
+            pro += (double)(r[1] - r[0]); loop += (double)(r[2] - r[1]); wait += (double)r[4]; bar += (double)r[6]; tiles += (double)r[5];
+        }
+        fprintf(stderr, "[k_rtzw prof] <%d> %d tasks: per wave: prologue %.0f, loop %.0f (%.0f per tile, %.1f tiles), waiting for own pieces %.0f per tile, at the barrier %.0f per tile\n",
+                MT, a.ntasks, pro / nw, loop / nw, loop / tiles, tiles / nw, wait / tiles, bar / tiles);
+    }
+    return;
+#endif
     hipLaunchKernelGGL((k_rtzw<MT>), dim3(a.ntasks), dim3(64 * RTZW_WAVES), sm, s, a);
 }
 
