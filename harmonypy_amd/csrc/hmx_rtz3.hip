@@ -433,8 +433,11 @@ __global__ __launch_bounds__(64 * RTZW_WAVES, 1) void k_rtzw(Rtz3Args a) {
     // (First version: barrier, requests, then per k-step "read fragments, multiply" behind `if (has tile)` branches: the
     // eight waves left every barrier in lock-step and paid every LDS latency together -- 1.43 ms per pass at configs[4],
     // slower than the kernel it replaces.)
+    // raw fragments of a k-step (two register sets) and what turns them into operands at USE time: the row-is-live factor,
+    // the PC-column masks and the one-hot values.  Masking at read time put a wait for the LDS data right behind every
+    // read -- and an in-order wave cannot issue the MFMAs queued behind that wait.
     float afr[2][MT];
-    float bq[2][2];
+    float zq[2][2], mq[2][2], oq[2][2], lmq[2];
     const int spare = DP - d;
     auto wait_mine = [&](int i) {                                   // this wave's pieces of tile i have landed
         asm volatile("" ::: "memory");
@@ -459,31 +462,28 @@ __global__ __launch_bounds__(64 * RTZW_WAVES, 1) void k_rtzw(Rtz3Args a) {
         const float* Rt = lds + (size_t)(i % RTZW_NBUF) * buf_floats;
         const float* Zt = Rt + 16 * Kp;
         const int cell = 4 * q + ks;
-        const bool live = cell < c_end - c0;                        // rows past the group's end count for nothing:
-        const float lm = live ? 1.f : 0.f;                          // as a factor, not a select (a select invites the compiler to
-        const float* rr = Rt + (size_t)cell * Kp;                   // branch around the read and wait for it; the rows are finite)
+        const bool live = cell < c_end - c0;                        // rows past the group's end count for nothing: a factor, not
+        lmq[set] = live ? 1.f : 0.f;                                // a select around the read (the rows in LDS are finite)
+        const float* rr = Rt + (size_t)cell * Kp;
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             const f32x4 v = ld4(rr + 64 * h + 4 * c16);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) afr[set][4 * h + j] = v[j] * lm;
+            for (int j = 0; j < 4; ++j) afr[set][4 * h + j] = v[j];
         }
 #pragma unroll
-        for (int j = 0; j < REM; ++j) afr[set][4 * H + j] = rr[64 * H + REM * c16 + j] * lm;
+        for (int j = 0; j < REM; ++j) afr[set][4 * H + j] = rr[64 * H + REM * c16 + j];
         const int bid = (bwv >> (8 * ks)) & 255;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             // B operand of this wave's column tile u for the lane's column c16: a PC column (Z value), a one-hot block column
-            // in the row padding of the last PC tile or in an extra tile, or nothing.  Written as z * mask + one-hot with the
-            // LDS read unconditional: as nested selects the compiler put the read under exec-mask branches and waited for
-            // it on the spot, eight times per tile (every row in LDS is finite, so z * 0 is 0).
+            // in the row padding of the last PC tile or in an extra tile, or nothing: z * mask + one-hot
             const int nt = u ? nt1 : nt0;
             const int col = 16 * min(nt, NTP - 1) + c16;            // (clamped: a read that is not used stays inside the tile)
-            const float z = Zt[(size_t)cell * DP + col];
-            const float m_pc = (nt < NTP && col < d && live) ? 1.f : 0.f;
+            zq[set][u] = Zt[(size_t)cell * DP + col];
+            mq[set][u] = (nt < NTP && col < d && live) ? 1.f : 0.f;
             const int blk_col = nt < NTP ? col - d : spare + 16 * (nt - NTP) + c16;   // block whose one-hot column this is (negative: none)
-            const float oh = (nt < NT && blk_col == bid && blk_col >= 0) ? 1.f : 0.f;
-            bq[set][u] = fmaf(z, m_pc, oh);
+            oq[set][u] = (nt < NT && blk_col == bid && blk_col >= 0) ? 1.f : 0.f;
         }
     };
     unsigned bw = 0, bw_next = 0;
@@ -499,10 +499,16 @@ __global__ __launch_bounds__(64 * RTZW_WAVES, 1) void k_rtzw(Rtz3Args a) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int set = ks & 1;
+            // operands of this k-step from the fragments read a whole k-step ago
+            float am[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) am[mt] = afr[set][mt] * lmq[set];
+            const float b0 = fmaf(zq[set][0], mq[set][0], oq[set][0]), b1 = fmaf(zq[set][1], mq[set][1], oq[set][1]);
+            __builtin_amdgcn_sched_barrier(0);
             if (ks < 3) read_frags(i, ks + 1, set ^ 1, bw);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                acc0[mt] = MFMA16(afr[set][mt], bq[set][0], acc0[mt]);
+                acc0[mt] = MFMA16(am[mt], b0, acc0[mt]);
                 if (ks == 3 && mt == MT / 2) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (i + 1 < n_tiles) {
@@ -515,7 +521,8 @@ __global__ __launch_bounds__(64 * RTZW_WAVES, 1) void k_rtzw(Rtz3Args a) {
                 }
             }
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc1[mt] = MFMA16(afr[set][mt], bq[set][1], acc1[mt]);
+            for (int mt = 0; mt < MT; ++mt) acc1[mt] = MFMA16(am[mt], b1, acc1[mt]);
+            __builtin_amdgcn_sched_barrier(0);                      // the next k-step's operands are formed after these MFMAs, not before
         }
     }
     R3STAMP8(2);
