@@ -321,8 +321,16 @@ class Engine:
         _check(load().hmx_comm_unique_id(buf))
         return buf.raw
 
-    def enable_timing(self, on=True):
-        _check(self._lib.hmx_enable_timing(self._h, int(on)))
+    def enable_timing(self, on=True, families=None):
+        """Bracket kernel launches with HIP events (``kernel_times``).  ``families``: names from ``KERNEL_FAMILIES`` to
+        bracket (default all): every bracketed launch costs two event records on the stream."""
+        if not on:
+            flag = 0
+        elif families is None:
+            flag = -1
+        else:
+            flag = sum(1 << KERNEL_FAMILIES.index(f) for f in families)
+        _check(self._lib.hmx_enable_timing(self._h, flag))
 
     def counters(self):
         """dict of the engine's event counters (hmx_counters)."""

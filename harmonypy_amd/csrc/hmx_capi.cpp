@@ -79,6 +79,7 @@ struct hmx_engine {
     int tiles_per_wave = 1;  // k_assign_lds grid sizing (HMX_TILES_PER_WAVE)
     hipStream_t stream = nullptr;
     bool uploaded = false, clustered = false, timing = false;
+    unsigned timing_mask = ~0u;  // kernel families that are bracketed with events while `timing` is on
 
     DevBuf<float> Zorig, Zcos, Zcorr, R, Y, Yacc, sigma, theta, Pr_b, lamb, rp, lrp, slab, W;
     DevBuf<int> group_cols, s_cells, s_tile_grp, task_t0, task_t1, task_grp;
@@ -250,7 +251,7 @@ struct Timed {
     hipEvent_t a = nullptr, b = nullptr;
     int fam;
     Timed(hmx_engine* e_, int fam_) : e(e_), fam(fam_) {
-        if (!e->timing) return;
+        if (!e->timing || !((e->timing_mask >> fam_) & 1u)) return;
         auto get = [&]() {
             hipEvent_t ev;
             if (!e->pool.empty()) { ev = e->pool.back(); e->pool.pop_back(); }
@@ -1784,6 +1785,7 @@ int hmx_enable_timing(hmx_engine* e, int on) {
     (void)hipStreamSynchronize(e->stream);
     drain_spans(e);
     e->timing = on != 0;
+    e->timing_mask = on < 0 ? ~0u : (unsigned)on;   // on > 0: bit f selects family f of hmx_kernel_times; on < 0: every family
     for (int i = 0; i < F_COUNT; ++i) { e->fam_ms[i] = 0; e->fam_n[i] = 0; }
     return HMX_OK;
 }

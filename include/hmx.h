@@ -238,8 +238,12 @@ int hmx_sync(hmx_engine* e);
 /* Device pointer of a state array (for callers that keep data resident). */
 int hmx_device_ptr(hmx_engine* e, int which, void** d_ptr, size_t* bytes);
 
-/* Average kernel time of the last call, per kernel family, measured with HIP events on
- * the engine's stream.  names_out receives a static NUL-separated list. */
+/* Kernel time per kernel family, measured with HIP events on the engine's stream while timing is on.
+ * hmx_enable_timing(e, on): on == 0 off; on < 0 every family; on > 0 a bit mask (bit f = family f in the order of
+ * names_out) -- every bracketed launch costs two event records on the stream (a few microseconds of queue time each: at C3 all
+ * families together slow a Harmony iteration by 11 %), so a caller that times a run brackets only what it reports.
+ * hmx_kernel_times: ms_out[2 f] = total milliseconds of family f, ms_out[2 f + 1] = launches; names_out receives a static
+ * NUL-separated list of the family names. */
 int hmx_kernel_times(hmx_engine* e, double* ms_out, int n, const char** names_out);
 int hmx_enable_timing(hmx_engine* e, int on);
 

@@ -1,0 +1,24 @@
+#!/bin/bash
+# SQ counters of the wide kernels (configs[4] shard): where the waves' cycles go
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+rm -rf gpurun_out/pmc_sq_c5 gpurun_out/pmc_sq2_c5
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --kernel-trace -d gpurun_out/pmc_sq_c5 -o p --output-format csv -- python bench.py --config c5 --steps 1 --warmup 1 --cpu-sample 0 --no-roofline --no-convergence > gpurun_out/pmc_sq_c5.json 2> gpurun_out/pmc_sq_c5.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d gpurun_out/pmc_sq2_c5 -o p --output-format csv -- python bench.py --config c5 --steps 1 --warmup 1 --cpu-sample 0 --no-roofline --no-convergence > gpurun_out/pmc_sq2_c5.json 2> gpurun_out/pmc_sq2_c5.err
+python - <<'PY'
+import csv, glob, collections, os
+for d0 in ("gpurun_out/pmc_sq_c5", "gpurun_out/pmc_sq2_c5"):
+    files = glob.glob(d0 + "/**/*counter_collection.csv", recursive=True)
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"][:44]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    with open(d0 + "_summary.txt", "w") as out:
+        for k, d in sorted(agg.items(), key=lambda kv: -sum(sum(v) for v in kv[1].values()))[:5]:
+            mean = {c: sum(v) / len(v) for c, v in d.items()}
+            line = f"{k:44s} n={len(next(iter(d.values()))):4d} " + " ".join(f"{c}={mean[c]:.4g}" for c in sorted(mean))
+            print(line); out.write(line + "\n")
+    for f in files:
+        if os.path.getsize(f) > 4_000_000: os.remove(f)
+PY
+find gpurun_out -name '*kernel_trace.csv' -size +4M -delete

@@ -76,6 +76,74 @@ __global__ __launch_bounds__(512, 1) void k2(float* out, unsigned long long* cyc
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
+// k_rtzw's k-step: 13 A operands (3 x ds_read_b128 + 1 x ds_read_b32, masked by a factor at use time), 2 B operands
+// (ds_read_b32, fma), 2 x 13 MFMAs on two accumulator sets; the next k-step's reads are issued before the MFMAs.
+// BAR: a workgroup barrier every 4 k-steps (k_rtzw's tile boundary).
+template <bool BAR>
+__global__ __launch_bounds__(512, 1) void k3(float* out, unsigned long long* cyc, int iters) {
+    __shared__ __attribute__((aligned(16))) float lds[8 * 64 * 24];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* my = lds + wv * 64 * 24;
+    for (int i = 0; i < 24; ++i) my[i * 64 + lane] = 1e-3f * (lane + i);
+    __syncthreads();
+    f32x4 acc0[13], acc1[13];
+    for (int i = 0; i < 13; ++i) { acc0[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    float raw[2][13], zr[2][2];
+    auto rd = [&](int set, int it) {
+        const float* p = my + ((it & 3) * 64);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + 4 * (lane & 15)), v1 = *reinterpret_cast<const f32x4*>(p + 256 + 4 * (lane & 15)),
+                    v2 = *reinterpret_cast<const f32x4*>(p + 512 + 4 * (lane & 15));
+        for (int j = 0; j < 4; ++j) { raw[set][j] = v0[j]; raw[set][4 + j] = v1[j]; raw[set][8 + j] = v2[j]; }
+        raw[set][12] = p[768 + lane];
+        zr[set][0] = p[832 + lane]; zr[set][1] = p[896 + lane];
+    };
+    rd(0, 0);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it0 = 0; it0 < iters; it0 += 4) {
+#pragma unroll
+      for (int u4 = 0; u4 < 4; ++u4) {
+        const int it = it0 + u4;
+        const int set = u4 & 1;
+        float am[13];
+        const float lm = (lane + it) & 1024 ? 0.f : 1.f;
+        for (int i = 0; i < 13; ++i) am[i] = raw[set][i] * lm;
+        const float b0 = fmaf(zr[set][0], lm, 0.f), b1 = fmaf(zr[set][1], lm, 1.f);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(set ^ 1, it + 1);
+#pragma unroll
+        for (int i = 0; i < 13; ++i) acc0[i] = MFMA16(am[i], b0, acc0[i]);
+#pragma unroll
+        for (int i = 0; i < 13; ++i) acc1[i] = MFMA16(am[i], b1, acc1[i]);
+        if (BAR && u4 == 3) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int i = 0; i < 13; ++i) s += acc0[i][0] + acc0[i][1] + acc0[i][2] + acc0[i][3] + acc1[i][0] + acc1[i][1] + acc1[i][2] + acc1[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+template <bool BAR>
+void run3(const char* name, int iters) {
+    const int threads = 512, wgs = 256;
+    float* out; unsigned long long* cyc;
+    hipMalloc(&out, (size_t)wgs * threads * 4); hipMalloc(&cyc, 8);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k3<BAR>), dim3(wgs), dim3(threads), 0, 0, out, cyc, 16);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k3<BAR>), dim3(wgs), dim3(threads), 0, 0, out, cyc, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+    const double mfma_per_simd = (double)iters * 26 * 2;
+    printf("%-60s %6.1f cycles per MFMA per SIMD slot | %6.2f ns | clock %.2f GHz | %.1f TF\n", name, (double)c / ((double)iters * 26) / 2,
+           ms * 1e6 / mfma_per_simd, (double)c / (ms * 1e6), 256.0 * 4 * mfma_per_simd * 2048 / (ms * 1e-3) / 1e12);
+    hipFree(out); hipFree(cyc);
+}
+
 template <int MODE>
 void run2(const char* name, int iters) {
     const int threads = 512, wgs = 256;
@@ -128,5 +196,7 @@ int main() {
     run2<1>("7x5 tiles, operands re-read from LDS per k-step", it);
     run2<2>("7x5 tiles, LDS re-read + compare/select B operands", it);
     run2<3>("7x5 tiles, exec-masked branchy asm block every 11 MFMAs", it);
+    run3<false>("k_rtzw k-step: 16 LDS reads, 13 mul, 2 x 13 MFMAs", 4 * it);
+    run3<true>("k_rtzw k-step + workgroup barrier every 4 k-steps", 4 * it);
     return 0;
 }
