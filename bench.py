@@ -77,6 +77,7 @@ def resolve_workload(config, gpus):
         return config, JOB_CELLS[config] // gpus, "strong"
     return config, CONFIGS[config][0], "weak"
 
+TIMED_LAUNCH_STRIDE = 4   # the dominant kernel's launches bracketed with HIP events inside the timed region: every 4th
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense (= the f32 vector rate)
 
@@ -236,9 +237,12 @@ def roofline_block(config, N, d, B, K, ktimes, steps, rounds, wide, ktimes_all=N
     HBM-bound, algorithmic bytes per cell 4d + 4K + 4 (Z_cos row, R row, list entry).
     C5 (wide shapes): k_assign_wide, one launch per update block: f32-MFMA-bound, 2 d K flop per cell."""
     import harmonypy_amd
-    tot, cnt = ktimes.get("assign_block", (0.0, 0))
-    per_launch_ms = tot / max(cnt, 1)
+    tot, cnt_timed = ktimes.get("assign_block", (0.0, 0))
+    per_launch_ms = tot / max(cnt_timed, 1)
     n_rounds = steps * rounds
+    # launches of the family in the timed region (the events bracket every TIMED_LAUNCH_STRIDE-th of them): from the
+    # one-step pass that bracketed everything
+    cnt = (ktimes_all["assign_block"][1] * steps) if ktimes_all and "assign_block" in ktimes_all else cnt_timed * TIMED_LAUNCH_STRIDE
     sweep = cnt <= n_rounds          # one launch per update_R sweep; else one launch per block
     cells_per_launch = N if sweep else N / 20.0
     fam_ms = {k: round(v[0], 3) for k, v in ktimes.items()}
@@ -255,7 +259,7 @@ def roofline_block(config, N, d, B, K, ktimes, steps, rounds, wide, ktimes_all=N
         roof = {"bound": "mfma", "kernel": "k_assign_wide (one launch per update block; K > 112 or d > 64)",
                 "achieved": achieved, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TF,
                 "traffic": None, "traffic_source": "not collected for this configuration",
-                "avg_launch_us": per_launch_ms * 1e3, "launches": cnt, "algorithmic_flops_per_launch": flops}
+                "avg_launch_us": per_launch_ms * 1e3, "launches": cnt, "launches_timed": cnt_timed, "algorithmic_flops_per_launch": flops}
     else:
         alg_bytes = cells_per_launch * (4 * d + 4 * K + 4)
         achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
@@ -272,7 +276,7 @@ def roofline_block(config, N, d, B, K, ktimes, steps, rounds, wide, ktimes_all=N
                         traffic = rec["hbm_bytes_corrected"]
         roof = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "avg_launch_us": per_launch_ms * 1e3, "launches": cnt, "algorithmic_bytes_per_launch": alg_bytes}
+                "avg_launch_us": per_launch_ms * 1e3, "launches": cnt, "launches_timed": cnt_timed, "algorithmic_bytes_per_launch": alg_bytes}
     round_bytes = N * (4 * d + 8 * K + 8)
     roof["round"] = {
         "algorithmic_bytes": round_bytes, "kernel_ms_per_round": t_round_kernels,
@@ -409,7 +413,8 @@ def main():
         ho._engine.enable_timing(True)
         step()
         ktimes_all = ho._engine.kernel_times()
-        ho._engine.enable_timing(True, families=["assign_block"])
+        # ... and of its launches every fourth: a pair of event records costs ~15 us of queue time, 5 % of a C3 round
+        ho._engine.enable_timing(True, families=["assign_block"], stride=TIMED_LAUNCH_STRIDE)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -26,7 +26,7 @@ EXPORTS = [
     "hmx_last_error", "hmx_abi_version", "hmx_create", "hmx_destroy", "hmx_upload", "hmx_init_cluster",
     "hmx_cluster_round", "hmx_cluster_round_seeded", "hmx_moe_correct_ridge", "hmx_get", "hmx_set", "hmx_sync", "hmx_device_ptr",
     "hmx_kernel_times", "hmx_enable_timing", "hmx_counters", "hmx_comm_unique_id", "hmx_comm_init", "hmx_set_host_allreduce",
-    "hmx_build_id", "hmx_has_sweep_kernel", "hmx_cluster", "hmx_kmeans_lloyd", "hmx_kmeans_seed", "hmx_compute_lisi", "hmx_get_rows", "hmx_set_ranks", "hmx_peer_export", "hmx_peer_attach", "hmx_peer_selftest", "hmx_peer_enable",
+    "hmx_build_id", "hmx_has_sweep_kernel", "hmx_cluster", "hmx_set_timing_stride", "hmx_kmeans_lloyd", "hmx_kmeans_seed", "hmx_compute_lisi", "hmx_get_rows", "hmx_set_ranks", "hmx_peer_export", "hmx_peer_attach", "hmx_peer_selftest", "hmx_peer_enable",
 ]
 HMX_PEER_HANDLE_BYTES = 64
 HMX_ABI_VERSION = 5
@@ -92,6 +92,7 @@ def load():
     lib.hmx_kernel_times.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_char_p)]
     lib.hmx_counters.argtypes = [vp, vp]
     lib.hmx_enable_timing.argtypes = [vp, C.c_int]
+    lib.hmx_set_timing_stride.argtypes = [vp, C.c_int]
     for name in EXPORTS:
         if name not in ("hmx_last_error", "hmx_destroy", "hmx_build_id"):
             getattr(lib, name).restype = C.c_int
@@ -321,9 +322,11 @@ class Engine:
         _check(load().hmx_comm_unique_id(buf))
         return buf.raw
 
-    def enable_timing(self, on=True, families=None):
+    def enable_timing(self, on=True, families=None, stride=1):
         """Bracket kernel launches with HIP events (``kernel_times``).  ``families``: names from ``KERNEL_FAMILIES`` to
-        bracket (default all): every bracketed launch costs two event records on the stream."""
+        bracket (default all); ``stride``: only every stride-th launch of a family.  Every bracketed launch costs two
+        event records on the stream."""
+        _check(self._lib.hmx_set_timing_stride(self._h, int(stride)))
         if not on:
             flag = 0
         elif families is None:

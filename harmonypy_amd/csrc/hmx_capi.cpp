@@ -80,6 +80,8 @@ struct hmx_engine {
     hipStream_t stream = nullptr;
     bool uploaded = false, clustered = false, timing = false;
     unsigned timing_mask = ~0u;  // kernel families that are bracketed with events while `timing` is on
+    int timing_stride = 1;       // ... every timing_stride-th launch of a family
+    long fam_seen[8] = {0};      // launches of a family since timing was switched on (bracketed or not)
 
     DevBuf<float> Zorig, Zcos, Zcorr, R, Y, Yacc, sigma, theta, Pr_b, lamb, rp, lrp, slab, W;
     DevBuf<int> group_cols, s_cells, s_tile_grp, task_t0, task_t1, task_grp;
@@ -252,6 +254,7 @@ struct Timed {
     int fam;
     Timed(hmx_engine* e_, int fam_) : e(e_), fam(fam_) {
         if (!e->timing || !((e->timing_mask >> fam_) & 1u)) return;
+        if ((e->fam_seen[fam_]++ % e->timing_stride) != 0) return;
         auto get = [&]() {
             hipEvent_t ev;
             if (!e->pool.empty()) { ev = e->pool.back(); e->pool.pop_back(); }
@@ -1786,7 +1789,13 @@ int hmx_enable_timing(hmx_engine* e, int on) {
     drain_spans(e);
     e->timing = on != 0;
     e->timing_mask = on < 0 ? ~0u : (unsigned)on;   // on > 0: bit f selects family f of hmx_kernel_times; on < 0: every family
-    for (int i = 0; i < F_COUNT; ++i) { e->fam_ms[i] = 0; e->fam_n[i] = 0; }
+    for (int i = 0; i < F_COUNT; ++i) { e->fam_ms[i] = 0; e->fam_n[i] = 0; e->fam_seen[i] = 0; }
+    return HMX_OK;
+}
+
+int hmx_set_timing_stride(hmx_engine* e, int stride) {
+    if (!e || stride < 1) return fail(HMX_ERR_ARG, "stride must be >= 1");
+    e->timing_stride = stride;
     return HMX_OK;
 }
 

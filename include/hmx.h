@@ -246,6 +246,9 @@ int hmx_device_ptr(hmx_engine* e, int which, void** d_ptr, size_t* bytes);
  * NUL-separated list of the family names. */
 int hmx_kernel_times(hmx_engine* e, double* ms_out, int n, const char** names_out);
 int hmx_enable_timing(hmx_engine* e, int on);
+/* Bracket only every stride-th launch of a timed family (default 1: every launch): a uniform sample of the launches,
+ * for callers whose timed loop must not carry the event records of every launch. */
+int hmx_set_timing_stride(hmx_engine* e, int stride);
 
 /* Event counters of the engine since hmx_create: out[0] collectives issued (sharded jobs), out[1] rounds whose
  * persistent sweep kernel gave up on a grid-wide wait and were repeated block by block (harmony.py:464-513 has no
