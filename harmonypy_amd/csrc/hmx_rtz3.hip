@@ -573,9 +573,9 @@ __global__ __launch_bounds__(RTZ3_FIN_THREADS) void k_rtz3_finish(Rtz3FinishArgs
         const size_t off = (size_t)(mt * NT + nt) * 256 + (size_t)(16 * (m >> 2) + n) * 4 + (m & 3);   // [tile][lane][r]: row m = 4 q + r, column n
         int g = -1;
         double acc = 0.0;
-        // the slab reads are latency-bound: eight independent loads in flight per thread (clamped, not predicated: a
+        // the slab reads are latency-bound: sixteen independent loads in flight per thread (clamped, not predicated: a
         // select on the loaded value keeps them one batch), then folded in task order (tasks are sorted by group)
-        constexpr int BATCH = 8;
+        constexpr int BATCH = 16;
         for (int w0 = sl; w0 < a.ntasks; w0 += BATCH * nslice) {
             float val[BATCH];
             int grp[BATCH];
