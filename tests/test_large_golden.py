@@ -89,7 +89,7 @@ def test_oracle_vs_reference_large(name):
     oo.ridge_dtype = np.dtype(np.float64)
     oo.moe_correct_ridge()
     rel3, max3, _, _, _ = check_z(name, oo.result()[rows], g, "oracle ridge_dtype=float64")
-    assert rel3 <= 1e-4 and max3 <= 1e-4
+    assert rel3 <= 2e-6 and max3 <= 2e-6                     # measured 3e-8 .. 1.2e-7 (R entering the ridge differs by 1e-6)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -108,5 +108,7 @@ def test_engine_vs_reference_large(name, monkeypatch):
     obj = {k: getattr(ho, k) for k in ("objective_kmeans", "objective_kmeans_dist", "objective_kmeans_entropy", "objective_kmeans_cross")}
     relR = check_pre_ridge(name, R[rows], R.astype(np.float64).sum(axis=0), ho.O, ho.E, obj, g)
     rel3, max3, rel1, max1, noise = check_z(name, ho.Z_corr[rows], g, f"engine (R relF={relR:.1e})")
-    assert rel3 <= 1e-4 and max3 <= 1e-4, f"{name}: Z_corr vs the reference's float64 ridge relF={rel3:.2e} max={max3:.2e}"
+    # measured 5e-8 .. 1.4e-7; the bar is the size of the R difference entering the ridge (1e-6), far below the 1e-4 of the
+    # small goldens and below the reference's own 1-vs-8-thread spread of (i)
+    assert rel3 <= 2e-6 and max3 <= 2e-6, f"{name}: Z_corr vs the reference's float64 ridge relF={rel3:.2e} max={max3:.2e}"
     assert rel1 <= max(1e-4, 3 * noise) and max1 <= max(1e-4, 3 * noise), f"{name}: Z_corr vs the plain reference relF={rel1:.2e}"
