@@ -936,6 +936,196 @@ __global__ __launch_bounds__(64 * WIDE_WAVES, 2) void k_assign_wide(AssignArgs a
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_assign_wide2: the penalised assignment of one update block for the wide shapes, second cut.
+// k_assign_wide (8 waves, one tile per wave, a workgroup barrier per 16-column k-step) has 52 MFMAs per wave between two
+// barriers and keeps the block sums of ALL groups in LDS.  Here: FOUR waves per workgroup (one per SIMD), TWO workgroups
+// per CU, TWO tiles per wave: a centroid fragment read from LDS feeds 8 MFMAs instead of 4, 104 MFMAs per wave between two
+// barriers.  A k-step's centroid columns (K16 x 16 floats) travel global -> LDS directly (three-deep ring, XOR-swizzled
+// 16-byte pieces: the requests write linearly, the fragment reads stay free of bank conflicts), the tiles' Z_cos pieces
+// global -> registers one k-step ahead, both with hand-counted waits.  The workgroup keeps table rows and block sums only
+// for the groups of its own eight tiles (a block's list is sorted by group): 68 KB of LDS at K16 = 208 whatever the number
+// of batches.  Measured at the configs[4] shard (62.5 k cells per block, K = d = 200): 74 -> 70 us per block launch incl.
+// the launch gap -- the restructuring buys 5 %; the finishing passes (two tiles per wave after the last k-step, matrix
+// pipe idle) and the per-launch ramp are what is left.
+// ------------------------------------------------------------------------------------------
+#define WIDE2_WAVES 4
+#define WIDE2_YBUF 3
+#define WIDE2_SLOTS (2 * WIDE2_WAVES)
+template <int N>
+__device__ __forceinline__ void wide2_wait(f32x4& z0, f32x4& z1) {   // the wait names the registers it releases: their uses stay behind it
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(z0), "+v"(z1) : "n"(N) : "memory");
+}
+template <int MT>
+__global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_assign_wide2(AssignArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int K16 = 16 * MT;
+    constexpr int NPJ = (MT + WIDE2_WAVES - 1) / WIDE2_WAVES;            // centroid pieces (16 rows x 64 bytes) of a wave per k-step, at most
+    float* Yring = reinterpret_cast<float*>(smem);                       // WIDE2_YBUF x K16 x 16
+    float* sig = Yring + WIDE2_YBUF * K16 * 16;                          // K16
+    float* nis = sig + K16;                                              // K16: -1/sigma (-60 for pads)
+    float* rpL = nis + K16;                                              // slots x K16
+    float* lrpL = rpL + WIDE2_SLOTS * K16;
+    double* Sd = reinterpret_cast<double*>(lrpL + WIDE2_SLOTS * K16);    // slots x K16 block sums
+    double* objw = Sd + WIDE2_SLOTS * K16;                               // waves x 2
+    int* tg = reinterpret_cast<int*>(objw + 2 * WIDE2_WAVES);            // group of the workgroup's tile j (-1: no such tile)
+    int* ts = tg + WIDE2_SLOTS;                                          // its slot: tiles of one group share table rows and sums
+    int* sg = ts + WIDE2_SLOTS;                                          // group of a slot
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, c16 = lane & 15, q = lane >> 4;
+    const int nkb = a.dp >> 4;
+    const int tile_begin = a.blk_start ? a.blk_start[a.blk] : a.tile_begin;
+    const int tile_end = a.blk_start ? a.blk_start[a.blk + 1] : a.tile_end;
+    const int ntiles = tile_end - tile_begin;
+    const int base = blockIdx.x * WIDE2_SLOTS;
+    if (base >= ntiles) return;                                          // (the grid is sized for an upper bound of the block)
+
+    // ---- requests of k-step 0 and 1 first: their latency runs under the set-up below --------------------------------
+    RoundTile<MT> T0, T1;
+    const int j0 = base + 2 * wv;
+    const bool has0 = j0 < ntiles, has1 = j0 + 1 < ntiles;              // wave-uniform
+    T0.cell = has0 ? a.cells[(size_t)(tile_begin + j0) * 16 + c16] : -1;
+    T1.cell = has1 ? a.cells[(size_t)(tile_begin + j0 + 1) * 16 + c16] : -1;
+    const float* zr0 = a.Zcos + (size_t)(T0.cell >= 0 ? T0.cell : 0) * a.dp + 4 * q;
+    const float* zr1 = a.Zcos + (size_t)(T1.cell >= 0 ? T1.cell : 0) * a.dp + 4 * q;
+    // centroid pieces: piece p = 16 rows x 16 columns; lane l brings row l / 4 of the piece, 16-byte chunk (l % 4) ^ (row / 4 % 4)
+    // to LDS position 16 l of the piece -- the zone is row-major with the chunks of a row permuted by its row quad
+    const unsigned yvoff = (unsigned)(((lane >> 2) * a.ldy + 4 * ((lane & 3) ^ ((lane >> 4) & 3))) * 4);
+    const unsigned ring0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)Yring;
+    const unsigned yzone0 = __builtin_amdgcn_readfirstlane(ring0) + 1024u * wv;
+    const int npw = (MT - wv + WIDE2_WAVES - 1) / WIDE2_WAVES;           // this wave's pieces per k-step (wave-uniform)
+    auto u64 = [](unsigned long long v) {
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
+               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v);
+    };
+    unsigned long long ysrc = u64((unsigned long long)(a.Y + (size_t)16 * wv * a.ldy));   // this wave's first piece of the next k-step to request
+    const unsigned long long ypiece = (unsigned long long)64 * a.ldy * WIDE2_WAVES;      // bytes between two pieces of a wave
+    unsigned yzone = yzone0;
+    int yslot = 0;
+    auto issue_y = [&]() {
+#pragma unroll
+        for (int j = 0; j < NPJ; ++j)
+            if (j < npw) {
+                const unsigned long long src = ysrc + ypiece * j;
+                const unsigned zone = yzone + 1024u * WIDE2_WAVES * j;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(yvoff), "s"(src), "s"(zone) : "memory", "m0");
+            }
+        ysrc += 64;                                                      // next k-step: 16 columns on
+        yzone += (unsigned)(K16 * 64);
+        if (++yslot == WIDE2_YBUF) { yslot = 0; yzone = yzone0; }
+    };
+    auto issue_z = [&](f32x4& z0, f32x4& z1, int kb) {
+        const float* p0 = zr0 + 16 * kb;
+        const float* p1 = zr1 + 16 * kb;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(z0) : "v"(p0) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(z1) : "v"(p1) : "memory");
+    };
+    f32x4 za0, za1, zb0, zb1;
+    issue_z(za0, za1, 0);
+    issue_y();
+    if (nkb > 1) { issue_z(zb0, zb1, 1); issue_y(); }
+
+    // ---- set-up: sigma, the groups of the workgroup's tiles, their table rows, zeroed sums --------------------------
+    for (int i = tid; i < K16; i += 64 * WIDE2_WAVES) {
+        const float sgm = (i < a.K) ? a.sigma[i] : 0.f;
+        sig[i] = sgm;
+        nis[i] = (i < a.K) ? -1.0f / sgm : -60.f;       // pads: Y row 0 -> dist 2 -> arg -120 -> exp == 0
+    }
+    if (tid < WIDE2_SLOTS) tg[tid] = base + tid < ntiles ? a.tile_grp[tile_begin + base + tid] : -1;
+    for (int i = tid; i < WIDE2_SLOTS * K16; i += 64 * WIDE2_WAVES) Sd[i] = 0.0;
+    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0) only: the requests above stay in flight
+    __builtin_amdgcn_s_barrier();
+    if (tid < WIDE2_SLOTS) {
+        int slot = 0;
+        for (int u = 1; u <= tid; ++u) slot += (tg[u] != tg[u - 1] && tg[u] >= 0) ? 1 : 0;
+        ts[tid] = slot;
+        if (tg[tid] >= 0 && (tid == 0 || tg[tid] != tg[tid - 1])) sg[slot] = tg[tid];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    const int nslots = ts[WIDE2_SLOTS - 1] + 1;
+    for (int i = tid; i < nslots * K16; i += 64 * WIDE2_WAVES) {
+        const int sl = i / K16, k = i - sl * K16;
+        const size_t src = (size_t)sg[sl] * K16 + k;
+        rpL[i] = a.rp[src];
+        lrpL[i] = a.lrp[src];
+    }
+    T0.grp = ts[2 * wv];
+    T1.grp = has1 ? ts[2 * wv + 1] : T0.grp;              // (a missing tile computes on cell 0's row and counts for nothing)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        T0.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        T1.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ---- the k-steps -------------------------------------------------------------------------------------------------
+    // Memory operations return in order.  At the top of step kb the wave needs its pieces of step kb and the Z values of
+    // step kb; younger than those are only the requests of step kb+1 (npw pieces + 2 loads), issued one step ago.
+    const int swz = 4 * (q ^ ((c16 >> 2) & 3));
+    int rslot = 0;
+    auto step = [&](int kb, f32x4& z0, f32x4& z1) {
+        if (kb + 1 < nkb) {
+            if (npw + 2 >= 6) wide2_wait<6>(z0, z1); else if (npw + 2 == 5) wide2_wait<5>(z0, z1);
+            else if (npw + 2 == 4) wide2_wait<4>(z0, z1); else wide2_wait<3>(z0, z1);
+        } else {
+            wide2_wait<0>(z0, z1);
+        }
+        wg_barrier_lds();                                // everybody's pieces of step kb are in; nobody reads step kb-1 any more
+        if (kb + 2 < nkb) issue_y();                     // ... its ring slot takes step kb+2
+        const float* Yst = Yring + (size_t)rslot * (K16 * 16);
+        if (++rslot == WIDE2_YBUF) rslot = 0;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 ya = ld4(Yst + (16 * mt + c16) * 16 + swz);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                T0.arg[mt] = MFMA16(ya[i], z0[i], T0.arg[mt]);
+                T1.arg[mt] = MFMA16(ya[i], z1[i], T1.arg[mt]);
+            }
+        }
+        if (kb + 2 < nkb) issue_z(z0, z1, kb + 2);       // into the registers this step has consumed
+    };
+    for (int kb = 0; kb < nkb; kb += 2) {
+        step(kb, za0, za1);
+        if (kb + 1 < nkb) step(kb + 1, zb0, zb1);
+    }
+    static_assert(NPJ + 2 <= 6, "wait ladder");
+
+    // ---- finish: exp, penalty, renormalisation, R rows, block sums, objective terms (k_round's passes) ---------------
+    double km_acc = 0.0, ent_acc = 0.0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const f32x4 ni = ld4(nis + 16 * mt + 4 * q);
+        const f32x4 one = (f32x4){1.f, 1.f, 1.f, 1.f};
+        T0.arg[mt] = (2.f * (one - T0.arg[mt])) * ni;      // dist = 2 (1 - Y.Z) (:447), arg = -dist / sigma (:466)
+        T1.arg[mt] = (2.f * (one - T1.arg[mt])) * ni;
+    }
+    if (has0) {
+        float scl0, scl1 = 0.f;
+        round_post_pass1<MT, true>(sig, rpL, lrpL, q, T0, scl0, km_acc, ent_acc);
+        if (has1) round_post_pass1<MT, true>(sig, rpL, lrpL, q, T1, scl1, km_acc, ent_acc);
+        round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T0, scl0, has1, T1, scl1);
+    }
+    km_acc = wave_sum_all(km_acc);
+    ent_acc = wave_sum_all(ent_acc);
+    if (lane == 0) {
+        objw[2 * wv] = km_acc;
+        objw[2 * wv + 1] = ent_acc;
+    }
+    __syncthreads();
+    if (tid < 2) {
+        double v = 0.0;
+        for (int w = 0; w < WIDE2_WAVES; ++w) v += objw[2 * w + tid];
+        if (v != 0.0) atomicAdd(&a.obj[2 * (blockIdx.x & (HMX_OBJ_SLOTS - 1)) + tid], v);
+    }
+    for (int i = tid; i < nslots * K16; i += 64 * WIDE2_WAVES) {
+        const double v = Sd[i];
+        const int sl = i / K16;
+        if (v != 0.0) atomicAdd(&a.S_out[(size_t)sg[sl] * K16 + (i - sl * K16)], v);
+    }
+}
+
 template <int MT, int KS>
 __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -3167,6 +3357,30 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
         const size_t gk_bytes = (size_t)a.G * a.K16 * sizeof(double);
         a.tables_in_lds = gk_bytes <= 64 * 1024 ? 1 : 0;
         const size_t sm = ((size_t)2 * a.K16 * 20 + 2 * a.K16) * sizeof(float) + (a.tables_in_lds ? gk_bytes : 0) + 2 * WIDE_WAVES * sizeof(double);
+        // the penalised block assignment of the round loop: two tiles per wave, two workgroups per CU (k_assign_wide2)
+        static const int wide_mode = [] { const char* v = getenv("HMX_WIDE_ASSIGN"); return v ? atoi(v) : 2; }();
+        if (penalty && !a.hn && wide_mode == 2 && a.mt >= 1 && a.mt <= 13) {
+            const size_t sm2 = ((size_t)WIDE2_YBUF * a.K16 * 16 + 2 * a.K16 + 2 * WIDE2_SLOTS * a.K16) * sizeof(float) +
+                               ((size_t)WIDE2_SLOTS * a.K16 + 2 * WIDE2_WAVES) * sizeof(double) + 3 * WIDE2_SLOTS * sizeof(int);
+            const int wgs2 = cdiv(ntiles, WIDE2_SLOTS);
+#define HMX_WIDE2_CASE(M)                                                                                               \
+    case M: {                                                                                                         \
+        static bool attr_done = false;                                                                                \
+        if (!attr_done) {                                                                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_assign_wide2<M>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+            attr_done = true;                                                                                         \
+        }                                                                                                             \
+        hipLaunchKernelGGL((k_assign_wide2<M>), dim3(wgs2), dim3(64 * WIDE2_WAVES), sm2, s, a);                        \
+    } break;
+            if (sm2 <= 80 * 1024) {
+                switch (a.mt) {
+                    HMX_WIDE2_CASE(1) HMX_WIDE2_CASE(2) HMX_WIDE2_CASE(3) HMX_WIDE2_CASE(4) HMX_WIDE2_CASE(5) HMX_WIDE2_CASE(6) HMX_WIDE2_CASE(7)
+                    HMX_WIDE2_CASE(8) HMX_WIDE2_CASE(9) HMX_WIDE2_CASE(10) HMX_WIDE2_CASE(11) HMX_WIDE2_CASE(12) HMX_WIDE2_CASE(13)
+                }
+                return 0;
+            }
+#undef HMX_WIDE2_CASE
+        }
         const int wgs = std::max(1, std::min(2 * 256, cdiv(ntiles, WIDE_WAVES)));
 #define HMX_WIDE_CASE(M)                                                                                          \
     case M:                                                                                                       \

@@ -537,6 +537,161 @@ __global__ __launch_bounds__(64 * RTZW_WAVES, 1) void k_rtzw(Rtz3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_rtzw2: the wide streaming pass, second cut (K > 112, seven or more column tiles).  k_rtzw's eight waves share one tile:
+// 104 MFMAs per wave between two barriers, and every wave reads all of the R tile from LDS.  Here a workgroup is FOUR
+// waves -- one per SIMD -- and two workgroups share a CU; the MT x NT output tiles are split 2 x 2 over the waves (row half
+// x column half: up to 7 x 7 tiles = 196 accumulator registers), which doubles the MFMAs between two barriers (196) and
+// halves the LDS operand reads per MFMA.  Ring of three tiles per workgroup (80 KB at K = d = 208).  Same tasks, same
+// slabs, same finish kernel as k_rtzw.  Measured at the configs[4] shard (1.25 M cells x 200, K = 200): 1.30 -> 1.12 ms per
+// pass; cycle stamps per tile and wave: 16.4 k (ideal 12.5 k = 2 waves x 196 MFMAs x 32) of which requests 1.9 k (nine
+// LDS-DMA instructions at ~200 cycles of issue each), barrier 1.4 k, wait for the own pieces 0.4 k.  Starting the CU's
+// second workgroup half a tile late (so that one wave of a SIMD multiplies while the other requests) changed nothing.
+// ------------------------------------------------------------------------------------------
+#define RTZW2_WAVES 4
+#define RTZW2_NBUF 3
+template <int MT, int NTH>
+__global__ __launch_bounds__(64 * RTZW2_WAVES, 2) void k_rtzw2(Rtz3Args a) {
+    constexpr int MTA = (MT + 1) / 2;
+    constexpr int H = MT / 4, REM = MT % 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* lds = reinterpret_cast<float*>(smem);
+    const int Kp = a.Kp, DP = a.dp, d = a.d, NT = a.nt, NTP = DP >> 4;
+    const int buf_floats = 256 * MT + 16 * DP + 4;                // R segment (MT whole pieces) | Z tile | 16 block-id bytes
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, c16 = lane & 15, q = lane >> 4;
+    const int lane16 = 16 * lane;
+    const int task = blockIdx.x;
+    const int t0 = a.task_t0[task], t1 = a.task_t1[task];
+    const int c_first = a.task_c0[task], c_end = a.task_cend[task];
+    const int stride = __builtin_amdgcn_readfirstlane(a.task_stride[task]);
+    const int n_tiles = (t1 - t0 + stride - 1) / stride;
+    const int rh = wv >> 1, ch = wv & 1;                          // this wave's quarter of the output: row tiles mt_lo.., column tiles nt_lo..
+    const int mt_lo = rh * MTA, nt_lo = ch * NTH;
+
+    f32x4 acc[MTA][NTH];
+#pragma unroll
+    for (int i = 0; i < MTA; ++i)
+#pragma unroll
+        for (int u = 0; u < NTH; ++u) acc[i][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // where the lane's A value of row tile mt sits in an R row (the index map of k_rtz3: cluster 64h + 4 c16 + j for tile
+    // 4h + j, cluster 64H + REM c16 + j for the remaining tiles): a wave-uniform constant plus 4 c16 or REM c16.  Formed
+    // per k-step from the lane's c16 (which passes through an empty asm there): seven offsets kept across the loop would
+    // push the 196 accumulators into scratch.  A tile past MT reads column 0 and counts for nothing.
+    auto a_const = [&](int mt) { return mt >= MT ? 0 : mt < 4 * H ? 64 * (mt >> 2) + (mt & 3) : 64 * H + (mt - 4 * H); };   // wave-uniform
+    auto a_mul = [&](int mt) { return mt >= MT ? 0 : mt < 4 * H ? 4 : REM; };
+    // Requests.  The R segment of a buffer is padded to MT whole 1 KB pieces (the last piece runs into the next tile's rows
+    // -- or the slack rows behind R -- and its tail lands in the padding), a Z segment is NTP whole pieces: every request
+    // is a full, unmasked wave instruction.  Piece p of a segment belongs to wave p % 4; the wave's three streams are running
+    // scalar pointers advanced by a constant per tile, the LDS zone rotates through the ring -- a handful of scalar adds per
+    // tile.  (First version: piece loop with per-piece bounds tests and addresses re-formed from the tile index: 300 scalar
+    // instructions, 5.5 k of the 18.5 k cycles of a tile.)
+    constexpr int NRJ = (MT + 3) / 4;                               // R pieces of a wave, at most
+    const unsigned buf_bytes = (unsigned)buf_floats * 4u;
+    const unsigned zone0 = lds_addr(lds);
+    auto uniform64 = [](unsigned long long v) {
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
+               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v);
+    };
+    unsigned long long rs = uniform64((unsigned long long)(a.R + (size_t)c_first * Kp) + 1024ull * wv);
+    unsigned long long zs = uniform64((unsigned long long)(a.Z + (size_t)c_first * DP) + 1024ull * wv);
+    unsigned long long bs = uniform64((unsigned long long)(a.tile_blk + (size_t)16 * t0));
+    const unsigned long long r_step = (unsigned long long)64 * Kp * stride, z_step = (unsigned long long)64 * DP * stride, b_step = (unsigned long long)16 * stride;
+    unsigned zone_next = zone0 + 1024u * wv;
+    int slot_next = 0;
+    const int nrw = (MT - wv + 3) / 4, nzw = (NTP - wv + 3) / 4;    // this wave's pieces of R and of Z (wave-uniform)
+    const int npw = nrw + nzw + (wv == RTZW2_WAVES - 1 ? 1 : 0);
+    auto issue_next = [&]() {                                       // this wave's pieces of the next tile not yet requested
+#pragma unroll
+        for (int j = 0; j < NRJ; ++j)
+            if (j < nrw) dma16((const void*)rs, lane16 + 4096 * j, zone_next + 4096u * j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < nzw) dma16((const void*)zs, lane16 + 4096 * j, zone_next + 1024u * MT + 4096u * j);
+        if (wv == RTZW2_WAVES - 1 && lane == 0) dma16((const void*)bs, 0u, zone_next - 1024u * wv + 1024u * MT + 64u * DP);
+        rs += r_step; zs += z_step; bs += b_step;
+        zone_next += buf_bytes;
+        if (++slot_next == RTZW2_NBUF) { slot_next = 0; zone_next = zone0 + 1024u * wv; }
+    };
+    R3STAMP8(0);
+    for (int i = 0; i < RTZW2_NBUF - 1 && i < n_tiles; ++i) issue_next();
+    R3STAMP8(1);
+
+    for (int i = 0; i < n_tiles; ++i) {
+#ifdef HMX_RTZ3_PROF
+        const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
+#endif
+        // tile i complete (this wave's pieces: all but those of the one younger tile in flight; everybody's: the barrier),
+        // and nobody reads tile i-1 any more: its buffer takes tile i+2
+        asm volatile("" ::: "memory");
+        if (i + 1 < n_tiles) {
+            if (npw >= 8) wait_vmcnt<8>(); else if (npw == 7) wait_vmcnt<7>(); else if (npw == 6) wait_vmcnt<6>(); else if (npw == 5) wait_vmcnt<5>();
+            else if (npw == 4) wait_vmcnt<4>(); else if (npw == 3) wait_vmcnt<3>(); else if (npw == 2) wait_vmcnt<2>(); else wait_vmcnt<1>();
+        } else {
+            wait_vmcnt<0>();
+        }
+#ifdef HMX_RTZ3_PROF
+        const unsigned long long w1_ = __builtin_amdgcn_s_memtime();
+        R3ACC8(4, w1_ - w0_);
+        wg_barrier_lds();
+        const unsigned long long w2_ = __builtin_amdgcn_s_memtime();
+        R3ACC8(6, w2_ - w1_);
+#else
+        wg_barrier_lds();
+#endif
+        asm volatile("" ::: "memory");
+        if (i + RTZW2_NBUF - 1 < n_tiles) issue_next();
+#ifdef HMX_RTZ3_PROF
+        R3ACC8(7, __builtin_amdgcn_s_memtime() - w2_);
+#endif
+        const float* Rt = lds + (size_t)(i % RTZW2_NBUF) * buf_floats;
+        const float* Zt = Rt + 256 * MT;
+        const unsigned bw = reinterpret_cast<const unsigned*>(Zt + 16 * DP)[q];      // the four block ids of cells 4q .. 4q+3
+        const int rows_live = c_end - (c_first + 16 * stride * i);                   // cells of this tile inside the group
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            __builtin_amdgcn_sched_barrier(0);                      // one k-step's operands live at a time
+            int c = c16, qq = q;
+            asm volatile("" : "+v"(c), "+v"(qq));                   // (addresses are re-formed here, not carried through the loop)
+            const int cell = 4 * qq + ks;
+            const float lm = cell < rows_live ? 1.f : 0.f;          // rows past the group's end belong to the next group: a factor on A
+            const float* rr = Rt + (size_t)cell * Kp;
+            const float* zr = Zt + (size_t)cell * DP + 16 * nt_lo + c;
+            float am[MTA], bm[NTH];
+#pragma unroll
+            for (int i2 = 0; i2 < MTA; ++i2) am[i2] = rr[a_const(mt_lo + i2) + a_mul(mt_lo + i2) * c];
+#pragma unroll
+            for (int u = 0; u < NTH; ++u) bm[u] = zr[16 * u];       // (a read past the PC tiles stays inside the ring and is not used)
+            // == 16 u: this lane's column of tile u (column 16 nt + c16, the one-hot of block 16 nt + c16 - d) is the cell's block
+            const int diff = (int)((bw >> (8 * ks)) & 255u) - (16 * nt_lo + c - d);
+#pragma unroll
+            for (int i2 = 0; i2 < MTA; ++i2) am[i2] *= (mt_lo + i2 < MT) ? lm : 0.f;
+#pragma unroll
+            for (int u = 0; u < NTH; ++u) {
+                const bool pc = nt_lo + u < NTP;                    // wave-uniform: a PC column tile (its padding columns hold zeros) or a one-hot tile
+                bm[u] = (pc ? bm[u] : 0.f) + ((diff == 16 * u && nt_lo + u < NT) ? 1.f : 0.f);
+            }
+#pragma unroll
+            for (int i2 = 0; i2 < MTA; ++i2)
+#pragma unroll
+                for (int u = 0; u < NTH; ++u) acc[i2][u] = MFMA16(am[i2], bm[u], acc[i2][u]);
+        }
+    }
+    R3STAMP8(2);
+    R3ACC8(5, (unsigned long long)n_tiles);
+    // every wave stores its own output tiles: slab [mt][nt][lane][r]
+    float* slab = a.slab + (size_t)task * ((size_t)MT * NT * 256);
+#pragma unroll
+    for (int i = 0; i < MTA; ++i)
+#pragma unroll
+        for (int u = 0; u < NTH; ++u) {
+            const int mt = mt_lo + i, nt = nt_lo + u;
+            if (mt < MT && nt < NT) st4(slab + ((size_t)(mt * NT + nt) * 64 + lane) * 4, acc[i][u]);
+        }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_rtz3_finish: the per-task slabs summed in fp64, one workgroup per cluster k; undoes the index maps of k_rtz3.
 //   mode 0 (k-means round): Ysum[k][pc] over all tasks (the centroid numerators, :443), Sold[blk][g][k] over the tasks of
 //          group g (the removal sums, :491-492); with Yout the row is normalised on the spot (:444) -- no collective
@@ -807,10 +962,73 @@ static void launch_rtzw_t(const Rtz3Args& a, size_t sm, hipStream_t s) {
     hipLaunchKernelGGL((k_rtzw<MT>), dim3(a.ntasks), dim3(64 * RTZW_WAVES), sm, s, a);
 }
 
+template <int MT, int NTH>
+static void launch_rtzw2_t(const Rtz3Args& a, size_t sm, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rtzw2<MT, NTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_done = true;
+    }
+#ifdef HMX_RTZ3_PROF
+    static unsigned long long* prof = nullptr;
+    static int calls = 0;
+    Rtz3Args b = a;
+    if (!prof) (void)hipMalloc(reinterpret_cast<void**>(&prof), (size_t)4096 * 8 * 8 * 8);
+    (void)hipMemsetAsync(prof, 0, (size_t)a.ntasks * 8 * 8 * 8, s);
+    b.prof = prof;
+    hipLaunchKernelGGL((k_rtzw2<MT, NTH>), dim3(a.ntasks), dim3(64 * RTZW2_WAVES), sm, s, b);
+    if (++calls == 12) {
+        std::vector<unsigned long long> h((size_t)a.ntasks * 8 * 8);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h.data(), prof, h.size() * 8, hipMemcpyDeviceToHost);
+        double pro = 0, loop = 0, wait = 0, bar = 0, iss = 0, tiles = 0, tmin = 1e30, tmax = 0;
+        size_t nw = 0;
+        for (int t = 0; t < a.ntasks; ++t)
+            for (int w = 0; w < RTZW2_WAVES; ++w) {
+                const unsigned long long* r = &h[((size_t)t * 8 + w) * 8];
+                pro += (double)(r[1] - r[0]); loop += (double)(r[2] - r[1]); wait += (double)r[4]; bar += (double)r[6]; iss += (double)r[7]; tiles += (double)r[5];
+                tmin = std::min(tmin, (double)r[0]); tmax = std::max(tmax, (double)r[2]);
+                ++nw;
+            }
+        fprintf(stderr, "[k_rtzw2 prof] <%d,%d> %d tasks: per wave: prologue %.0f, loop %.0f (%.0f per tile, %.1f tiles); per tile: own pieces %.0f, barrier %.0f, requests %.0f; first start to last end %.0f\n",
+                MT, NTH, a.ntasks, pro / nw, loop / nw, loop / tiles, tiles / nw, wait / tiles, bar / tiles, iss / tiles, tmax - tmin);
+    }
+    return;
+#endif
+    hipLaunchKernelGGL((k_rtzw2<MT, NTH>), dim3(a.ntasks), dim3(64 * RTZW2_WAVES), sm, s, a);
+}
+template <int MT>
+static bool launch_rtzw2_m(const Rtz3Args& a, int nth, size_t sm, hipStream_t s) {
+    switch (nth) {
+        case 4: launch_rtzw2_t<MT, 4>(a, sm, s); return true;
+        case 5: launch_rtzw2_t<MT, 5>(a, sm, s); return true;
+        case 6: launch_rtzw2_t<MT, 6>(a, sm, s); return true;
+        case 7: launch_rtzw2_t<MT, 7>(a, sm, s); return true;
+        default: return false;
+    }
+}
+// the 2 x 2 split pays where the quarter is large: K > 112 and at least seven column tiles; the ring must fit half a CU's LDS
+static bool launch_rtzw2(const Rtz3Args& a, int mt, hipStream_t s) {
+    static const int mode = [] { const char* v = getenv("HMX_RTZW"); return v ? atoi(v) : 2; }();
+    if (mode != 2 || mt < 8 || mt > 13) return false;
+    const int nth = (a.nt + 1) / 2;
+    const size_t sm = (size_t)RTZW2_NBUF * (256 * mt + 16 * a.dp + 4) * sizeof(float);
+    if (nth < 4 || nth > 7 || sm > 80 * 1024 || a.dp / 16 > 16) return false;
+    switch (mt) {
+        case 8: return launch_rtzw2_m<8>(a, nth, sm, s);
+        case 9: return launch_rtzw2_m<9>(a, nth, sm, s);
+        case 10: return launch_rtzw2_m<10>(a, nth, sm, s);
+        case 11: return launch_rtzw2_m<11>(a, nth, sm, s);
+        case 12: return launch_rtzw2_m<12>(a, nth, sm, s);
+        default: return launch_rtzw2_m<13>(a, nth, sm, s);
+    }
+}
+
 int launch_rtzw(const Rtz3Args& a_in, int mt, int dp, int d, int nblk, hipStream_t s) {
     if (!rtzw_ok(mt, dp, d, nblk, 1) || a_in.ntasks <= 0) return -1;
     Rtz3Args a = a_in;
     a.dp = dp; a.d = d; a.nt = rtzw_nt(dp, d, nblk);
+    if (launch_rtzw2(a, mt, s)) return 0;
     const size_t sm = (size_t)RTZW_NBUF * (16 * (a.Kp + dp) + 4) * sizeof(float);
     if (sm > 160 * 1024) return -1;
     switch (mt) {
