@@ -670,10 +670,11 @@ int hmx_compute_lisi(int32_t device_id, const double* X, int64_t n, int32_t d, c
     if (d < 1 || d > 208) return fail(HMX_ERR_ARG, "d must be in [1, 208]");
     if (n_labels < 1) return fail(HMX_ERR_ARG, "n_labels must be >= 1");
     const int nn = (int)(perplexity * 3);                                     // lisi.py:53
-    // the float32 pass keeps the LISI_KEEP best candidates of a query for the exact float64 ranking: 8 of them are
-    // slack for rank inversions of the approximation at the boundary (lisi.py:53 itself takes any perplexity)
-    if (!(perplexity > 0) || nn < 2 || nn > LISI_KEEP - 8)
-        return fail(HMX_ERR_ARG, "perplexity: 3*perplexity must lie in [2, %d] neighbours in this build (got %d)", LISI_KEEP - 8, nn);
+    // the float32 pass keeps the best cap / 2 candidates of a query for the exact float64 ranking: 8 of them are slack for
+    // rank inversions of the approximation at the boundary; three list sizes (lisi.py:53 itself takes any perplexity)
+    const int cap = (perplexity > 0 && nn >= 2) ? lisi_list_cap(nn) : 0;
+    if (cap == 0)
+        return fail(HMX_ERR_ARG, "perplexity: 3*perplexity must lie in [2, %d] neighbours in this build (got %d)", LISI_MAX_NEIGHBOURS, nn);
     if (nn > n) return fail(HMX_ERR_ARG, "Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld", nn, (long long)n);
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -692,7 +693,7 @@ int hmx_compute_lisi(int32_t device_id, const double* X, int64_t n, int32_t d, c
     } guard{X64, sums, out, kd, X32, cn, lists, counts, labels, ki};
     int rc;
     if ((rc = X64.reserve((size_t)n * d)) || (rc = sums.reserve(d)) || (rc = out.reserve((size_t)n * n_labels)) ||
-        (rc = X32.reserve((size_t)npad * dp)) || (rc = cn.reserve(npad)) || (rc = lists.reserve((size_t)npad * LISI_CAP)) ||
+        (rc = X32.reserve((size_t)npad * dp)) || (rc = cn.reserve(npad)) || (rc = lists.reserve((size_t)npad * cap)) ||
         (rc = counts.reserve(n)) || (rc = labels.reserve((size_t)n * n_labels)))
         return rc;
     if (knn_dist_out && ((rc = kd.reserve((size_t)n * M)) || (rc = ki.reserve((size_t)n * M)))) return rc;
@@ -701,7 +702,7 @@ int hmx_compute_lisi(int32_t device_id, const double* X, int64_t n, int32_t d, c
     HIP_TRY(hipMemcpyAsync(labels.p, label_codes, (size_t)n * n_labels * sizeof(int), hipMemcpyHostToDevice, s));
     launch_lisi_prepare(X64.p, n, npad, d, dp, sums.p, X32.p, cn.p, s);
     LisiKnnArgs ka{};
-    ka.X = X32.p; ka.cn = cn.p; ka.n = n; ka.npad = npad; ka.dp = dp; ka.lists = lists.p; ka.counts = counts.p;
+    ka.X = X32.p; ka.cn = cn.p; ka.n = n; ka.npad = npad; ka.dp = dp; ka.lists = lists.p; ka.counts = counts.p; ka.cap = cap;
 #ifdef LISI_PROF
     DevBuf<unsigned long long> prof;
     if ((rc = prof.reserve(8))) return rc;
@@ -720,7 +721,7 @@ int hmx_compute_lisi(int32_t device_id, const double* X, int64_t n, int32_t d, c
     }
 #endif
     LisiFinishArgs fa{};
-    fa.X = X64.p; fa.n = n; fa.d = d; fa.nn = nn; fa.n_labels = n_labels; fa.lists = lists.p; fa.counts = counts.p;
+    fa.X = X64.p; fa.n = n; fa.d = d; fa.nn = nn; fa.n_labels = n_labels; fa.lists = lists.p; fa.counts = counts.p; fa.cap = cap;
     fa.labels = labels.p; fa.perplexity = perplexity; fa.tol = 1e-5;         // lisi.py:75
     fa.out = out.p; fa.knn_dist = kd.p; fa.knn_idx = ki.p;
     launch_lisi_finish(fa, s);

@@ -233,16 +233,16 @@ size_t peer_box_doubles(int n_ranks, size_t GK);
 void launch_peer_selftest(double* const* peer_box, double* my_box, int n_ranks, int rank, size_t GK, unsigned long long token,
                           unsigned* result, hipStream_t s);
 // LISI (hmx_lisi.hip)
-#define LISI_CAP 256          // entries of a query's candidate list
-#define LISI_KEEP 128         // survivors of a list compaction = candidates of the exact ranking
 #define LISI_KNN_WAVES 4
-#define LISI_FIN_WAVES 4
+#define LISI_MAX_NEIGHBOURS (2048 - 8)   /* 3 * perplexity of the largest candidate-list size */
 struct LisiKnnArgs {
     const float* X;                 // npad x dp centred float32 rows (zero padded)
     const float* cn;                // npad squared norms, +inf for padding rows
     int64_t n, npad;
     int dp;
-    unsigned long long* lists;      // npad x LISI_CAP (order bits of the key << 32 | candidate)
+    int cap;                        // entries of a query's candidate list: 256, 1024 or 4096 (lisi_list_cap); the best cap / 2 survive a
+                                    // compaction and are ranked exactly in float64 (8 of them are slack for rank inversions of float32)
+    unsigned long long* lists;      // npad x cap (order bits of the key << 32 | candidate)
     int* counts;                    // n: entries of the final, sorted list
     unsigned long long* prof;       // cycle sums per loop segment (LISI_PROF builds), else null
 };
@@ -250,6 +250,7 @@ struct LisiFinishArgs {
     const double* X;                // n x d float64 input
     int64_t n;
     int d, nn, n_labels;            // nn = neighbours asked of the search (the cell itself included)
+    int cap;                        // as LisiKnnArgs.cap
     const unsigned long long* lists;
     const int* counts;
     const int* labels;              // n_labels x n category codes
@@ -260,6 +261,7 @@ struct LisiFinishArgs {
 };
 void launch_lisi_prepare(const double* X, int64_t n, int64_t npad, int d, int dp, double* sums, float* X32, float* cn, hipStream_t s);
 int launch_lisi_knn(const LisiKnnArgs& a, hipStream_t s);
+int lisi_list_cap(int nn);          // 0: more neighbours than the largest list ranks
 void launch_lisi_finish(const LisiFinishArgs& a, hipStream_t s);
 
 // k-means++ seeding on the device (k_seed_*): n points of d floats, row-major X and its transpose Xt

@@ -75,12 +75,13 @@ __global__ __launch_bounds__(256) void k_lisi_center(const double* __restrict__ 
     if (l16 == 0) cn[row] = row < n ? ss : __builtin_inff();
 }
 
-// ---- wave-level bitonic sort of 256 keys in LDS (ascending) ------------------------------------
-__device__ __forceinline__ void wave_sort256(unsigned long long* scr, int lane) {
-    for (int k = 2; k <= 256; k <<= 1) {
+// ---- wave-level bitonic sort of N keys in LDS (ascending), N / 128 compare-exchanges per lane and step ---------
+template <int N>
+__device__ __forceinline__ void wave_sort(unsigned long long* scr, int lane) {
+    for (int k = 2; k <= N; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < N / 128; ++h) {
                 const int p = lane + 64 * h;
                 const int i = ((p / j) * 2 * j) + (p % j);
                 const int l = i + j;
@@ -93,16 +94,20 @@ __device__ __forceinline__ void wave_sort256(unsigned long long* scr, int lane) 
     }
 }
 
-template <int KS16, int QT>
-__global__ __launch_bounds__(64 * LISI_KNN_WAVES, 3) void k_lisi_knn(LisiKnnArgs a) {
-    __shared__ unsigned long long scr_all[LISI_KNN_WAVES][LISI_CAP];
+// Candidate lists come in three sizes (CAP entries, the best CAP / 2 kept by a compaction and ranked exactly afterwards):
+// 256 for 3 * perplexity <= 120 neighbours (the reference's default is 90), 1024 up to 504, 4096 up to 2040.  The large
+// sizes keep the sort scratch in dynamic LDS (32 KB / 128 KB per workgroup) and so run fewer workgroups per CU.
+template <int KS16, int QT, int CAP>
+__global__ __launch_bounds__(64 * LISI_KNN_WAVES, CAP == 256 ? 3 : 1) void k_lisi_knn(LisiKnnArgs a) {
+    constexpr int KEEP = CAP / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned long long scr_all[];   // waves x CAP
     __shared__ int cnt_all[LISI_KNN_WAVES][16 * QT];
     __shared__ float tau_all[LISI_KNN_WAVES][16 * QT];
     constexpr int LDW = 16 * KS16 + 4;                       // padded row: conflict-free 16-byte fragment reads
     __shared__ __attribute__((aligned(16))) float stage[2][16 * LDW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c16 = lane & 15, q = lane >> 4;
-    unsigned long long* scr = scr_all[wv];
+    unsigned long long* scr = scr_all + (size_t)wv * CAP;
     int* cnt = cnt_all[wv];
     float* tau = tau_all[wv];
     const int64_t qbase = ((int64_t)blockIdx.x * LISI_KNN_WAVES + wv) * (16 * QT);   // < npad: npad is a multiple of 256
@@ -118,20 +123,20 @@ __global__ __launch_bounds__(64 * LISI_KNN_WAVES, 3) void k_lisi_knn(LisiKnnArgs
 #pragma unroll
     for (int t = 0; t < QT; ++t) th[t] = __builtin_inff();
 
-    // sort one query's list, keep the best LISI_KEEP, tighten its threshold
+    // sort one query's list, keep the best KEEP, tighten its threshold
     auto compact = [&](int slot) {
         const int c = cnt[slot];
-        unsigned long long* lst = a.lists + (size_t)(qbase + slot) * LISI_CAP;
-#pragma unroll
-        for (int h = 0; h < LISI_CAP / 64; ++h) { const int i = lane + 64 * h; scr[i] = i < c ? ld_l2(lst + i) : ~0ull; }
+        unsigned long long* lst = a.lists + (size_t)(qbase + slot) * CAP;
+#pragma unroll 4
+        for (int h = 0; h < CAP / 64; ++h) { const int i = lane + 64 * h; scr[i] = i < c ? ld_l2(lst + i) : ~0ull; }
         wave_fence();
-        wave_sort256(scr, lane);
-        const int keep = min(c, LISI_KEEP);
-#pragma unroll
-        for (int h = 0; h < LISI_KEEP / 64; ++h) { const int i = lane + 64 * h; if (i < keep) lst[i] = scr[i]; }
+        wave_sort<CAP>(scr, lane);
+        const int keep = min(c, KEEP);
+#pragma unroll 4
+        for (int h = 0; h < KEEP / 64; ++h) { const int i = lane + 64 * h; if (i < keep) lst[i] = scr[i]; }
         if (lane == 0) {
             cnt[slot] = keep;
-            if (c >= LISI_KEEP) tau[slot] = order_float((unsigned)(scr[LISI_KEEP - 1] >> 32));
+            if (c >= KEEP) tau[slot] = order_float((unsigned)(scr[KEEP - 1] >> 32));
         }
         wave_fence();
     };
@@ -216,16 +221,16 @@ __global__ __launch_bounds__(64 * LISI_KNN_WAVES, 3) void k_lisi_knn(LisiKnnArgs
                 const int t = j >> 2, r = j & 3;
                 const int slot = atomicAdd(&cnt[16 * t + c16], 1);
                 const unsigned long long ent = ((unsigned long long)order_bits(kv) << 32) | (unsigned)(16 * tile + 4 * q + r);
-                unsigned long long* dst = a.lists + (size_t)(qbase + 16 * t + c16) * LISI_CAP + slot;
+                unsigned long long* dst = a.lists + (size_t)(qbase + 16 * t + c16) * CAP + slot;
                 asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(ent) : "memory");
-                full |= slot >= LISI_CAP - 16;                          // the list now holds more than CAP-16 entries
+                full |= slot >= CAP - 16;                          // the list now holds more than CAP-16 entries
             }
         }
         if (__any(full)) {
             wave_fence();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the list entries are in L2
             for (int slot = 0; slot < 16 * QT; ++slot)
-                if (cnt[slot] > LISI_CAP - 16) compact(slot);           // wave-uniform
+                if (cnt[slot] > CAP - 16) compact(slot);           // wave-uniform
 #pragma unroll
             for (int t = 0; t < QT; ++t) th[t] = tau[16 * t + c16];
         }
@@ -296,24 +301,26 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-__global__ __launch_bounds__(64 * LISI_FIN_WAVES) void k_lisi_finish(LisiFinishArgs a) {
-    __shared__ unsigned long long key_all[LISI_FIN_WAVES][LISI_KEEP];
-    __shared__ int idx_all[LISI_FIN_WAVES][LISI_KEEP];
-    __shared__ double p_all[LISI_FIN_WAVES][LISI_KEEP];
-    __shared__ int lab_all[LISI_FIN_WAVES][LISI_KEEP];
+template <int KEEP, int FW>
+__global__ __launch_bounds__(64 * FW) void k_lisi_finish(LisiFinishArgs a) {
+    constexpr int NH = KEEP / 64;                                       // list positions per lane
+    __shared__ unsigned long long key_all[FW][KEEP];
+    __shared__ int idx_all[FW][KEEP];
+    __shared__ double p_all[FW][KEEP];
+    __shared__ int lab_all[FW][KEEP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t cell = (int64_t)blockIdx.x * LISI_FIN_WAVES + wv;
+    const int64_t cell = (int64_t)blockIdx.x * FW + wv;
     if (cell >= a.n) return;
     unsigned long long* key = key_all[wv];
     int* idx = idx_all[wv];
     double* P = p_all[wv];
     int* lab = lab_all[wv];
     const int c = a.counts[cell];
-    const unsigned long long* lst = a.lists + (size_t)cell * LISI_CAP;
+    const unsigned long long* lst = a.lists + (size_t)cell * (2 * KEEP);
     const double* xq = a.X + (size_t)cell * a.d;
     // exact squared distances to the survivors, float64 from direct differences
-#pragma unroll
-    for (int h = 0; h < LISI_KEEP / 64; ++h) {
+#pragma unroll 2
+    for (int h = 0; h < NH; ++h) {
         const int i = lane + 64 * h;
         unsigned long long kb = ~0ull;
         int id = 0x7FFFFFFF;
@@ -327,25 +334,29 @@ __global__ __launch_bounds__(64 * LISI_FIN_WAVES) void k_lisi_finish(LisiFinishA
         key[i] = kb; idx[i] = id;
     }
     wave_fence();
-    // bitonic sort of 128 (distance, index) pairs, ties by index
-    for (int k = 2; k <= LISI_KEEP; k <<= 1) {
+    // bitonic sort of the KEEP (distance, index) pairs, ties by index
+    for (int k = 2; k <= KEEP; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            const int i = ((lane / j) * 2 * j) + (lane % j);
-            const int l = i + j;
-            const bool up = (i & k) == 0;
-            const unsigned long long ka = key[i], kb = key[l];
-            const int ia = idx[i], ib = idx[l];
-            const bool gt = ka > kb || (ka == kb && ia > ib);
-            if (gt == up) { key[i] = kb; key[l] = ka; idx[i] = ib; idx[l] = ia; }
+#pragma unroll
+            for (int h = 0; h < KEEP / 128; ++h) {
+                const int p = lane + 64 * h;
+                const int i = ((p / j) * 2 * j) + (p % j);
+                const int l = i + j;
+                const bool up = (i & k) == 0;
+                const unsigned long long ka = key[i], kb = key[l];
+                const int ia = idx[i], ib = idx[l];
+                const bool gt = ka > kb || (ka == kb && ia > ib);
+                if (gt == up) { key[i] = kb; key[l] = ka; idx[i] = ib; idx[l] = ia; }
+            }
             wave_fence();
         }
     }
     // neighbours = ranks 1 .. nn-1 (the first column is dropped, lisi.py:58-60)
     const int M = a.nn - 1;
-    double D[2];
-    int nid[2];
+    double D[NH];
+    int nid[NH];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
         const int j = lane + 64 * h;
         D[h] = j < M ? sqrt(__longlong_as_double((long long)key[j + 1])) : 0.0;
         nid[h] = j < M ? idx[j + 1] : 0;
@@ -354,19 +365,26 @@ __global__ __launch_bounds__(64 * LISI_FIN_WAVES) void k_lisi_finish(LisiFinishA
     // lisi.py:83-119: search beta so that the entropy of P = exp(-beta D) is log(perplexity)
     const double logU = log(a.perplexity);
     double beta = 1.0, betamin = -__builtin_inf(), betamax = __builtin_inf();
-    double H = 0.0, Pn[2];
+    double H = 0.0, Pn[NH];
     auto entropy = [&]() {
-        double p[2], s = 0.0, sd = 0.0;
+        double p[NH], s = 0.0, sd = 0.0;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
             p[h] = (lane + 64 * h) < M ? exp(-D[h] * beta) : 0.0;
             s += p[h];
             sd += D[h] * p[h];
         }
         s = wave_sum(s);
         sd = wave_sum(sd);
-        if (s == 0.0) { H = 0.0; Pn[0] = Pn[1] = 0.0; }
-        else { H = log(s) + beta * sd / s; Pn[0] = p[0] / s; Pn[1] = p[1] / s; }
+        if (s == 0.0) {
+            H = 0.0;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) Pn[h] = 0.0;
+        } else {
+            H = log(s) + beta * sd / s;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) Pn[h] = p[h] / s;
+        }
     };
     entropy();
     double Hdiff = H - logU;
@@ -384,15 +402,15 @@ __global__ __launch_bounds__(64 * LISI_FIN_WAVES) void k_lisi_finish(LisiFinishA
     }
     // lisi.py:120-132: squared probability mass per category = sum_j P_j * (mass of j's category)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) { const int j = lane + 64 * h; if (j < LISI_KEEP) P[j] = j < M ? Pn[h] : 0.0; }
+    for (int h = 0; h < NH; ++h) { const int j = lane + 64 * h; P[j] = j < M ? Pn[h] : 0.0; }
     wave_fence();
     for (int L = 0; L < a.n_labels; ++L) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) { const int j = lane + 64 * h; if (j < M) lab[j] = a.labels[(size_t)L * a.n + nid[h]]; }
+        for (int h = 0; h < NH; ++h) { const int j = lane + 64 * h; if (j < M) lab[j] = a.labels[(size_t)L * a.n + nid[h]]; }
         wave_fence();
         double part = 0.0;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
             const int j = lane + 64 * h;
             if (j < M) {
                 const int mine = lab[j];
@@ -408,12 +426,24 @@ __global__ __launch_bounds__(64 * LISI_FIN_WAVES) void k_lisi_finish(LisiFinishA
     }
 }
 
-template <int KS16>
-void launch_knn_qt(const LisiKnnArgs& a, hipStream_t s) {
+template <int KS16, int CAP>
+void launch_knn_cap(const LisiKnnArgs& a, hipStream_t s) {
     constexpr int QT = KS16 <= 4 ? 4 : KS16 <= 8 ? 2 : 1;
     const int64_t waves = (a.npad + 16 * QT - 1) / (16 * QT);
     const int wgs = (int)((waves + LISI_KNN_WAVES - 1) / LISI_KNN_WAVES);
-    hipLaunchKernelGGL((k_lisi_knn<KS16, QT>), dim3(wgs), dim3(64 * LISI_KNN_WAVES), 0, s, a);
+    const size_t sm = (size_t)LISI_KNN_WAVES * CAP * sizeof(unsigned long long);
+    static bool attr_done = false;
+    if (!attr_done && sm > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lisi_knn<KS16, QT, CAP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_lisi_knn<KS16, QT, CAP>), dim3(wgs), dim3(64 * LISI_KNN_WAVES), sm, s, a);
+}
+template <int KS16>
+void launch_knn_qt(const LisiKnnArgs& a, hipStream_t s) {
+    if (a.cap <= 256) launch_knn_cap<KS16, 256>(a, s);
+    else if (a.cap <= 1024) launch_knn_cap<KS16, 1024>(a, s);
+    else launch_knn_cap<KS16, 4096>(a, s);
 }
 
 }  // namespace
@@ -445,5 +475,9 @@ int launch_lisi_knn(const LisiKnnArgs& a, hipStream_t s) {
 }
 
 void launch_lisi_finish(const LisiFinishArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_lisi_finish, dim3((unsigned)((a.n + LISI_FIN_WAVES - 1) / LISI_FIN_WAVES)), dim3(64 * LISI_FIN_WAVES), 0, s, a);
+    if (a.cap <= 256) hipLaunchKernelGGL((k_lisi_finish<128, 4>), dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, s, a);
+    else if (a.cap <= 1024) hipLaunchKernelGGL((k_lisi_finish<512, 4>), dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_lisi_finish<2048, 1>), dim3((unsigned)a.n), dim3(64), 0, s, a);
 }
+
+int lisi_list_cap(int nn) { return nn <= 128 - 8 ? 256 : nn <= 512 - 8 ? 1024 : nn <= 2048 - 8 ? 4096 : 0; }

@@ -38,8 +38,10 @@ def compute_lisi(
     (distances, indices), nearest first -- what the reference gets from ``knn.kneighbors`` after
     dropping the first column (lisi.py:55-60).
 
-    Limit of this build: ``3 * perplexity <= 120`` neighbours (perplexity <= 40; the reference takes any): a larger
-    value raises ``ValueError``.
+    Limit of this build: ``3 * perplexity <= 2040`` neighbours (perplexity <= 680; the reference takes any): a larger
+    value raises ``ValueError``.  Up to 120 neighbours (perplexity 40; the default is 30) the search keeps 256
+    candidates per cell, up to 504 it keeps 1024, beyond 4096 -- each step costs memory (8 bytes x candidates x cells)
+    and speed.
     """
     if isinstance(label_colnames, str):
         label_colnames = [label_colnames]

@@ -156,11 +156,12 @@ int hmx_init_cluster(hmx_engine* e, const float* Y0, double obj_out[4]);
  * `compute_simpson`), on the device.  X: n x d row-major float64 (host).  label_codes: n_labels x n
  * category codes (one row per label column, as pd.Categorical(...).codes).  perplexity: as the
  * reference's; the search asks for int(3*perplexity) neighbours (the cell itself included, then
- * dropped, lisi.py:53-60), at most 128.  lisi_out: n x n_labels row-major float64 (-1 where the
+ * dropped, lisi.py:53-60), at most 2040 (perplexity 680).  lisi_out: n x n_labels row-major float64 (-1 where the
  * reference returns -1).  knn_dist_out / knn_idx_out (both or neither, may be NULL): the
  * int(3*perplexity)-1 neighbours of every cell, nearest first, n x (nn-1).
- * Neighbours are exact: a float32 MFMA pass preselects 128 candidates per cell, float64 distances
- * from direct differences rank them.  Independent of any engine handle. */
+ * Neighbours are exact: a float32 MFMA pass preselects 128 candidates per cell (512 above 120
+ * neighbours, 2048 above 504), float64 distances from direct differences rank them.  Independent of
+ * any engine handle. */
 int hmx_compute_lisi(int32_t device_id, const double* X, int64_t n, int32_t d, const int32_t* label_codes,
                      int32_t n_labels, double perplexity, double* lisi_out, double* knn_dist_out,
                      int32_t* knn_idx_out);

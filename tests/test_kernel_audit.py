@@ -37,7 +37,7 @@ def _toolchain_matches():
 KNOWN_SPILLS = {
     "_Z12k_assign_ldsILi7ELb1EEv10AssignArgs": 5,
     "_Z5k_rtzILi7ELi4EEv7RtzArgs": 4,
-    "_ZN12_GLOBAL__N_110k_lisi_knnILi4ELi4EEEv11LisiKnnArgs": 3,      # the 50-PC LISI search
+    "_ZN12_GLOBAL__N_110k_lisi_knnILi4ELi4ELi256EEEv11LisiKnnArgs": 3,      # the 50-PC LISI search
     "_Z6k_rtz3ILi7ELi8ELi1EEv8Rtz3Args": 20,                           # K > 96 with d <= 32 and 33..48 update blocks
 }
 

@@ -56,7 +56,10 @@ def test_device_lisi_matches_reference(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,d,perp,seed", [(1000, 2, 30, 0), (5000, 50, 30, 1), (777, 20, 10, 2), (4099, 64, 40, 3),
-                                          (1500, 100, 30, 4), (1200, 200, 20, 5), (91, 3, 30, 6)])
+                                          (1500, 100, 30, 4), (1200, 200, 20, 5), (91, 3, 30, 6),
+                                          # the larger candidate lists: 1024 entries (up to 504 neighbours), 4096 (up to 2040)
+                                          (3000, 50, 41, 7), (2500, 20, 100, 8), (1800, 8, 168, 9), (2600, 50, 200, 10),
+                                          (2100, 16, 680, 11)])
 def test_device_neighbours_are_exact(n, d, perp, seed):
     """Neighbour sets, order and distances against the float64 brute-force search of the oracle."""
     import harmonypy_amd as hm
@@ -80,8 +83,8 @@ def test_device_lisi_errors():
     meta = pd.DataFrame({"a": ["x"] * 50})
     with pytest.raises(ValueError):
         hm.compute_lisi(X, meta, ["a"], 30)                           # 90 neighbours of 50 points (sklearn's ValueError)
-    with pytest.raises(Exception):
-        hm.compute_lisi(X, meta, ["a"], 60)                           # more than 128 candidates
+    with pytest.raises(ValueError):
+        hm.compute_lisi(X, meta, ["a"], 60)                           # 180 neighbours of 50 points
     with pytest.raises(ValueError):
         hm.compute_lisi(X, meta, ["a"], 5, device="cpu")
     assert hm.compute_lisi(X, meta, ["a"], 5).shape == (50, 1)
@@ -89,10 +92,11 @@ def test_device_lisi_errors():
 
 
 def test_perplexity_beyond_the_build_limit_is_a_value_error():
-    """3 * perplexity > 120 neighbours: refused with ValueError before any device work (lisi.py:53 takes any)."""
+    """3 * perplexity > 2040 neighbours (the largest candidate list): refused with ValueError before any device work
+    (lisi.py:53 takes any)."""
     import pandas as pd
     import harmonypy_amd
     X = np.random.default_rng(0).normal(size=(500, 5))
     meta = pd.DataFrame({"b": np.arange(500) % 3})
     with pytest.raises(ValueError, match="perplexity"):
-        harmonypy_amd.compute_lisi(X, meta, ["b"], perplexity=41)
+        harmonypy_amd.compute_lisi(X, meta, ["b"], perplexity=681)
