@@ -256,7 +256,7 @@ def roofline_block(config, N, d, B, K, ktimes, steps, rounds, wide, ktimes_all=N
     if wide:
         flops = cells_per_launch * 2.0 * d * K
         achieved = flops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": "k_assign_wide (one launch per update block; K > 112 or d > 64)",
+        roof = {"bound": "mfma", "kernel": "k_assign_wide2 (one launch per update block; K > 112 or d > 64)",
                 "achieved": achieved, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TF,
                 "traffic": None, "traffic_source": "not collected for this configuration",
                 "avg_launch_us": per_launch_ms * 1e3, "launches": cnt, "launches_timed": cnt_timed, "algorithmic_flops_per_launch": flops}
@@ -307,9 +307,22 @@ def side_config(name, rounds, steps, warmup, device):
         step()
     ho._engine.sync()
     dt = time.perf_counter() - t0
+    # whole-step roofline of the side entry from its wall time (no per-kernel events here): a round moves 4d + 8K + 8
+    # algorithmic bytes and 4 d K flops per cell (distance product + R^T.Z), the ridge step 12d + 8K bytes and 4 d K flops
+    # (statistics + correction) -- SURVEY section 8d's per-cell figures; the wide shapes are priced against the f32 MFMA peak
+    t_step = dt / steps
+    step_bytes = N * (rounds * (4.0 * d + 8 * K + 8) + 12.0 * d + 8 * K)
+    step_flops = N * (rounds + 1) * 4.0 * d * K
+    wide = K > 112 or d > 64
+    roof = ({"bound": "mfma", "achieved": step_flops / t_step / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+             "frac": step_flops / t_step / 1e12 / F32_MFMA_PEAK_TF} if wide else
+            {"bound": "hbm", "achieved": step_bytes / t_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": step_bytes / t_step / 1e9 / HBM_PEAK_GBS})
+    roof["scope"] = "whole step (wall time of the loop, launch gaps included)"
     return {"workload": f"BASELINE configs[{CONFIG_INDEX[name]}] ({name.upper()}): {N} cells x {d} PCs, "
                         f"{B} batches, K={K}; step = {rounds} k-means rounds + 1 ridge correction",
-            "value": N * steps / dt, "unit": "cells/sec/Harmony-iteration", "ms_per_step": 1e3 * dt / steps, "steps": steps}
+            "value": N * steps / dt, "unit": "cells/sec/Harmony-iteration", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+            "roofline": roof}
 
 
 def main():
