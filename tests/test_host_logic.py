@@ -49,7 +49,7 @@ def test_lisi_fails_loudly_without_gpu_and_checks_arguments():
     with pytest.raises(ValueError):
         hm.compute_lisi(X[:50], meta.iloc[:50], ["a"], 30)            # 90 neighbours of 50 points (sklearn's ValueError text)
     with pytest.raises(ValueError):
-        hm.compute_lisi(X, meta, ["a"], 50)                           # 150 > the 120 neighbours this build ranks exactly
+        hm.compute_lisi(X, meta, ["a"], 700)                          # 2100 > the 2040 neighbours the largest candidate list ranks exactly
     if not torch.cuda.is_available():
         with pytest.raises(_capi.HmxError) as ei:
             hm.compute_lisi(X, meta, ["a"], 30)
