@@ -256,7 +256,8 @@ def roofline_block(config, N, d, B, K, ktimes, steps, rounds, wide, ktimes_all=N
     if wide:
         flops = cells_per_launch * 2.0 * d * K
         achieved = flops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": "k_assign_wide2 (one launch per update block; K > 112 or d > 64)",
+        roof = {"bound": "mfma", "kernel": ("k_round_wide (one persistent launch per update_R sweep; K > 112 or d > 64)" if sweep else
+                                            "k_assign_wide2 (one launch per update block; K > 112 or d > 64)"),
                 "achieved": achieved, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TF,
                 "traffic": None, "traffic_source": "not collected for this configuration",
                 "avg_launch_us": per_launch_ms * 1e3, "launches": cnt, "launches_timed": cnt_timed, "algorithmic_flops_per_launch": flops}

@@ -406,7 +406,7 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
             (rc = e->R.reserve((N + 16) * e->Kp + e->K16 + 64)) || (rc = e->Osave.reserve(GK)) || (rc = e->Y.reserve((size_t)e->K16 * e->ldy)) ||
             (rc = e->Yacc.reserve((size_t)e->K16 * e->ldy)) || (rc = e->sigma.reserve(e->K16)) ||
             (rc = e->theta.reserve(e->B)) || (rc = e->Pr_b.reserve(e->B)) || (rc = e->lamb.reserve(e->B + 1)) ||
-            (rc = e->rp.reserve(GK)) || (rc = e->lrp.reserve(GK)) || (rc = e->group_cols.reserve((size_t)e->G * e->V)) ||
+            (rc = e->rp.reserve(GK * e->nblk)) || (rc = e->lrp.reserve(GK * e->nblk)) || (rc = e->group_cols.reserve((size_t)e->G * e->V)) ||
             (rc = e->Ogrp.reserve(GK)) || (rc = e->Tmass.reserve(e->K16)) || (rc = e->Ohist.reserve(GK * e->nblk)) ||
             (rc = e->W.reserve(GK * e->ldy)) || (rc = e->lists[0].blk_start.reserve(e->nblk + 1)) ||
             (rc = e->lists[1].blk_start.reserve(e->nblk + 1)))
@@ -421,8 +421,8 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
             e->Sr = e->objacc + n_obj;
             e->Oxr = e->Sr + GK * e->ldy;
         }
-        if ((rc = e->Sslots.reserve(GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 1 + 128)) || (rc = e->wait_stats.reserve(4))) break;   // + slack: the per-round fill is rounded up to 1 KB
-        (void)hipMemsetAsync(e->wait_stats.p, 0, 4 * sizeof(unsigned long long), e->stream);
+        if ((rc = e->Sslots.reserve(GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 1 + 128)) || (rc = e->wait_stats.reserve(8))) break;   // + slack: the per-round fill is rounded up to 1 KB
+        (void)hipMemsetAsync(e->wait_stats.p, 0, 8 * sizeof(unsigned long long), e->stream);
         e->sync_words.p = reinterpret_cast<unsigned*>(e->Sslots.p + GK * (e->nblk + 1) * HMX_ROUND_SLOTS);   // borrowed tail
         e->sync_words.n = 2;
         if (hipHostMalloc(reinterpret_cast<void**>(&e->sync_host), 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
@@ -954,6 +954,12 @@ static int lloyd_wide(hmx_engine* e, const float* centers_in, int n_iter, float*
 }
 
 static void note_sweep_timeout(hmx_engine* e) {
+    {
+        unsigned long long ws[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (e->wait_stats.p && hipMemcpy(ws, e->wait_stats.p, sizeof ws, hipMemcpyDeviceToHost) == hipSuccess && (ws[5] || ws[6] || ws[7]))
+            fprintf(stderr, "[hmx] rank %d: wide sweep diagnosis: %llu compute workgroups gave up (latest in block %llu); service workgroup gave up "
+                            "waiting for block %llu with %llu arrivals counted\n", e->rank, ws[5], ws[4] ? ws[4] - 1 : 0ull, ws[6], ws[7]);
+    }
     if (e->n_sweep_fallbacks++ == 0)
         fprintf(stderr, "[hmx] rank %d: a grid-wide wait of the sweep kernel timed out; the round is repeated with one launch per "
                         "block (HMX_ROUND_MODE=blocks avoids the persistent kernel altogether)\n", e->rank);
@@ -1093,6 +1099,8 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
 #endif
     const bool mega = persistent && e->mt <= 7 && round_row_floats(e->d) == e->dp &&
                       round_lds_bytes(e->K16, e->dp, e->G, e->B, e->V) <= HMX_ROUND_LDS_LIMIT;
+    // wide shapes (K > 112 or d > 64), one batch variable, single engine: the persistent sweep with a service workgroup
+    const bool mega_wide = persistent && !mega && !sharded(e) && round_wide_ok(e->mt, e->dp, e->K16, e->G, e->B, e->V);
     const bool r3 = streaming_rtz(e);
     // a single engine on the persistent sweep: k_rtz3_finish normalises the centroids itself (no collective is due in
     // between) and does the sweep kernel's fills -- three launches per round
@@ -1146,19 +1154,20 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         }
     }
     if (before_sweep && (rc = before_sweep())) return rc;   // side-stream work that should run beside the sweep, not beside the R^T.Z pass
-    if (mega) {
-        // the whole sweep in one persistent launch (k_round); closes O, T and the objective itself
+    if (mega || mega_wide) {
+        // the whole sweep in one persistent launch (k_round / k_round_wide); closes O, T and the objective itself
         if (!fused) {
             // the slot tables and the two sync words (carved from the same allocation): one fill (size rounded up to 1 KB
             // inside the allocation: an odd size makes the runtime launch a second fill kernel for the tail); O at the
             // start of the round is kept for an exact replay
-            HIP_TRY(hipMemsetAsync(e->Sslots.p, 0, (((GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 1) * sizeof(double) + 1023) / 1024) * 1024, e->stream));
+            HIP_TRY(hipMemsetAsync(e->Sslots.p, 0, (((GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 2) * sizeof(double) + 1023) / 1024) * 1024, e->stream));   // (+ the table flag of k_round_wide behind the two sync words)
             HIP_TRY(hipMemcpyAsync(e->Osave.p, e->Ogrp.p, GK * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
         }
         int max_upper = 0;
         for (int b = 0; b < e->nblk; ++b) max_upper = std::max(max_upper, tiles_upper[b]);
         const bool multi = e->peers_enabled && e->n_ranks > 1;
-        int wgs = std::min(e->n_cus - (multi ? 1 : 0), std::max(1, (max_upper + 13) / 14));   // ~14 of a workgroup's 16 tile slots: 224 of 256 CUs at C3, the rest serve the second stream
+        int wgs = mega_wide ? std::min(2 * e->n_cus - 1, std::max(1, (max_upper + 7) / 8))   // two workgroups per CU, one slot for the service workgroup
+                            : std::min(e->n_cus - (multi ? 1 : 0), std::max(1, (max_upper + 13) / 14));   // ~14 of a workgroup's 16 tile slots: 224 of 256 CUs at C3, the rest serve the second stream
         // (sharded: every rank sizes its grid from its own share; the grid only decides how this rank's tiles are dealt out)
         if (e->round_wgs_cap > 0) wgs = std::min(wgs, e->round_wgs_cap);
         {
@@ -1182,9 +1191,28 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
             if (prof.reserve((size_t)wgs * e->nblk * 16)) return -1;
             ra.prof = prof.p;
 #endif
+            if (mega_wide) {
+                ra.rp_tab = e->rp.p; ra.lrp_tab = e->lrp.p; ra.table_flag = e->sync_words.p + 2;
+                if (launch_round_wide(ra, e->mt, wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported shape for k_round_wide");
+#ifdef HMX_ROUND_PROF
+                if (++prof_rounds == 12) {
+                    std::vector<unsigned long long> h((size_t)(wgs + 1) * 4);
+                    (void)hipStreamSynchronize(e->stream);
+                    (void)hipMemcpy(h.data(), prof.p, h.size() * 8, hipMemcpyDeviceToHost);
+                    double m[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0};
+                    for (int w = 0; w < wgs; ++w)
+                        for (int k = 0; k < 4; ++k) { m[k] += (double)h[(size_t)w * 4 + k]; mx[k] = std::max(mx[k], (double)h[(size_t)w * 4 + k]); }
+                    fprintf(stderr, "[k_round_wide prof] %d compute workgroups, cycles per block (mean / slowest workgroup): distance product %.0f / %.0f, wait for the tables %.0f / %.0f, finish %.0f / %.0f, publish + arrive %.0f / %.0f\n",
+                            wgs, m[0] / wgs / e->nblk, mx[0] / e->nblk, m[1] / wgs / e->nblk, mx[1] / e->nblk, m[2] / wgs / e->nblk, mx[2] / e->nblk, m[3] / wgs / e->nblk, mx[3] / e->nblk);
+                    const unsigned long long* sv = &h[(size_t)wgs * 4];
+                    fprintf(stderr, "[k_round_wide prof] service workgroup, cycles per block: waiting for arrivals %.0f, fold + cluster mass %.0f, tables + flag %.0f\n",
+                            (double)sv[0] / e->nblk, (double)sv[1] / e->nblk, (double)sv[2] / e->nblk);
+                }
+#endif
+            } else
             if (launch_round(ra, e->mt, multi ? wgs + 1 : wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported shape for k_round");
 #ifdef HMX_ROUND_PROF
-            if (++prof_rounds == 25) {   // one round in steady state: phase durations over workgroups and blocks
+            if (!mega_wide && ++prof_rounds == 25) {   // one round in steady state: phase durations over workgroups and blocks
                 std::vector<unsigned long long> h((size_t)wgs * e->nblk * 16);
                 (void)hipStreamSynchronize(e->stream);
                 (void)hipMemcpy(h.data(), prof.p, h.size() * 8, hipMemcpyDeviceToHost);
@@ -1351,6 +1379,12 @@ static int seeded_round(hmx_engine* e, int flags, uint64_t seed, int64_t cells_p
     // kernel, which leaves a few CUs idle.  The scratch tables (chunk_tab, run_*) are free by then.
     auto prefetch = [&]() -> int {
         if (!e->prefetch_lists || !e->stream2) return 0;
+        // k_round_wide fills every CU with two workgroups and needs all of them resident: with the list kernels of the side
+        // stream in flight when it is launched, half of its grid (the service workgroup included) was not placed until the
+        // first half had given up (measured).  There the next round's lists are built on the main stream, behind the sweep.
+        if (e->round_mode == 1 && !sharded(e) && !(e->mt <= 7 && round_row_floats(e->d) == e->dp) &&
+            round_wide_ok(e->mt, e->dp, e->K16, e->G, e->B, e->V))
+            return 0;
         HIP_TRY(hipEventRecord(e->pre_event, e->stream));
         HIP_TRY(hipStreamWaitEvent(e->stream2, e->pre_event, 0));
         build(counter + 1, e->cur ^ 1, e->stream2);

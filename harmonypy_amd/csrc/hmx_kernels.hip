@@ -713,6 +713,9 @@ __device__ __forceinline__ void round_post_pass1(const float* sig, const float* 
 // second pass for the two tiles a wave carries: R rows out, sums over the 16 cells of a tile into
 // the block's (group, cluster) table.  Tiles of one group (the usual case: a wave's tiles are
 // neighbours in the block's group-sorted list) share one cross-lane reduction.
+#ifndef HMX_ROUND_RETURNING
+#define HMX_ROUND_RETURNING 0   /* 1: the slot atomics of k_round return their old value (see k_round_wide's service workgroup for why one might want that) */
+#endif
 #ifndef HMX_ROUND_SUMS
 #define HMX_ROUND_SUMS 0   /* 1 (experiment): a wave's block sums go to its own fp32 slots in LDS (plain stores), summed at publish time, instead of fp64 LDS atomics on shared addresses */
 #endif
@@ -1126,6 +1129,359 @@ __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_assign_wide2(AssignArgs
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_round_wide: the whole update_R sweep of the wide shapes (K <= 208, d <= 208) in ONE persistent launch -- k_assign_wide2's
+// tile pass inside a loop over the update blocks, with k_round's hand-off.  The centroid table does not fit the LDS, so it
+// is streamed per k-step as in k_assign_wide2, and the (group, cluster) tables do not fit beside it either (24 B x G x K16 =
+// 160 KB at 32 batches), so the roles are split:
+//   * compute workgroups (4 waves, 2 per CU, 8 tiles per pass): distance GEMM of the next block's first tiles BEFORE the
+//     wait (it does not depend on the tables), then the table rows of their own tiles' groups from the global table, finish,
+//     block sums of their own groups -> fp64 atomics into the block's slot table, arrive;
+//   * ONE service workgroup (the last of the grid) owns O (fp64, in its LDS): when all compute workgroups have arrived for
+//     block b-1 it folds their sums in, takes block b's removal sums out, rebuilds ratio^theta and its log for all (group,
+//     cluster) pairs (:491-499), writes them to block b's global table with returning agent-scope exchanges and raises a flag
+//     -- while the compute workgroups multiply.  It closes the sweep (O, cluster mass, cross-entropy term, :405-411).
+// One batch variable only (group g is batch g); other cases stay on one launch per block.  All waits are bounded.
+// ------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_round_wide(RoundArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int K16 = 16 * MT;
+    constexpr int NPJ = (MT + WIDE2_WAVES - 1) / WIDE2_WAVES;
+    constexpr int NTHR = 64 * WIDE2_WAVES;
+    const int GK = a.G * K16;
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, c16 = lane & 15, q = lane >> 4;
+    const int nwg = gridDim.x - 1;                                       // compute workgroups
+    const int wg = blockIdx.x;
+
+    if (wg == nwg) {
+        // ================= service workgroup: O and the tables ========================================================
+        double* Ocur = reinterpret_cast<double*>(smem);                  // G x K16
+        double* Tm = Ocur + GK;                                          // K16
+        double* red = Tm + K16;                                          // waves
+        bool sfail = false;
+        for (int i = tid; i < GK; i += NTHR) Ocur[i] = a.O_start[i];
+        __syncthreads();
+#ifdef HMX_ROUND_PROF
+        unsigned long long sf[4] = {0, 0, 0, 0}, st = __builtin_amdgcn_s_memtime();
+#define SVSTAMP(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); sf[k] += now_ - st; st = now_; }
+#else
+#define SVSTAMP(k)
+#endif
+        for (int b = 0; b <= a.nblk; ++b) {
+            if (b > 0) {
+                if (wv == 0 && !sfail) {
+                    const unsigned want = (unsigned)b * (unsigned)nwg;
+                    unsigned spins = 0;
+                    if (a.spin_limit == 0) sfail = true;                 // test knob: give up without looking
+                    while (!sfail && ld_agent(a.counter) < want) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > a.spin_limit) sfail = true;
+                    }
+                    if (sfail && lane == 0 && a.wait_stats) {             // diagnosis: the block it waited for, the arrivals it saw
+                        atomicMax(a.wait_stats + 6, (unsigned long long)b);
+                        atomicMax(a.wait_stats + 7, (unsigned long long)ld_agent(a.counter));
+                    }
+                }
+                __syncthreads();
+            }
+            SVSTAMP(0)
+            for (int i = tid; i < GK; i += NTHR) {                       // (:491-492 for block b, :506-507 for block b-1)
+                double o = Ocur[i];
+                if (b > 0) o += ld_agent(a.S_new + (size_t)(b - 1) * GK + i);
+                if (b < a.nblk) o -= a.S_old[(size_t)b * GK + i];
+                Ocur[i] = o;
+            }
+            __syncthreads();
+            for (int k = tid; k < K16; k += NTHR) {
+                double t = 0.0;
+                for (int g = 0; g < a.G; ++g) t += Ocur[(size_t)g * K16 + k];
+                Tm[k] = t;
+            }
+            __syncthreads();
+            SVSTAMP(1)
+            if (b == a.nblk) break;
+            float* rpo = a.rp_tab + (size_t)b * GK;                          // a table of its own per block
+            float* lrpo = a.lrp_tab + (size_t)b * GK;
+            for (int i = tid; i < GK; i += NTHR) {
+                const int g = i / K16, k = i - g * K16;
+                const float O = (float)Ocur[i];
+                const float E = (float)Tm[k] * a.Pr_b[g];                   // :491 (E kept as mass T)
+                const float oe = fmaxf(O + E, 1e-8f);                       // :495-496
+                const float ratio = fminf(fmaxf(E / oe, 1e-8f), 1.0f);      // :497-498
+                const float rp = pow_unit(ratio, a.theta[g]);               // :499
+                xchg_agent(rpo + i, rp);
+                xchg_agent(lrpo + i, __builtin_amdgcn_logf(rp) * 0.693147182464599609375f);
+            }
+            // Table entries and flag are RETURNING exchanges at agent scope: vmcnt(0) then means every entry has been performed
+            // where other XCDs read it, and only then -- barrier -- the flag goes up.  Measured on the way here (40 k cells x 200,
+            // 20 compute workgroups that reach the wait before the table is ready): plain agent-scope stores (relaxed; or with
+            // a release on the flag and an acquire in the readers), and non-returning exchanges, all let readers see the flag
+            // before some rows: a third of the rounds had a few hundred wrong cells, differently in every run.  A non-returning
+            // atomic / a store is acknowledged when accepted, not when performed.
+            WAIT_VMEM_ALL();
+            __syncthreads();
+            if (tid == 0) xchg_agent(a.table_flag, (unsigned)(b + 1));
+            SVSTAMP(2)
+        }
+#ifdef HMX_ROUND_PROF
+        if (tid == 0 && a.prof)
+            for (int k = 0; k < 4; ++k) a.prof[(size_t)wg * 4 + k] = sf[k];
+#endif
+        // ---- close the sweep: O, cluster mass, cross-entropy term (:405-411; one batch variable: group g is batch g) ------
+        double part = 0.0;
+        for (int i = tid; i < GK; i += NTHR) {
+            const int g = i / K16, k = i - g * K16;
+            a.O_out[i] = Ocur[i];
+            if (g == 0) a.T_out[k] = Tm[k];
+            const float sgm = (k < a.K) ? a.sigma[k] : 0.f;
+            const float O = (float)Ocur[i];
+            const float Oc = fmaxf(O, 1e-8f);                               // :407
+            const float Ec = fmaxf((float)Tm[k] * a.Pr_b[g], 1e-8f);        // :408
+            const float tl = a.theta[g] * logf((Oc + Ec) / Ec);             // :409-410
+            part += (double)(sgm * O * tl);
+        }
+        part = wave_sum_all(part);
+        if (lane == 0) red[wv] = part;
+        __syncthreads();
+        if (tid == 0) {
+            double v = 0.0;
+            for (int w = 0; w < WIDE2_WAVES; ++w) v += red[w];
+            atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS], v);
+            if (sfail) {
+                atomicExch(a.error, 1u);
+                atomicAdd(&a.obj[0], __builtin_nan(""));
+                atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS + 1], 1.0);
+            }
+        }
+        return;
+    }
+
+    // ================= compute workgroups ===========================================================================
+    float* Yring = reinterpret_cast<float*>(smem);                       // WIDE2_YBUF x K16 x 16
+    float* sig = Yring + WIDE2_YBUF * K16 * 16;                          // K16
+    float* nis = sig + K16;
+    float* rpL = nis + K16;                                              // slots x K16
+    float* lrpL = rpL + WIDE2_SLOTS * K16;
+    double* Sd = reinterpret_cast<double*>(lrpL + WIDE2_SLOTS * K16);    // slots x K16 block sums
+    double* objw = Sd + WIDE2_SLOTS * K16;                               // waves x 2
+    int* tg = reinterpret_cast<int*>(objw + 2 * WIDE2_WAVES);            // group of the pass's tile j (-1: none)
+    int* ts = tg + WIDE2_SLOTS;                                          // its slot
+    int* sg = ts + WIDE2_SLOTS;                                          // group of a slot
+    const int nkb = a.dp >> 4;
+    for (int i = tid; i < K16; i += NTHR) {
+        const float sgm = (i < a.K) ? a.sigma[i] : 0.f;
+        sig[i] = sgm;
+        nis[i] = (i < a.K) ? -1.0f / sgm : -60.f;
+    }
+    for (int i = tid; i < WIDE2_SLOTS * K16; i += NTHR) Sd[i] = 0.0;
+    __syncthreads();
+
+    const unsigned yvoff = (unsigned)(((lane >> 2) * a.ldy + 4 * ((lane & 3) ^ ((lane >> 4) & 3))) * 4);
+    const unsigned ring0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)Yring;
+    const unsigned yzone0 = __builtin_amdgcn_readfirstlane(ring0) + 1024u * wv;
+    const int npw = (MT - wv + WIDE2_WAVES - 1) / WIDE2_WAVES;
+    auto u64 = [](unsigned long long v) {
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
+               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v);
+    };
+    const unsigned long long ysrc0 = u64((unsigned long long)(a.Y + (size_t)16 * wv * a.ldy));
+    const unsigned long long ypiece = (unsigned long long)64 * a.ldy * WIDE2_WAVES;
+    const int swz = 4 * (q ^ ((c16 >> 2) & 3));
+    unsigned long long ysrc = ysrc0;
+    unsigned yzone = yzone0;
+    int yslot = 0, rslot = 0;                                            // ring positions of the next request / the next read: they run on across tiles
+    double km_acc = 0.0, ent_acc = 0.0;
+    bool failed = false;                                                 // (lives in wave 0)
+    unsigned ws_n = 0, ws_sum = 0, ws_max = 0;
+
+    RoundTile<MT> T0, T1;
+    // distance GEMM of the tile pair (first tile: block-list position j0) -> exponent arguments in T0 / T1
+    auto gemm = [&](int tb, int ntl, int j0) {
+        const bool has0 = j0 < ntl, has1 = j0 + 1 < ntl;
+        T0.cell = has0 ? a.cells[(size_t)(tb + j0) * 16 + c16] : -1;
+        T1.cell = has1 ? a.cells[(size_t)(tb + j0 + 1) * 16 + c16] : -1;
+        const float* zr0 = a.Zcos + (size_t)(T0.cell >= 0 ? T0.cell : 0) * a.dp + 4 * q;
+        const float* zr1 = a.Zcos + (size_t)(T1.cell >= 0 ? T1.cell : 0) * a.dp + 4 * q;
+        auto issue_y = [&]() {
+#pragma unroll
+            for (int j = 0; j < NPJ; ++j)
+                if (j < npw) {
+                    const unsigned long long src = ysrc + ypiece * j;
+                    const unsigned zone = yzone + 1024u * WIDE2_WAVES * j;
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(yvoff), "s"(src), "s"(zone) : "memory", "m0");
+                }
+            ysrc += 64;
+            yzone += (unsigned)(K16 * 64);
+            if (++yslot == WIDE2_YBUF) { yslot = 0; yzone = yzone0; }
+        };
+        auto issue_z = [&](f32x4& z0, f32x4& z1, int kb) {
+            const float* p0 = zr0 + 16 * kb;
+            const float* p1 = zr1 + 16 * kb;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(z0) : "v"(p0) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(z1) : "v"(p1) : "memory");
+        };
+        ysrc = ysrc0;
+        f32x4 za0, za1, zb0, zb1;
+        // (the ring slots about to be refilled were last read before the previous pass's final barriers)
+        issue_z(za0, za1, 0);
+        issue_y();
+        if (nkb > 1) { issue_z(zb0, zb1, 1); issue_y(); }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            T0.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            T1.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        auto step = [&](int kb, f32x4& z0, f32x4& z1) {
+            if (kb + 1 < nkb) {
+                if (npw + 2 >= 6) wide2_wait<6>(z0, z1); else if (npw + 2 == 5) wide2_wait<5>(z0, z1);
+                else if (npw + 2 == 4) wide2_wait<4>(z0, z1); else wide2_wait<3>(z0, z1);
+            } else {
+                wide2_wait<0>(z0, z1);
+            }
+            wg_barrier_lds();
+            if (kb + 2 < nkb) issue_y();
+            const float* Yst = Yring + (size_t)rslot * (K16 * 16);
+            if (++rslot == WIDE2_YBUF) rslot = 0;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f32x4 ya = ld4(Yst + (16 * mt + c16) * 16 + swz);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    T0.arg[mt] = MFMA16(ya[i], z0[i], T0.arg[mt]);
+                    T1.arg[mt] = MFMA16(ya[i], z1[i], T1.arg[mt]);
+                }
+            }
+            if (kb + 2 < nkb) issue_z(z0, z1, kb + 2);
+        };
+        for (int kb = 0; kb < nkb; kb += 2) {
+            step(kb, za0, za1);
+            if (kb + 1 < nkb) step(kb + 1, zb0, zb1);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 ni = ld4(nis + 16 * mt + 4 * q);
+            const f32x4 one = (f32x4){1.f, 1.f, 1.f, 1.f};
+            T0.arg[mt] = (2.f * (one - T0.arg[mt])) * ni;
+            T1.arg[mt] = (2.f * (one - T1.arg[mt])) * ni;
+        }
+    };
+    // table rows of the pass's groups (block b's tables have been flagged), finish, block sums out
+    auto finish = [&](int b, int tb, int ntl, int base) {
+        if (tid < WIDE2_SLOTS) tg[tid] = base + tid < ntl ? a.tile_grp[tb + base + tid] : -1;
+        wg_barrier_lds();
+        if (tid < WIDE2_SLOTS) {
+            int slot = 0;
+            for (int u = 1; u <= tid; ++u) slot += (tg[u] != tg[u - 1] && tg[u] >= 0) ? 1 : 0;
+            ts[tid] = slot;
+            if (tg[tid] >= 0 && (tid == 0 || tg[tid] != tg[tid - 1])) sg[slot] = tg[tid];
+        }
+        wg_barrier_lds();
+        const int nslots = ts[WIDE2_SLOTS - 1] + 1;
+        const float* rpi = a.rp_tab + (size_t)b * GK;
+        const float* lrpi = a.lrp_tab + (size_t)b * GK;
+        for (int i = tid; i < nslots * K16; i += NTHR) {
+            const int sl = i / K16, k = i - sl * K16;
+            const size_t src = (size_t)sg[sl] * K16 + k;
+            rpL[i] = ld_agent(rpi + src);
+            lrpL[i] = ld_agent(lrpi + src);
+        }
+        wg_barrier_lds();
+        const int j0 = base + 2 * wv;
+        const bool has0 = j0 < ntl, has1 = j0 + 1 < ntl;
+        T0.grp = ts[2 * wv];
+        T1.grp = has1 ? ts[2 * wv + 1] : T0.grp;
+        if (has0) {
+            float scl0, scl1 = 0.f;
+            round_post_pass1<MT, true>(sig, rpL, lrpL, q, T0, scl0, km_acc, ent_acc);
+            if (has1) round_post_pass1<MT, true>(sig, rpL, lrpL, q, T1, scl1, km_acc, ent_acc);
+            round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T0, scl0, has1, T1, scl1);
+        }
+        wg_barrier_lds();
+        double* dst = a.S_new + (size_t)b * GK;
+        for (int i = tid; i < nslots * K16; i += NTHR) {
+            const double v = Sd[i];
+            const int sl = i / K16;
+            if (v != 0.0) {   // returning: performed, not merely accepted, when the wave's vmcnt(0) before the arrival is through
+                const double old = atomicAdd(dst + (size_t)sg[sl] * K16 + (i - sl * K16), v);
+                asm volatile("" ::"v"(old));
+            }
+            Sd[i] = 0.0;
+        }
+    };
+
+    const int pass_tiles = nwg * WIDE2_SLOTS;
+#ifdef HMX_ROUND_PROF
+    unsigned long long pf[4] = {0, 0, 0, 0}, pt = __builtin_amdgcn_s_memtime();
+#define RWSTAMP(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pf[k] += now_ - pt; pt = now_; }
+#else
+#define RWSTAMP(k)
+#endif
+    for (int b = 0; b < a.nblk; ++b) {
+        const int tb = a.blk_start[b], ntl = a.blk_start[b + 1] - tb;
+        bool first = true;
+        // one call site for the tile pass (the code of two would not fit the instruction cache beside each other)
+        for (int base = wg * WIDE2_SLOTS; first || base < ntl; base += pass_tiles) {
+            const bool any = base < ntl;                                 // workgroup-uniform (false only in a first trip without tiles)
+            if (any) gemm(tb, ntl, base + 2 * wv);                       // table-independent: the first one runs while the service workgroup builds block b's tables
+            RWSTAMP(0)
+            if (first) {
+                // ---- wait for the tables of block b ------------------------------------------------------------------
+                if (wv == 0 && !failed) {
+                    unsigned spins = 0;
+                    if (a.spin_limit == 0) failed = true;                // test knob: give up without looking
+                    while (!failed && ld_agent(a.table_flag) < (unsigned)(b + 1)) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > a.spin_limit) failed = true;
+                    }
+                    ws_n += 1; ws_sum += spins; ws_max = max(ws_max, spins);
+                }
+                wg_barrier_lds();
+                first = false;
+                RWSTAMP(1)
+            }
+            if (any) finish(b, tb, ntl, base);
+            RWSTAMP(2)
+        }
+        // ---- the block's sums are performed, then arrive ---------------------------------------------------------------
+        WAIT_VMEM_ALL();
+        wg_barrier_lds();
+        if (tid == 0) __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        RWSTAMP(3)
+    }
+#ifdef HMX_ROUND_PROF
+    if (tid == 0 && a.prof)
+        for (int k = 0; k < 4; ++k) a.prof[(size_t)wg * 4 + k] = pf[k];
+#endif
+    if (tid == 0 && a.wait_stats) {
+        atomicAdd(a.wait_stats, (unsigned long long)ws_n);
+        atomicAdd(a.wait_stats + 1, (unsigned long long)ws_sum);
+        atomicMax(a.wait_stats + 2, (unsigned long long)ws_max);
+    }
+    km_acc = wave_sum_all(km_acc);
+    ent_acc = wave_sum_all(ent_acc);
+    if (lane == 0) {
+        objw[2 * wv] = km_acc;
+        objw[2 * wv + 1] = ent_acc;
+    }
+    __syncthreads();
+    if (tid < 2) {
+        double v = 0.0;
+        for (int w = 0; w < WIDE2_WAVES; ++w) v += objw[2 * w + tid];
+        if (v != 0.0) atomicAdd(&a.obj[2 * (wg & (HMX_OBJ_SLOTS - 1)) + tid], v);
+    }
+    if (tid == 0) {
+        if (failed) {
+            if (a.wait_stats) atomicAdd(a.wait_stats + 5, 1ull);          // diagnosis: workgroups that gave up
+            atomicExch(a.error, 1u);
+            atomicAdd(&a.obj[0], __builtin_nan(""));
+            atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS + 1], 1.0);
+        }
+    }
+}
+
 template <int MT, int KS>
 __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1499,7 +1855,11 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                 for (int sl = 0; sl < ROUND_WAVES * ROUND_TPW; ++sl)
                     if (Sg[sl] == g) v += (double)Sw[sl * K16 + k];
 #endif
+#if HMX_ROUND_RETURNING
+                if (v != 0.0) { const double old = atomicAdd(dst + i, v); asm volatile("" ::"v"(old)); }
+#else
                 if (v != 0.0) atomicAdd(dst + i, v);
+#endif
             }
         }
         WAIT_VMEM_ALL();   // the sums are performed (and the next operands landed)
@@ -3516,6 +3876,39 @@ int launch_round(const RoundArgs& a_in, int mt, int wgs, hipStream_t s) {
         case 52: launch_round_ks<13>(a, mt, wgs, sm, s); break;
         case 64: launch_round_ks<16>(a, mt, wgs, sm, s); break;
         default: return -1;
+    }
+    return 0;
+}
+
+static size_t round_wide_lds(int K16, int G) {
+    const size_t compute = ((size_t)WIDE2_YBUF * K16 * 16 + 2 * K16 + 2 * WIDE2_SLOTS * K16) * sizeof(float) +
+                           ((size_t)WIDE2_SLOTS * K16 + 2 * WIDE2_WAVES) * sizeof(double) + (3 * WIDE2_SLOTS + 4) * sizeof(int);
+    const size_t service = ((size_t)G * K16 + K16 + WIDE2_WAVES) * sizeof(double);
+    return std::max(compute, service);
+}
+// opt-in (HMX_WIDE_SWEEP=1): measured slower than one launch per block -- its hand-off crosses the
+// memory system six times per block under the compute workgroups' own traffic
+bool round_wide_ok(int mt, int dp, int K16, int G, int B, int V) {
+    const char* v = getenv("HMX_WIDE_SWEEP");
+    return v && atoi(v) != 0 && V == 1 && G == B && mt >= 8 && mt <= 13 && dp % 16 == 0 && round_wide_lds(K16, G) <= 80 * 1024;
+}
+template <int MT>
+static void launch_round_wide_t(const RoundArgs& a, int wgs, size_t sm, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_round_wide<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_round_wide<MT>), dim3(wgs + 1), dim3(64 * WIDE2_WAVES), sm, s, a);
+}
+int launch_round_wide(const RoundArgs& a, int mt, int wgs, hipStream_t s) {
+    if (!round_wide_ok(mt, a.dp, a.K16, a.G, a.B, a.V) || wgs < 1) return -1;
+    const size_t sm = round_wide_lds(a.K16, a.G);
+    switch (mt) {
+        case 8: launch_round_wide_t<8>(a, wgs, sm, s); break;   case 9: launch_round_wide_t<9>(a, wgs, sm, s); break;
+        case 10: launch_round_wide_t<10>(a, wgs, sm, s); break; case 11: launch_round_wide_t<11>(a, wgs, sm, s); break;
+        case 12: launch_round_wide_t<12>(a, wgs, sm, s); break;
+        default: launch_round_wide_t<13>(a, wgs, sm, s); break;
     }
     return 0;
 }

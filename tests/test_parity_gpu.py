@@ -430,6 +430,23 @@ def test_sweep_timeout_falls_back_to_blocks(sweep, monkeypatch, capfd):
         assert min(cors) > 0.99, min(cors)
 
 
+def test_wide_sweep_opt_in_matches_oracle_and_survives_timeouts(monkeypatch, capfd):
+    """HMX_WIDE_SWEEP=1: the persistent sweep of the wide shapes (k_round_wide: compute workgroups + one service workgroup
+    that owns O and the per-block tables) -- opt-in because it measured slower than one launch per block (DESIGN.md
+    section 3).  Same parity bar as the default path on the configs[4] shape; with HMX_SPIN_LIMIT=0 every wait gives up and
+    the rounds are replayed exactly, block by block."""
+    monkeypatch.setenv("HMX_WIDE_SWEEP", "1")
+    ho = _bench_path_case(40_000, 200, 32, 200, monkeypatch, ridge_dtype=np.float32, rounds=(3, 2))
+    cnt = ho._engine.counters()
+    assert cnt["sweep_waits"] > 0 and cnt["sweep_fallbacks"] == 0, cnt      # the persistent kernel ran, nothing timed out
+    monkeypatch.setenv("HMX_SPIN_LIMIT", "0")
+    hf = _bench_path_case(40_000, 200, 32, 200, monkeypatch, ridge_dtype=np.float32, rounds=(3, 2))
+    assert hf._engine.counters()["sweep_fallbacks"] == 2
+    assert "timed out" in capfd.readouterr().err
+    rel_f, max_rel = assert_z_close(hf.Z_corr, ho.Z_corr, what="Z_corr after replayed rounds vs the undisturbed wide sweep")
+    print(f"wide sweep, every sweep timed out: relF={rel_f:.2e} max={max_rel:.2e}")
+
+
 # ------------------------------------------------------------------------------------------
 # device-side update order (hmx_cluster_round_seeded)
 # ------------------------------------------------------------------------------------------
