@@ -102,6 +102,10 @@ __device__ __forceinline__ unsigned long long ld_sys(const unsigned long long* p
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ void st_sys(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void xchg_sys(double* p, double v) {   // returning: performed at the peer when the wave's vmcnt(0) is through (see xchg_agent)
+    const double old = __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("" ::"v"(old));
+}
 __device__ __forceinline__ void st_sys(unsigned long long* p, unsigned long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }

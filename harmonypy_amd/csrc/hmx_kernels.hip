@@ -714,7 +714,12 @@ __device__ __forceinline__ void round_post_pass1(const float* sig, const float* 
 // the block's (group, cluster) table.  Tiles of one group (the usual case: a wave's tiles are
 // neighbours in the block's group-sorted list) share one cross-lane reduction.
 #ifndef HMX_ROUND_RETURNING
-#define HMX_ROUND_RETURNING 0   /* 1: the slot atomics of k_round return their old value (see k_round_wide's service workgroup for why one might want that) */
+/* 1 (default): the slot atomics of k_round (and the peer-box writes of its gateway workgroup) RETURN their old value, so the
+   wave's vmcnt(0) before the arrival means "performed", not "accepted".  k_round_wide's hand-off showed what the difference
+   can be: a flag raised behind non-returning atomics or stores was seen by other XCDs before some of the data.  k_round queues
+   at most two atomics per thread and never showed it in any parity run, but "never observed" is not an ordering guarantee.
+   Measured cost at C3: 3.67 -> 3.75 ms of sweeps per Harmony iteration (+2 %). */
+#define HMX_ROUND_RETURNING 1
 #endif
 #ifndef HMX_ROUND_SUMS
 #define HMX_ROUND_SUMS 0   /* 1 (experiment): a wave's block sums go to its own fp32 slots in LDS (plain stores), summed at publish time, instead of fp64 LDS atomics on shared addresses */
@@ -1544,7 +1549,11 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                 double v = 0.0;
 #pragma unroll
                 for (int s = 0; s < HMX_ROUND_SLOTS; ++s) v += ld_agent(sn + (size_t)s * GK);
+#if HMX_ROUND_RETURNING
+                for (int r = 0; r < a.n_ranks; ++r) xchg_sys(a.peer_box[r] + box_data(a.n_ranks, GK, b & 1, a.rank) + i, v);
+#else
                 for (int r = 0; r < a.n_ranks; ++r) st_sys(a.peer_box[r] + box_data(a.n_ranks, GK, b & 1, a.rank) + i, v);
+#endif
             }
             WAIT_VMEM_ALL();
             __syncthreads();
@@ -3816,7 +3825,11 @@ __global__ __launch_bounds__(256) void k_peer_selftest(double* const* peer_box, 
         const unsigned long long tk = token * 16ull + (unsigned long long)it;
         const int par = it & 1;
         for (int r = 0; r < n_ranks; ++r)
+#if HMX_ROUND_RETURNING
+            for (int i = tid; i < npay; i += 256) xchg_sys(peer_box[r] + box_data(n_ranks, GK, par, rank) + i, (double)(tk % 1000003ull) + i);
+#else
             for (int i = tid; i < npay; i += 256) st_sys(peer_box[r] + box_data(n_ranks, GK, par, rank) + i, (double)(tk % 1000003ull) + i);
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid < n_ranks) st_sys(reinterpret_cast<unsigned long long*>(peer_box[tid]) + tok0 + rank, tk);
