@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_assign_wide2(AssignArgs
     auto step = [&](int kb, f32x4& z0, f32x4& z1) {
         if (kb + 1 < nkb) {
             if (npw + 2 >= 6) wide2_wait<6>(z0, z1); else if (npw + 2 == 5) wide2_wait<5>(z0, z1);
-            else if (npw + 2 == 4) wide2_wait<4>(z0, z1); else wide2_wait<3>(z0, z1);
+            else if (npw + 2 == 4) wide2_wait<4>(z0, z1); else if (npw + 2 == 3) wide2_wait<3>(z0, z1); else wide2_wait<2>(z0, z1);   // (a wave without pieces: K16 < 64)
         } else {
             wide2_wait<0>(z0, z1);
         }
@@ -1342,7 +1342,7 @@ __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_round_wide(RoundArgs a)
         auto step = [&](int kb, f32x4& z0, f32x4& z1) {
             if (kb + 1 < nkb) {
                 if (npw + 2 >= 6) wide2_wait<6>(z0, z1); else if (npw + 2 == 5) wide2_wait<5>(z0, z1);
-                else if (npw + 2 == 4) wide2_wait<4>(z0, z1); else wide2_wait<3>(z0, z1);
+                else if (npw + 2 == 4) wide2_wait<4>(z0, z1); else if (npw + 2 == 3) wide2_wait<3>(z0, z1); else wide2_wait<2>(z0, z1);   // (a wave without pieces: K16 < 64)
             } else {
                 wide2_wait<0>(z0, z1);
             }
@@ -3728,7 +3728,7 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
         const size_t sm = ((size_t)2 * a.K16 * 20 + 2 * a.K16) * sizeof(float) + (a.tables_in_lds ? gk_bytes : 0) + 2 * WIDE_WAVES * sizeof(double);
         // the penalised block assignment of the round loop: two tiles per wave, two workgroups per CU (k_assign_wide2)
         static const int wide_mode = [] { const char* v = getenv("HMX_WIDE_ASSIGN"); return v ? atoi(v) : 2; }();
-        if (penalty && !a.hn && wide_mode == 2 && a.mt >= 1 && a.mt <= 13) {
+        if (penalty && !a.hn && wide_mode == 2 && a.mt >= 8 && a.mt <= 13) {   // (K > 112: what the parity suite covers; below, the 8-wave kernel)
             const size_t sm2 = ((size_t)WIDE2_YBUF * a.K16 * 16 + 2 * a.K16 + 2 * WIDE2_SLOTS * a.K16) * sizeof(float) +
                                ((size_t)WIDE2_SLOTS * a.K16 + 2 * WIDE2_WAVES) * sizeof(double) + 3 * WIDE2_SLOTS * sizeof(int);
             const int wgs2 = cdiv(ntiles, WIDE2_SLOTS);
@@ -3743,7 +3743,6 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
     } break;
             if (sm2 <= 80 * 1024) {
                 switch (a.mt) {
-                    HMX_WIDE2_CASE(1) HMX_WIDE2_CASE(2) HMX_WIDE2_CASE(3) HMX_WIDE2_CASE(4) HMX_WIDE2_CASE(5) HMX_WIDE2_CASE(6) HMX_WIDE2_CASE(7)
                     HMX_WIDE2_CASE(8) HMX_WIDE2_CASE(9) HMX_WIDE2_CASE(10) HMX_WIDE2_CASE(11) HMX_WIDE2_CASE(12) HMX_WIDE2_CASE(13)
                 }
                 return 0;
