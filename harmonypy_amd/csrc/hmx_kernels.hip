@@ -3728,12 +3728,7 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
         const size_t sm = ((size_t)2 * a.K16 * 20 + 2 * a.K16) * sizeof(float) + (a.tables_in_lds ? gk_bytes : 0) + 2 * WIDE_WAVES * sizeof(double);
         // the penalised block assignment of the round loop: two tiles per wave, two workgroups per CU (k_assign_wide2)
         static const int wide_mode = [] { const char* v = getenv("HMX_WIDE_ASSIGN"); return v ? atoi(v) : 2; }();
-#ifdef HMX_WIDE2_ALL   /* experiment: every cluster-tile count */
-        const int wide2_min_mt = 1;
-#else
-        const int wide2_min_mt = 8;   // K > 112: what the parity suite covers; below, the 8-wave kernel
-#endif
-        if (penalty && !a.hn && wide_mode == 2 && a.mt >= wide2_min_mt && a.mt <= 13) {
+        if (penalty && !a.hn && wide_mode == 2 && a.mt >= 8 && a.mt <= 13) {   // (K > 112: what the parity suite covers; below, the 8-wave kernel)
             const size_t sm2 = ((size_t)WIDE2_YBUF * a.K16 * 16 + 2 * a.K16 + 2 * WIDE2_SLOTS * a.K16) * sizeof(float) +
                                ((size_t)WIDE2_SLOTS * a.K16 + 2 * WIDE2_WAVES) * sizeof(double) + 3 * WIDE2_SLOTS * sizeof(int);
             const int wgs2 = cdiv(ntiles, WIDE2_SLOTS);
@@ -3748,9 +3743,6 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
     } break;
             if (sm2 <= 80 * 1024) {
                 switch (a.mt) {
-#ifdef HMX_WIDE2_ALL
-                    HMX_WIDE2_CASE(1) HMX_WIDE2_CASE(2) HMX_WIDE2_CASE(3) HMX_WIDE2_CASE(4) HMX_WIDE2_CASE(5) HMX_WIDE2_CASE(6) HMX_WIDE2_CASE(7)
-#endif
                     HMX_WIDE2_CASE(8) HMX_WIDE2_CASE(9) HMX_WIDE2_CASE(10) HMX_WIDE2_CASE(11) HMX_WIDE2_CASE(12) HMX_WIDE2_CASE(13)
                 }
                 return 0;

@@ -1,4 +1,5 @@
-"""Debug aid: k_assign_wide2 on small cluster counts (library built with -DHMX_WIDE2_ALL) against the oracle."""
+"""Debug aid: k_assign_wide2 on small cluster counts against the oracle -- needs a library in which launch_assign's `a.mt >= 8`
+test is lifted and k_assign_wide2<1..7> are instantiated (hmx_kernels.hip, HMX_WIDE2_CASE)."""
 import os, sys
 import numpy as np, pandas as pd
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
