@@ -406,7 +406,7 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
             (rc = e->R.reserve((N + 16) * e->Kp + e->K16 + 64)) || (rc = e->Osave.reserve(GK)) || (rc = e->Y.reserve((size_t)e->K16 * e->ldy)) ||
             (rc = e->Yacc.reserve((size_t)e->K16 * e->ldy)) || (rc = e->sigma.reserve(e->K16)) ||
             (rc = e->theta.reserve(e->B)) || (rc = e->Pr_b.reserve(e->B)) || (rc = e->lamb.reserve(e->B + 1)) ||
-            (rc = e->rp.reserve(GK * e->nblk)) || (rc = e->lrp.reserve(GK * e->nblk)) || (rc = e->group_cols.reserve((size_t)e->G * e->V)) ||
+            (rc = e->rp.reserve(2 * GK * e->nblk)) || (rc = e->lrp.reserve(GK)) || (rc = e->group_cols.reserve((size_t)e->G * e->V)) ||
             (rc = e->Ogrp.reserve(GK)) || (rc = e->Tmass.reserve(e->K16)) || (rc = e->Ohist.reserve(GK * e->nblk)) ||
             (rc = e->W.reserve(GK * e->ldy)) || (rc = e->lists[0].blk_start.reserve(e->nblk + 1)) ||
             (rc = e->lists[1].blk_start.reserve(e->nblk + 1)))
@@ -421,7 +421,7 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
             e->Sr = e->objacc + n_obj;
             e->Oxr = e->Sr + GK * e->ldy;
         }
-        if ((rc = e->Sslots.reserve(GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 1 + 128)) || (rc = e->wait_stats.reserve(8))) break;   // + slack: the per-round fill is rounded up to 1 KB
+        if ((rc = e->Sslots.reserve(GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 1 + 256)) || (rc = e->wait_stats.reserve(8))) break;   // + slack: the per-round fill is rounded up to 1 KB
         (void)hipMemsetAsync(e->wait_stats.p, 0, 8 * sizeof(unsigned long long), e->stream);
         e->sync_words.p = reinterpret_cast<unsigned*>(e->Sslots.p + GK * (e->nblk + 1) * HMX_ROUND_SLOTS);   // borrowed tail
         e->sync_words.n = 2;
@@ -1160,7 +1160,7 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
             // the slot tables and the two sync words (carved from the same allocation): one fill (size rounded up to 1 KB
             // inside the allocation: an odd size makes the runtime launch a second fill kernel for the tail); O at the
             // start of the round is kept for an exact replay
-            HIP_TRY(hipMemsetAsync(e->Sslots.p, 0, (((GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 2) * sizeof(double) + 1023) / 1024) * 1024, e->stream));   // (+ the table flag of k_round_wide behind the two sync words)
+            HIP_TRY(hipMemsetAsync(e->Sslots.p, 0, (((GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 2 + HMX_MAX_BLOCKS / 2) * sizeof(double) + 1023) / 1024) * 1024, e->stream));   // (+ k_round_wide's per-block arrival counters behind the two sync words)
             HIP_TRY(hipMemcpyAsync(e->Osave.p, e->Ogrp.p, GK * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
         }
         int max_upper = 0;
@@ -1193,6 +1193,8 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
 #endif
             if (mega_wide) {
                 ra.rp_tab = e->rp.p; ra.lrp_tab = e->lrp.p; ra.table_flag = e->sync_words.p + 2;
+                e->round_epoch += 64;                 // tags of this launch's table entries: epoch + block + 1, never seen before
+                ra.epoch = e->round_epoch;
                 if (launch_round_wide(ra, e->mt, wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported shape for k_round_wide");
 #ifdef HMX_ROUND_PROF
                 if (++prof_rounds == 12) {

@@ -61,9 +61,9 @@ struct RoundArgs {
     int n_ranks, rank;
     int K, Kp, K16, dp, ldy, ldy_lds, G, B, V, nblk;
     // k_round_wide only: the diversity tables of every block, written by the service workgroup
-    float* rp_tab;             // nblk x G x K16
-    float* lrp_tab;            // nblk x G x K16
-    unsigned* table_flag;      // = b + 1 once the tables of block b are complete (zeroed by the caller)
+    float* rp_tab;             // nblk x G x K16 entries of 8 bytes: {ratio^theta (float), epoch + block + 1 (unsigned)}
+    float* lrp_tab;            // (unused)
+    unsigned* table_flag;      // nblk arrival counters, one per block (zeroed by the caller)
 };
 
 // One whole update_R sweep (all blocks) in one persistent launch (k_sweep, hmx_sweep.hip): distance product, reassignment,

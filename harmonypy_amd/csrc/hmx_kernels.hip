@@ -1136,16 +1136,18 @@ __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_assign_wide2(AssignArgs
 
 // ------------------------------------------------------------------------------------------
 // k_round_wide: the whole update_R sweep of the wide shapes (K <= 208, d <= 208) in ONE persistent launch -- k_assign_wide2's
-// tile pass inside a loop over the update blocks, with k_round's hand-off.  The centroid table does not fit the LDS, so it
-// is streamed per k-step as in k_assign_wide2, and the (group, cluster) tables do not fit beside it either (24 B x G x K16 =
-// 160 KB at 32 batches), so the roles are split:
-//   * compute workgroups (4 waves, 2 per CU, 8 tiles per pass): distance GEMM of the next block's first tiles BEFORE the
-//     wait (it does not depend on the tables), then the table rows of their own tiles' groups from the global table, finish,
-//     block sums of their own groups -> fp64 atomics into the block's slot table, arrive;
+// tile pass inside a loop over the update blocks.  OPT-IN (HMX_WIDE_SWEEP=1): measured 78 us per block at the configs[4] shard
+// against 73 us for one launch per block.  The centroid table does not fit the LDS, so it is streamed
+// per k-step as in k_assign_wide2, and the (group, cluster) tables do not fit beside it either (24 B x G x K16 = 160 KB at 32
+// batches), so the roles are split:
+//   * compute workgroups (4 waves, 2 per CU, 8 tiles per pass): distance GEMM of the block's first tiles BEFORE the tables
+//     are needed (it does not depend on them), then the table rows of their own tiles' groups from the block's global table --
+//     self-validating 8-byte entries, polled -- finish, block sums of their own groups -> returning fp64 atomics into the
+//     block's slot table, arrive on the block's own counter;
 //   * ONE service workgroup (the last of the grid) owns O (fp64, in its LDS): when all compute workgroups have arrived for
-//     block b-1 it folds their sums in, takes block b's removal sums out, rebuilds ratio^theta and its log for all (group,
-//     cluster) pairs (:491-499), writes them to block b's global table with returning agent-scope exchanges and raises a flag
-//     -- while the compute workgroups multiply.  It closes the sweep (O, cluster mass, cross-entropy term, :405-411).
+//     block b-1 it folds their sums in, takes block b's removal sums out, rebuilds ratio^theta for all (group, cluster)
+//     pairs (:491-499) and stores block b's table -- while the compute workgroups multiply.  It closes the sweep (O,
+//     cluster mass, cross-entropy term, :405-411).
 // One batch variable only (group g is batch g); other cases stay on one launch per block.  All waits are bounded.
 // ------------------------------------------------------------------------------------------
 template <int MT>
@@ -1178,16 +1180,18 @@ __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_round_wide(RoundArgs a)
         for (int b = 0; b <= a.nblk; ++b) {
             if (b > 0) {
                 if (wv == 0 && !sfail) {
-                    const unsigned want = (unsigned)b * (unsigned)nwg;
+                    // one arrival counter per block: a workgroup without tiles in a block arrives at once, blocks ahead of the
+                    // others -- with a single running count its early arrivals would stand in for workgroups still at work
+                    const unsigned* arrived = a.table_flag + (b - 1);
                     unsigned spins = 0;
                     if (a.spin_limit == 0) sfail = true;                 // test knob: give up without looking
-                    while (!sfail && ld_agent(a.counter) < want) {
+                    while (!sfail && ld_agent(arrived) < (unsigned)nwg) {
                         __builtin_amdgcn_s_sleep(1);
                         if (++spins > a.spin_limit) sfail = true;
                     }
                     if (sfail && lane == 0 && a.wait_stats) {             // diagnosis: the block it waited for, the arrivals it saw
                         atomicMax(a.wait_stats + 6, (unsigned long long)b);
-                        atomicMax(a.wait_stats + 7, (unsigned long long)ld_agent(a.counter));
+                        atomicMax(a.wait_stats + 7, (unsigned long long)ld_agent(arrived));
                     }
                 }
                 __syncthreads();
@@ -1208,27 +1212,24 @@ __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_round_wide(RoundArgs a)
             __syncthreads();
             SVSTAMP(1)
             if (b == a.nblk) break;
-            float* rpo = a.rp_tab + (size_t)b * GK;                          // a table of its own per block
-            float* lrpo = a.lrp_tab + (size_t)b * GK;
+            // block b's table: 8-byte entries {ratio^theta, tag of (launch, block)}, ONE agent-scope store each: an entry whose tag
+            // is right IS block b's value, so there is no flag and nothing to order -- the readers poll the data itself.
+            // (What a flag needs, measured here at 40 k cells x 200 with 20 compute workgroups that reach the wait before the
+            // table is ready: behind relaxed agent-scope stores + vmcnt(0) + barrier, behind the same with release / acquire,
+            // and behind NON-returning exchanges, other XCDs saw the flag before some rows -- a third of the rounds had a few
+            // hundred wrong cells, differently in every run; behind RETURNING exchanges it was correct, but the service
+            // workgroup then needs 65 us per block under the compute workgroups' memory traffic.)
+            unsigned long long* tabo = reinterpret_cast<unsigned long long*>(a.rp_tab) + (size_t)b * GK;
+            const unsigned long long tag = (unsigned long long)((unsigned)a.epoch + (unsigned)b + 1u) << 32;
             for (int i = tid; i < GK; i += NTHR) {
-                const int g = i / K16, k = i - g * K16;
+                const int g = i / K16, k2 = i - g * K16;
                 const float O = (float)Ocur[i];
-                const float E = (float)Tm[k] * a.Pr_b[g];                   // :491 (E kept as mass T)
+                const float E = (float)Tm[k2] * a.Pr_b[g];                  // :491 (E kept as mass T)
                 const float oe = fmaxf(O + E, 1e-8f);                       // :495-496
                 const float ratio = fminf(fmaxf(E / oe, 1e-8f), 1.0f);      // :497-498
                 const float rp = pow_unit(ratio, a.theta[g]);               // :499
-                xchg_agent(rpo + i, rp);
-                xchg_agent(lrpo + i, __builtin_amdgcn_logf(rp) * 0.693147182464599609375f);
+                __hip_atomic_store(tabo + i, tag | (unsigned long long)__float_as_uint(rp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            // Table entries and flag are RETURNING exchanges at agent scope: vmcnt(0) then means every entry has been performed
-            // where other XCDs read it, and only then -- barrier -- the flag goes up.  Measured on the way here (40 k cells x 200,
-            // 20 compute workgroups that reach the wait before the table is ready): plain agent-scope stores (relaxed; or with
-            // a release on the flag and an acquire in the readers), and non-returning exchanges, all let readers see the flag
-            // before some rows: a third of the rounds had a few hundred wrong cells, differently in every run.  A non-returning
-            // atomic / a store is acknowledged when accepted, not when performed.
-            WAIT_VMEM_ALL();
-            __syncthreads();
-            if (tid == 0) xchg_agent(a.table_flag, (unsigned)(b + 1));
             SVSTAMP(2)
         }
 #ifdef HMX_ROUND_PROF
@@ -1299,7 +1300,7 @@ __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_round_wide(RoundArgs a)
     unsigned yzone = yzone0;
     int yslot = 0, rslot = 0;                                            // ring positions of the next request / the next read: they run on across tiles
     double km_acc = 0.0, ent_acc = 0.0;
-    bool failed = false;                                                 // (lives in wave 0)
+    bool failed = false;                                                 // per thread: a wait of its own gave up
     unsigned ws_n = 0, ws_sum = 0, ws_max = 0;
 
     RoundTile<MT> T0, T1;
@@ -1385,13 +1386,25 @@ __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_round_wide(RoundArgs a)
         }
         wg_barrier_lds();
         const int nslots = ts[WIDE2_SLOTS - 1] + 1;
-        const float* rpi = a.rp_tab + (size_t)b * GK;
-        const float* lrpi = a.lrp_tab + (size_t)b * GK;
+        const unsigned long long* tabi = reinterpret_cast<const unsigned long long*>(a.rp_tab) + (size_t)b * GK;
+        const unsigned tag = (unsigned)a.epoch + (unsigned)b + 1u;
         for (int i = tid; i < nslots * K16; i += NTHR) {
             const int sl = i / K16, k = i - sl * K16;
-            const size_t src = (size_t)sg[sl] * K16 + k;
-            rpL[i] = ld_agent(rpi + src);
-            lrpL[i] = ld_agent(lrpi + src);
+            const unsigned long long* src = tabi + (size_t)sg[sl] * K16 + k;
+            unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            bool gave_up = a.spin_limit == 0 || failed;                  // (spin_limit 0: test knob, give up without looking)
+            while ((unsigned)(v >> 32) != tag && !gave_up) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > a.spin_limit) gave_up = true;
+                v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (gave_up) failed = true;                                  // this thread stops waiting: the launch is lost
+            if (tid == 0) { ws_n += 1; ws_sum += spins; ws_max = max(ws_max, spins); }
+            const float rp = __uint_as_float((unsigned)v);
+            const bool good = (unsigned)(v >> 32) == tag && !gave_up;
+            rpL[i] = good ? rp : 1.f;                                    // (after a time-out: keep the arithmetic finite)
+            lrpL[i] = good ? __builtin_amdgcn_logf(rp) * 0.693147182464599609375f : 0.f;
         }
         wg_barrier_lds();
         const int j0 = base + 2 * wv;
@@ -1432,28 +1445,14 @@ __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_round_wide(RoundArgs a)
             const bool any = base < ntl;                                 // workgroup-uniform (false only in a first trip without tiles)
             if (any) gemm(tb, ntl, base + 2 * wv);                       // table-independent: the first one runs while the service workgroup builds block b's tables
             RWSTAMP(0)
-            if (first) {
-                // ---- wait for the tables of block b ------------------------------------------------------------------
-                if (wv == 0 && !failed) {
-                    unsigned spins = 0;
-                    if (a.spin_limit == 0) failed = true;                // test knob: give up without looking
-                    while (!failed && ld_agent(a.table_flag) < (unsigned)(b + 1)) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if (++spins > a.spin_limit) failed = true;
-                    }
-                    ws_n += 1; ws_sum += spins; ws_max = max(ws_max, spins);
-                }
-                wg_barrier_lds();
-                first = false;
-                RWSTAMP(1)
-            }
+            first = false;
             if (any) finish(b, tb, ntl, base);
             RWSTAMP(2)
         }
         // ---- the block's sums are performed, then arrive ---------------------------------------------------------------
         WAIT_VMEM_ALL();
         wg_barrier_lds();
-        if (tid == 0) __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_fetch_add(a.table_flag + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // this block's own counter
         RWSTAMP(3)
     }
 #ifdef HMX_ROUND_PROF
@@ -1477,8 +1476,9 @@ __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_round_wide(RoundArgs a)
         for (int w = 0; w < WIDE2_WAVES; ++w) v += objw[2 * w + tid];
         if (v != 0.0) atomicAdd(&a.obj[2 * (wg & (HMX_OBJ_SLOTS - 1)) + tid], v);
     }
+    const bool any_failed = __syncthreads_or(failed ? 1 : 0) != 0;
     if (tid == 0) {
-        if (failed) {
+        if (any_failed) {
             if (a.wait_stats) atomicAdd(a.wait_stats + 5, 1ull);          // diagnosis: workgroups that gave up
             atomicExch(a.error, 1u);
             atomicAdd(&a.obj[0], __builtin_nan(""));

@@ -39,6 +39,12 @@ KNOWN_SPILLS = {
     "_Z5k_rtzILi7ELi4EEv7RtzArgs": 4,
     "_ZN12_GLOBAL__N_110k_lisi_knnILi4ELi4ELi256EEEv11LisiKnnArgs": 3,      # the 50-PC LISI search
     "_Z6k_rtz3ILi7ELi8ELi1EEv8Rtz3Args": 20,                           # K > 96 with d <= 32 and 33..48 update blocks
+    # the opt-in persistent sweep of the wide shapes (HMX_WIDE_SWEEP=1): the exponent arguments of two tiles (8 MT registers)
+    # are live across the loop that polls the table entries -- spilled around it, outside the distance product
+    "_Z12k_round_wideILi10EEv9RoundArgs": 25,
+    "_Z12k_round_wideILi11EEv9RoundArgs": 52,
+    "_Z12k_round_wideILi12EEv9RoundArgs": 73,
+    "_Z12k_round_wideILi13EEv9RoundArgs": 100,
 }
 
 
