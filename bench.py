@@ -77,7 +77,7 @@ def resolve_workload(config, gpus):
         return config, JOB_CELLS[config] // gpus, "strong"
     return config, CONFIGS[config][0], "weak"
 
-TIMED_LAUNCH_STRIDE = 7   # the dominant kernel's launches bracketed with HIP events inside the timed region: every 7th (coprime with the 10 rounds of a step)
+TIMED_LAUNCH_STRIDE = 4   # the dominant kernel's launches bracketed with HIP events inside the timed region: every 4th (every 7th left 8 samples per default run: one delayed launch moved the average by 5 %)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense (= the f32 vector rate)
 
