@@ -3,7 +3,7 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-os.environ["HMX_UPDATE_ORDER"] = "device"
+os.environ.setdefault("HMX_UPDATE_ORDER", "device")
 from bench import quick_centroids, synthetic_dataset
 from oracle.harmony_oracle import OracleHarmony, prepare_inputs
 from test_parity_gpu import _device_perm_source, _run_engine
