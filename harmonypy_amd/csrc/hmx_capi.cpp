@@ -1099,8 +1099,6 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
 #endif
     const bool mega = persistent && e->mt <= 7 && round_row_floats(e->d) == e->dp &&
                       round_lds_bytes(e->K16, e->dp, e->G, e->B, e->V) <= HMX_ROUND_LDS_LIMIT;
-    // wide shapes (K > 112 or d > 64), one batch variable, single engine: the persistent sweep with a service workgroup
-    const bool mega_wide = persistent && !mega && !sharded(e) && round_wide_ok(e->mt, e->dp, e->K16, e->G, e->B, e->V);
     const bool r3 = streaming_rtz(e);
     // a single engine on the persistent sweep: k_rtz3_finish normalises the centroids itself (no collective is due in
     // between) and does the sweep kernel's fills -- three launches per round
@@ -1154,20 +1152,19 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         }
     }
     if (before_sweep && (rc = before_sweep())) return rc;   // side-stream work that should run beside the sweep, not beside the R^T.Z pass
-    if (mega || mega_wide) {
-        // the whole sweep in one persistent launch (k_round / k_round_wide); closes O, T and the objective itself
+    if (mega) {
+        // the whole sweep in one persistent launch (k_round); closes O, T and the objective itself
         if (!fused) {
             // the slot tables and the two sync words (carved from the same allocation): one fill (size rounded up to 1 KB
             // inside the allocation: an odd size makes the runtime launch a second fill kernel for the tail); O at the
             // start of the round is kept for an exact replay
-            HIP_TRY(hipMemsetAsync(e->Sslots.p, 0, (((GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 2 + HMX_MAX_BLOCKS / 2) * sizeof(double) + 1023) / 1024) * 1024, e->stream));   // (+ k_round_wide's per-block arrival counters behind the two sync words)
+            HIP_TRY(hipMemsetAsync(e->Sslots.p, 0, (((GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 2 + HMX_MAX_BLOCKS / 2) * sizeof(double) + 1023) / 1024) * 1024, e->stream));
             HIP_TRY(hipMemcpyAsync(e->Osave.p, e->Ogrp.p, GK * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
         }
         int max_upper = 0;
         for (int b = 0; b < e->nblk; ++b) max_upper = std::max(max_upper, tiles_upper[b]);
         const bool multi = e->peers_enabled && e->n_ranks > 1;
-        int wgs = mega_wide ? std::min(2 * e->n_cus - 1, std::max(1, (max_upper + 7) / 8))   // two workgroups per CU, one slot for the service workgroup
-                            : std::min(e->n_cus - (multi ? 1 : 0), std::max(1, (max_upper + 13) / 14));   // ~14 of a workgroup's 16 tile slots: 224 of 256 CUs at C3, the rest serve the second stream
+        int wgs = std::min(e->n_cus - (multi ? 1 : 0), std::max(1, (max_upper + 13) / 14));   // ~14 of a workgroup's 16 tile slots: 224 of 256 CUs at C3, the rest serve the second stream
         // (sharded: every rank sizes its grid from its own share; the grid only decides how this rank's tiles are dealt out)
         if (e->round_wgs_cap > 0) wgs = std::min(wgs, e->round_wgs_cap);
         {
@@ -1191,30 +1188,9 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
             if (prof.reserve((size_t)wgs * e->nblk * 16)) return -1;
             ra.prof = prof.p;
 #endif
-            if (mega_wide) {
-                ra.rp_tab = e->rp.p; ra.lrp_tab = e->lrp.p; ra.table_flag = e->sync_words.p + 2;
-                e->round_epoch += 64;                 // tags of this launch's table entries: epoch + block + 1, never seen before
-                ra.epoch = e->round_epoch;
-                if (launch_round_wide(ra, e->mt, wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported shape for k_round_wide");
-#ifdef HMX_ROUND_PROF
-                if (++prof_rounds == 12) {
-                    std::vector<unsigned long long> h((size_t)(wgs + 1) * 4);
-                    (void)hipStreamSynchronize(e->stream);
-                    (void)hipMemcpy(h.data(), prof.p, h.size() * 8, hipMemcpyDeviceToHost);
-                    double m[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0};
-                    for (int w = 0; w < wgs; ++w)
-                        for (int k = 0; k < 4; ++k) { m[k] += (double)h[(size_t)w * 4 + k]; mx[k] = std::max(mx[k], (double)h[(size_t)w * 4 + k]); }
-                    fprintf(stderr, "[k_round_wide prof] %d compute workgroups, cycles per block (mean / slowest workgroup): distance product %.0f / %.0f, wait for the tables %.0f / %.0f, finish %.0f / %.0f, publish + arrive %.0f / %.0f\n",
-                            wgs, m[0] / wgs / e->nblk, mx[0] / e->nblk, m[1] / wgs / e->nblk, mx[1] / e->nblk, m[2] / wgs / e->nblk, mx[2] / e->nblk, m[3] / wgs / e->nblk, mx[3] / e->nblk);
-                    const unsigned long long* sv = &h[(size_t)wgs * 4];
-                    fprintf(stderr, "[k_round_wide prof] service workgroup, cycles per block: waiting for arrivals %.0f, fold + cluster mass %.0f, tables + flag %.0f\n",
-                            (double)sv[0] / e->nblk, (double)sv[1] / e->nblk, (double)sv[2] / e->nblk);
-                }
-#endif
-            } else
             if (launch_round(ra, e->mt, multi ? wgs + 1 : wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported shape for k_round");
 #ifdef HMX_ROUND_PROF
-            if (!mega_wide && ++prof_rounds == 25) {   // one round in steady state: phase durations over workgroups and blocks
+            if (++prof_rounds == 25) {   // one round in steady state: phase durations over workgroups and blocks
                 std::vector<unsigned long long> h((size_t)wgs * e->nblk * 16);
                 (void)hipStreamSynchronize(e->stream);
                 (void)hipMemcpy(h.data(), prof.p, h.size() * 8, hipMemcpyDeviceToHost);
@@ -1381,12 +1357,6 @@ static int seeded_round(hmx_engine* e, int flags, uint64_t seed, int64_t cells_p
     // kernel, which leaves a few CUs idle.  The scratch tables (chunk_tab, run_*) are free by then.
     auto prefetch = [&]() -> int {
         if (!e->prefetch_lists || !e->stream2) return 0;
-        // k_round_wide fills every CU with two workgroups and needs all of them resident: with the list kernels of the side
-        // stream in flight when it is launched, half of its grid (the service workgroup included) was not placed until the
-        // first half had given up (measured).  There the next round's lists are built on the main stream, behind the sweep.
-        if (e->round_mode == 1 && !sharded(e) && !(e->mt <= 7 && round_row_floats(e->d) == e->dp) &&
-            round_wide_ok(e->mt, e->dp, e->K16, e->G, e->B, e->V))
-            return 0;
         HIP_TRY(hipEventRecord(e->pre_event, e->stream));
         HIP_TRY(hipStreamWaitEvent(e->stream2, e->pre_event, 0));
         build(counter + 1, e->cur ^ 1, e->stream2);

@@ -85,7 +85,8 @@ __device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // a value handed to other workgroups as a RETURNING read-modify-write at agent scope: the old value comes back from where the
 // exchange was performed, so the writer's vmcnt(0) means "performed", not merely "accepted" (a non-returning atomic or a store
-// is acknowledged earlier: a flag raised behind it was seen by other XCDs before the data -- k_round_wide, measured)
+// is acknowledged earlier: a flag raised behind it was seen by other XCDs before the data -- measured in round 3 on the persistent
+// wide sweep)
 __device__ __forceinline__ void xchg_agent(float* p, float v) {
     const float old = __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("" ::"v"(old));

@@ -60,10 +60,6 @@ struct RoundArgs {
     unsigned spin_limit;       // polls a wait may take before it gives up
     int n_ranks, rank;
     int K, Kp, K16, dp, ldy, ldy_lds, G, B, V, nblk;
-    // k_round_wide only: the diversity tables of every block, written by the service workgroup
-    float* rp_tab;             // nblk x G x K16 entries of 8 bytes: {ratio^theta (float), epoch + block + 1 (unsigned)}
-    float* lrp_tab;            // (unused)
-    unsigned* table_flag;      // nblk arrival counters, one per block (zeroed by the caller)
 };
 
 // One whole update_R sweep (all blocks) in one persistent launch (k_sweep, hmx_sweep.hip): distance product, reassignment,
@@ -233,8 +229,6 @@ size_t round_lds_bytes(int K16, int dp, int G, int B, int V);
 #define HMX_ROUND_LDS_LIMIT (size_t)(159 * 1024)
 int round_row_floats(int d);
 int launch_round(const RoundArgs& a, int mt, int wgs, hipStream_t s);
-bool round_wide_ok(int mt, int dp, int K16, int G, int B, int V);
-int launch_round_wide(const RoundArgs& a, int mt, int wgs, hipStream_t s);   // wgs compute workgroups + 1 service workgroup
 size_t peer_box_doubles(int n_ranks, size_t GK);
 void launch_peer_selftest(double* const* peer_box, double* my_box, int n_ranks, int rank, size_t GK, unsigned long long token,
                           unsigned* result, hipStream_t s);

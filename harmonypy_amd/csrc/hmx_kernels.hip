@@ -20,6 +20,7 @@
 
 #include "hmx_internal.h"
 #include "hmx_device.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------
 // Row normalisation: Z_cos = Z / ||Z||_2 per cell (harmony.py:238, 569)
@@ -715,7 +716,7 @@ __device__ __forceinline__ void round_post_pass1(const float* sig, const float* 
 // neighbours in the block's group-sorted list) share one cross-lane reduction.
 #ifndef HMX_ROUND_RETURNING
 /* 1 (default): the slot atomics of k_round (and the peer-box writes of its gateway workgroup) RETURN their old value, so the
-   wave's vmcnt(0) before the arrival means "performed", not "accepted".  k_round_wide's hand-off showed what the difference
+   wave's vmcnt(0) before the arrival means "performed", not "accepted".  The persistent wide sweep of round 3 showed what the difference
    can be: a flag raised behind non-returning atomics or stores was seen by other XCDs before some of the data.  k_round queues
    at most two atomics per thread and never showed it in any parity run, but "never observed" is not an ordering guarantee.
    Measured cost at C3: 3.67 -> 3.75 ms of sweeps per Harmony iteration (+2 %). */
@@ -960,9 +961,22 @@ __global__ __launch_bounds__(64 * WIDE_WAVES, 2) void k_assign_wide(AssignArgs a
 #define WIDE2_WAVES 4
 #define WIDE2_YBUF 3
 #define WIDE2_SLOTS (2 * WIDE2_WAVES)
+// The tiles' Z_cos pieces are ORDINARY loads (the compiler sees them and waits for them itself); only the centroid pieces,
+// which have no destination registers, are inline-assembly LDS-DMA requests with a hand-counted wait in front of the
+// barrier.  Rounds 2-3 issued the Z pieces from inline assembly too (global_load_dwordx4 with an "=&v" result) and released
+// them with asm("s_waitcnt vmcnt(N)" : "+v"(z0), "+v"(z1)) "so that their uses stay behind the wait".  The compiler knows
+// nothing of a load it cannot see: a tied ("+v") operand is lowered as `COPY out = in` in FRONT of the statement, and the
+// copies that resolve a loop-carried value may land anywhere between the load and the wait -- the shipped code read the
+// load destinations (4 x v_mov_b64) BEFORE the s_waitcnt on every rung of the wait ladder but one, i.e. in flight.  With
+// 13 cluster tiles a k-step lasts 3 k cycles and the loads, issued two steps ahead, had always landed; with two cluster
+// tiles (K = 20) a step is 16 MFMAs and waves 2, 3 copied stale registers in some runs: "a few dozen rows of R off by more
+// than 1e-4" = one wave's tile pair (round-3 DESIGN section 8 item 4; the same statement served the tile pass of round 3's
+// persistent wide sweep, whose small-block failures have the same signature).  scripts/kernel_audit.py --inflight now follows
+// every register a vector-memory load writes through the BUILT code of every kernel and fails if anything touches it before
+// a wait has retired the load (tests/test_kernel_audit.py).
 template <int N>
-__device__ __forceinline__ void wide2_wait(f32x4& z0, f32x4& z1) {   // the wait names the registers it releases: their uses stay behind it
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(z0), "+v"(z1) : "n"(N) : "memory");
+__device__ __forceinline__ void wide2_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 template <int MT>
 __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_assign_wide2(AssignArgs a) {
@@ -1001,38 +1015,50 @@ __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_assign_wide2(AssignArgs
     // to LDS position 16 l of the piece -- the zone is row-major with the chunks of a row permuted by its row quad
     const unsigned yvoff = (unsigned)(((lane >> 2) * a.ldy + 4 * ((lane & 3) ^ ((lane >> 4) & 3))) * 4);
     const unsigned ring0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)Yring;
-    const unsigned yzone0 = __builtin_amdgcn_readfirstlane(ring0) + 1024u * wv;
-    const int npw = (MT - wv + WIDE2_WAVES - 1) / WIDE2_WAVES;           // this wave's pieces per k-step (wave-uniform)
     auto u64 = [](unsigned long long v) {
         return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v);
     };
-    unsigned long long ysrc = u64((unsigned long long)(a.Y + (size_t)16 * wv * a.ldy));   // this wave's first piece of the next k-step to request
-    const unsigned long long ypiece = (unsigned long long)64 * a.ldy * WIDE2_WAVES;      // bytes between two pieces of a wave
+    // EVERY wave asks for NPJ pieces per k-step: wave w owns pieces w, w + 4, ...; a wave that owns fewer (K16 not a multiple
+    // of 64) asks for the last piece of the step once more -- the same bytes to the same zone, harmless -- so that the number
+    // of requests in flight is a compile-time constant and the waits below need no per-wave case distinction
+    unsigned long long ysrc = u64((unsigned long long)a.Y);             // column block of the next k-step to request
+    unsigned ypoff[NPJ], yzoff[NPJ];                                    // (wave-uniform) the wave's pieces: byte offset in Y, zone offset in a ring slot
+#pragma unroll
+    for (int j = 0; j < NPJ; ++j) {
+        const int pj = min(wv + WIDE2_WAVES * j, MT - 1);
+        ypoff[j] = (unsigned)(64 * pj * a.ldy);
+        yzoff[j] = 1024u * (unsigned)pj;
+    }
+    const unsigned yzone0 = __builtin_amdgcn_readfirstlane(ring0);
     unsigned yzone = yzone0;
     int yslot = 0;
     auto issue_y = [&]() {
 #pragma unroll
-        for (int j = 0; j < NPJ; ++j)
-            if (j < npw) {
-                const unsigned long long src = ysrc + ypiece * j;
-                const unsigned zone = yzone + 1024u * WIDE2_WAVES * j;
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(yvoff), "s"(src), "s"(zone) : "memory", "m0");
-            }
+        for (int j = 0; j < NPJ; ++j) {
+            const unsigned long long src = ysrc + ypoff[j];
+            const unsigned zone = yzone + yzoff[j];
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(yvoff), "s"(src), "s"(zone) : "memory", "m0");
+        }
         ysrc += 64;                                                      // next k-step: 16 columns on
         yzone += (unsigned)(K16 * 64);
         if (++yslot == WIDE2_YBUF) { yslot = 0; yzone = yzone0; }
     };
-    auto issue_z = [&](f32x4& z0, f32x4& z1, int kb) {
-        const float* p0 = zr0 + 16 * kb;
-        const float* p1 = zr1 + 16 * kb;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(z0) : "v"(p0) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(z1) : "v"(p1) : "memory");
+    auto issue_z = [&](f32x4& z0, f32x4& z1, int kb) {   // ordinary loads, pinned where they are written
+        __builtin_amdgcn_sched_barrier(0);
+        z0 = ld4(zr0 + 16 * kb);
+        z1 = ld4(zr1 + 16 * kb);
+        __builtin_amdgcn_sched_barrier(0);
     };
     f32x4 za0, za1, zb0, zb1;
-    issue_z(za0, za1, 0);
+    // (pieces before Z values, as in the steps below; with an odd number of k-steps > 1 the B registers take step 0)
+    const bool b_first = nkb > 1 && (nkb & 1);
     issue_y();
-    if (nkb > 1) { issue_z(zb0, zb1, 1); issue_y(); }
+    if (b_first) issue_z(zb0, zb1, 0); else issue_z(za0, za1, 0);
+    if (nkb > 1) {
+        issue_y();
+        if (b_first) issue_z(za0, za1, 1); else issue_z(zb0, zb1, 1);
+    }
 
     // ---- set-up: sigma, the groups of the workgroup's tiles, their table rows, zeroed sums --------------------------
     for (int i = tid; i < K16; i += 64 * WIDE2_WAVES) {
@@ -1068,37 +1094,64 @@ __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_assign_wide2(AssignArgs
     }
 
     // ---- the k-steps -------------------------------------------------------------------------------------------------
-    // Memory operations return in order.  At the top of step kb the wave needs its pieces of step kb and the Z values of
-    // step kb; younger than those are only the requests of step kb+1 (npw pieces + 2 loads), issued one step ago.
+    // Memory operations return in order.  At the top of step kb the workgroup needs everybody's centroid pieces of step kb;
+    // younger than a wave's own are only the requests of step kb+1 (NPJ pieces + 2 loads), issued one step ago.  The Z values
+    // of step kb are waited for by the compiler, in front of their first use (it counts only its own loads, i.e. it waits
+    // for a little more than it must: the pieces of step kb+1, a whole step old by then).
+    // Three kinds of step, so that no load is issued under a condition inside the main loop (the compiler's wait insertion
+    // joins the paths of a conditional issue conservatively -- it then drains the counter before every step):
+    //   F  multiply, request step kb + 2      (kb + 2 < nkb)
+    //   N  multiply                           (kb + 2 == nkb: step kb + 1 is still in flight)
+    //   L  wait for everything, multiply      (the last step)
     const int swz = 4 * (q ^ ((c16 >> 2) & 3));
     int rslot = 0;
-    auto step = [&](int kb, f32x4& z0, f32x4& z1) {
-        if (kb + 1 < nkb) {
-            if (npw + 2 >= 6) wide2_wait<6>(z0, z1); else if (npw + 2 == 5) wide2_wait<5>(z0, z1);
-            else if (npw + 2 == 4) wide2_wait<4>(z0, z1); else if (npw + 2 == 3) wide2_wait<3>(z0, z1); else wide2_wait<2>(z0, z1);   // (a wave without pieces: K16 < 64)
-        } else {
-            wide2_wait<0>(z0, z1);
+    auto mfma_tile = [&](const float* Yst, int mt, const f32x4& z0, const f32x4& z1) {
+        const f32x4 ya = ld4(Yst + (16 * mt + c16) * 16 + swz);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            T0.arg[mt] = MFMA16(ya[i], z0[i], T0.arg[mt]);
+            T1.arg[mt] = MFMA16(ya[i], z1[i], T1.arg[mt]);
         }
+    };
+    auto step = [&](auto kind, int kb, f32x4& z0, f32x4& z1) {
+        constexpr int KIND = decltype(kind)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        // this wave's pieces of step kb have landed: younger are z(kb) x 2, the pieces of step kb+1 and z(kb+1) x 2
+        if constexpr (KIND == 2) wide2_wait<0>(); else wide2_wait<NPJ + 4>();
         wg_barrier_lds();                                // everybody's pieces of step kb are in; nobody reads step kb-1 any more
-        if (kb + 2 < nkb) issue_y();                     // ... its ring slot takes step kb+2
         const float* Yst = Yring + (size_t)rslot * (K16 * 16);
         if (++rslot == WIDE2_YBUF) rslot = 0;
+        // The first cluster tile is where the compiler waits for z(kb) -- counting its own loads only: "all but z(kb+1) x 2".
+        // The requests of step kb+2 go out BEHIND that wait (in front of it they would be the youngest operations in flight
+        // and the wait would drain z(kb+1), issued a moment ago); the pieces of step kb+1 are older than z(kb+1): no loss.
+        mfma_tile(Yst, 0, z0, z1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (KIND == 0) issue_y();              // into the ring slot of step kb-1
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 ya = ld4(Yst + (16 * mt + c16) * 16 + swz);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                T0.arg[mt] = MFMA16(ya[i], z0[i], T0.arg[mt]);
-                T1.arg[mt] = MFMA16(ya[i], z1[i], T1.arg[mt]);
-            }
-        }
-        if (kb + 2 < nkb) issue_z(z0, z1, kb + 2);       // into the registers this step has consumed
+        for (int mt = 1; mt < MT; ++mt) mfma_tile(Yst, mt, z0, z1);
+        if constexpr (KIND == 0) issue_z(z0, z1, kb + 2);   // into the registers this step has consumed
+        __builtin_amdgcn_sched_barrier(0);
     };
-    for (int kb = 0; kb < nkb; kb += 2) {
-        step(kb, za0, za1);
-        if (kb + 1 < nkb) step(kb + 1, zb0, zb1);
+    {
+        const std::integral_constant<int, 0> F;
+        const std::integral_constant<int, 1> N;
+        const std::integral_constant<int, 2> L;
+        if (nkb == 1) {
+            step(L, 0, za0, za1);
+        } else {
+            // an odd number of steps starts on the B registers (see the first requests above), so that every sequence ends
+            // with the same two steps: ... F(A) F(B) | N(A) L(B)
+            int kb = 0;
+            if (nkb & 1) { step(F, 0, zb0, zb1); kb = 1; }
+            for (; kb + 3 < nkb; kb += 2) {
+                step(F, kb, za0, za1);
+                step(F, kb + 1, zb0, zb1);
+            }
+            step(N, kb, za0, za1);
+            step(L, kb + 1, zb0, zb1);
+        }
     }
-    static_assert(NPJ + 2 <= 6, "wait ladder");
 
     // ---- finish: exp, penalty, renormalisation, R rows, block sums, objective terms (k_round's passes) ---------------
     double km_acc = 0.0, ent_acc = 0.0;
@@ -1131,359 +1184,6 @@ __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_assign_wide2(AssignArgs
         const double v = Sd[i];
         const int sl = i / K16;
         if (v != 0.0) atomicAdd(&a.S_out[(size_t)sg[sl] * K16 + (i - sl * K16)], v);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_round_wide: the whole update_R sweep of the wide shapes (K <= 208, d <= 208) in ONE persistent launch -- k_assign_wide2's
-// tile pass inside a loop over the update blocks.  OPT-IN (HMX_WIDE_SWEEP=1): measured 78 us per block at the configs[4] shard
-// against 73 us for one launch per block.  The centroid table does not fit the LDS, so it is streamed
-// per k-step as in k_assign_wide2, and the (group, cluster) tables do not fit beside it either (24 B x G x K16 = 160 KB at 32
-// batches), so the roles are split:
-//   * compute workgroups (4 waves, 2 per CU, 8 tiles per pass): distance GEMM of the block's first tiles BEFORE the tables
-//     are needed (it does not depend on them), then the table rows of their own tiles' groups from the block's global table --
-//     self-validating 8-byte entries, polled -- finish, block sums of their own groups -> returning fp64 atomics into the
-//     block's slot table, arrive on the block's own counter;
-//   * ONE service workgroup (the last of the grid) owns O (fp64, in its LDS): when all compute workgroups have arrived for
-//     block b-1 it folds their sums in, takes block b's removal sums out, rebuilds ratio^theta for all (group, cluster)
-//     pairs (:491-499) and stores block b's table -- while the compute workgroups multiply.  It closes the sweep (O,
-//     cluster mass, cross-entropy term, :405-411).
-// One batch variable only (group g is batch g); other cases stay on one launch per block.  All waits are bounded.
-// ------------------------------------------------------------------------------------------
-template <int MT>
-__global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_round_wide(RoundArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int K16 = 16 * MT;
-    constexpr int NPJ = (MT + WIDE2_WAVES - 1) / WIDE2_WAVES;
-    constexpr int NTHR = 64 * WIDE2_WAVES;
-    const int GK = a.G * K16;
-    const int tid = threadIdx.x;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63, c16 = lane & 15, q = lane >> 4;
-    const int nwg = gridDim.x - 1;                                       // compute workgroups
-    const int wg = blockIdx.x;
-
-    if (wg == nwg) {
-        // ================= service workgroup: O and the tables ========================================================
-        double* Ocur = reinterpret_cast<double*>(smem);                  // G x K16
-        double* Tm = Ocur + GK;                                          // K16
-        double* red = Tm + K16;                                          // waves
-        bool sfail = false;
-        for (int i = tid; i < GK; i += NTHR) Ocur[i] = a.O_start[i];
-        __syncthreads();
-#ifdef HMX_ROUND_PROF
-        unsigned long long sf[4] = {0, 0, 0, 0}, st = __builtin_amdgcn_s_memtime();
-#define SVSTAMP(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); sf[k] += now_ - st; st = now_; }
-#else
-#define SVSTAMP(k)
-#endif
-        for (int b = 0; b <= a.nblk; ++b) {
-            if (b > 0) {
-                if (wv == 0 && !sfail) {
-                    // one arrival counter per block: a workgroup without tiles in a block arrives at once, blocks ahead of the
-                    // others -- with a single running count its early arrivals would stand in for workgroups still at work
-                    const unsigned* arrived = a.table_flag + (b - 1);
-                    unsigned spins = 0;
-                    if (a.spin_limit == 0) sfail = true;                 // test knob: give up without looking
-                    while (!sfail && ld_agent(arrived) < (unsigned)nwg) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if (++spins > a.spin_limit) sfail = true;
-                    }
-                    if (sfail && lane == 0 && a.wait_stats) {             // diagnosis: the block it waited for, the arrivals it saw
-                        atomicMax(a.wait_stats + 6, (unsigned long long)b);
-                        atomicMax(a.wait_stats + 7, (unsigned long long)ld_agent(arrived));
-                    }
-                }
-                __syncthreads();
-            }
-            SVSTAMP(0)
-            for (int i = tid; i < GK; i += NTHR) {                       // (:491-492 for block b, :506-507 for block b-1)
-                double o = Ocur[i];
-                if (b > 0) o += ld_agent(a.S_new + (size_t)(b - 1) * GK + i);
-                if (b < a.nblk) o -= a.S_old[(size_t)b * GK + i];
-                Ocur[i] = o;
-            }
-            __syncthreads();
-            for (int k = tid; k < K16; k += NTHR) {
-                double t = 0.0;
-                for (int g = 0; g < a.G; ++g) t += Ocur[(size_t)g * K16 + k];
-                Tm[k] = t;
-            }
-            __syncthreads();
-            SVSTAMP(1)
-            if (b == a.nblk) break;
-            // block b's table: 8-byte entries {ratio^theta, tag of (launch, block)}, ONE agent-scope store each: an entry whose tag
-            // is right IS block b's value, so there is no flag and nothing to order -- the readers poll the data itself.
-            // (What a flag needs, measured here at 40 k cells x 200 with 20 compute workgroups that reach the wait before the
-            // table is ready: behind relaxed agent-scope stores + vmcnt(0) + barrier, behind the same with release / acquire,
-            // and behind NON-returning exchanges, other XCDs saw the flag before some rows -- a third of the rounds had a few
-            // hundred wrong cells, differently in every run; behind RETURNING exchanges it was correct, but the service
-            // workgroup then needs 65 us per block under the compute workgroups' memory traffic.)
-            unsigned long long* tabo = reinterpret_cast<unsigned long long*>(a.rp_tab) + (size_t)b * GK;
-            const unsigned long long tag = (unsigned long long)((unsigned)a.epoch + (unsigned)b + 1u) << 32;
-            for (int i = tid; i < GK; i += NTHR) {
-                const int g = i / K16, k2 = i - g * K16;
-                const float O = (float)Ocur[i];
-                const float E = (float)Tm[k2] * a.Pr_b[g];                  // :491 (E kept as mass T)
-                const float oe = fmaxf(O + E, 1e-8f);                       // :495-496
-                const float ratio = fminf(fmaxf(E / oe, 1e-8f), 1.0f);      // :497-498
-                const float rp = pow_unit(ratio, a.theta[g]);               // :499
-                __hip_atomic_store(tabo + i, tag | (unsigned long long)__float_as_uint(rp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            SVSTAMP(2)
-        }
-#ifdef HMX_ROUND_PROF
-        if (tid == 0 && a.prof)
-            for (int k = 0; k < 4; ++k) a.prof[(size_t)wg * 4 + k] = sf[k];
-#endif
-        // ---- close the sweep: O, cluster mass, cross-entropy term (:405-411; one batch variable: group g is batch g) ------
-        double part = 0.0;
-        for (int i = tid; i < GK; i += NTHR) {
-            const int g = i / K16, k = i - g * K16;
-            a.O_out[i] = Ocur[i];
-            if (g == 0) a.T_out[k] = Tm[k];
-            const float sgm = (k < a.K) ? a.sigma[k] : 0.f;
-            const float O = (float)Ocur[i];
-            const float Oc = fmaxf(O, 1e-8f);                               // :407
-            const float Ec = fmaxf((float)Tm[k] * a.Pr_b[g], 1e-8f);        // :408
-            const float tl = a.theta[g] * logf((Oc + Ec) / Ec);             // :409-410
-            part += (double)(sgm * O * tl);
-        }
-        part = wave_sum_all(part);
-        if (lane == 0) red[wv] = part;
-        __syncthreads();
-        if (tid == 0) {
-            double v = 0.0;
-            for (int w = 0; w < WIDE2_WAVES; ++w) v += red[w];
-            atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS], v);
-            if (sfail) {
-                atomicExch(a.error, 1u);
-                atomicAdd(&a.obj[0], __builtin_nan(""));
-                atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS + 1], 1.0);
-            }
-        }
-        return;
-    }
-
-    // ================= compute workgroups ===========================================================================
-    float* Yring = reinterpret_cast<float*>(smem);                       // WIDE2_YBUF x K16 x 16
-    float* sig = Yring + WIDE2_YBUF * K16 * 16;                          // K16
-    float* nis = sig + K16;
-    float* rpL = nis + K16;                                              // slots x K16
-    float* lrpL = rpL + WIDE2_SLOTS * K16;
-    double* Sd = reinterpret_cast<double*>(lrpL + WIDE2_SLOTS * K16);    // slots x K16 block sums
-    double* objw = Sd + WIDE2_SLOTS * K16;                               // waves x 2
-    int* tg = reinterpret_cast<int*>(objw + 2 * WIDE2_WAVES);            // group of the pass's tile j (-1: none)
-    int* ts = tg + WIDE2_SLOTS;                                          // its slot
-    int* sg = ts + WIDE2_SLOTS;                                          // group of a slot
-    const int nkb = a.dp >> 4;
-    for (int i = tid; i < K16; i += NTHR) {
-        const float sgm = (i < a.K) ? a.sigma[i] : 0.f;
-        sig[i] = sgm;
-        nis[i] = (i < a.K) ? -1.0f / sgm : -60.f;
-    }
-    for (int i = tid; i < WIDE2_SLOTS * K16; i += NTHR) Sd[i] = 0.0;
-    __syncthreads();
-
-    const unsigned yvoff = (unsigned)(((lane >> 2) * a.ldy + 4 * ((lane & 3) ^ ((lane >> 4) & 3))) * 4);
-    const unsigned ring0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)Yring;
-    const unsigned yzone0 = __builtin_amdgcn_readfirstlane(ring0) + 1024u * wv;
-    const int npw = (MT - wv + WIDE2_WAVES - 1) / WIDE2_WAVES;
-    auto u64 = [](unsigned long long v) {
-        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
-               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v);
-    };
-    const unsigned long long ysrc0 = u64((unsigned long long)(a.Y + (size_t)16 * wv * a.ldy));
-    const unsigned long long ypiece = (unsigned long long)64 * a.ldy * WIDE2_WAVES;
-    const int swz = 4 * (q ^ ((c16 >> 2) & 3));
-    unsigned long long ysrc = ysrc0;
-    unsigned yzone = yzone0;
-    int yslot = 0, rslot = 0;                                            // ring positions of the next request / the next read: they run on across tiles
-    double km_acc = 0.0, ent_acc = 0.0;
-    bool failed = false;                                                 // per thread: a wait of its own gave up
-    unsigned ws_n = 0, ws_sum = 0, ws_max = 0;
-
-    RoundTile<MT> T0, T1;
-    // distance GEMM of the tile pair (first tile: block-list position j0) -> exponent arguments in T0 / T1
-    auto gemm = [&](int tb, int ntl, int j0) {
-        const bool has0 = j0 < ntl, has1 = j0 + 1 < ntl;
-        T0.cell = has0 ? a.cells[(size_t)(tb + j0) * 16 + c16] : -1;
-        T1.cell = has1 ? a.cells[(size_t)(tb + j0 + 1) * 16 + c16] : -1;
-        const float* zr0 = a.Zcos + (size_t)(T0.cell >= 0 ? T0.cell : 0) * a.dp + 4 * q;
-        const float* zr1 = a.Zcos + (size_t)(T1.cell >= 0 ? T1.cell : 0) * a.dp + 4 * q;
-        auto issue_y = [&]() {
-#pragma unroll
-            for (int j = 0; j < NPJ; ++j)
-                if (j < npw) {
-                    const unsigned long long src = ysrc + ypiece * j;
-                    const unsigned zone = yzone + 1024u * WIDE2_WAVES * j;
-                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(yvoff), "s"(src), "s"(zone) : "memory", "m0");
-                }
-            ysrc += 64;
-            yzone += (unsigned)(K16 * 64);
-            if (++yslot == WIDE2_YBUF) { yslot = 0; yzone = yzone0; }
-        };
-        auto issue_z = [&](f32x4& z0, f32x4& z1, int kb) {
-            const float* p0 = zr0 + 16 * kb;
-            const float* p1 = zr1 + 16 * kb;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(z0) : "v"(p0) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(z1) : "v"(p1) : "memory");
-        };
-        ysrc = ysrc0;
-        f32x4 za0, za1, zb0, zb1;
-        // (the ring slots about to be refilled were last read before the previous pass's final barriers)
-        issue_z(za0, za1, 0);
-        issue_y();
-        if (nkb > 1) { issue_z(zb0, zb1, 1); issue_y(); }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            T0.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            T1.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        auto step = [&](int kb, f32x4& z0, f32x4& z1) {
-            if (kb + 1 < nkb) {
-                if (npw + 2 >= 6) wide2_wait<6>(z0, z1); else if (npw + 2 == 5) wide2_wait<5>(z0, z1);
-                else if (npw + 2 == 4) wide2_wait<4>(z0, z1); else if (npw + 2 == 3) wide2_wait<3>(z0, z1); else wide2_wait<2>(z0, z1);   // (a wave without pieces: K16 < 64)
-            } else {
-                wide2_wait<0>(z0, z1);
-            }
-            wg_barrier_lds();
-            if (kb + 2 < nkb) issue_y();
-            const float* Yst = Yring + (size_t)rslot * (K16 * 16);
-            if (++rslot == WIDE2_YBUF) rslot = 0;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const f32x4 ya = ld4(Yst + (16 * mt + c16) * 16 + swz);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    T0.arg[mt] = MFMA16(ya[i], z0[i], T0.arg[mt]);
-                    T1.arg[mt] = MFMA16(ya[i], z1[i], T1.arg[mt]);
-                }
-            }
-            if (kb + 2 < nkb) issue_z(z0, z1, kb + 2);
-        };
-        for (int kb = 0; kb < nkb; kb += 2) {
-            step(kb, za0, za1);
-            if (kb + 1 < nkb) step(kb + 1, zb0, zb1);
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 ni = ld4(nis + 16 * mt + 4 * q);
-            const f32x4 one = (f32x4){1.f, 1.f, 1.f, 1.f};
-            T0.arg[mt] = (2.f * (one - T0.arg[mt])) * ni;
-            T1.arg[mt] = (2.f * (one - T1.arg[mt])) * ni;
-        }
-    };
-    // table rows of the pass's groups (block b's tables have been flagged), finish, block sums out
-    auto finish = [&](int b, int tb, int ntl, int base) {
-        if (tid < WIDE2_SLOTS) tg[tid] = base + tid < ntl ? a.tile_grp[tb + base + tid] : -1;
-        wg_barrier_lds();
-        if (tid < WIDE2_SLOTS) {
-            int slot = 0;
-            for (int u = 1; u <= tid; ++u) slot += (tg[u] != tg[u - 1] && tg[u] >= 0) ? 1 : 0;
-            ts[tid] = slot;
-            if (tg[tid] >= 0 && (tid == 0 || tg[tid] != tg[tid - 1])) sg[slot] = tg[tid];
-        }
-        wg_barrier_lds();
-        const int nslots = ts[WIDE2_SLOTS - 1] + 1;
-        const unsigned long long* tabi = reinterpret_cast<const unsigned long long*>(a.rp_tab) + (size_t)b * GK;
-        const unsigned tag = (unsigned)a.epoch + (unsigned)b + 1u;
-        for (int i = tid; i < nslots * K16; i += NTHR) {
-            const int sl = i / K16, k = i - sl * K16;
-            const unsigned long long* src = tabi + (size_t)sg[sl] * K16 + k;
-            unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
-            bool gave_up = a.spin_limit == 0 || failed;                  // (spin_limit 0: test knob, give up without looking)
-            while ((unsigned)(v >> 32) != tag && !gave_up) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > a.spin_limit) gave_up = true;
-                v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (gave_up) failed = true;                                  // this thread stops waiting: the launch is lost
-            if (tid == 0) { ws_n += 1; ws_sum += spins; ws_max = max(ws_max, spins); }
-            const float rp = __uint_as_float((unsigned)v);
-            const bool good = (unsigned)(v >> 32) == tag && !gave_up;
-            rpL[i] = good ? rp : 1.f;                                    // (after a time-out: keep the arithmetic finite)
-            lrpL[i] = good ? __builtin_amdgcn_logf(rp) * 0.693147182464599609375f : 0.f;
-        }
-        wg_barrier_lds();
-        const int j0 = base + 2 * wv;
-        const bool has0 = j0 < ntl, has1 = j0 + 1 < ntl;
-        T0.grp = ts[2 * wv];
-        T1.grp = has1 ? ts[2 * wv + 1] : T0.grp;
-        if (has0) {
-            float scl0, scl1 = 0.f;
-            round_post_pass1<MT, true>(sig, rpL, lrpL, q, T0, scl0, km_acc, ent_acc);
-            if (has1) round_post_pass1<MT, true>(sig, rpL, lrpL, q, T1, scl1, km_acc, ent_acc);
-            round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T0, scl0, has1, T1, scl1);
-        }
-        wg_barrier_lds();
-        double* dst = a.S_new + (size_t)b * GK;
-        for (int i = tid; i < nslots * K16; i += NTHR) {
-            const double v = Sd[i];
-            const int sl = i / K16;
-            if (v != 0.0) {   // returning: performed, not merely accepted, when the wave's vmcnt(0) before the arrival is through
-                const double old = atomicAdd(dst + (size_t)sg[sl] * K16 + (i - sl * K16), v);
-                asm volatile("" ::"v"(old));
-            }
-            Sd[i] = 0.0;
-        }
-    };
-
-    const int pass_tiles = nwg * WIDE2_SLOTS;
-#ifdef HMX_ROUND_PROF
-    unsigned long long pf[4] = {0, 0, 0, 0}, pt = __builtin_amdgcn_s_memtime();
-#define RWSTAMP(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pf[k] += now_ - pt; pt = now_; }
-#else
-#define RWSTAMP(k)
-#endif
-    for (int b = 0; b < a.nblk; ++b) {
-        const int tb = a.blk_start[b], ntl = a.blk_start[b + 1] - tb;
-        bool first = true;
-        // one call site for the tile pass (the code of two would not fit the instruction cache beside each other)
-        for (int base = wg * WIDE2_SLOTS; first || base < ntl; base += pass_tiles) {
-            const bool any = base < ntl;                                 // workgroup-uniform (false only in a first trip without tiles)
-            if (any) gemm(tb, ntl, base + 2 * wv);                       // table-independent: the first one runs while the service workgroup builds block b's tables
-            RWSTAMP(0)
-            first = false;
-            if (any) finish(b, tb, ntl, base);
-            RWSTAMP(2)
-        }
-        // ---- the block's sums are performed, then arrive ---------------------------------------------------------------
-        WAIT_VMEM_ALL();
-        wg_barrier_lds();
-        if (tid == 0) __hip_atomic_fetch_add(a.table_flag + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // this block's own counter
-        RWSTAMP(3)
-    }
-#ifdef HMX_ROUND_PROF
-    if (tid == 0 && a.prof)
-        for (int k = 0; k < 4; ++k) a.prof[(size_t)wg * 4 + k] = pf[k];
-#endif
-    if (tid == 0 && a.wait_stats) {
-        atomicAdd(a.wait_stats, (unsigned long long)ws_n);
-        atomicAdd(a.wait_stats + 1, (unsigned long long)ws_sum);
-        atomicMax(a.wait_stats + 2, (unsigned long long)ws_max);
-    }
-    km_acc = wave_sum_all(km_acc);
-    ent_acc = wave_sum_all(ent_acc);
-    if (lane == 0) {
-        objw[2 * wv] = km_acc;
-        objw[2 * wv + 1] = ent_acc;
-    }
-    __syncthreads();
-    if (tid < 2) {
-        double v = 0.0;
-        for (int w = 0; w < WIDE2_WAVES; ++w) v += objw[2 * w + tid];
-        if (v != 0.0) atomicAdd(&a.obj[2 * (wg & (HMX_OBJ_SLOTS - 1)) + tid], v);
-    }
-    const bool any_failed = __syncthreads_or(failed ? 1 : 0) != 0;
-    if (tid == 0) {
-        if (any_failed) {
-            if (a.wait_stats) atomicAdd(a.wait_stats + 5, 1ull);          // diagnosis: workgroups that gave up
-            atomicExch(a.error, 1u);
-            atomicAdd(&a.obj[0], __builtin_nan(""));
-            atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS + 1], 1.0);
-        }
     }
 }
 
@@ -3728,7 +3428,7 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
         const size_t sm = ((size_t)2 * a.K16 * 20 + 2 * a.K16) * sizeof(float) + (a.tables_in_lds ? gk_bytes : 0) + 2 * WIDE_WAVES * sizeof(double);
         // the penalised block assignment of the round loop: two tiles per wave, two workgroups per CU (k_assign_wide2)
         static const int wide_mode = [] { const char* v = getenv("HMX_WIDE_ASSIGN"); return v ? atoi(v) : 2; }();
-        if (penalty && !a.hn && wide_mode == 2 && a.mt >= 8 && a.mt <= 13) {   // (K > 112: what the parity suite covers; below, the 8-wave kernel)
+        if (penalty && !a.hn && wide_mode == 2 && a.mt >= 1 && a.mt <= 13) {
             const size_t sm2 = ((size_t)WIDE2_YBUF * a.K16 * 16 + 2 * a.K16 + 2 * WIDE2_SLOTS * a.K16) * sizeof(float) +
                                ((size_t)WIDE2_SLOTS * a.K16 + 2 * WIDE2_WAVES) * sizeof(double) + 3 * WIDE2_SLOTS * sizeof(int);
             const int wgs2 = cdiv(ntiles, WIDE2_SLOTS);
@@ -3743,6 +3443,7 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
     } break;
             if (sm2 <= 80 * 1024) {
                 switch (a.mt) {
+                    HMX_WIDE2_CASE(1) HMX_WIDE2_CASE(2) HMX_WIDE2_CASE(3) HMX_WIDE2_CASE(4) HMX_WIDE2_CASE(5) HMX_WIDE2_CASE(6) HMX_WIDE2_CASE(7)
                     HMX_WIDE2_CASE(8) HMX_WIDE2_CASE(9) HMX_WIDE2_CASE(10) HMX_WIDE2_CASE(11) HMX_WIDE2_CASE(12) HMX_WIDE2_CASE(13)
                 }
                 return 0;
@@ -3888,39 +3589,6 @@ int launch_round(const RoundArgs& a_in, int mt, int wgs, hipStream_t s) {
         case 52: launch_round_ks<13>(a, mt, wgs, sm, s); break;
         case 64: launch_round_ks<16>(a, mt, wgs, sm, s); break;
         default: return -1;
-    }
-    return 0;
-}
-
-static size_t round_wide_lds(int K16, int G) {
-    const size_t compute = ((size_t)WIDE2_YBUF * K16 * 16 + 2 * K16 + 2 * WIDE2_SLOTS * K16) * sizeof(float) +
-                           ((size_t)WIDE2_SLOTS * K16 + 2 * WIDE2_WAVES) * sizeof(double) + (3 * WIDE2_SLOTS + 4) * sizeof(int);
-    const size_t service = ((size_t)G * K16 + K16 + WIDE2_WAVES) * sizeof(double);
-    return std::max(compute, service);
-}
-// opt-in (HMX_WIDE_SWEEP=1): measured slower than one launch per block -- its hand-off crosses the
-// memory system six times per block under the compute workgroups' own traffic
-bool round_wide_ok(int mt, int dp, int K16, int G, int B, int V) {
-    const char* v = getenv("HMX_WIDE_SWEEP");
-    return v && atoi(v) != 0 && V == 1 && G == B && mt >= 8 && mt <= 13 && dp % 16 == 0 && round_wide_lds(K16, G) <= 80 * 1024;
-}
-template <int MT>
-static void launch_round_wide_t(const RoundArgs& a, int wgs, size_t sm, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_round_wide<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((k_round_wide<MT>), dim3(wgs + 1), dim3(64 * WIDE2_WAVES), sm, s, a);
-}
-int launch_round_wide(const RoundArgs& a, int mt, int wgs, hipStream_t s) {
-    if (!round_wide_ok(mt, a.dp, a.K16, a.G, a.B, a.V) || wgs < 1) return -1;
-    const size_t sm = round_wide_lds(a.K16, a.G);
-    switch (mt) {
-        case 8: launch_round_wide_t<8>(a, wgs, sm, s); break;   case 9: launch_round_wide_t<9>(a, wgs, sm, s); break;
-        case 10: launch_round_wide_t<10>(a, wgs, sm, s); break; case 11: launch_round_wide_t<11>(a, wgs, sm, s); break;
-        case 12: launch_round_wide_t<12>(a, wgs, sm, s); break;
-        default: launch_round_wide_t<13>(a, wgs, sm, s); break;
     }
     return 0;
 }

@@ -85,6 +85,128 @@ def instruction_counts(co, names):
     return res
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# Loads in flight: nothing may touch the destination registers of a vector-memory load before a wait has retired it.
+# The compiler keeps that rule for the loads it issues; a load issued from INLINE ASSEMBLY (k_assign_wide2's Z pieces)
+# is invisible to its wait insertion, and rounds 2-3 shipped a kernel whose `v_mov` copies of such registers sat in
+# front of the hand-counted s_waitcnt (DESIGN.md section 3, "the wait that named its registers").  This pass replays the
+# gfx9 rule on the BUILT code of every kernel: vector-memory operations retire in order, `s_waitcnt vmcnt(N)` leaves at
+# most the N youngest outstanding (the counter saturates at 63); every control-flow path is followed (states = queues
+# of destination register sets, explored to a fixed point).
+# ------------------------------------------------------------------------------------------------------------------
+_VMEM = re.compile(r"^(global|flat|buffer|scratch|tbuffer)_(load|store|atomic)")
+_VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+def _vregs(text):
+    out = set()
+    for m in _VREG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def _parse_function(body):
+    """[(mnemonic, operand text)], {label: index}"""
+    ins, labels = [], {}
+    for line in body.split("\n"):
+        line = line.split("//")[0].strip()
+        if not line:
+            continue
+        m = re.match(r"^[0-9a-f]+ <(L\d+)>:$", line)
+        if m:
+            labels[m.group(1)] = len(ins)
+            continue
+        parts = line.split(None, 1)
+        ins.append((parts[0], parts[1] if len(parts) > 1 else ""))
+    return ins, labels
+
+
+def inflight_hazards_in(body):
+    """hazards of one kernel's disassembly (llvm-objdump -d --symbolize-operands): [(text, registers, instruction index)].
+    State at an instruction = {register with a load in flight: number of YOUNGER vector-memory operations}; an operation
+    ages every entry by one (64 outstanding cannot exist: the counter saturates), `vmcnt(N)` retires the entries with at
+    least N younger operations, a join keeps the smaller count -- a monotone data-flow problem, solved to its fixed point.
+    A load whose own DESTINATION is still in flight is not reported (two loads into one register retire in order and the
+    first value is dead: that is what the two mutually exclusive copies of k_round's request code look like to a
+    path-insensitive walk); anything else that names such a register is."""
+    ins, labels = _parse_function(body)
+    n = len(ins)
+    state = [None] * (n + 1)
+    state[0] = {}
+    hazards = {}
+    work = [0]
+
+    def merge(pc, st):
+        if pc > n:
+            return
+        cur = state[pc]
+        if cur is None:
+            state[pc] = dict(st)
+            work.append(pc)
+            return
+        changed = False
+        for r, c in st.items():
+            if r not in cur or c < cur[r]:
+                cur[r] = c
+                changed = True
+        if changed:
+            work.append(pc)
+
+    while work:
+        pc = work.pop()
+        if pc >= n:
+            continue
+        st = state[pc]
+        mn, ops = ins[pc]
+        out = st
+        if mn == "s_waitcnt":
+            m = re.search(r"vmcnt\((\d+)\)", ops)
+            if m:
+                lim = int(m.group(1))
+                out = {r: c for r, c in st.items() if c < lim}
+        else:
+            regs = _vregs(ops)
+            vmem = _VMEM.match(mn) is not None
+            dest = set()
+            if vmem:
+                returning = "_load" in mn or ("_atomic" in mn and re.search(r"\b(sc0|glc)\b", ops) is not None)
+                if returning and not mn.startswith("global_load_lds"):
+                    dest = _vregs(ops.split(",")[0])
+            touched = (regs - dest if vmem else regs) & set(st)
+            if touched:
+                hazards[pc] = (f"{mn} {ops}", sorted(touched), pc)
+            if vmem:
+                out = {r: c + 1 for r, c in st.items() if c + 1 < 64}
+                for r in dest:
+                    out[r] = 0
+        if mn == "s_endpgm":
+            continue
+        if mn == "s_branch":
+            merge(labels[ops.strip()], out)
+            continue
+        if mn.startswith("s_cbranch"):
+            merge(labels[ops.strip()], out)
+        merge(pc + 1, out)
+    return [hazards[k] for k in sorted(hazards)]
+
+
+def inflight_hazards(lib=None, name_filter=""):
+    """{kernel: [(text, registers, index)]} for every kernel of the library"""
+    lib = lib or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "harmonypy_amd", "libhmx.so")
+    res = {}
+    with tempfile.TemporaryDirectory() as wd:
+        for co in extract_code_objects(lib, wd):
+            names = set(kernel_metadata(co))
+            dis = _run(os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", "--symbolize-operands", co)
+            for m in re.finditer(r"^[0-9a-f]+ <([^>]+)>:\n(.*?)(?=^[0-9a-f]+ <[^L][^>]*>:|\Z)", dis, re.M | re.S):
+                if m.group(1) in names and name_filter in m.group(1):
+                    res[m.group(1)] = inflight_hazards_in(m.group(2))
+    return res
+
+
 def demangle(names):
     try:
         out = subprocess.run([os.path.join(LLVM, "llvm-cxxfilt")], input="\n".join(names), capture_output=True, text=True, check=True).stdout
@@ -111,7 +233,14 @@ if __name__ == "__main__":
     if not tools_available():
         sys.exit(f"LLVM tools not found under {LLVM}")
     lib = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].endswith(".so") else None
-    flt = sys.argv[-1] if len(sys.argv) > 1 and not sys.argv[-1].endswith(".so") else ""
+    flt = sys.argv[-1] if len(sys.argv) > 1 and not sys.argv[-1].endswith(".so") and sys.argv[-1] != "--inflight" else ""
+    if "--inflight" in sys.argv:
+        hz = inflight_hazards(lib, flt if flt != "--inflight" else "")
+        bad = {k: v for k, v in hz.items() if v}
+        print(f"{len(hz)} kernels followed, {len(bad)} with a register touched while a load into it was in flight")
+        for k, v in bad.items():
+            print(" ", demangle([k])[k], v[:6])
+        sys.exit(1 if bad else 0)
     rows = audit(lib, flt)
     print(f"{'kernel':58s} {'vgpr':>5s} {'sgpr':>5s} {'vspill':>6s} {'sspill':>6s} {'scratchB':>8s} {'KB':>6s} {'mfma':>5s} {'flat':>5s} {'scr':>4s} {'dma':>4s} {'vm0':>4s} {'bar':>4s}")
     for r in rows:

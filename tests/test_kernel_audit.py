@@ -39,12 +39,6 @@ KNOWN_SPILLS = {
     "_Z5k_rtzILi7ELi4EEv7RtzArgs": 4,
     "_ZN12_GLOBAL__N_110k_lisi_knnILi4ELi4ELi256EEEv11LisiKnnArgs": 3,      # the 50-PC LISI search
     "_Z6k_rtz3ILi7ELi8ELi1EEv8Rtz3Args": 20,                           # K > 96 with d <= 32 and 33..48 update blocks
-    # the opt-in persistent sweep of the wide shapes (HMX_WIDE_SWEEP=1): the exponent arguments of two tiles (8 MT registers)
-    # are live across the loop that polls the table entries -- spilled around it, outside the distance product
-    "_Z12k_round_wideILi10EEv9RoundArgs": 25,
-    "_Z12k_round_wideILi11EEv9RoundArgs": 52,
-    "_Z12k_round_wideILi12EEv9RoundArgs": 73,
-    "_Z12k_round_wideILi13EEv9RoundArgs": 100,
 }
 
 
@@ -107,3 +101,41 @@ def test_sweep_kernel_keeps_lds_pointers_and_uses_lds_dma(rows):
         assert r["lds_dma"] >= 16, f"{r['name']}: rows must travel global -> LDS directly"
         assert r["flat"] <= 2, f"{r['name']}: {r['flat']} flat memory operations (an LDS pointer lost its address space?)"
         assert r["mfma"] > 0
+
+
+def test_nothing_touches_a_register_with_a_load_in_flight():
+    """Every kernel of the built library, every control-flow path: no instruction reads or overwrites the destination
+    register of a vector-memory load before an s_waitcnt has retired that load (in-order retirement, `vmcnt(N)` leaves the N
+    youngest operations outstanding).  The compiler guarantees this for the loads it issues itself; it cannot for loads
+    issued from inline assembly -- rounds 2-3 shipped k_assign_wide2 with `v_mov` copies of such registers in FRONT of the
+    hand-counted wait (right only while a k-step outlasted the memory latency: DESIGN.md section 3).  The walk is
+    path-insensitive, so it also rejects code that is right only because two branches always go together."""
+    hz = kernel_audit.inflight_hazards(LIB)
+    assert len(hz) > 100
+    bad = {k: v[:4] for k, v in hz.items() if v}
+    assert not bad, f"registers touched while a load into them is in flight: {bad}"
+
+
+def test_inflight_walk_finds_the_round3_defect():
+    """The walk on a reduction of what round 3 shipped (copy in front of the wait) and of what it should have been."""
+    wrong = """
+	global_load_dwordx4 v[2:5], v[10:11], off
+	global_load_dwordx4 v[6:9], v[12:13], off
+	s_cbranch_scc1 L1
+	v_mov_b64_e32 v[20:21], v[2:3]
+	s_waitcnt vmcnt(1)
+	s_branch L2
+0000000000000100 <L1>:
+	s_waitcnt vmcnt(1)
+	v_mov_b64_e32 v[20:21], v[2:3]
+0000000000000110 <L2>:
+	v_mfma_f32_16x16x4_f32 v[30:33], v40, v20, v[30:33]
+	s_endpgm
+"""
+    found = kernel_audit.inflight_hazards_in(wrong)
+    assert len(found) == 1 and found[0][1] == [2, 3] and found[0][2] == 3
+    right = wrong.replace("\tv_mov_b64_e32 v[20:21], v[2:3]\n\ts_waitcnt vmcnt(1)\n\ts_branch L2", "\ts_waitcnt vmcnt(1)\n\tv_mov_b64_e32 v[20:21], v[2:3]\n\ts_branch L2")
+    assert right != wrong and kernel_audit.inflight_hazards_in(right) == []
+    # the second load is still in flight behind vmcnt(1)
+    late = right.replace("v_mfma_f32_16x16x4_f32 v[30:33], v40, v20, v[30:33]", "v_mfma_f32_16x16x4_f32 v[30:33], v40, v6, v[30:33]")
+    assert [h[1] for h in kernel_audit.inflight_hazards_in(late)] == [[6]]
