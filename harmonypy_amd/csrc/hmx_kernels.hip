@@ -580,13 +580,21 @@ __device__ __forceinline__ void round_issue_z(const float* __restrict__ Zcos, in
     for (int s = 0; s < NT; ++s) Z.zt[s] = zr[16 * NF + 4 * s + q];
 }
 
-// table-independent half of a tile: distance GEMM against the LDS-resident centroids -> exponent arguments
-template <int MT, int KS>
+// table-independent half of a tile: distance GEMM against the LDS-resident centroids -> exponent arguments.
+// LOG2 (k_round): the centroid rows in LDS are pre-scaled by c_k = 2 log2(e) / sigma_k and `nis` holds -c_k, so the
+// accumulators START at -c_k and the products land directly on  -dist / sigma * log2(e) = c_k (y.z - 1)  -- the argument of
+// the hardware exp2 (:447, :466) -- and the three VALU operations per entry of the conversion are gone.  The rounding of
+// the scaled dot product (magnitudes up to c_k ~ 29: 2e-6 absolute in the argument) is what 2 (1 - y.z) / sigma carried
+// already (the rounding of y.z, 1e-7, times 2 / sigma).
+#ifndef HMX_ROUND_EXP2
+#define HMX_ROUND_EXP2 1
+#endif
+template <int MT, int KS, bool LOG2 = false>
 __device__ __forceinline__ void round_compute(const float* Ys, const float* nis, int LDY, int c16, int q,
                                               const RoundZ<KS>& Z, RoundTile<MT>& T) {
     constexpr int NF = KS / 4, NT = KS % 4;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) T.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt) T.arg[mt] = LOG2 ? ld4(nis + 16 * mt + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
 #pragma unroll
@@ -603,11 +611,13 @@ __device__ __forceinline__ void round_compute(const float* Ys, const float* nis,
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) T.arg[mt] = MFMA16(Ys[(size_t)(16 * mt + c16) * LDY + col], Z.zt[s], T.arg[mt]);
     }
+    if (!LOG2) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const f32x4 ni = ld4(nis + 16 * mt + 4 * q);
-        const f32x4 one = (f32x4){1.f, 1.f, 1.f, 1.f};
-        T.arg[mt] = (2.f * (one - T.arg[mt])) * ni;          // dist = 2 (1 - Y.Z) (:447), arg = -dist / sigma (:466)
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 ni = ld4(nis + 16 * mt + 4 * q);
+            const f32x4 one = (f32x4){1.f, 1.f, 1.f, 1.f};
+            T.arg[mt] = (2.f * (one - T.arg[mt])) * ni;          // dist = 2 (1 - Y.Z) (:447), arg = -dist / sigma (:466)
+        }
     }
 }
 
@@ -632,57 +642,54 @@ __device__ __forceinline__ void round_rows_from_lds(const float* zt, int c16, in
 // Padded clusters carry arg = -120 (exp underflows to an exact 0) and sigma 0.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-#ifndef HMX_PACKED
-#define HMX_PACKED 0
+// LOG2: the arguments are in log2 units (round_compute<.., true>): one v_exp_f32 per entry, the sum of t sigma arg is scaled
+// by ln 2 once per tile.  A2TAB: the term  sum t sigma log(ratio^theta)  is NOT accumulated here -- summed over the cells of a
+// block it equals  sum_(g,k) log(ratio^theta)[g][k] sigma_k S[g][k]  with S the block sums of the new R that the caller
+// keeps anyway (k_round adds it when it publishes them): one fma per entry and the log table's reads are gone.
+#ifndef HMX_ROUND_A2TAB
+#define HMX_ROUND_A2TAB 1
 #endif
-__device__ __forceinline__ f32x2 fast_exp2(f32x2 x) {   // fast_exp on a pair, finite arguments only
-    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f;
-    const f32x2 th = x * L2E_HI;
-    f32x2 tl = __builtin_elementwise_fma(x, (f32x2){L2E_HI, L2E_HI}, -th);
-    tl = __builtin_elementwise_fma(x, (f32x2){L2E_LO, L2E_LO}, tl);
-    f32x2 p;
-    p.x = __builtin_amdgcn_exp2f(th.x);
-    p.y = __builtin_amdgcn_exp2f(th.y);
-    return __builtin_elementwise_fma(p, tl * 0.693147182464599609375f, p);
-}
-
-template <int MT, bool PENALTY = true>
+#ifndef HMX_ROUND_PK
+#define HMX_ROUND_PK 1
+#endif
+template <int MT, bool PENALTY = true, bool LOG2 = false, bool A2TAB = false>
 __device__ __forceinline__ void round_post_pass1(const float* sig, const float* rpT, const float* lrpT, int q,
                                                  RoundTile<MT>& T, float& scl, double& km_acc, double& ent_acc) {
     constexpr int K16 = 16 * MT;
     const float* rp = PENALTY ? rpT + (size_t)T.grp * K16 : nullptr;
     const float* lrp = PENALTY ? lrpT + (size_t)T.grp * K16 : nullptr;
-#if HMX_PACKED
-    f32x2 e1v = {0.f, 0.f}, uv = {0.f, 0.f}, a1v = {0.f, 0.f}, a2v = {0.f, 0.f}, a3v = {0.f, 0.f};
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const f32x4 pw = ld4(rp + 16 * mt + 4 * q);
-        const f32x4 lp = ld4(lrp + 16 * mt + 4 * q);
-        const f32x4 sg = ld4(sig + 16 * mt + 4 * q);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const f32x2 arg = h ? T.arg[mt].zw : T.arg[mt].xy;
-            const f32x2 pwh = h ? pw.zw : pw.xy, lph = h ? lp.zw : lp.xy, sgh = h ? sg.zw : sg.xy;
-            const f32x2 ex = fast_exp2(arg);                 // :467
-            e1v += ex;
-            const f32x2 t = ex * pwh;                        // :500 (the 1/e1 of :468 cancels, see above)
-            const f32x2 ts = t * sgh;
-            uv += t;
-            a1v = __builtin_elementwise_fma(ts, arg, a1v);
-            a2v = __builtin_elementwise_fma(ts, lph, a2v);
-            a3v += ts;
-            if (h) T.arg[mt].zw = t; else T.arg[mt].xy = t;
-        }
-    }
-    const float e1 = wave_sum_q(e1v.x + e1v.y);            // column sum of :468
-    const float us = wave_sum_q(uv.x + uv.y);
-    const float a1 = a1v.x + a1v.y, a2 = a2v.x + a2v.y, a3 = a3v.x + a3v.y;
-#else
     float e1 = 0.f, us = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#if HMX_ROUND_PK
+    if (LOG2 && A2TAB && PENALTY) {
+        // the same arithmetic on pairs of entries: v_pk_mul / v_pk_add / v_pk_fma do two fp32 operations per lane and
+        // issue slot, so an entry costs one v_exp_f32 + three packed operations instead of one + seven
+        f32x2 e1v = {0.f, 0.f}, usv = {0.f, 0.f}, a1v = {0.f, 0.f}, a3v = {0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 pw = ld4(rp + 16 * mt + 4 * q);
+            const f32x4 sg = ld4(sig + 16 * mt + 4 * q);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x2 arg = h ? T.arg[mt].zw : T.arg[mt].xy;
+                f32x2 ex;
+                ex.x = __builtin_amdgcn_exp2f(arg.x);                // :467
+                ex.y = __builtin_amdgcn_exp2f(arg.y);
+                e1v += ex;
+                const f32x2 t = ex * (h ? pw.zw : pw.xy);            // :500
+                const f32x2 ts = t * (h ? sg.zw : sg.xy);
+                usv += t;
+                a1v = __builtin_elementwise_fma(ts, arg, a1v);
+                a3v += ts;
+                if (h) T.arg[mt].zw = t; else T.arg[mt].xy = t;
+            }
+        }
+        e1 = e1v.x + e1v.y; us = usv.x + usv.y; a1 = a1v.x + a1v.y; a3 = a3v.x + a3v.y;
+    } else
+#endif
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const f32x4 pw = PENALTY ? ld4(rp + 16 * mt + 4 * q) : (f32x4){1.f, 1.f, 1.f, 1.f};   // no penalty: init_cluster (:383-385)
-        const f32x4 lp = PENALTY ? ld4(lrp + 16 * mt + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 lp = (PENALTY && !A2TAB) ? ld4(lrp + 16 * mt + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
         const f32x4 sg = ld4(sig + 16 * mt + 4 * q);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -690,21 +697,21 @@ __device__ __forceinline__ void round_post_pass1(const float* sig, const float* 
 #if HMX_RABL & 4
             const float ex = arg * 0.001f + 1.0f;
 #else
-            const float ex = fast_exp_finite(arg);           // :467
+            const float ex = LOG2 ? __builtin_amdgcn_exp2f(arg) : fast_exp_finite(arg);           // :467
 #endif
             e1 += ex;
             const float t = ex * pw[r];                      // :500 (the 1/e1 of :468 cancels, see above)
             const float ts = t * sg[r];
             us += t;
             a1 = fmaf(ts, arg, a1);
-            a2 = fmaf(ts, lp[r], a2);
+            if (!A2TAB) a2 = fmaf(ts, lp[r], a2);
             a3 += ts;
             T.arg[mt][r] = t;
         }
     }
     e1 = wave_sum_q(e1);                                   // column sum of :468
     us = wave_sum_q(us);
-#endif
+    if (LOG2) a1 *= 0.693147182464599609375f;
     const float den = fmaxf(us, 1e-8f * e1);               // e1 * max(sum R_new, 1e-8)   (:501-502)
     scl = (T.cell >= 0) ? 1.0f / den : 0.f;                // dead lanes (list padding) contribute exact zeros
     km_acc -= (double)(scl * a1);
@@ -1278,15 +1285,20 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         if (a.V == 1) bgrp[a.group_cols[i]] = i;
     }
     for (int i = tid; i < a.nblk + 3; i += ROUND_THREADS) bs[i] = a.blk_start[min(i, a.nblk)];
+    constexpr bool LOG2 = HMX_ROUND_EXP2 != 0, A2TAB = HMX_ROUND_A2TAB != 0;
+    constexpr float TWO_LOG2E = 2.885390081777926814f;
     for (int i = tid; i < K16; i += ROUND_THREADS) {
         const float sgm = (i < a.K) ? a.sigma[i] : 0.f;
         sig[i] = sgm;
-        nis[i] = (i < a.K) ? -1.0f / sgm : -60.f;   // pads: Y row 0 -> dist 2 -> arg -120 -> exp == 0
+        if (LOG2) nis[i] = (i < a.K) ? -(TWO_LOG2E / sgm) : -200.f;   // the accumulators start here; pads: Y row 0 -> 2^-200 == 0
+        else nis[i] = (i < a.K) ? -1.0f / sgm : -60.f;               // pads: Y row 0 -> dist 2 -> arg -120 -> exp == 0
     }
     for (int i = tid; i < GK; i += ROUND_THREADS) Ocur[i] = a.O_start[i];
     for (int i = tid; i < K16 * KS; i += ROUND_THREADS) {
         const int row = i / KS, c4 = i - row * KS;
-        st4(Ys0 + (size_t)row * LDY + 4 * c4, ld4(a.Y + (size_t)row * a.ldy + 4 * c4));
+        f32x4 y = ld4(a.Y + (size_t)row * a.ldy + 4 * c4);
+        if (LOG2) y *= (row < a.K) ? TWO_LOG2E / a.sigma[row] : 0.f;   // rows scaled by c_k: the products are exp2 arguments
+        st4(Ys0 + (size_t)row * LDY + 4 * c4, y);
     }
     __syncthreads();
     (void)NF; (void)NT;
@@ -1375,11 +1387,11 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         const bool second = wv >= ROUND_WAVES / 2;
         if (!second) request();
         __builtin_amdgcn_sched_barrier(0);
-        round_compute<MT, KS>(Ys, nis, LDY, c16, q, Zf[0], T[0]);
+        round_compute<MT, KS, LOG2>(Ys, nis, LDY, c16, q, Zf[0], T[0]);
         __builtin_amdgcn_sched_barrier(0);
         if (second) request();
         __builtin_amdgcn_sched_barrier(0);
-        round_compute<MT, KS>(Ys, nis, LDY, c16, q, Zf[1], T[1]);
+        round_compute<MT, KS, LOG2>(Ys, nis, LDY, c16, q, Zf[1], T[1]);
         __builtin_amdgcn_sched_barrier(0);
     };
 #pragma unroll
@@ -1519,9 +1531,9 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         if (j_first < ntl) {
             float scl0, scl1 = 0.f;
             const bool has1 = j_first + 1 < ntl;
-            round_post_pass1<MT>(sig, rpT, lrpT, q, T[0], scl0, km_acc, ent_acc);
+            round_post_pass1<MT, true, LOG2, A2TAB>(sig, rpT, lrpT, q, T[0], scl0, km_acc, ent_acc);
             __builtin_amdgcn_sched_barrier(0);
-            if (has1) round_post_pass1<MT>(sig, rpT, lrpT, q, T[1], scl1, km_acc, ent_acc);
+            if (has1) round_post_pass1<MT, true, LOG2, A2TAB>(sig, rpT, lrpT, q, T[1], scl1, km_acc, ent_acc);
             __builtin_amdgcn_sched_barrier(0);
 #if HMX_ROUND_SUMS
             round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T[0], scl0, has1, T[1], scl1, Sw + (size_t)(wv * ROUND_TPW) * K16, Sw + (size_t)(wv * ROUND_TPW + 1) * K16);
@@ -1545,9 +1557,9 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                 X.cell = a.cells[(size_t)(tb + j + u) * 16 + c16];
                 X.grp = a.tile_grp[tb + j + u];
                 round_issue_z<KS>(a.Zcos, X.cell, q, XZ);
-                round_compute<MT, KS>(Ys, nis, LDY, c16, q, XZ, X);
+                round_compute<MT, KS, LOG2>(Ys, nis, LDY, c16, q, XZ, X);
                 float sclx;
-                round_post_pass1<MT>(sig, rpT, lrpT, q, X, sclx, km_acc, ent_acc);
+                round_post_pass1<MT, true, LOG2, A2TAB>(sig, rpT, lrpT, q, X, sclx, km_acc, ent_acc);
                 round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, X, sclx, false, X, 0.f);
             }
         }
@@ -1556,6 +1568,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         // ---- publish the block's new sums, then arrive ---------------------------------------
         {
             double* dst = a.S_new + ((size_t)b * HMX_ROUND_SLOTS + (wg % HMX_ROUND_SLOTS)) * GK;
+            double a2s = 0.0;
             for (int i = tid; i < GK; i += ROUND_THREADS) {
                 double v = Sd[i];
 #if HMX_ROUND_SUMS
@@ -1564,12 +1577,14 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                 for (int sl = 0; sl < ROUND_WAVES * ROUND_TPW; ++sl)
                     if (Sg[sl] == g) v += (double)Sw[sl * K16 + k];
 #endif
+                if (A2TAB) a2s += v * (double)(lrpT[i] * sig[i % K16]);   // sum over this block's cells of R sigma log(ratio^theta) (:402), see round_post_pass1
 #if HMX_ROUND_RETURNING
                 if (v != 0.0) { const double old = atomicAdd(dst + i, v); asm volatile("" ::"v"(old)); }
 #else
                 if (v != 0.0) atomicAdd(dst + i, v);
 #endif
             }
+            if (A2TAB) ent_acc += a2s;
         }
         WAIT_VMEM_ALL();   // the sums are performed (and the next operands landed)
         wg_barrier_lds();

@@ -112,3 +112,62 @@ def test_engine_vs_reference_large(name, monkeypatch):
     # small goldens and below the reference's own 1-vs-8-thread spread of (i)
     assert rel3 <= 2e-6 and max3 <= 2e-6, f"{name}: Z_corr vs the reference's float64 ridge relF={rel3:.2e} max={max3:.2e}"
     assert rel1 <= max(1e-4, 3 * noise) and max1 <= max(1e-4, 3 * noise), f"{name}: Z_corr vs the plain reference relF={rel1:.2e}"
+
+
+# ------------------------------------------------------------------------------------------------
+# The benchmarked size on the benchmarked path: BASELINE configs[2], 1M cells, through hmx_cluster with the update order
+# built on the device -- against a run of the REFERENCE ITSELF on the same blocks (tests/golden/make_c3_full.py replaces
+# harmony.py:471's randperm by the engine's keyed bijection; 5 rounds + 1 ridge).
+# ------------------------------------------------------------------------------------------------
+def load_c3_full():
+    from bench import synthetic_dataset
+    g = np.load(os.path.join(GOLDEN, "large_c3full.npz"))
+    N, d, B, K, seed, rounds = (int(x) for x in g["shape"])
+    Z, meta = synthetic_dataset(N, d, B, K, seed=0, cell_seed=0)     # bench.py's configs[2] data set (rank 0)
+    return Z, meta, K, seed, rounds, g
+
+
+def test_c3_full_golden_is_self_consistent():
+    """CPU: the fixture is what its recipe says (shape, sample, histories) and the reference's R rows are distributions;
+    the oracle is NOT run at this size here (two minutes of NumPy) -- it is pinned by the thirteen smaller goldens."""
+    g = np.load(os.path.join(GOLDEN, "large_c3full.npz"))
+    N, d, B, K, seed, rounds = (int(x) for x in g["shape"])
+    assert (N, d, B, K, seed, rounds) == (1_000_000, 50, 8, 100, 0, 5)
+    assert np.array_equal(g["rows"], np.linspace(0, N - 1, 2000).astype(np.int64))
+    assert g["R_rows"].shape == (2000, K) and g["Zcorr_rows_ridge64"].shape == (2000, d) and g["Y0"].shape == (d, K)
+    np.testing.assert_allclose(g["R_rows"].sum(axis=1), 1.0, atol=1e-5)
+    np.testing.assert_allclose(g["R_colsum"].sum(), N, rtol=1e-6)
+    np.testing.assert_allclose(g["O"].sum(), N, rtol=1e-5)
+    assert len(g["objective_kmeans"]) == rounds + 1 and [int(r) for r in g["kmeans_rounds"]] == [rounds]
+    assert float(g["R_rows_relF_between_the_two_runs"]) == 0.0      # (i) and (iii) differ in the ridge step only
+    assert 1e-4 < float(g["plain_vs_ridge64_relF"]) < 2e-3          # the plain fp32 ridge is no pin at this size (5e-4)
+
+
+@pytest.mark.gpu
+def test_engine_vs_reference_c3_full_on_the_bench_path(monkeypatch):
+    """What `python bench.py` times, at the size it is timed on: configs[2]'s 1M cells, device-built update order, the rounds
+    of the iteration inside hmx_cluster (objective read-back deferred), next round's lists on the side stream.  R rows and
+    column sums, O, E and the four objective histories against the plain reference; Z_corr against the reference's own
+    ridge in float64 at 2e-6 (and no further from the plain reference than 3x its distance from that)."""
+    from harmonypy_amd import harmony as H
+    monkeypatch.setenv("HMX_UPDATE_ORDER", "device")
+    Z, meta, K, seed, rounds, g = load_c3_full()
+    rows = g["rows"]
+    ho = H.run_harmony(Z, meta, ["batch"], nclust=K, max_iter_harmony=0, verbose=False, random_state=seed, _y0=g["Y0"])
+    assert ho.update_order == "device"
+    ho.cluster(_rounds=rounds)                               # hmx_cluster: all rounds in one call
+    cnt = ho._engine.counters()
+    assert cnt["sweep_waits"] > 0 and cnt["sweep_fallbacks"] == 0, cnt     # the persistent sweep ran
+    R = ho.R
+    obj = {k: getattr(ho, k) for k in ("objective_kmeans", "objective_kmeans_dist", "objective_kmeans_entropy", "objective_kmeans_cross")}
+    relR = check_pre_ridge("c3full", R[rows], R.astype(np.float64).sum(axis=0), ho.O, ho.E, obj, g)
+    ho.moe_correct_ridge()
+    Zr = ho.Z_corr[rows]
+    absmax = float(g["Zcorr_absmax"])
+    rel3, max3 = rows_err(Zr, g["Zcorr_rows_ridge64"], absmax)
+    rel1, max1 = rows_err(Zr, g["Zcorr_rows_plain"], absmax)
+    spread = float(g["plain_vs_ridge64_relF"])
+    print(f"engine c3full (1M cells, bench path; R relF={relR:.1e}): Z_corr vs (iii) reference ridge in float64 relF={rel3:.2e} "
+          f"max={max3:.2e}; vs (i) plain relF={rel1:.2e} (plain vs (iii): {spread:.1e})")
+    assert rel3 <= 2e-6 and max3 <= 2e-6, f"Z_corr vs the reference's float64 ridge relF={rel3:.2e} max={max3:.2e}"
+    assert rel1 <= 3 * spread
