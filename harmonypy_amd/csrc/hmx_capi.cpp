@@ -121,6 +121,9 @@ struct hmx_engine {
     double* obj_defer = nullptr; // pinned: objective blocks of rounds whose read-back was deferred (hmx_cluster)
     hipEvent_t sync_event = nullptr;
     long clean_sweeps = 0;       // persistent sweeps that were read back at once and had no time-out
+    long n_sweep_launches = 0;   // persistent sweeps launched (HMX_TEST_FAIL_SWEEP counts them)
+    long test_fail_sweep = -1;   // HMX_TEST_FAIL_SWEEP=k: the k-th persistent sweep (0-based) runs with spin limit 0 (tests: a time-out in a deferred round)
+    unsigned* frozen() const { return reinterpret_cast<unsigned*>(wait_stats.p + 3); }   // sticky time-out word (see hmx_cluster)
     // transport for sharded jobs (null / 1 = single engine)
     void* nccl_comm = nullptr;
     int n_ranks = 1, rank = 0;
@@ -389,6 +392,7 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
     }
 #endif
     if (const char* rk = getenv("HMX_RTZ")) e->rtz_kernel = atoi(rk) == 2 ? 2 : 3;
+    if (const char* fs = getenv("HMX_TEST_FAIL_SWEEP")) e->test_fail_sweep = atol(fs);
     if (const char* sl = getenv("HMX_SPIN_LIMIT")) e->spin_limit = (unsigned)std::max(0L, atol(sl));   // 0: every wait of the persistent kernels gives up at once (tests)
     int rc = 0;
     do {
@@ -865,6 +869,7 @@ static int rtz3_pass(hmx_engine* e, int mode, const unsigned char* tile_blk, int
         r.R = e->R.p; r.Z = mode == 1 ? e->Zorig.p : e->Zcos.p; r.tile_blk = tile_blk;
         r.task_t0 = e->t3_t0.p; r.task_t1 = e->t3_t1.p; r.task_stride = e->t3_stride.p; r.task_c0 = e->t3_c0.p; r.task_cend = e->t3_cend.p;
         r.slab = e->slab.p; r.ntasks = e->ntasks3; r.Kp = e->Kp;
+        r.frozen = duties ? e->frozen() : nullptr;   // (the fused round of a single engine: the only path whose read-back is deferred)
         if (wide ? launch_rtzw(r, e->mt, e->dp, e->d, nblk_cols, e->stream) : launch_rtz3(r, e->mt, e->dp, nblk_cols, e->stream))
             return fail(HMX_ERR_ARG, "unsupported shape for the streaming R^T.Z pass");
     }
@@ -877,6 +882,7 @@ static int rtz3_pass(hmx_engine* e, int mode, const unsigned char* tile_blk, int
     f.K = e->K; f.K16 = e->K16; f.d = e->d; f.ld = e->ldy; f.G = e->G; f.nblk = nblk_cols; f.mode = mode == 0 ? 0 : 1;
     f.Ysum = e->Yacc64; f.Yout = normalize ? e->Y.p : nullptr; f.Sold = e->Sold; f.Sr = e->Sr; f.Oxr = e->Oxr;
     if (duties) {
+        f.frozen = e->frozen();
         f.zero_p = e->Sslots.p; f.zero_n = GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 1;   // slot tables + the two sync words
         f.zero2_p = e->objacc; f.zero2_n = 2 * HMX_OBJ_SLOTS + 2;
         f.copy_src = e->Ogrp.p; f.copy_dst = e->Osave.p; f.copy_n = (int)GK;
@@ -1077,11 +1083,32 @@ static int blocks_loop(hmx_engine* e, int flags, const std::vector<int>& tiles_u
     return 0;
 }
 
+// A grid-wide wait of the persistent sweep gave up: EXACT replay of the round, block by block, from the round's own start
+// -- O as it was (Osave), the removal sums and centroids the failed launch used (Sold, Y: untouched by it), the round's own
+// lists (lists[cur]).  Rows the failed launch already replaced are computed again: a new row depends on Z_cos, Y and its
+// block's table, never on the old row.  The sticky word that makes later kernels stand still is cleared here (the stream
+// is drained first: nothing that tests it may still be queued), and whatever was prepared ahead on the side stream is void.
+static int replay_round(hmx_engine* e, int flags, const std::vector<int>& tiles_upper, double obj_out[4]) {
+    int rc;
+    const size_t GK = (size_t)e->G * e->K16;
+    note_sweep_timeout(e);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->stream2) HIP_TRY(hipStreamSynchronize(e->stream2));
+    e->pre_valid = false;
+    e->pre_outstanding = false;
+    e->clean_sweeps = 0;        // no read-back is deferred again before a sweep has been seen to complete
+    HIP_TRY(hipMemsetAsync(e->frozen(), 0, sizeof(unsigned long long), e->stream));
+    HIP_TRY(hipMemcpyAsync(e->Ogrp.p, e->Osave.p, GK * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    HIP_TRY(hipMemsetAsync(e->Snew, 0, (size_t)((e->objacc + 2 * HMX_OBJ_SLOTS + 2) - e->Snew) * sizeof(double), e->stream));
+    if ((rc = blocks_loop(e, flags, tiles_upper))) return rc;
+    return read_objective(e, obj_out);
+}
+
 // Kernel sequence of one round; the lists (cells, tile groups, block_tile_start) and, for the streaming R^T.Z pass, the
 // block ids in static tile order (tile_blk) are already in device memory.  tiles_upper[b] bounds the tile count of block b
 // (grid sizing only).
 static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::vector<int>& tiles_upper, double obj_out[4],
-                      const std::function<int()>& before_sweep = nullptr, double* defer_slot = nullptr) {
+                      const std::function<int()>& before_sweep = nullptr, double* defer_slot = nullptr, bool no_replay = false) {
     int rc;
     const size_t GK = (size_t)e->G * e->K16;
     const bool persistent = (flags & HMX_ROUND_UPDATE_R) && e->round_mode == 1 && (!sharded(e) || e->peers_enabled);
@@ -1177,6 +1204,8 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
             ra.counter = e->sync_words.p; ra.error = e->sync_words.p + 1; ra.wait_stats = e->wait_stats.p;
             ra.K = e->K; ra.Kp = e->Kp; ra.K16 = e->K16; ra.dp = e->dp; ra.ldy = e->ldy; ra.G = e->G; ra.B = e->B; ra.V = e->V;
             ra.nblk = e->nblk; ra.spin_limit = e->spin_limit;
+            ra.frozen = e->frozen();
+            if (e->n_sweep_launches++ == e->test_fail_sweep) ra.spin_limit = 0;
             if (multi) {
                 ra.peer_box = e->peer_dev.p; ra.my_box = e->box; ra.n_ranks = e->n_ranks; ra.rank = e->rank;
                 ra.epoch = e->round_epoch;
@@ -1242,16 +1271,8 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
         }
         if ((rc = read_objective(e, obj_out))) return rc;
         if (e->obj_host[2 * HMX_OBJ_SLOTS + 1] == 0.0) e->clean_sweeps++;
-        if (e->obj_host[2 * HMX_OBJ_SLOTS + 1] != 0.0) {
-            // EXACT replay, block by block, from the round's own start: O as it was (Osave), the removal sums and centroids
-            // the failed launch used (Sold, Y: untouched by it), the round's own lists.  Rows the failed launch already
-            // replaced are computed again -- a new row depends on Z_cos, Y and its block's table, never on the old row.
-            note_sweep_timeout(e);
-            HIP_TRY(hipMemcpyAsync(e->Ogrp.p, e->Osave.p, GK * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-            HIP_TRY(hipMemsetAsync(e->Snew, 0, (size_t)((e->objacc + 2 * HMX_OBJ_SLOTS + 2) - e->Snew) * sizeof(double), e->stream));
-            if ((rc = blocks_loop(e, flags, tiles_upper))) return rc;
-            return read_objective(e, obj_out);
-        }
+        if (e->obj_host[2 * HMX_OBJ_SLOTS + 1] != 0.0)   // (no_replay: older rounds of this cluster() call are still unread -- the caller finds the first that failed)
+            return no_replay ? 2 : replay_round(e, flags, tiles_upper, obj_out);
         return 0;
     }
     if (flags & HMX_ROUND_UPDATE_R) {
@@ -1315,7 +1336,11 @@ int hmx_cluster_round(hmx_engine* e, int flags, const int32_t* cells, int64_t n_
 
 // One round whose update order comes from the keyed bijection (seed, round counter): lists built on the device, the
 // next round's lists prepared on the second stream beside the sweep kernel.
-static int seeded_round(hmx_engine* e, int flags, uint64_t seed, int64_t cells_per_block, double obj_out[4], double* defer_slot = nullptr) {
+// Returns 0, 1 (objective read-back deferred into defer_slot) or 2 (no_replay: a wait timed out, nothing was repeated).
+// replay_only: the lists of the round are built and the round is REPLAYED block by block from the state a timed-out sweep
+// left (replay_round) -- no R^T.Z pass, no sweep kernel.
+static int seeded_round(hmx_engine* e, int flags, uint64_t seed, int64_t cells_per_block, double obj_out[4], double* defer_slot = nullptr,
+                        bool no_replay = false, bool replay_only = false) {
     int rc;
     const int nkeys = e->nblk * e->G;
     const int nchunks = order_chunks(e->N);
@@ -1341,6 +1366,7 @@ static int seeded_round(hmx_engine* e, int flags, uint64_t seed, int64_t cells_p
         o.gstart = e->gstart.p; o.chunk_tab = e->chunk_tab.p; o.run_count = e->run_count.p; o.run_start = e->run_start.p;
         o.blk_start = e->lists[which].blk_start.p; o.cells = e->lists[which].cells.p; o.tile_grp = e->lists[which].tile_grp.p;
         if (streaming_rtz(e)) { o.tile_blk = e->tile_blk[which].p; o.s_tile_start = e->s_tile_start.p; }   // block ids in static tile order, by the way
+        o.frozen = e->frozen();
         launch_order(o, s);
     };
     const uint64_t counter = e->seeded_rounds++;
@@ -1356,7 +1382,7 @@ static int seeded_round(hmx_engine* e, int flags, uint64_t seed, int64_t cells_p
     // next round's lists depend on (seed, counter) only: they are built on the second stream beside the sweep
     // kernel, which leaves a few CUs idle.  The scratch tables (chunk_tab, run_*) are free by then.
     auto prefetch = [&]() -> int {
-        if (!e->prefetch_lists || !e->stream2) return 0;
+        if (!e->prefetch_lists || !e->stream2 || replay_only) return 0;
         HIP_TRY(hipEventRecord(e->pre_event, e->stream));
         HIP_TRY(hipStreamWaitEvent(e->stream2, e->pre_event, 0));
         build(counter + 1, e->cur ^ 1, e->stream2);
@@ -1393,7 +1419,8 @@ static int seeded_round(hmx_engine* e, int flags, uint64_t seed, int64_t cells_p
         for (int b = 0; b < e->nblk; ++b) upper[b] = bs[b + 1] - bs[b];
         total = bs[e->nblk];
     }
-    return round_body(e, flags, total, upper, obj_out, prefetch, defer_slot);
+    if (replay_only) return replay_round(e, flags, upper, obj_out);
+    return round_body(e, flags, total, upper, obj_out, prefetch, defer_slot, no_replay);
 }
 
 int hmx_cluster_round_seeded(hmx_engine* e, int flags, uint64_t seed, int64_t cells_per_block, double obj_out[4]) {
@@ -1427,38 +1454,49 @@ int hmx_cluster(hmx_engine* e, uint64_t seed, int64_t cells_per_block, int max_r
     // are folded when round window + 1 (or the last round) is read -- the history is the same, the host round trip is paid
     // only where the algorithm needs it.  A run of forced rounds is treated like a natural one: from round window + 1 on
     // every round is read back before the next starts, as the test of harmony.py:517-523 would require.
+    // A time-out in a round whose read-back was deferred is noticed late, but nothing is lost: the sweep kernel that gave up
+    // set a sticky word, and every kernel queued behind it -- the R^T.Z pass, its finish kernel, the sweep and the list
+    // builds of the later rounds -- found it set and returned at once.  So the device still holds exactly what the failed
+    // round left (R rows are only ever outputs; O at its start, its removal sums and centroids are untouched), the unread
+    // objective blocks all repeat the failed round's, and the call resumes there: the round's lists are rebuilt (they depend
+    // on seed and counter only), the round is replayed block by block (replay_round), the rounds behind it run again.
+    const uint64_t counter0 = e->seeded_rounds;
     int first_pending = 0, n_pending = 0;
-    auto resolve = [&]() -> int {   // the deferred blocks have landed (the stream was waited for since)
-        for (int j = 0; j < n_pending; ++j) {
-            const double* blk = e->obj_defer + (size_t)j * (2 * HMX_OBJ_SLOTS + 2);
-            if (blk[2 * HMX_OBJ_SLOTS + 1] != 0.0)
-                return fail(HMX_ERR_STATE, "a grid-wide wait of the sweep kernel timed out in round %d of this call, whose objective "
-                                           "was read late: the assignment is void (HMX_ROUND_MODE=blocks avoids the persistent kernel)",
-                            first_pending + j);
-            fold_objective(blk, obj_out + 4 * (size_t)(first_pending + j));
-        }
-        n_pending = 0;
-        return 0;
-    };
     for (int i = 0; i < n; ++i) {
         double* o = obj_out + 4 * (size_t)i;
-        const bool decision = i > window;
-        const bool may_defer = !decision && i + 1 < n && n_pending < HMX_DEFER_MAX;
+        const bool may_defer = !(i > window) && i + 1 < n && n_pending < HMX_DEFER_MAX;
         rc = seeded_round(e, HMX_ROUND_ALL, seed, cells_per_block, o,
-                          may_defer ? e->obj_defer + (size_t)n_pending * (2 * HMX_OBJ_SLOTS + 2) : nullptr);
+                          may_defer ? e->obj_defer + (size_t)n_pending * (2 * HMX_OBJ_SLOTS + 2) : nullptr, n_pending > 0);
         if (rc < 0) return rc;
         if (rc == 1) {                                              // deferred
             if (n_pending == 0) first_pending = i;
             ++n_pending;
             continue;
         }
-        if ((rc = resolve())) return rc;                            // this round was read back: everything older has landed
+        // this round was read back: everything older has landed
+        int failed_round = rc == 2 ? i : -1;
+        for (int j = 0; j < n_pending; ++j) {
+            const double* blk = e->obj_defer + (size_t)j * (2 * HMX_OBJ_SLOTS + 2);
+            if (blk[2 * HMX_OBJ_SLOTS + 1] != 0.0) { failed_round = first_pending + j; break; }
+            fold_objective(blk, obj_out + 4 * (size_t)(first_pending + j));
+        }
+        n_pending = 0;
+        if (failed_round >= 0) {
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            if (e->stream2) HIP_TRY(hipStreamSynchronize(e->stream2));
+            HIP_TRY(hipMemsetAsync(e->frozen(), 0, sizeof(unsigned long long), e->stream));   // the list build below must run
+            e->pre_valid = false;
+            e->pre_outstanding = false;
+            e->seeded_rounds = counter0 + (uint64_t)failed_round;
+            i = failed_round;
+            if ((rc = seeded_round(e, HMX_ROUND_ALL, seed, cells_per_block, obj_out + 4 * (size_t)i, nullptr, false, true))) return rc < 0 ? rc : fail(HMX_ERR_STATE, "replay of round %d failed", i);
+        }
         for (size_t j = hist.size(); j <= (size_t)i; ++j) {
             const double* oj = obj_out + 4 * j;
             hist.push_back((oj[0] + oj[1] + oj[2]) * norm_const);   // :413
         }
         *rounds_out = i + 1;
-        if (forced_rounds < 0 && decision) {                        // :455-458
+        if (forced_rounds < 0 && i > window) {                      // :455-458
             double obj_old = 0.0, obj_new = 0.0;                    // :519-522, summed left to right like Python's sum()
             const size_t m = hist.size();
             for (int j = 0; j < window; ++j) obj_old += hist[m - window - 1 + j];
@@ -1466,9 +1504,7 @@ int hmx_cluster(hmx_engine* e, uint64_t seed, int64_t cells_per_block, int max_r
             if (std::fabs(obj_old - obj_new) / std::fabs(obj_old) < epsilon) break;
         }
     }
-    if (n_pending > 0) {                                            // (cannot happen: the last round is always read back)
-        if ((rc = wait_stream(e)) || (rc = resolve())) return rc;
-    }
+    if (n_pending > 0) return fail(HMX_ERR_STATE, "internal: %d objective blocks unread at the end of hmx_cluster", n_pending);   // (the last round is always read back)
     *rounds_out = (int)std::max<size_t>(hist.size(), (size_t)*rounds_out);
     return HMX_OK;
 }

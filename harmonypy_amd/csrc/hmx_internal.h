@@ -51,6 +51,7 @@ struct RoundArgs {
     const float* theta;
     unsigned* counter;       // arrivals (zeroed by the caller)
     unsigned* error;         // set to 1 when a wait gave up (zeroed by the caller)
+    unsigned* frozen;        // sticky: set with `error`, cleared by the HOST only -- every kernel of a later round returns at once while it is set (see hmx_cluster)
     unsigned long long* wait_stats;   // {waits, polls that found the hand-off incomplete, most polls of one wait}: accumulated
     unsigned long long* prof;  // HMX_ROUND_PROF builds: wgs x nblk x 8 time stamps (or null)
     // cells sharded over ranks: the block sums travel through peer boxes (null / 1: single engine)
@@ -122,6 +123,7 @@ struct Rtz3Args {
     const int* task_cend;      // first cell behind the task's group
     float* slab;               // ntasks x MT x NT x 256 accumulators, [tile][lane][r]
     unsigned long long* prof;  // -DHMX_RTZ3_PROF builds: ntasks x waves x 8 time stamps (else null)
+    const unsigned* frozen;    // non-zero: an earlier sweep of this cluster() call timed out -- do nothing (or null)
     int ntasks, Kp;
     int dp, d, nt;             // k_rtzw (wide shapes; set by its launcher): row floats of Z, PCs, output column tiles
 };
@@ -140,6 +142,7 @@ struct Rtz3FinishArgs {
     size_t zero_n;
     double* zero2_p;
     size_t zero2_n;
+    const unsigned* frozen;    // as Rtz3Args.frozen: a frozen engine keeps Y, Sold, Osave and the objective block of the failed round
     const double* copy_src;    // copy duty: O at the start of the round, kept for an exact replay (or null)
     double* copy_dst;
     int copy_n;
@@ -218,6 +221,7 @@ struct OrderArgs {
     // (position of internal cell c of group g: 16 * s_tile_start[g] + c - gstart[g]); null = not wanted
     unsigned char* tile_blk;
     const int* s_tile_start;
+    const unsigned* frozen;  // non-zero: leave the lists alone (they may be the lists of a round that is about to be replayed), or null
 };
 
 size_t sweep_lds_bytes(int K16, int d, int G, int B, int V, int nblk);

@@ -1196,6 +1196,7 @@ __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_assign_wide2(AssignArgs
 
 template <int MT, int KS>
 __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
+    if (a.frozen && *a.frozen) return;   // an earlier sweep of this cluster() call timed out: R, O, the objective block stay as it left them
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int K16 = 16 * MT;
     constexpr int NF = KS / 4, NT = KS % 4;
@@ -1269,7 +1270,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                        a.epoch + (unsigned long long)b + 1ull);
         }
         if (gfail && tid == 0) {
-            atomicExch(a.error, 1u);
+            atomicExch(a.error, 1u); if (a.frozen) atomicExch(a.frozen, 1u);
             atomicAdd(&a.obj[0], __builtin_nan(""));
             atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS + 1], 1.0);   // every rank sees the count of failures in the all-reduce of the objective block
         }
@@ -1621,7 +1622,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         if (v != 0.0) atomicAdd(&a.obj[2 * (wg & (HMX_OBJ_SLOTS - 1)) + tid], v);
     }
     if (failed && tid == 0) {
-        atomicExch(a.error, 1u);
+        atomicExch(a.error, 1u); if (a.frozen) atomicExch(a.frozen, 1u);
         atomicAdd(&a.obj[0], __builtin_nan(""));
         atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS + 1], 1.0);   // the host (every rank's, after the all-reduce) replays the round block by block
     }
@@ -1634,7 +1635,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             const unsigned want = (unsigned)a.nblk * (unsigned)nwg;
             while (ld_agent(a.counter) < want) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > a.spin_limit) { if (lane == 0) { atomicExch(a.error, 1u); atomicAdd(&a.obj[0], __builtin_nan("")); atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS + 1], 1.0); } break; }
+                if (++spins > a.spin_limit) { if (lane == 0) { atomicExch(a.error, 1u); if (a.frozen) atomicExch(a.frozen, 1u); atomicAdd(&a.obj[0], __builtin_nan("")); atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS + 1], 1.0); } break; }
             }
         } else {
             const unsigned long long want = a.epoch + (unsigned long long)a.nblk;
@@ -1643,7 +1644,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                 const bool ok = lane >= a.n_ranks || ld_sys(fl + lane) >= want;
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > a.spin_limit) { if (lane == 0) { atomicExch(a.error, 1u); atomicAdd(&a.obj[0], __builtin_nan("")); atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS + 1], 1.0); } break; }
+                if (++spins > a.spin_limit) { if (lane == 0) { atomicExch(a.error, 1u); if (a.frozen) atomicExch(a.frozen, 1u); atomicAdd(&a.obj[0], __builtin_nan("")); atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS + 1], 1.0); } break; }
             }
         }
     }
@@ -3105,6 +3106,7 @@ __device__ __forceinline__ int group_of_cell(const int* __restrict__ gstart, int
 // chunk_tab is laid out [key][chunk] so that the scan below reads contiguous counts.
 template <int MODE>
 __global__ __launch_bounds__(64) void k_order_pass(OrderArgs a) {
+    if (a.frozen && *a.frozen) return;   // a sweep timed out and the host has not looked yet: these may be the lists it will replay
     extern __shared__ int cnt[];  // nkeys running counters of this chunk
     const int lane = threadIdx.x;
     const int chunk = blockIdx.x, nchunks = gridDim.x;
@@ -3156,6 +3158,7 @@ __global__ __launch_bounds__(64) void k_order_pass(OrderArgs a) {
 
 // One workgroup per key: exclusive scan of the per-chunk counts (in place) and the run length.
 __global__ __launch_bounds__(256) void k_order_scan(OrderArgs a, int nchunks) {
+    if (a.frozen && *a.frozen) return;   // a sweep timed out and the host has not looked yet: these may be the lists it will replay
     __shared__ int part[256];
     const int key = blockIdx.x, tid = threadIdx.x;
     int* tab = a.chunk_tab + (size_t)key * nchunks;
@@ -3183,6 +3186,7 @@ __global__ __launch_bounds__(256) void k_order_scan(OrderArgs a, int nchunks) {
 // One workgroup per key (block, group): its run start (every workgroup sums the padded lengths of the
 // keys before its own -- a few hundred integers), block_tile_start, the run's padding and tile groups.
 __global__ __launch_bounds__(256) void k_order_runs(OrderArgs a) {
+    if (a.frozen && *a.frozen) return;   // a sweep timed out and the host has not looked yet: these may be the lists it will replay
     __shared__ int part[256];
     const int nkeys = a.nblk * a.G;
     const int key = blockIdx.x, tid = threadIdx.x;

@@ -85,6 +85,7 @@ __device__ __forceinline__ void wait_vmcnt() {   // gfx9 encoding: vmcnt[3:0] | 
 #endif
 template <int MT, int KS, int NTB>
 __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
+    if (a.frozen && *a.frozen) return;   // an earlier sweep of this cluster() call timed out: the state stays as that round left it
     constexpr int NT = 4 + NTB, DP = 4 * KS;
     constexpr int NR = MT, NZ = (KS + 3) / 4, NI = NR + NZ + 1;   // VMEM operations per tile: R pieces, Z pieces, block ids
     constexpr int H = MT / 4, REM = MT % 4;
@@ -700,6 +701,7 @@ __global__ __launch_bounds__(64 * RTZW2_WAVES, 2) void k_rtzw2(Rtz3Args a) {
 // ------------------------------------------------------------------------------------------
 #define RTZ3_FIN_THREADS 1024   /* many short chains of dependent-free loads: the slab reads are latency-bound */
 __global__ __launch_bounds__(RTZ3_FIN_THREADS) void k_rtz3_finish(Rtz3FinishArgs a) {
+    if (a.frozen && *a.frozen) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* tab = reinterpret_cast<double*>(smem);                  // G x NV
     const int NT = a.wide ? a.NT : 4 + a.NTB, NV = 16 * NT, DP = 4 * a.KS;
