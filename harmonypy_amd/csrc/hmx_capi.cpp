@@ -860,7 +860,7 @@ struct Rtz3Duties { bool on = false; };
 //   mode 2: the same statistics of Z_cos (member sums and counts of the device k-means' hard assignment).
 static int rtz3_pass(hmx_engine* e, int mode, const unsigned char* tile_blk, int nblk_cols, bool normalize, bool duties) {
     int rc;
-    const bool wide = !use_rtz3(e);
+    const bool wide = !(use_rtz3(e) && rtz3_ok(e->mt, e->dp, nblk_cols, e->G));   // (mode 2 comes here for wide shapes whatever the rounds' kernel is)
     if ((rc = e->slab.reserve((size_t)e->ntasks3 * (wide ? rtzw_slab_floats(e->mt, e->dp, e->d, nblk_cols) : rtz3_slab_floats(e->mt, e->dp, nblk_cols)))))
         return rc;
     {
@@ -929,7 +929,11 @@ static int centroid_pass(hmx_engine* e) {
 // R^T.Z statistics of that assignment (the streaming pass over Z_cos, summed over ranks like the ridge statistics).
 static int lloyd_wide(hmx_engine* e, const float* centers_in, int n_iter, float* centers_out) {
     int rc;
-    if (!streaming_rtz(e)) return fail(HMX_ERR_ARG, "device k-means for K > 112 or d > 64 needs the streaming R^T.Z pass (consecutive cells in every static tile)");
+    // the member sums are ONE block column of the streaming pass (k_rtzw with all block ids 0), whatever kernel the rounds use
+    // (HMX_RTZ=2) and however many update blocks they have: only the layout and the finish kernel's per-group table matter
+    if (!(e->static_contig && e->ntasks3 > 0 && rtzw_ok(e->mt, e->dp, e->d, 1, e->G)))
+        return fail(HMX_ERR_ARG, "device k-means for K > 112 or d > 64 needs consecutive cells in every static tile and at most %d batch groups at this width "
+                                 "(the caller falls back to Lloyd iterations on a subsample)", (int)(150 * 1024 / (16 * rtzw_nt(e->dp, e->d, 1) * sizeof(double))));
     if ((rc = use_device(e))) return rc;
     e->clustered = false;   // R serves as scratch: whatever assignment the engine held is void until hmx_init_cluster runs (again)
     const size_t nsum = (size_t)e->K16 * (e->d + 1), GK = (size_t)e->G * e->K16;

@@ -654,11 +654,38 @@ class Harmony:
         self._lap("kmeans_seeds")
         # max_iter=25 (harmony.py:371) Lloyd iterations over ALL cells on the device -- wide shapes (K > 112 or d > 64) too:
         # hard assignment as a one-hot R, member sums as the R^T.Z statistics of it (hmx_kmeans_lloyd)
-        centers = self._engine.kmeans_lloyd(centers, 25)
+        try:
+            centers = self._engine.kmeans_lloyd(centers, 25)
+        except _capi.HmxError as ex:
+            # wide shapes only: the device Lloyd needs the streaming R^T.Z pass with one block column (hmx_capi.cpp, lloyd_wide);
+            # more batch groups than its finish kernel tabulates (85 at 200 PCs), or a caller-built layout whose static tiles
+            # do not hold consecutive cells, run the 25 iterations on a subsample on the host instead (sklearn's Lloyd from
+            # the same seeds -- what harmony.py:370-372 does on all cells)
+            if not self._wide_shape():
+                raise
+            logger.warning(f"device k-means unavailable for this shape ({ex}); Lloyd iterations on a subsample on the host")
+            centers = self._host_lloyd_on_subsample(centers, random_state)
         self._lap("kmeans_lloyd")
         if self.verbose:
             logger.info("KMeans initialization complete.")
         return np.ascontiguousarray(centers.T)
+
+    def _host_lloyd_on_subsample(self, centers, random_state, cells=200_000):
+        from sklearn.cluster import KMeans
+        n = max(1, int(round(cells * self.N / self.N_global)))
+        take = np.linspace(0, self.N - 1, min(n, self.N)).astype(np.int64)
+        sub = self._engine.get_rows(_capi.HMX_Z_COS, take)
+        if self.shard is not None:
+            parts = self.shard.allgather_object(sub)
+            sub = np.concatenate(parts, axis=0) if self.shard.rank == 0 else None
+        out = None
+        if sub is not None:
+            km = KMeans(n_clusters=self.K, init=np.ascontiguousarray(centers, dtype=np.float32), n_init=1, max_iter=25,
+                        random_state=random_state).fit(np.ascontiguousarray(sub, dtype=np.float32))
+            out = np.asarray(km.cluster_centers_, dtype=np.float32)
+        if self.shard is not None:
+            out = self.shard.broadcast_object(out)
+        return out
 
     # ------------------------------------------------------------------
     # harmony.py:394-417: the three sums come back from the device with the round

@@ -67,6 +67,30 @@ def test_sharded_oracle_reproduces_reference_golden(case, tmp_path):
     np.testing.assert_array_equal(res[0]["objective_kmeans"], res[1]["objective_kmeans"])
 
 
+@pytest.mark.parametrize("world,case", [(4, "pbmc_short"), (4, "pbmc_two_vars"), (8, "pbmc_default"), (8, "pbmc_short")])
+def test_sharded_oracle_world_4_and_8(world, case, tmp_path):
+    """The same with 4 and 8 ranks (the C ABI allows 8: hmx_set_ranks): uneven contiguous slices of the donor-sorted
+    pbmc cells, so most ranks hold a SINGLE donor (their other batch groups are empty) and no rank sees every level --
+    batch levels, proportions and the cluster count must be the job's, and summing only the small tables over the ranks
+    must still give the reference's unsharded Z_corr within 1e-4 and its objective histories."""
+    data, meta, vars_use, kw, g = load_case(case)
+    res = launch("oracle", case, tmp_path, world=world)
+    los, his = [int(r["lo"]) for r in res], [int(r["hi"]) for r in res]
+    assert los[0] == 0 and his[-1] == data.shape[0] and los[1:] == his[:-1]
+    sizes = np.diff([0] + his)
+    assert sizes.min() > 0 and sizes.max() - sizes.min() > 100                     # uneven slices
+    donors_per_rank = [meta["donor"].iloc[lo:hi].nunique() for lo, hi in zip(los, his)]
+    assert min(donors_per_rank) == 1 and meta["donor"].nunique() > 1               # ranks that hold one batch level only
+    Z = np.concatenate([r["Z_corr"] for r in res], axis=0)
+    rel_f, max_rel = assert_z_close(Z, g["Z_corr"])
+    print(f"{case}, {world} ranks (donors per rank {donors_per_rank}): sharded oracle vs reference relF={rel_f:.2e} max={max_rel:.2e}")
+    for r in res:
+        np.testing.assert_allclose(r["objective_kmeans"], g["objective_kmeans"], rtol=2e-5)
+        np.testing.assert_allclose(r["objective_harmony"], g["objective_harmony"], rtol=2e-5)
+        assert list(r["kmeans_rounds"]) == [int(x) for x in g["kmeans_rounds"]]
+        np.testing.assert_array_equal(r["objective_kmeans"], res[0]["objective_kmeans"])   # every rank walks the same history
+
+
 def test_sharded_front_end_equals_unsharded(tmp_path):
     """Batch levels, batch proportions, cluster count and theta/tau scaling are those of the
     whole job on every rank (harmony.py:123-173 evaluated on the unsharded input)."""

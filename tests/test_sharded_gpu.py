@@ -123,3 +123,35 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["cells_total"] == 120000
     assert len(line["ranks"]["per_rank"]) == 2 and line["ranks"]["transports"] == ["host+peer"]
     assert line["ranks"]["peer_exchange_on_all"] and line["value"] > 0
+
+
+def test_bench_four_ranks_on_one_gpu(tmp_path):
+    """`python bench.py --gpus 4`: four ranks (gloo + four engines on the one GPU of the box, 50 compute workgroups + a
+    gateway each so that all four persistent sweeps are resident together), BASELINE configs[3]'s shape split in four.  The
+    in-kernel exchange of the per-block sums must be on for every rank (peer boxes through IPC, 4-way flags), nothing may time
+    out, and every rank issues the same small number of collectives: per round one for the removal sums and centroid
+    numerators and one for the objective block, plus one per ridge step -- not one per update block."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HMX_BENCH_BACKEND="gloo", HMX_ROUND_WGS="50", HMX_BENCH_CELLS="40000")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    steps, warmup, rounds = 2, 1, 10
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", str(steps), "--warmup", str(warmup),
+                        "--cpu-sample", "0", "--no-convergence"], capture_output=True, text=True, env=env, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 4 and line["scaling"] == "strong" and line["config"]["cells_total"] == 160000
+    ranks = line["ranks"]
+    assert len(ranks["per_rank"]) == 4 and ranks["transports"] == ["host+peer"] and ranks["peer_exchange_on_all"]
+    assert all(pr["fallback_rounds"] == 0 and pr["sweep_waits"] > 0 for pr in ranks["per_rank"]), ranks["per_rank"]
+    assert len(ranks["collectives_per_rank"]) == 1                          # every rank issued the same number
+    per_step = (rounds * 2 + 1)
+    total = ranks["collectives_per_rank"][0]
+    print("4 ranks on one GPU:", round(line["value"] / 1e6, 1), "M cells/s/iteration; collectives per rank", total)
+    # warm-up + timed steps (+ the one-off collectives of set-up and init_cluster): far below the 20 per round of the
+    # one-collective-per-block path (rounds * 22 per step)
+    assert (steps + warmup) * per_step <= total <= (steps + warmup) * per_step + 40, total
