@@ -309,10 +309,10 @@ def side_config(name, rounds, steps, warmup, device):
     ho._engine.sync()
     dt = time.perf_counter() - t0
     # whole-step roofline of the side entry from its wall time (no per-kernel events here): a round moves 4d + 8K + 8
-    # algorithmic bytes and 4 d K flops per cell (distance product + R^T.Z), the ridge step 12d + 8K bytes and 4 d K flops
+    # algorithmic bytes and 4 d K flops per cell (distance product + R^T.Z), the ridge step 8K + 16d + 8 bytes and 4 d K flops
     # (statistics + correction) -- SURVEY section 8d's per-cell figures; the wide shapes are priced against the f32 MFMA peak
     t_step = dt / steps
-    step_bytes = N * (rounds * (4.0 * d + 8 * K + 8) + 12.0 * d + 8 * K)
+    step_bytes = N * (rounds * (4.0 * d + 8 * K + 8) + 8.0 * K + 16 * d + 8)
     step_flops = N * (rounds + 1) * 4.0 * d * K
     wide = K > 112 or d > 64
     roof = ({"bound": "mfma", "achieved": step_flops / t_step / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
@@ -490,8 +490,14 @@ def main():
     job = (f"BASELINE configs[{CONFIG_INDEX[config]}] ({config.upper()}): " +
            (f"{N * world} cells x {d} PCs, {B} batches, K={K} sharded over {world} GPUs ({N} cells per GPU)" if scaling == "strong"
             else f"{N} cells x {d} PCs, {B} batches, K={K} per GPU"))
+    import hashlib
+    import socket
     out = {
         "metric": "cells/sec/Harmony-iteration", "value": value, "unit": "cells/sec/Harmony-iteration",
+        # which machine: the same build measures 5-6 % apart on different boxes of the pool, so a
+        # difference between two lines is progress only if their `box` agrees or an A/B on ONE box backs it (profiles/*ab*)
+        "box": hashlib.sha256(socket.gethostname().encode()).hexdigest()[:8],
+        "box_to_box_spread_note": "same build: 5-6 % between boxes; gains are claimed from same-box A/B runs (profiles/r04_ab_*.txt)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {

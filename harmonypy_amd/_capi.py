@@ -26,10 +26,10 @@ EXPORTS = [
     "hmx_last_error", "hmx_abi_version", "hmx_create", "hmx_destroy", "hmx_upload", "hmx_init_cluster",
     "hmx_cluster_round", "hmx_cluster_round_seeded", "hmx_moe_correct_ridge", "hmx_get", "hmx_set", "hmx_sync", "hmx_device_ptr",
     "hmx_kernel_times", "hmx_enable_timing", "hmx_counters", "hmx_comm_unique_id", "hmx_comm_init", "hmx_set_host_allreduce",
-    "hmx_build_id", "hmx_has_sweep_kernel", "hmx_cluster", "hmx_set_timing_stride", "hmx_kmeans_lloyd", "hmx_kmeans_seed", "hmx_compute_lisi", "hmx_get_rows", "hmx_set_ranks", "hmx_peer_export", "hmx_peer_attach", "hmx_peer_selftest", "hmx_peer_enable",
+    "hmx_build_id", "hmx_has_sweep_kernel", "hmx_cluster", "hmx_set_timing_stride", "hmx_set_timing_families", "hmx_kmeans_lloyd", "hmx_kmeans_seed", "hmx_compute_lisi", "hmx_get_rows", "hmx_set_ranks", "hmx_peer_export", "hmx_peer_attach", "hmx_peer_selftest", "hmx_peer_enable",
 ]
 HMX_PEER_HANDLE_BYTES = 64
-HMX_ABI_VERSION = 5
+HMX_ABI_VERSION = 6
 HMX_UNIQUE_ID_BYTES = 128
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
 
@@ -93,6 +93,7 @@ def load():
     lib.hmx_counters.argtypes = [vp, vp]
     lib.hmx_enable_timing.argtypes = [vp, C.c_int]
     lib.hmx_set_timing_stride.argtypes = [vp, C.c_int]
+    lib.hmx_set_timing_families.argtypes = [vp, C.c_uint]
     for name in EXPORTS:
         if name not in ("hmx_last_error", "hmx_destroy", "hmx_build_id"):
             getattr(lib, name).restype = C.c_int
@@ -327,13 +328,10 @@ class Engine:
         bracket (default all); ``stride``: only every stride-th launch of a family.  Every bracketed launch costs two
         event records on the stream."""
         _check(self._lib.hmx_set_timing_stride(self._h, int(stride)))
-        if not on:
-            flag = 0
-        elif families is None:
-            flag = -1
-        else:
-            flag = sum(1 << KERNEL_FAMILIES.index(f) for f in families)
-        _check(self._lib.hmx_enable_timing(self._h, flag))
+        if on:
+            mask = 0xFFFFFFFF if families is None else sum(1 << KERNEL_FAMILIES.index(f) for f in families)
+            _check(self._lib.hmx_set_timing_families(self._h, mask))
+        _check(self._lib.hmx_enable_timing(self._h, 1 if on else 0))
 
     def counters(self):
         """dict of the engine's event counters (hmx_counters)."""

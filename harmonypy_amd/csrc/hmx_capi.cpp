@@ -1834,9 +1834,15 @@ int hmx_enable_timing(hmx_engine* e, int on) {
     (void)hipSetDevice(e->cfg.device_id);
     (void)hipStreamSynchronize(e->stream);
     drain_spans(e);
-    e->timing = on != 0;
-    e->timing_mask = on < 0 ? ~0u : (unsigned)on;   // on > 0: bit f selects family f of hmx_kernel_times; on < 0: every family
+    e->timing = on != 0;                            // any non-zero value: the families selected by hmx_set_timing_families (default: all)
     for (int i = 0; i < F_COUNT; ++i) { e->fam_ms[i] = 0; e->fam_n[i] = 0; e->fam_seen[i] = 0; }
+    return HMX_OK;
+}
+
+int hmx_set_timing_families(hmx_engine* e, unsigned mask) {
+    if (!e) return fail(HMX_ERR_ARG, "null argument");
+    if (mask == 0) return fail(HMX_ERR_ARG, "empty family mask (hmx_enable_timing(e, 0) turns timing off)");
+    e->timing_mask = mask;                          // bit f selects family f of hmx_kernel_times
     return HMX_OK;
 }
 

@@ -652,21 +652,21 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef HMX_ROUND_PK
 #define HMX_ROUND_PK 1
 #endif
-template <int MT, bool PENALTY = true, bool LOG2 = false, bool A2TAB = false>
+template <int MT, bool PENALTY = true, bool LOG2 = false, bool A2TAB = false, bool PK = (HMX_ROUND_PK != 0)>
 __device__ __forceinline__ void round_post_pass1(const float* sig, const float* rpT, const float* lrpT, int q,
                                                  RoundTile<MT>& T, float& scl, double& km_acc, double& ent_acc) {
     constexpr int K16 = 16 * MT;
     const float* rp = PENALTY ? rpT + (size_t)T.grp * K16 : nullptr;
     const float* lrp = PENALTY ? lrpT + (size_t)T.grp * K16 : nullptr;
     float e1 = 0.f, us = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#if HMX_ROUND_PK
-    if (LOG2 && A2TAB && PENALTY) {
+    if (PK && LOG2 && PENALTY) {
         // the same arithmetic on pairs of entries: v_pk_mul / v_pk_add / v_pk_fma do two fp32 operations per lane and
         // issue slot, so an entry costs one v_exp_f32 + three packed operations instead of one + seven
-        f32x2 e1v = {0.f, 0.f}, usv = {0.f, 0.f}, a1v = {0.f, 0.f}, a3v = {0.f, 0.f};
+        f32x2 e1v = {0.f, 0.f}, usv = {0.f, 0.f}, a1v = {0.f, 0.f}, a2v = {0.f, 0.f}, a3v = {0.f, 0.f};
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const f32x4 pw = ld4(rp + 16 * mt + 4 * q);
+            const f32x4 lp = !A2TAB ? ld4(lrp + 16 * mt + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
             const f32x4 sg = ld4(sig + 16 * mt + 4 * q);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -679,13 +679,13 @@ __device__ __forceinline__ void round_post_pass1(const float* sig, const float* 
                 const f32x2 ts = t * (h ? sg.zw : sg.xy);
                 usv += t;
                 a1v = __builtin_elementwise_fma(ts, arg, a1v);
+                if (!A2TAB) a2v = __builtin_elementwise_fma(ts, h ? lp.zw : lp.xy, a2v);
                 a3v += ts;
                 if (h) T.arg[mt].zw = t; else T.arg[mt].xy = t;
             }
         }
-        e1 = e1v.x + e1v.y; us = usv.x + usv.y; a1 = a1v.x + a1v.y; a3 = a3v.x + a3v.y;
+        e1 = e1v.x + e1v.y; us = usv.x + usv.y; a1 = a1v.x + a1v.y; a2 = a2v.x + a2v.y; a3 = a3v.x + a3v.y;
     } else
-#endif
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const f32x4 pw = PENALTY ? ld4(rp + 16 * mt + 4 * q) : (f32x4){1.f, 1.f, 1.f, 1.f};   // no penalty: init_cluster (:383-385)
@@ -729,12 +729,58 @@ __device__ __forceinline__ void round_post_pass1(const float* sig, const float* 
    Measured cost at C3: 3.67 -> 3.75 ms of sweeps per Harmony iteration (+2 %). */
 #define HMX_ROUND_RETURNING 1
 #endif
-#ifndef HMX_ROUND_SUMS
-#define HMX_ROUND_SUMS 0   /* 1 (experiment): a wave's block sums go to its own fp32 slots in LDS (plain stores), summed at publish time, instead of fp64 LDS atomics on shared addresses */
+// Sums of NV = 4 MT per-lane values over the 16 lanes of each DPP row (the 16 cells of a tile; a row = one q), delivered
+// SCATTERED: lane c16 ends up with the total of value bitrev4(c16) of each group of 16 values.  Four butterfly stages; in
+// stage s a lane keeps one value of every pair and hands the other to its partner -- row_mirror / row_half_mirror /
+// quad_perm [3,2,1,0] / quad_perm [1,0,3,2], each keeping the bits the earlier stages decided on -- so 16 values cost
+// 8 + 4 + 2 + 1 pairs x (2 selects + 1 DPP add) = 45 operations instead of 16 x 5 for sixteen full row sums, and the
+// result is one value per lane: ONE conversion and ONE fp64 LDS add per group of 16 clusters and wave instead of 16 x 4.
+#ifndef HMX_ROUND_RS
+#define HMX_ROUND_RS 1
 #endif
+template <int N>
+__device__ __forceinline__ float rs16(const float (&v)[N], int c16) {   // N <= 16 live values, the rest count as zero
+    static_assert(N >= 1 && N <= 16, "group of 16");
+    float a[8], b4[4], c2[2];
+    const bool k3 = (c16 & 8) != 0, k2 = (c16 & 4) != 0, k1 = (c16 & 2) != 0, k0 = (c16 & 1) != 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float A = 2 * j < N ? v[2 * j] : 0.f, B = 2 * j + 1 < N ? v[2 * j + 1] : 0.f;
+        if (2 * j >= N) { a[j] = 0.f; continue; }
+        const float keep = k3 ? B : A, send = k3 ? A : B;
+        a[j] = keep + DPP_F(send, 0x140);     // row_mirror: lane 15 - l
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (4 * j >= N) { b4[j] = 0.f; continue; }
+        const float keep = k2 ? a[2 * j + 1] : a[2 * j], send = k2 ? a[2 * j] : a[2 * j + 1];
+        b4[j] = keep + DPP_F(send, 0x141);    // row_half_mirror: lane l ^ 7
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (8 * j >= N) { c2[j] = 0.f; continue; }
+        const float keep = k1 ? b4[2 * j + 1] : b4[2 * j], send = k1 ? b4[2 * j] : b4[2 * j + 1];
+        c2[j] = keep + DPP_F(send, 0x1B);     // quad_perm [3,2,1,0]: lane l ^ 3
+    }
+    const float keep = k0 ? c2[1] : c2[0], send = k0 ? c2[0] : c2[1];
+    return keep + DPP_F(send, 0xB1);          // quad_perm [1,0,3,2]: lane l ^ 1
+}
+// one group of up to four cluster tiles (16 values per lane): scatter-reduce over the tile's cells, one fp64 LDS add per lane
+template <int NM>
+__device__ __forceinline__ void block_sums_rs(const f32x4 (&sm)[NM], double* sd, int c16, int q) {
+    const int i = ((c16 & 1) << 3) | ((c16 & 2) << 1) | ((c16 & 4) >> 1) | ((c16 & 8) >> 3);   // the value this lane ends up with
+    float v[4 * NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[4 * m + r] = sm[m][r];
+    const float tot = rs16<4 * NM>(v, c16);
+    if (i < 4 * NM) atomicAdd(sd + 16 * (i >> 2) + 4 * q + (i & 3), (double)tot);   // value i = cluster tile i / 4 of the group, register i % 4
+}
+
 template <int MT>
 __device__ __forceinline__ void round_post_pass2(float* R, int Kp, double* Sd, int c16, int q, const RoundTile<MT>& T0,
-                                                 float scl0, bool has1, const RoundTile<MT>& T1, float scl1, float* slot0 = nullptr, float* slot1 = nullptr) {
+                                                 float scl0, bool has1, const RoundTile<MT>& T1, float scl1) {
     constexpr int K16 = 16 * MT;
     const bool live0 = T0.cell >= 0, live1 = has1 && T1.cell >= 0;
     float* row0 = R + (size_t)(live0 ? T0.cell : 0) * Kp;
@@ -743,6 +789,36 @@ __device__ __forceinline__ void round_post_pass2(float* R, int Kp, double* Sd, i
     double* sd0 = Sd + (size_t)T0.grp * K16;
     double* sd1 = Sd + (size_t)T1.grp * K16;
     if (!has1) scl1 = 0.f;
+#if HMX_ROUND_RS
+    // four cluster tiles at a time: R rows out, then the group's 16 values per lane summed over the cells (:506-507)
+    auto group = [&](auto nm_c, int g) {
+        constexpr int NM = decltype(nm_c)::value;
+        f32x4 rv0[NM], rv1[NM];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int mt = 4 * g + m, col = 16 * mt + 4 * q;
+            rv0[m] = T0.arg[mt] * scl0;                    // :503
+            rv1[m] = T1.arg[mt] * scl1;
+#if !(HMX_RABL & 2)
+            if (live0 && col < Kp) st4(row0 + col, rv0[m]);
+            if (live1 && col < Kp) st4(row1 + col, rv1[m]);
+#endif
+        }
+#if !(HMX_RABL & 1)
+        if (joint || !has1) {                              // one table row for both tiles (scl1 == 0 without a second tile)
+#pragma unroll
+            for (int m = 0; m < NM; ++m) rv0[m] += rv1[m];
+            block_sums_rs<NM>(rv0, sd0 + 64 * g, c16, q);
+        } else {
+            block_sums_rs<NM>(rv0, sd0 + 64 * g, c16, q);
+            block_sums_rs<NM>(rv1, sd1 + 64 * g, c16, q);
+        }
+#endif
+    };
+#pragma unroll
+    for (int g = 0; g < MT / 4; ++g) group(std::integral_constant<int, 4>{}, g);
+    if constexpr (MT % 4 != 0) group(std::integral_constant<int, (MT % 4 ? MT % 4 : 1)>{}, MT / 4);
+#else
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int col = 16 * mt + 4 * q;
@@ -759,11 +835,8 @@ __device__ __forceinline__ void round_post_pass2(float* R, int Kp, double* Sd, i
 #pragma unroll
             for (int r = 0; r < 4; ++r) ss[r] = row16_sum(sm[r]);      // (:506-507)
             if (c16 == 0) {
-                if (HMX_ROUND_SUMS && slot0) st4(slot0 + col, ss);
-                else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) atomicAdd(sd0 + col + r, (double)ss[r]);
-                }
             }
         } else {
             f32x4 s0, s1;
@@ -773,20 +846,16 @@ __device__ __forceinline__ void round_post_pass2(float* R, int Kp, double* Sd, i
                 s1[r] = row16_sum(rv1[r]);
             }
             if (c16 == 0) {
-                if (HMX_ROUND_SUMS && slot0) {
-                    st4(slot0 + col, s0);
-                    if (has1) st4(slot1 + col, s1);
-                } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     atomicAdd(sd0 + col + r, (double)s0[r]);
                     if (has1) atomicAdd(sd1 + col + r, (double)s1[r]);
                 }
-                }
             }
         }
 #endif
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -992,7 +1061,7 @@ __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_assign_wide2(AssignArgs
     constexpr int NPJ = (MT + WIDE2_WAVES - 1) / WIDE2_WAVES;            // centroid pieces (16 rows x 64 bytes) of a wave per k-step, at most
     float* Yring = reinterpret_cast<float*>(smem);                       // WIDE2_YBUF x K16 x 16
     float* sig = Yring + WIDE2_YBUF * K16 * 16;                          // K16
-    float* nis = sig + K16;                                              // K16: -1/sigma (-60 for pads)
+    float* nis = sig + K16;                                              // K16: -2 log2(e) / sigma (-200 for pads)
     float* rpL = nis + K16;                                              // slots x K16
     float* lrpL = rpL + WIDE2_SLOTS * K16;
     double* Sd = reinterpret_cast<double*>(lrpL + WIDE2_SLOTS * K16);    // slots x K16 block sums
@@ -1071,7 +1140,7 @@ __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_assign_wide2(AssignArgs
     for (int i = tid; i < K16; i += 64 * WIDE2_WAVES) {
         const float sgm = (i < a.K) ? a.sigma[i] : 0.f;
         sig[i] = sgm;
-        nis[i] = (i < a.K) ? -1.0f / sgm : -60.f;       // pads: Y row 0 -> dist 2 -> arg -120 -> exp == 0
+        nis[i] = (i < a.K) ? -(2.885390081777926814f / sgm) : -200.f;   // -c_k = -2 log2(e) / sigma_k; pads: Y row 0 -> 2^-200 == 0
     }
     if (tid < WIDE2_SLOTS) tg[tid] = base + tid < ntiles ? a.tile_grp[tile_begin + base + tid] : -1;
     for (int i = tid; i < WIDE2_SLOTS * K16; i += 64 * WIDE2_WAVES) Sd[i] = 0.0;
@@ -1164,15 +1233,14 @@ __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_assign_wide2(AssignArgs
     double km_acc = 0.0, ent_acc = 0.0;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const f32x4 ni = ld4(nis + 16 * mt + 4 * q);
-        const f32x4 one = (f32x4){1.f, 1.f, 1.f, 1.f};
-        T0.arg[mt] = (2.f * (one - T0.arg[mt])) * ni;      // dist = 2 (1 - Y.Z) (:447), arg = -dist / sigma (:466)
-        T1.arg[mt] = (2.f * (one - T1.arg[mt])) * ni;
+        const f32x4 ni = ld4(nis + 16 * mt + 4 * q);       // dist = 2 (1 - Y.Z) (:447), arg = -dist / sigma (:466), here in log2 units:
+        T0.arg[mt] = __builtin_elementwise_fma(T0.arg[mt], -ni, ni);   // c_k (y.z - 1), the argument of the hardware exp2 (one fma per entry)
+        T1.arg[mt] = __builtin_elementwise_fma(T1.arg[mt], -ni, ni);
     }
     if (has0) {
         float scl0, scl1 = 0.f;
-        round_post_pass1<MT, true>(sig, rpL, lrpL, q, T0, scl0, km_acc, ent_acc);
-        if (has1) round_post_pass1<MT, true>(sig, rpL, lrpL, q, T1, scl1, km_acc, ent_acc);
+        round_post_pass1<MT, true, true, false, (HMX_ROUND_PK != 0 && MT <= 8)>(sig, rpL, lrpL, q, T0, scl0, km_acc, ent_acc);
+        if (has1) round_post_pass1<MT, true, true, false, (HMX_ROUND_PK != 0 && MT <= 8)>(sig, rpL, lrpL, q, T1, scl1, km_acc, ent_acc);
         round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T0, scl0, has1, T1, scl1);
     }
     km_acc = wave_sum_all(km_acc);
@@ -1223,12 +1291,6 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     int* gcol = reinterpret_cast<int*>(tht + a.B);                       // G x V
     int* bgrp = gcol + a.G * a.V;                                        // B: the group holding batch b (V == 1)
     int* bs = bgrp + a.B;                                                // nblk + 3 tile offsets (two sentinels)
-#if HMX_ROUND_SUMS
-    // waves x tiles x K16 block sums of the wave's tiles, 16-byte aligned as an OFFSET from the LDS base (a pointer rebuilt
-    // from an integer would lose its address space)
-    float* Sw = Ys0 + (((reinterpret_cast<float*>(bs + a.nblk + 3) - Ys0) + 3) & ~(ptrdiff_t)3);
-    int* Sg = reinterpret_cast<int*>(Sw + ROUND_WAVES * ROUND_TPW * K16); // their groups (-1: no tile)
-#endif
 
     int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the wave's landing zones and roles are wave-uniform
@@ -1536,18 +1598,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             if (has1) round_post_pass1<MT, true, LOG2, A2TAB>(sig, rpT, lrpT, q, T[1], scl1, km_acc, ent_acc);
             __builtin_amdgcn_sched_barrier(0);
-#if HMX_ROUND_SUMS
-            round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T[0], scl0, has1, T[1], scl1, Sw + (size_t)(wv * ROUND_TPW) * K16, Sw + (size_t)(wv * ROUND_TPW + 1) * K16);
-            if (lane == 0) {
-                Sg[wv * ROUND_TPW] = T[0].grp;
-                Sg[wv * ROUND_TPW + 1] = (has1 && T[1].grp != T[0].grp) ? T[1].grp : -1;
-            }
-        } else if (lane == 0) {
-            Sg[wv * ROUND_TPW] = -1;
-            Sg[wv * ROUND_TPW + 1] = -1;
-#else
             round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T[0], scl0, has1, T[1], scl1);
-#endif
         }
         for (int j = j_first + j_slot; j < ntl; j += j_slot) {   // blocks larger than the grid carries
 #pragma unroll 1
@@ -1572,12 +1623,6 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             double a2s = 0.0;
             for (int i = tid; i < GK; i += ROUND_THREADS) {
                 double v = Sd[i];
-#if HMX_ROUND_SUMS
-                const int g = i / K16, k = i - g * K16;
-#pragma unroll
-                for (int sl = 0; sl < ROUND_WAVES * ROUND_TPW; ++sl)
-                    if (Sg[sl] == g) v += (double)Sw[sl * K16 + k];
-#endif
                 if (A2TAB) a2s += v * (double)(lrpT[i] * sig[i % K16]);   // sum over this block's cells of R sigma log(ratio^theta) (:402), see round_post_pass1
 #if HMX_ROUND_RETURNING
                 if (v != 0.0) { const double old = atomicAdd(dst + i, v); asm volatile("" ::"v"(old)); }
@@ -3503,9 +3548,6 @@ size_t round_lds_bytes(int K16, int dp, int G, int B, int V) {
     // sigma, -1/sigma, rp, lrp, rpc (V > 1) | O, S, T, objective scratch (fp64) | Pr_b, theta, group_cols (V <= 8), bgrp, block offsets | landing zones
     return ((size_t)K16 * lds_ldy(dp) + 2 * (size_t)K16 + 2 * GK + (V == 1 ? 0 : (size_t)K16 * B)) * 4 + (2 * GK + K16 + 2 * ROUND_WAVES) * 8 +
            (3 * (size_t)B + (size_t)G * 8 + 64) * 4 + 16 + (size_t)ROUND_WAVES * ROUND_TPW * 16 * dp * 4
-#if HMX_ROUND_SUMS
-           + 64 + (size_t)ROUND_WAVES * ROUND_TPW * (K16 + 1) * 4
-#endif
         ;
 }
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HMX_ABI_VERSION 5
+#define HMX_ABI_VERSION 6
 #define HMX_TILE 16 /* cells per tile */
 /* limits of this build, checked by hmx_create (the reference has none: harmony.py:123-124 caps only the default K) */
 #define HMX_MAX_CLUSTERS 208
@@ -240,13 +240,16 @@ int hmx_sync(hmx_engine* e);
 int hmx_device_ptr(hmx_engine* e, int which, void** d_ptr, size_t* bytes);
 
 /* Kernel time per kernel family, measured with HIP events on the engine's stream while timing is on.
- * hmx_enable_timing(e, on): on == 0 off; on < 0 every family; on > 0 a bit mask (bit f = family f in the order of
- * names_out) -- every bracketed launch costs two event records on the stream (a few microseconds of queue time each: at C3 all
- * families together slow a Harmony iteration by 11 %), so a caller that times a run brackets only what it reports.
+ * hmx_enable_timing(e, on): on == 0 off, anything else on -- for every family, or for the families last selected with
+ * hmx_set_timing_families(e, mask) (bit f = family f in the order of names_out; ABI 5 passed the mask as `on`, which made
+ * on == 1 mean "family 0 only": since ABI 6 the switch is a switch again).  Every bracketed launch costs two event records on
+ * the stream (a few microseconds of queue time each: at C3 all families together slow a Harmony iteration by 11 %), so a
+ * caller that times a run brackets only what it reports.
  * hmx_kernel_times: ms_out[2 f] = total milliseconds of family f, ms_out[2 f + 1] = launches; names_out receives a static
  * NUL-separated list of the family names. */
 int hmx_kernel_times(hmx_engine* e, double* ms_out, int n, const char** names_out);
 int hmx_enable_timing(hmx_engine* e, int on);
+int hmx_set_timing_families(hmx_engine* e, unsigned mask);
 /* Bracket only every stride-th launch of a timed family (default 1: every launch): a uniform sample of the launches,
  * for callers whose timed loop must not carry the event records of every launch. */
 int hmx_set_timing_stride(hmx_engine* e, int stride);

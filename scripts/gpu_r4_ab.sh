@@ -13,7 +13,7 @@ fi
 for rep in 1 2; do
 for lib in "$@"; do
   if [ "$lib" = default ]; then unset HMX_LIB; else export HMX_LIB=$PWD/$lib; fi
-  for cfg in c3 c2; do
+  for cfg in ${CFGS:-c3 c2}; do
     timeout 300 python bench.py --config $cfg --steps 8 --warmup 2 --cpu-sample 0 --no-convergence --no-lisi > gpurun_out/ab.json 2> gpurun_out/ab.err
     python - "$lib" "$cfg" <<'PY'
 import json, sys
