@@ -674,15 +674,15 @@ def test_device_kmeans_initialisation_wide_shapes(monkeypatch):
     assert min(cors) > 0.98, min(cors)
 
 
-@pytest.mark.parametrize("how", ["HMX_RTZ=2", "90 batch groups"])
+@pytest.mark.parametrize("how", ["HMX_RTZ=2", "100 batch groups"])
 def test_device_kmeans_wide_shapes_without_the_streaming_round_pass(how, monkeypatch, caplog):
     """HMX_KMEANS=device on wide shapes must not depend on how the ROUNDS form R^T.Z: with HMX_RTZ=2 (list-order kernel for the
     rounds) the Lloyd pass still streams its one block column on the device; with more batch groups than the finish kernel
-    tabulates at 200 PCs (85) the engine says so and the Lloyd iterations run on a subsample on the host -- in round 3 both
+    tabulates at 200 PCs (92) the engine says so and the Lloyd iterations run on a subsample on the host -- in round 3 both
     raised HmxError out of run_harmony."""
     rng = np.random.default_rng(6)
-    B = 90 if how.startswith("90") else 3
-    N, d, K = 6000, 200 if B == 90 else 80, 20 if B == 90 else 120
+    B = 100 if how.startswith("100") else 3
+    N, d, K = 6000, 200 if B == 100 else 80, 20 if B == 100 else 120
     cent = rng.normal(size=(15, d)) * 2.0
     batch = rng.integers(0, B, size=N)
     batch[:B] = np.arange(B)
@@ -695,7 +695,7 @@ def test_device_kmeans_wide_shapes_without_the_streaming_round_pass(how, monkeyp
     with caplog.at_level(logging.WARNING, logger="harmonypy_amd"):
         ho = _hm().run_harmony(Z, meta, ["b"], nclust=K, verbose=False, max_iter_harmony=2)
     fell_back = any("Lloyd iterations on a subsample on the host" in r.getMessage() for r in caplog.records)
-    assert fell_back == (B == 90), [r.getMessage() for r in caplog.records]
+    assert fell_back == (B == 100), [r.getMessage() for r in caplog.records]
     assert ho._wide_shape() and ho._kmeans_mode() == "device" and np.isfinite(ho.Z_corr).all()
     np.testing.assert_allclose(np.linalg.norm(ho.Y, axis=0), 1.0, atol=3e-6)
     np.testing.assert_allclose(ho.R.sum(axis=1), 1.0, atol=3e-6)
