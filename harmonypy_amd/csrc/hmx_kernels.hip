@@ -738,9 +738,6 @@ __device__ __forceinline__ void round_post_pass1(const float* sig, const float* 
 #ifndef HMX_ROUND_RS
 #define HMX_ROUND_RS 1
 #endif
-#ifndef HMX_ROUND_REQ_EARLY
-#define HMX_ROUND_REQ_EARLY 1
-#endif
 template <int N>
 __device__ __forceinline__ float rs16(const float (&v)[N], int c16) {   // N <= 16 live values, the rest count as zero
     static_assert(N >= 1 && N <= 16, "group of 16");
@@ -1300,8 +1297,6 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     int lane = tid & 63;
     int c16 = lane & 15, q = lane >> 4;   // (refreshed per block, see the sweep loop)
     const bool multi = a.n_ranks > 1;
-    // single engine: the next block's row requests are issued under the flight of the hand-off's loads (see the fold below)
-    const bool early = HMX_ROUND_REQ_EARLY != 0 && !multi;
     const int wg = blockIdx.x, nwg = multi ? gridDim.x - 1 : gridDim.x;   // compute workgroups
     unsigned long long* my_flags = multi ? reinterpret_cast<unsigned long long*>(a.my_box + box_flags(a.n_ranks, GK)) : nullptr;
 
@@ -1407,29 +1402,16 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             src[it] = a.Zcos + (size_t)(cell >= 0 ? cell : 0) * (4 * KS) + 4 * piece;
         }
 #pragma unroll
-        for (int k = 0; k < NIT; ++k) {
+        for (int it = 0; it < NIT; ++it) {
             // Issued as inline assembly on purpose: after the builtin the compiler waits for vmcnt(0) before the next
             // LDS read of ANY address (it cannot tell the landing zone from the centroid table), i.e. for the rows.
             // The waits it computes for its own loads stay correct: memory operations return in order.
-            // The last, partial piece (16 KS not a multiple of 64: its lanes past the tile are masked off) goes FIRST: the
-            // early-request path below counts on the NCH / 64 whole pieces being the youngest operations in flight.
-            const int it = (k + NIT - 1) % NIT;
             const unsigned zone = __builtin_amdgcn_readfirstlane(
                 (unsigned)(size_t)(__attribute__((address_space(3))) void*)(dst + 256 * it));
             if (64 * (it + 1) <= NCH || 64 * it + lane < NCH)
                 asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                              :: "v"(src[it]), "s"(zone) : "memory", "m0");
         }
-    };
-    // ids of the tiles two blocks ahead: clamped loads, the "no such tile" case applied when they are shifted in -- a
-    // predicated load or a select here would be waited for at once, and with it every row request in flight
-    auto load_ids2 = [&](int blk_ids, int u) {
-        const int j = j_first + u;
-        const int t0 = bs[blk_ids], t1 = bs[blk_ids + 1];
-        valid2[u] = j < t1 - t0;
-        const int tl = max(min(t0 + j, bs[a.nblk] - 1), 0);   // (a shard may hold no tile at all)
-        cell2[u] = a.cells[(size_t)tl * 16 + c16];
-        grp2[u] = a.tile_grp[tl];
     };
     const float* Ys = Ys0;
     // ---- prologue: block 0 computed, block 1's ids landed ---------------------------------------
@@ -1444,7 +1426,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     // this phase, the partner wave's MFMAs cover them -- and far from the hand-off: a wave's memory operations return
     // in order, so a request in flight in front of the poll or of the hand-off's loads would be waited for by them.
     // By the next poll these rows have had a whole distance GEMM to land; they are used a block later.
-    auto tile_step = [&](int blk_ids, bool with_requests) {
+    auto tile_step = [&](int blk_ids) {
         RoundZ<KS> Zf[ROUND_TPW];
 #pragma unroll
         for (int u = 0; u < ROUND_TPW; ++u) round_rows_from_lds<KS>(zb[u], c16, q, Zf[u]);
@@ -1453,18 +1435,24 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
 #pragma unroll
         for (int u = 0; u < ROUND_TPW; ++u) {
             issue_rows(cell1[u], zb[u]);
-            load_ids2(blk_ids, u);
+            // ids of the block after: clamped loads, the "no such tile" case applied when they are shifted in -- a
+            // predicated load or a select here would be waited for at once, and with it every row request above
+            const int j = j_first + u;
+            const int t0 = bs[blk_ids], t1 = bs[blk_ids + 1];
+            valid2[u] = j < t1 - t0;
+            const int tl = max(min(t0 + j, bs[a.nblk] - 1), 0);   // (a shard may hold no tile at all)
+            cell2[u] = a.cells[(size_t)tl * 16 + c16];
+            grp2[u] = a.tile_grp[tl];
         }
         };
-        // (requests here only when they were not issued under the hand-off's loads, see the fold in the sweep loop)
         // the two waves of a SIMD stagger the request code: one issues it while the other's first tile keeps the pipe busy
         static_assert(ROUND_TPW == 2, "tile_step is written for two tiles per wave");
         const bool second = wv >= ROUND_WAVES / 2;
-        if (with_requests && !second) request();
+        if (!second) request();
         __builtin_amdgcn_sched_barrier(0);
         round_compute<MT, KS, LOG2>(Ys, nis, LDY, c16, q, Zf[0], T[0]);
         __builtin_amdgcn_sched_barrier(0);
-        if (with_requests && second) request();
+        if (second) request();
         __builtin_amdgcn_sched_barrier(0);
         round_compute<MT, KS, LOG2>(Ys, nis, LDY, c16, q, Zf[1], T[1]);
         __builtin_amdgcn_sched_barrier(0);
@@ -1472,7 +1460,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
 #pragma unroll
     for (int u = 0; u < ROUND_TPW; ++u) issue_rows(T[u].cell, zb[u]);
     WAIT_VMEM_ALL();   // landed (nothing else orders an LDS read behind an LDS-DMA)
-    tile_step(2, !early);
+    tile_step(2);
 
     for (int b = 0; b < a.nblk; ++b) {
         const int tb = bs[b], ntl = bs[b + 1] - tb;
@@ -1519,68 +1507,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         wg_barrier_lds();
         RSTAMP(1);
         // ---- O without this block, with the previous block's new sums (:491-492, 506-507) ---
-        int fold_from = tid;
-        if (early) {
-            // The first two entries of every thread, with the row requests of block b+1 riding under the flight of their
-            // loads: here the wave has nothing else to do (the loads take one trip through the fabric, 2.6 k cycles under the
-            // row stores' traffic), whereas in front of the distance GEMM the ~150 instructions of the request code were
-            // serial time (14.5 k cycles for 11.6 k of MFMA).  Memory operations return in order, so the hand-off's loads must
-            // be issued BEFORE the requests and released by a wait that leaves the requests in flight -- which the compiler,
-            // blind to inline-assembly operations, cannot compute: the loads are inline assembly too, the wait names how many
-            // younger operations may stay outstanding (the 16 KS / 64 WHOLE pieces of each tile; the partial piece, whose
-            // lanes may all be masked off, goes first and is waited for), and scripts/kernel_audit.py --inflight checks on the
-            // built code that nothing touches the destinations before that wait.  The ids two blocks ahead are ordinary loads
-            // issued in front of everything (the compiler waits for them a block later).
-            constexpr int NFULL = (16 * KS) / 64;
-            // (no case distinction for the last block: its requests re-read cell 0's row into zones nobody reads again --
-            // one straight-line sequence, so that the wait below is right on every path the audit can imagine)
-#pragma unroll
-            for (int u = 0; u < ROUND_TPW; ++u) load_ids2(b + 2, u);   // (bs[] carries two sentinels past the last block)
-            __builtin_amdgcn_sched_barrier(0);
-            const int i0 = min(tid, GK - 1), i1 = min(tid + ROUND_THREADS, GK - 1);    // clamped, not predicated
-            double so0, so1, ad0[HMX_ROUND_SLOTS], ad1[HMX_ROUND_SLOTS];
-            {
-                const double* p0 = a.S_old + (size_t)b * GK + i0;
-                const double* p1 = a.S_old + (size_t)b * GK + i1;
-                asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(so0) : "v"(p0) : "memory");
-                asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(so1) : "v"(p1) : "memory");
-            }
-            const bool have_new = b > 0 && !(HMX_RABL & 8);
-            if (have_new) {
-                const double* sn = a.S_new + (size_t)(b - 1) * HMX_ROUND_SLOTS * GK;
-#pragma unroll
-                for (int sl = 0; sl < HMX_ROUND_SLOTS; ++sl) {          // agent scope (sc1), as ld_agent
-                    const double* p0 = sn + (size_t)sl * GK + i0;
-                    const double* p1 = sn + (size_t)sl * GK + i1;
-                    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=&v"(ad0[sl]) : "v"(p0) : "memory");
-                    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=&v"(ad1[sl]) : "v"(p1) : "memory");
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < ROUND_TPW; ++u) issue_rows(cell1[u], zb[u]);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ROUND_TPW * NFULL) : "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (tid < GK) {
-                double o = Ocur[tid] - so0;
-                if (have_new) {
-#pragma unroll
-                    for (int sl = 0; sl < HMX_ROUND_SLOTS; ++sl) o += ad0[sl];
-                }
-                Ocur[tid] = o;
-                Sd[tid] = 0.0;
-            }
-            if (tid + ROUND_THREADS < GK) {
-                double o = Ocur[tid + ROUND_THREADS] - so1;
-                if (have_new) {
-#pragma unroll
-                    for (int sl = 0; sl < HMX_ROUND_SLOTS; ++sl) o += ad1[sl];
-                }
-                Ocur[tid + ROUND_THREADS] = o;
-                Sd[tid + ROUND_THREADS] = 0.0;
-            }
-            fold_from = tid + 2 * ROUND_THREADS;                       // (more than 1024 table entries: the rest as before)
-        }
-        for (int base = fold_from; base < GK; base += 2 * ROUND_THREADS) {   // two entries per thread and trip, all loads in flight together
+        for (int base = tid; base < GK; base += 2 * ROUND_THREADS) {   // two entries per thread and trip, all loads in flight together
             double add[2][8], so[2];
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
@@ -1717,7 +1644,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             cell1[u] = valid2[u] ? cell2[u] : -1;
             grp1[u] = valid2[u] ? grp2[u] : 0;
         }
-        if (b + 1 < a.nblk) tile_step(b + 3, !early);   // rows landed: vmcnt(0) above
+        if (b + 1 < a.nblk) tile_step(b + 3);   // rows landed: vmcnt(0) above
         RSTAMP(5);
     }
 
