@@ -122,7 +122,6 @@ struct hmx_engine {
     hipEvent_t sync_event = nullptr;
     long clean_sweeps = 0;       // persistent sweeps that were read back at once and had no time-out
     long n_sweep_launches = 0;   // persistent sweeps launched (HMX_TEST_FAIL_SWEEP counts them)
-    bool wide_table_fusion = true;   // HMX_WIDE_TABLE=separate: one k_block_table launch per block beside k_assign_wide2 (A/B)
     long test_fail_sweep = -1;   // HMX_TEST_FAIL_SWEEP=k: the k-th persistent sweep (0-based) runs with spin limit 0 (tests: a time-out in a deferred round)
     unsigned* frozen() const { return reinterpret_cast<unsigned*>(wait_stats.p + 3); }   // sticky time-out word (see hmx_cluster)
     // transport for sharded jobs (null / 1 = single engine)
@@ -394,7 +393,6 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
 #endif
     if (const char* rk = getenv("HMX_RTZ")) e->rtz_kernel = atoi(rk) == 2 ? 2 : 3;
     if (const char* fs = getenv("HMX_TEST_FAIL_SWEEP")) e->test_fail_sweep = atol(fs);
-    if (const char* wt = getenv("HMX_WIDE_TABLE")) e->wide_table_fusion = std::string(wt) != "separate";
     if (const char* sl = getenv("HMX_SPIN_LIMIT")) e->spin_limit = (unsigned)std::max(0L, atol(sl));   // 0: every wait of the persistent kernels gives up at once (tests)
     int rc = 0;
     do {
@@ -1049,12 +1047,8 @@ static int round_sweep(hmx_engine* e, int flags, const std::vector<int>& tiles_u
 static int blocks_loop(hmx_engine* e, int flags, const std::vector<int>& tiles_upper) {
     int rc;
     const size_t GK = (size_t)e->G * e->K16;
-    // a single engine with one batch variable on the wide assignment kernel: the launch of block b builds block b+1's table
-    // itself (its last workgroup, AssignArgs.done) -- one launch per block instead of two
-    const bool can_fuse = !sharded(e) && e->V == 1 && e->wide_table_fusion;
-    bool table_done = false;
     for (int b = 0; b < e->nblk; ++b) {
-        if (!table_done) {
+        {
             Timed t(e, F_BLOCK_TABLE);
             TableArgs ta = table_args(e);
             ta.O_prev = (b == 0) ? e->Ogrp.p : e->Ohist.p + GK * (b - 1);
@@ -1064,35 +1058,19 @@ static int blocks_loop(hmx_engine* e, int flags, const std::vector<int>& tiles_u
             ta.rp = e->rp.p; ta.lrp = e->lrp.p;
             launch_block_table(ta, e->K16, e->stream);
         }
-        table_done = false;
         if (tiles_upper[b] > 0) {
             Timed t(e, F_ASSIGN_BLOCK);
             AssignArgs a = assign_args(e);
             a.cells = e->lists[e->cur].cells.p; a.tile_grp = e->lists[e->cur].tile_grp.p; a.S_out = e->Snew + GK * b;
             a.blk_start = e->lists[e->cur].blk_start.p; a.blk = b;
             a.tile_begin = 0; a.tile_end = tiles_upper[b];
-            if (can_fuse) {
-                const bool closing = b == e->nblk - 1;
-                a.done = reinterpret_cast<unsigned*>(e->wait_stats.p + 4);
-                a.nt_O_prev = e->Ohist.p + GK * b;
-                a.nt_S_sub = closing ? nullptr : e->Sold + GK * (b + 1);
-                a.nt_O_out = closing ? e->Ogrp.p : e->Ohist.p + GK * (b + 1);
-                a.nt_T_out = closing ? e->Tmass.p : nullptr;
-                a.nt_rp = closing ? nullptr : e->rp.p;
-                a.nt_lrp = closing ? nullptr : e->lrp.p;
-                a.nt_obj_cross = closing && (flags & HMX_ROUND_OBJECTIVE) ? e->objacc + 2 * HMX_OBJ_SLOTS : nullptr;
-                a.nt_Pr_b = e->Pr_b.p; a.nt_theta = e->theta.p; a.nt_group_cols = e->group_cols.p;
-            }
-            const int took = launch_assign(a, true, e->max_wgs, e->stream);
-            if (took < 0) return fail(HMX_ERR_ARG, "unsupported cluster count");
-            table_done = took == 2;
+            if (launch_assign(a, true, e->max_wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported cluster count");
         }
         // the block's new sums (:506-507) over all ranks; the last block takes the two objective
         // sums (:399, :402) along: objacc follows Snew in xch
         const bool last = b == e->nblk - 1;
         if ((rc = sum_over_ranks(e, e->Snew + GK * b, GK + (last ? 2 * HMX_OBJ_SLOTS : 0)))) return rc;
     }
-    if (table_done) return 0;                                   // the last launch closed the sweep
     Timed t(e, F_BLOCK_TABLE);
     TableArgs ta = table_args(e);  // close the round: O, T state and the cross-entropy term
     ta.O_prev = e->Ohist.p + GK * (e->nblk - 1);

@@ -27,20 +27,6 @@ struct AssignArgs {
     int G, ldy_lds, tables_in_lds, tiles_per_wave, ablate;
     const float* hn;       // k_assign_wide without penalty only: half squared norms of the centres in Y (+inf for pads) -> HARD
                            // assignment of the device k-means (a one-hot row of R per cell) instead of the softmax; null otherwise
-    // k_assign_wide2 only: the workgroup that finishes LAST builds the diversity table of the NEXT block (or closes the sweep)
-    // -- the arithmetic of k_block_table for one batch variable -- so that a block costs one launch instead of two
-    // (harmony.py:491-499 between two blocks of :476-507).  done == null: no such duty.
-    unsigned* done;        // arrival counter of the launch (zero at launch; the last workgroup zeroes it again)
-    const double* nt_O_prev;   // G x K16: O as this block's table saw it
-    const double* nt_S_sub;    // G x K16 removal sums of the next block, or null (closing the sweep)
-    double* nt_O_out;      // G x K16
-    double* nt_T_out;      // K16 or null
-    float* nt_rp;          // G x K16 or null (closing the sweep)
-    float* nt_lrp;
-    double* nt_obj_cross;  // or null
-    const float* nt_Pr_b;  // B
-    const float* nt_theta;
-    const int* nt_group_cols;  // G: the batch of group g (one batch variable)
 };
 
 #define HMX_ROUND_SLOTS 4 /* k_round: a block's new sums are spread over this many fp64 tables */

@@ -1054,61 +1054,6 @@ template <int N>
 __device__ __forceinline__ void wide2_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-// The workgroup that arrives last (all sums of the block are performed: returning adds, vmcnt(0), barrier, then one counter
-// increment per workgroup) builds the next block's table for everybody: one thread per cluster, the groups in a loop.
-//   O = O_prev + S_new(this block) - S_old(next block)   T = sum_g O   E = T Pr_b   ratio = clamp(E / clamp(O + E)) ** theta
-// exactly k_block_table's arithmetic for one batch variable (group g is batch g).  Without nt_rp it closes the sweep: O, the
-// cluster mass and the cross-entropy term of the objective (harmony.py:405-411).
-template <int MT>
-__device__ __forceinline__ void wide2_arrive_and_close(const AssignArgs& a, unsigned char* smem) {
-    constexpr int K16 = 16 * MT;
-    const int tid = threadIdx.x;
-    __shared__ unsigned last_flag;
-    WAIT_VMEM_ALL();
-    __syncthreads();
-    if (tid == 0) last_flag = __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
-    __syncthreads();
-    if (!last_flag) return;
-    double part = 0.0;
-    for (int k = tid; k < K16; k += 64 * WIDE2_WAVES) {
-        double T = 0.0;
-        for (int g = 0; g < a.G; ++g) {
-            const size_t i = (size_t)g * K16 + k;
-            double o = a.nt_O_prev[i] + ld_agent(a.S_out + i);       // (the other workgroups' adds: agent-scope loads)
-            if (a.nt_S_sub) o -= a.nt_S_sub[i];
-            a.nt_O_out[i] = o;
-            T += o;
-        }
-        if (a.nt_T_out) a.nt_T_out[k] = T;
-        const float sig = a.sigma[k];
-        for (int gg = 0; gg < a.G; ++gg) {
-            const size_t i = (size_t)gg * K16 + k;
-            const int g = a.nt_group_cols[gg];
-            const float O = (float)a.nt_O_out[i];
-            if (a.nt_rp) {
-                const float E = (float)T * a.nt_Pr_b[g];
-                const float oe = fmaxf(O + E, 1e-8f);                       // :495-496
-                const float ratio = fminf(fmaxf(E / oe, 1e-8f), 1.0f);      // :497-498
-                const float rp = powf(ratio, a.nt_theta[g]);                // :499
-                a.nt_rp[i] = rp;
-                a.nt_lrp[i] = logf(rp);
-            }
-            if (a.nt_obj_cross) {
-                const float Oc = fmaxf(O, 1e-8f);                           // :407
-                const float Ec = fmaxf((float)T * a.nt_Pr_b[g], 1e-8f);     // :408
-                const float tl = a.nt_theta[g] * logf((Oc + Ec) / Ec);      // :409-410
-                part += (double)(sig * O * tl);
-            }
-        }
-    }
-    if (a.nt_obj_cross) {
-        part = wave_sum_all(part);
-        if ((tid & 63) == 0 && part != 0.0) atomicAdd(a.nt_obj_cross, part);
-    }
-    if (tid == 0) *a.done = 0u;                                          // for the next launch (kernel boundary in between)
-    (void)smem;
-}
-
 template <int MT>
 __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_assign_wide2(AssignArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1132,10 +1077,7 @@ __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_assign_wide2(AssignArgs
     const int tile_end = a.blk_start ? a.blk_start[a.blk + 1] : a.tile_end;
     const int ntiles = tile_end - tile_begin;
     const int base = blockIdx.x * WIDE2_SLOTS;
-    if (base >= ntiles) {                                                // (the grid is sized for an upper bound of the block)
-        if (a.done) wide2_arrive_and_close<MT>(a, smem);
-        return;
-    }
+    if (base >= ntiles) return;                                          // (the grid is sized for an upper bound of the block)
 
     // ---- requests of k-step 0 and 1 first: their latency runs under the set-up below --------------------------------
     RoundTile<MT> T0, T1;
@@ -1316,12 +1258,8 @@ __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_assign_wide2(AssignArgs
     for (int i = tid; i < nslots * K16; i += 64 * WIDE2_WAVES) {
         const double v = Sd[i];
         const int sl = i / K16;
-        if (v != 0.0) {   // returning: behind the wave's vmcnt(0) the add is PERFORMED (what an arrival counter needs, see xchg_agent)
-            const double old = atomicAdd(&a.S_out[(size_t)sg[sl] * K16 + (i - sl * K16)], v);
-            asm volatile("" ::"v"(old));
-        }
+        if (v != 0.0) atomicAdd(&a.S_out[(size_t)sg[sl] * K16 + (i - sl * K16)], v);
     }
-    if (a.done) wide2_arrive_and_close<MT>(a, smem);
 }
 
 template <int MT, int KS>
@@ -3567,16 +3505,15 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
         }                                                                                                             \
         hipLaunchKernelGGL((k_assign_wide2<M>), dim3(wgs2), dim3(64 * WIDE2_WAVES), sm2, s, a);                        \
     } break;
-            if (sm2 + 64 <= 80 * 1024) {
+            if (sm2 <= 80 * 1024) {
                 switch (a.mt) {
                     HMX_WIDE2_CASE(1) HMX_WIDE2_CASE(2) HMX_WIDE2_CASE(3) HMX_WIDE2_CASE(4) HMX_WIDE2_CASE(5) HMX_WIDE2_CASE(6) HMX_WIDE2_CASE(7)
                     HMX_WIDE2_CASE(8) HMX_WIDE2_CASE(9) HMX_WIDE2_CASE(10) HMX_WIDE2_CASE(11) HMX_WIDE2_CASE(12) HMX_WIDE2_CASE(13)
                 }
-                return a.done ? 2 : 0;                       // 2: the last workgroup builds the next block's table (AssignArgs.done)
+                return 0;
             }
 #undef HMX_WIDE2_CASE
         }
-        a.done = nullptr;
         const int wgs = std::max(1, std::min(2 * 256, cdiv(ntiles, WIDE_WAVES)));
 #define HMX_WIDE_CASE(M)                                                                                          \
     case M:                                                                                                       \

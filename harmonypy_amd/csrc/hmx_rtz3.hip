@@ -648,24 +648,31 @@ __global__ __launch_bounds__(64 * RTZW2_WAVES, 2) void k_rtzw2(Rtz3Args a) {
 #endif
         const float* Rt = lds + (size_t)(i % RTZW2_NBUF) * buf_floats;
         const float* Zt = Rt + 256 * MT;
-        const unsigned bw = reinterpret_cast<const unsigned*>(Zt + 16 * DP)[q];      // the four block ids of cells 4q .. 4q+3
+        const i32x4 bw4 = *reinterpret_cast<const i32x4*>(Zt + 16 * DP);            // the sixteen block ids of the tile
         const int rows_live = c_end - (c_first + 16 * stride * i);                   // cells of this tile inside the group
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             __builtin_amdgcn_sched_barrier(0);                      // one k-step's operands live at a time
             int c = c16, qq = q;
             asm volatile("" : "+v"(c), "+v"(qq));                   // (addresses are re-formed here, not carried through the loop)
-            const int cell = 4 * qq + ks;
+            // k index (ks, q) <-> cell 4 ks + q: the four rows a k-step reads are NEIGHBOURS.  (With cell 4 q + ks, as in
+            // k_rtz3, they are four rows apart: 4 x 208 floats = 13 x 64 banks at this width, so the four 16-lane groups of a
+            // wave read the same 16 banks -- round 3's counters: 65 % of this kernel's LDS cycles were bank conflicts.  Rows one
+            // apart are 208 = 3 x 64 + 16 floats apart: the groups take four different bank quarters.)
+            const int cell = 4 * ks + qq;
             const float lm = cell < rows_live ? 1.f : 0.f;          // rows past the group's end belong to the next group: a factor on A
             const float* rr = Rt + (size_t)cell * Kp;
             const float* zr = Zt + (size_t)cell * DP + 16 * nt_lo + c;
             float am[MTA], bm[NTH];
+            // (A values as single reads: the 196 accumulators of the 7 x 7 instance leave no room for 16-byte tuples -- tried in
+            // round 4: 98 spilled registers.  With neighbouring rows their 16-byte stride over c16 and the 200-float row stride
+            // spread the four 16-lane groups over all banks as well.)
 #pragma unroll
             for (int i2 = 0; i2 < MTA; ++i2) am[i2] = rr[a_const(mt_lo + i2) + a_mul(mt_lo + i2) * c];
 #pragma unroll
             for (int u = 0; u < NTH; ++u) bm[u] = zr[16 * u];       // (a read past the PC tiles stays inside the ring and is not used)
             // == 16 u: this lane's column of tile u (column 16 nt + c16, the one-hot of block 16 nt + c16 - d) is the cell's block
-            const int diff = (int)((bw >> (8 * ks)) & 255u) - (16 * nt_lo + c - d);
+            const int diff = (int)(((unsigned)bw4[ks] >> (8 * qq)) & 255u) - (16 * nt_lo + c - d);
 #pragma unroll
             for (int i2 = 0; i2 < MTA; ++i2) am[i2] *= (mt_lo + i2 < MT) ? lm : 0.f;
 #pragma unroll
