@@ -541,7 +541,9 @@ def main():
         t_l = time.perf_counter()
         before = harmonypy_amd.compute_lisi(Z[take], meta_l, ["batch"], 30, device=f"cuda:{local_rank}")
         t_l = time.perf_counter() - t_l
-        after = harmonypy_amd.compute_lisi(ho2.Z_corr[take], meta_l, ["batch"], 30, device=f"cuda:{local_rank}")
+        Zc_take = ho2.Z_corr[take]
+        del ho2                                                     # (the side configurations below get the GPU to themselves)
+        after = harmonypy_amd.compute_lisi(Zc_take, meta_l, ["batch"], 30, device=f"cuda:{local_rank}")
         out["lisi"] = {"cells": int(len(take)), "pcs": d, "perplexity": 30, "seconds": t_l, "cells_per_sec": len(take) / t_l,
                        "batches": B, "batch_lisi_before": float(before.mean()), "batch_lisi_after": float(after.mean()),
                        "note": "host float64 input to host output, exact neighbours; not part of `value`"}
@@ -549,7 +551,7 @@ def main():
         # BASELINE configs[1] (69k cells x 50 PCs, 4 batches, K=30) measured the same way, for reference: it is
         # latency-bound (its working set lives in the L3; 20 sequential hand-offs per round), so the headline
         # figure is quoted on configs[2], the roofline point
-        out["configs_1"] = side_config("c2", args.rounds, steps=10, warmup=2, device=f"cuda:{local_rank}")
+        out["configs_1"] = side_config("c2", args.rounds, steps=20, warmup=5, device=f"cuda:{local_rank}")
         # all 10M cells of BASELINE configs[3] on this ONE GPU (the N=1 point of the strong-scaling curve `--gpus N`
         # measures), and the per-GPU shard of configs[4] on 8 GPUs (wide-PC regime)
         del Z, meta

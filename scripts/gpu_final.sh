@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -q -rP 2>&1 > gpurun_out/pytest_gpu_full.log
-grep -E "passed|failed|error|same schedule|diverged|bench path|2 shards|Z_corr vs|time-out replay|1 vs 2|wide sweep" gpurun_out/pytest_gpu_full.log | tail -70 > gpurun_out/pytest_gpu.log
+grep -E "passed|failed|error|same schedule|diverged|bench path|2 shards|Z_corr vs|time-out|1 vs 2|wide path|configs.4. shape|c3full|4 ranks" gpurun_out/pytest_gpu_full.log | tail -70 > gpurun_out/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1
 timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
 rm -rf gpurun_out/prof
