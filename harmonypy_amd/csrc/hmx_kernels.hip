@@ -738,9 +738,6 @@ __device__ __forceinline__ void round_post_pass1(const float* sig, const float* 
 #ifndef HMX_ROUND_RS
 #define HMX_ROUND_RS 1
 #endif
-#ifndef HMX_ROUND_LATE_ROWS
-#define HMX_ROUND_LATE_ROWS 1
-#endif
 template <int N>
 __device__ __forceinline__ float rs16(const float (&v)[N], int c16) {   // N <= 16 live values, the rest count as zero
     static_assert(N >= 1 && N <= 16, "group of 16");
@@ -781,10 +778,7 @@ __device__ __forceinline__ void block_sums_rs(const f32x4 (&sm)[NM], double* sd,
     if (i < 4 * NM) atomicAdd(sd + 16 * (i >> 2) + 4 * q + (i & 3), (double)tot);   // value i = cluster tile i / 4 of the group, register i % 4
 }
 
-// STORE = false: the sums only -- the caller writes the rows later (round_store_rows): k_round does so BEHIND its arrival, so
-// that the block's 20 MB of R rows drain under the next distance GEMM instead of in front of the hand-off (memory operations
-// retire in order: a wave that has row stores in flight cannot see its slot adds acknowledged before them).
-template <int MT, bool STORE = true>
+template <int MT>
 __device__ __forceinline__ void round_post_pass2(float* R, int Kp, double* Sd, int c16, int q, const RoundTile<MT>& T0,
                                                  float scl0, bool has1, const RoundTile<MT>& T1, float scl1) {
     constexpr int K16 = 16 * MT;
@@ -806,8 +800,8 @@ __device__ __forceinline__ void round_post_pass2(float* R, int Kp, double* Sd, i
             rv0[m] = T0.arg[mt] * scl0;                    // :503
             rv1[m] = T1.arg[mt] * scl1;
 #if !(HMX_RABL & 2)
-            if (STORE && live0 && col < Kp) st4(row0 + col, rv0[m]);
-            if (STORE && live1 && col < Kp) st4(row1 + col, rv1[m]);
+            if (live0 && col < Kp) st4(row0 + col, rv0[m]);
+            if (live1 && col < Kp) st4(row1 + col, rv1[m]);
 #endif
         }
 #if !(HMX_RABL & 1)
@@ -862,23 +856,6 @@ __device__ __forceinline__ void round_post_pass2(float* R, int Kp, double* Sd, i
 #endif
     }
 #endif
-}
-
-// the R rows of the two tiles a wave carries (:503), from the t values still in its registers
-template <int MT>
-__device__ __forceinline__ void round_store_rows(float* R, int Kp, int q, const RoundTile<MT>& T0, float scl0, bool has1,
-                                                 const RoundTile<MT>& T1, float scl1) {
-    const bool live0 = T0.cell >= 0, live1 = has1 && T1.cell >= 0;
-    float* row0 = R + (size_t)(live0 ? T0.cell : 0) * Kp;
-    float* row1 = R + (size_t)(live1 ? T1.cell : 0) * Kp;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int col = 16 * mt + 4 * q;
-#if !(HMX_RABL & 2)
-        if (live0 && col < Kp) st4(row0 + col, T0.arg[mt] * scl0);
-        if (live1 && col < Kp) st4(row1 + col, T1.arg[mt] * scl1);
-#endif
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1614,14 +1591,14 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         wg_barrier_lds();
         RSTAMP(2);
         // ---- finish this block's tiles --------------------------------------------------------
-        float scl0 = 0.f, scl1 = 0.f;
-        const bool has0 = j_first < ntl, has1 = j_first + 1 < ntl;
-        if (has0) {
+        if (j_first < ntl) {
+            float scl0, scl1 = 0.f;
+            const bool has1 = j_first + 1 < ntl;
             round_post_pass1<MT, true, LOG2, A2TAB>(sig, rpT, lrpT, q, T[0], scl0, km_acc, ent_acc);
             __builtin_amdgcn_sched_barrier(0);
             if (has1) round_post_pass1<MT, true, LOG2, A2TAB>(sig, rpT, lrpT, q, T[1], scl1, km_acc, ent_acc);
             __builtin_amdgcn_sched_barrier(0);
-            round_post_pass2<MT, HMX_ROUND_LATE_ROWS == 0>(a.R, a.Kp, Sd, c16, q, T[0], scl0, has1, T[1], scl1);   // (rows: behind the arrival)
+            round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T[0], scl0, has1, T[1], scl1);
         }
         for (int j = j_first + j_slot; j < ntl; j += j_slot) {   // blocks larger than the grid carries
 #pragma unroll 1
@@ -1659,7 +1636,6 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         wg_barrier_lds();
         if (tid == 0) __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         RSTAMP(4);
-        if (HMX_ROUND_LATE_ROWS && has0) round_store_rows<MT>(a.R, a.Kp, q, T[0], scl0, has1, T[1], scl1);   // they drain under the distance GEMM below
         // ---- table-independent half of the next block's tiles: overlaps the hand-off ----------
 #pragma unroll
         for (int u = 0; u < ROUND_TPW; ++u) {
