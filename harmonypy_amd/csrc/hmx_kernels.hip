@@ -738,6 +738,9 @@ __device__ __forceinline__ void round_post_pass1(const float* sig, const float* 
 #ifndef HMX_ROUND_RS
 #define HMX_ROUND_RS 1
 #endif
+#ifndef HMX_ROUND_PUBWAVE
+#define HMX_ROUND_PUBWAVE 1
+#endif
 template <int N>
 __device__ __forceinline__ float rs16(const float (&v)[N], int c16) {   // N <= 16 live values, the rest count as zero
     static_assert(N >= 1 && N <= 16, "group of 16");
@@ -1365,14 +1368,27 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     }
     __syncthreads();
     (void)NF; (void)NT;
+    // The grid is sized for ~14 of a workgroup's 16 tile slots, so the last wave of a workgroup never owns a tile: it becomes
+    // the PUBLISHER -- after the finishing pass it alone adds the workgroup's block sums to the slot table and arrives.  Its
+    // vmcnt(0) covers only its own (returning) adds, whereas a wave that has just written 14 R rows sees its adds
+    // acknowledged behind those stores (memory operations retire in order): the arrival no longer waits for the block's row
+    // stores, and the other waves go straight on to the next distance GEMM.  Only when that wave owns no tile in ANY block
+    // and the table is small enough for one wave (else the round-3 protocol: everybody publishes, barrier, one arrival).
+    bool pubwave = false;
+    if (HMX_ROUND_PUBWAVE && GK <= 1024) {
+        int max_ntl = 0;
+        for (int bb = 0; bb < a.nblk; ++bb) max_ntl = max(max_ntl, bs[bb + 1] - bs[bb]);
+        pubwave = ROUND_TPW * (blockIdx.x + (multi ? (int)gridDim.x - 1 : (int)gridDim.x) * (ROUND_WAVES - 1)) >= max_ntl;
+    }
+    const bool service = pubwave && wv == ROUND_WAVES - 1;        // wave-uniform
 
     RoundTile<MT> T[ROUND_TPW];
     float* zb[ROUND_TPW];
 #pragma unroll
     for (int u = 0; u < ROUND_TPW; ++u) zb[u] = zbuf + (size_t)(wv * ROUND_TPW + u) * 16 * (4 * KS);
     int cell1[ROUND_TPW], grp1[ROUND_TPW];   // ids of block b+1's tiles (landed)
-    int cell2[ROUND_TPW], grp2[ROUND_TPW];   // ids of block b+2's tiles (travelling: raw loads, untouched until they are shifted in)
-    bool valid2[ROUND_TPW];
+    int cell2[ROUND_TPW] = {0, 0}, grp2[ROUND_TPW] = {0, 0};   // ids of block b+2's tiles (travelling: raw loads, untouched until they are shifted in)
+    bool valid2[ROUND_TPW] = {false, false};
     double km_acc = 0.0, ent_acc = 0.0;
     bool failed = false;
     unsigned ws_n = 0, ws_sum = 0, ws_max = 0;   // this workgroup's grid-wide waits (wave 0)
@@ -1457,10 +1473,12 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         round_compute<MT, KS, LOG2>(Ys, nis, LDY, c16, q, Zf[1], T[1]);
         __builtin_amdgcn_sched_barrier(0);
     };
+    if (!service) {
 #pragma unroll
-    for (int u = 0; u < ROUND_TPW; ++u) issue_rows(T[u].cell, zb[u]);
-    WAIT_VMEM_ALL();   // landed (nothing else orders an LDS read behind an LDS-DMA)
-    tile_step(2);
+        for (int u = 0; u < ROUND_TPW; ++u) issue_rows(T[u].cell, zb[u]);
+        WAIT_VMEM_ALL();   // landed (nothing else orders an LDS read behind an LDS-DMA)
+        tile_step(2);
+    }
 
     for (int b = 0; b < a.nblk; ++b) {
         const int tb = bs[b], ntl = bs[b + 1] - tb;
@@ -1618,6 +1636,22 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         wg_barrier_lds();
         RSTAMP(3);
         // ---- publish the block's new sums, then arrive ---------------------------------------
+        if (pubwave) {
+            if (service) {
+                double* dst = a.S_new + ((size_t)b * HMX_ROUND_SLOTS + (wg % HMX_ROUND_SLOTS)) * GK;
+                double a2s = 0.0;
+                for (int i = lane; i < GK; i += 64) {
+                    const double v = Sd[i];
+                    if (A2TAB) a2s += v * (double)(lrpT[i] * sig[i % K16]);   // (:402), see round_post_pass1
+                    if (v != 0.0) { const double old = atomicAdd(dst + i, v); asm volatile("" ::"v"(old)); }   // returning: performed behind vmcnt(0)
+                }
+                if (A2TAB) ent_acc += a2s;
+                WAIT_VMEM_ALL();
+                if (lane == 0) __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                WAIT_VMEM_ALL();   // this wave's row stores (and the next operands landed); nobody waits for it
+            }
+        } else {
         {
             double* dst = a.S_new + ((size_t)b * HMX_ROUND_SLOTS + (wg % HMX_ROUND_SLOTS)) * GK;
             double a2s = 0.0;
@@ -1635,6 +1669,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         WAIT_VMEM_ALL();   // the sums are performed (and the next operands landed)
         wg_barrier_lds();
         if (tid == 0) __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         RSTAMP(4);
         // ---- table-independent half of the next block's tiles: overlaps the hand-off ----------
 #pragma unroll
@@ -1644,7 +1679,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             cell1[u] = valid2[u] ? cell2[u] : -1;
             grp1[u] = valid2[u] ? grp2[u] : 0;
         }
-        if (b + 1 < a.nblk) tile_step(b + 3);   // rows landed: vmcnt(0) above
+        if (b + 1 < a.nblk && !service) tile_step(b + 3);   // rows landed: vmcnt(0) above
         RSTAMP(5);
     }
 
