@@ -1640,13 +1640,23 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             if (service) {
                 double* dst = a.S_new + ((size_t)b * HMX_ROUND_SLOTS + (wg % HMX_ROUND_SLOTS)) * GK;
                 double a2s = 0.0;
-                for (int i = lane; i < GK; i += 64) {
-                    const double v = Sd[i];
-                    if (A2TAB) a2s += v * (double)(lrpT[i] * sig[i % K16]);   // (:402), see round_post_pass1
-                    if (v != 0.0) { const double old = atomicAdd(dst + i, v); asm volatile("" ::"v"(old)); }   // returning: performed behind vmcnt(0)
+                // all adds in flight together (each one's old value is only looked at behind the last: one round trip, not
+                // sixteen); returning, so that behind the wave's vmcnt(0) they are PERFORMED
+                double olds[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int i = lane + 64 * t;
+                    olds[t] = 0.0;
+                    if (i < GK) {
+                        const double v = Sd[i];
+                        if (A2TAB) a2s += v * (double)(lrpT[i] * sig[i % K16]);   // (:402), see round_post_pass1
+                        if (v != 0.0) olds[t] = atomicAdd(dst + i, v);
+                    }
                 }
                 if (A2TAB) ent_acc += a2s;
                 WAIT_VMEM_ALL();
+#pragma unroll
+                for (int t = 0; t < 16; ++t) asm volatile("" ::"v"(olds[t]));
                 if (lane == 0) __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 WAIT_VMEM_ALL();   // this wave's row stores (and the next operands landed); nobody waits for it
