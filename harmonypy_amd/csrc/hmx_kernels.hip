@@ -1373,9 +1373,11 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     // vmcnt(0) covers only its own (returning) adds, whereas a wave that has just written 14 R rows sees its adds
     // acknowledged behind those stores (memory operations retire in order): the arrival no longer waits for the block's row
     // stores, and the other waves go straight on to the next distance GEMM.  Only when that wave owns no tile in ANY block
-    // and the table is small enough for one wave (else the round-3 protocol: everybody publishes, barrier, one arrival).
+    // and the table is SMALL (at most four adds per lane): measured on one box (profiles/r04_ab_k_round_publisher_wave.txt),
+    // configs[1] (G K16 = 128) 129.5-131.8 -> 126.7 us per sweep, but C3 (896 entries: 14 adds per lane from ONE wave, behind
+    // the other waves' row stores in the CU's memory pipeline) 322 -> 390 us -- there everybody publishes as before.
     bool pubwave = false;
-    if (HMX_ROUND_PUBWAVE && GK <= 1024) {
+    if (HMX_ROUND_PUBWAVE && GK <= 256) {
         int max_ntl = 0;
         for (int bb = 0; bb < a.nblk; ++bb) max_ntl = max(max_ntl, bs[bb + 1] - bs[bb]);
         pubwave = ROUND_TPW * (blockIdx.x + (multi ? (int)gridDim.x - 1 : (int)gridDim.x) * (ROUND_WAVES - 1)) >= max_ntl;
@@ -1641,10 +1643,10 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                 double* dst = a.S_new + ((size_t)b * HMX_ROUND_SLOTS + (wg % HMX_ROUND_SLOTS)) * GK;
                 double a2s = 0.0;
                 // all adds in flight together (each one's old value is only looked at behind the last: one round trip, not
-                // sixteen); returning, so that behind the wave's vmcnt(0) they are PERFORMED
-                double olds[16];
+                // four); returning, so that behind the wave's vmcnt(0) they are PERFORMED
+                double olds[4];
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
+                for (int t = 0; t < 4; ++t) {
                     const int i = lane + 64 * t;
                     olds[t] = 0.0;
                     if (i < GK) {
@@ -1656,7 +1658,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                 if (A2TAB) ent_acc += a2s;
                 WAIT_VMEM_ALL();
 #pragma unroll
-                for (int t = 0; t < 16; ++t) asm volatile("" ::"v"(olds[t]));
+                for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(olds[t]));
                 if (lane == 0) __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 WAIT_VMEM_ALL();   // this wave's row stores (and the next operands landed); nobody waits for it
