@@ -352,6 +352,18 @@ def test_bench_path_parity_c3_shape(monkeypatch):
     _bench_path_case(150_000, 50, 8, 100, monkeypatch, ridge_dtype=np.float64)
 
 
+@pytest.mark.parametrize("wgs", [6, 23])
+def test_bench_path_parity_blocks_larger_than_the_grid(wgs, monkeypatch):
+    """More tiles per update block than the sweep's grid has slots (what a GPU holding more than ~1.4 M cells sees): a wave
+    then carries a STREAM of tile pairs through every block -- here forced with a small grid (HMX_ROUND_WGS: 6 or 23
+    workgroups for 477 tiles per block: five pairs per wave and block, ragged over the waves / one or two) -- same checks as
+    the C3 shape: objectives 2e-5, R 1e-4, Z_corr 1e-4 against the oracle on the same device order."""
+    monkeypatch.setenv("HMX_ROUND_WGS", str(wgs))
+    ho = _bench_path_case(150_000, 50, 8, 100, monkeypatch, ridge_dtype=np.float64, rounds=(3, 2))
+    cnt = ho._engine.counters()
+    assert cnt["sweep_waits"] > 0 and cnt["sweep_fallbacks"] == 0, cnt
+
+
 def test_bench_path_parity_many_batches(monkeypatch):
     """30 batch groups at K=100, d=50: the most the one-launch sweep serves (its LDS tables grow with the group
     count: 161 KB of the CU's 160 KiB here); same checks as the C3 shape, and the persistent
