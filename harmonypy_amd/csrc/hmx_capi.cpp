@@ -114,6 +114,7 @@ struct hmx_engine {
     int sweep_kernel = 0;        // 0: k_round + R^T.Z pass with the removal sums (faster at C3: DESIGN.md §3), 1: k_sweep (hmx_sweep.hip; HMX_SWEEP=1)
     unsigned spin_limit = 1u << 24;  // polls a grid-wide wait may take (HMX_SPIN_LIMIT; tests shrink it to force the fall-back)
     long n_sweep_fallbacks = 0;  // rounds repeated through the per-block path after a wait timed out
+    long n_sweeps_bf16 = 0;      // sweeps launched on the bf16-pipe instances of k_round (round_uses_bf16_pipe)
     DevBuf<unsigned long long> wait_stats;   // {waits, incomplete polls, most polls of one wait} of the sweep kernels' grid-wide waits
     DevBuf<double> xch;
     double *Sold = nullptr, *Yacc64 = nullptr, *Snew = nullptr, *objacc = nullptr, *Sr = nullptr, *Oxr = nullptr;
@@ -1123,7 +1124,7 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
     }
 #endif
     const bool mega = persistent && e->mt <= 7 && round_row_floats(e->d) == e->dp &&
-                      round_lds_bytes(e->K16, e->dp, e->G, e->B, e->V) <= HMX_ROUND_LDS_LIMIT;
+                      round_lds_bytes(e->K16, e->dp, e->G, e->B, e->V, false) <= HMX_ROUND_LDS_LIMIT;
     const bool r3 = streaming_rtz(e);
     // a single engine on the persistent sweep: k_rtz3_finish normalises the centroids itself (no collective is due in
     // between) and does the sweep kernel's fills -- three launches per round
@@ -1216,6 +1217,7 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
             ra.prof = prof.p;
 #endif
             if (launch_round(ra, e->mt, multi ? wgs + 1 : wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported shape for k_round");
+            if (round_uses_bf16_pipe(ra.K16, ra.dp, ra.G, ra.B, ra.V)) e->n_sweeps_bf16++;
 #ifdef HMX_ROUND_PROF
             if (++prof_rounds == 25) {   // one round in steady state: phase durations over workgroups and blocks
                 std::vector<unsigned long long> h((size_t)wgs * e->nblk * 16);
@@ -1251,6 +1253,18 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
                         }
                     const double n = (double)wgs * (e->nblk - 1);
                     fprintf(stderr, "[k_round prof] wait split: gather issue %.0f, poll %.0f (%.1f spins), syncthreads %.0f\n", s1 / n, s2 / n, sp / n, s3 / n);
+                }
+                {   // the tile step of wave 0 (blocks 0 .. nblk-2): ids + row fragments, requests, split + start values, k-step 0, the rest
+                    double s[5] = {0, 0, 0, 0, 0};
+                    for (int w = 0; w < wgs; ++w)
+                        for (int b = 0; b + 1 < e->nblk; ++b) {
+                            const unsigned long long* r = &h[((size_t)w * e->nblk + b) * 16];
+                            if (!r[11] || !r[13]) continue;
+                            s[0] += (double)(r[11] - r[4]); s[1] += (double)(r[12] - r[11]); s[2] += (double)(r[13] - r[12]);
+                            s[3] += (double)(r[14] - r[13]); s[4] += (double)(r[5] - r[14]);
+                        }
+                    const double n = (double)wgs * (e->nblk - 1);
+                    fprintf(stderr, "[k_round prof] pre(next) split: fragments %.0f, requests %.0f, split %.0f, k-step 0 %.0f, rest %.0f\n", s[0] / n, s[1] / n, s[2] / n, s[3] / n, s[4] / n);
                 }
                 fprintf(stderr, "[k_round prof] whole sweep mean %.0f ticks over %d workgroups\n", tot / wgs, wgs);
             }
@@ -1815,7 +1829,7 @@ int hmx_counters(hmx_engine* e, int64_t out[8]) {
     out[0] = e->n_collectives;
     out[1] = e->n_sweep_fallbacks;
     out[2] = (int64_t)e->seeded_rounds;
-    out[3] = 0;
+    out[3] = e->n_sweeps_bf16;
     out[4] = (int64_t)ws[0];
     out[5] = (int64_t)ws[1];
     out[6] = (int64_t)ws[2];

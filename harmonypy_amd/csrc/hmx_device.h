@@ -44,6 +44,42 @@ __device__ __forceinline__ double wave_sum_all(double v) {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// ---- fp32 products on the bf16 matrix pipe ("three-term split") --------------------------------------------------
+// gfx950 has no xf32 and its f32-input MFMA runs at the vector rate (16x16x4: 32 cycles per SIMD for 2 x 16 x 16 x 4
+// flops); v_mfma_f32_16x16x32_bf16 does eight times the K in half the cycles.  An fp32 value is the EXACT sum of three
+// bf16 values, x = h + m + l: h = RNE(x) to 8 significant bits, m = RNE(x - h), l = x - h - m (both subtractions are
+// exact, and what is left after m has at most 8 significant bits).  A product of two bf16 values is exact in fp32 and
+// the matrix pipe accumulates in fp32, so
+//     x y = hh + (hm + mh) + (mm + hl + lh) + [ml + lm + ll],      |[...]| <= 2^-23 |x y|  (|m| <= 2^-8 |x|, |l| <= 2^-16 |x|),
+// i.e. six bf16 MFMAs give the fp32 product sum up to 2^-23 of ONE product -- against the rounding of the fp32
+// accumulator (2^-24 of the running sum of all d products) that vanishes: in tests/test_split_gemm.py the six-product
+// form is as close to the float64 value as the f32-input MFMA, a shade closer in fact (the accumulator is rounded 6
+// times per 32 k instead of 8), and adding the dropped terms changes nothing -- at 6 x 16 cycles per 32 k against 8 x 32.
+// Fragment conventions of v_mfma_f32_16x16x32_bf16:
+//   A operand: lane l holds A[i = l&15][k = 8 (l>>4) .. +8] (8 bf16 = 4 registers), B likewise B[k][j = l&15], C/D as above.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+__device__ __forceinline__ u32x4 ld4u(const unsigned* p) { return *reinterpret_cast<const u32x4*>(p); }
+// two floats -> two bf16 in one register (v_cvt_pk_bf16_f32, round to nearest even), and back (exact)
+__device__ __forceinline__ unsigned bf16_pack(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
+__device__ __forceinline__ f32x2 bf16_widen(unsigned p) {
+    f32x2 r;
+    r.x = __uint_as_float(p << 16);
+    r.y = __uint_as_float(p & 0xffff0000u);
+    return r;
+}
+// x = h + m + l exactly (pairs: 3 conversions, 2 packed subtractions, 4 shifts / masks)
+__device__ __forceinline__ void bf16_split3(f32x2 x, unsigned& h, unsigned& m, unsigned& l) {
+    h = bf16_pack(x);
+    const f32x2 r1 = x - bf16_widen(h);
+    m = bf16_pack(r1);
+    l = bf16_pack(r1 - bf16_widen(m));
+}
+
 // sum over the 16 lanes of a DPP row (the lanes that share q); every lane of the row gets the total
 #define DPP_F(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xF, 0xF, true))
 __device__ __forceinline__ float row16_sum(float v) {

@@ -228,7 +228,8 @@ size_t sweep_lds_bytes(int K16, int d, int G, int B, int V, int nblk);
 int sweep_row_floats(int d);
 int sweep_waves();
 int launch_sweep(const SweepArgs& a, int mt, int d, int wgs, hipStream_t s);
-size_t round_lds_bytes(int K16, int dp, int G, int B, int V);
+size_t round_lds_bytes(int K16, int dp, int G, int B, int V, bool bf3);
+bool round_uses_bf16_pipe(int K16, int dp, int G, int B, int V);   // which k_round instance launch_round picks
 // k_round has no static LDS and one workgroup per CU: everything the CU has (160 KB), less a small margin
 #define HMX_ROUND_LDS_LIMIT (size_t)(159 * 1024)
 int round_row_floats(int d);

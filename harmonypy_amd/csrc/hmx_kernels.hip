@@ -541,8 +541,10 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES, 4) void k_assign_lds(AssignArgs 
 #endif
 #ifdef HMX_ROUND_PROF   /* timing experiments only: per-workgroup phase stamps (s_memtime) */
 #define RSTAMP(slot) do { if (tid == 0 && a.prof) a.prof[((size_t)wg * a.nblk + b) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TSTAMP(slot) do { if (tid == 0 && a.prof && prof_b >= 0) a.prof[((size_t)wg * a.nblk + prof_b) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define RSTAMP(slot) do { } while (0)
+#define TSTAMP(slot) do { } while (0)
 #endif
 // s_waitcnt vmcnt(0) as the builtin (gfx9 encoding: vmcnt 0, expcnt 7, lgkmcnt 15), so that the compiler's own wait
 // insertion knows nothing is outstanding afterwards; as inline assembly it is invisible to it and every later
@@ -617,6 +619,178 @@ __device__ __forceinline__ void round_compute(const float* Ys, const float* nis,
             const f32x4 ni = ld4(nis + 16 * mt + 4 * q);
             const f32x4 one = (f32x4){1.f, 1.f, 1.f, 1.f};
             T.arg[mt] = (2.f * (one - T.arg[mt])) * ni;          // dist = 2 (1 - Y.Z) (:447), arg = -dist / sigma (:466)
+        }
+    }
+}
+
+// ---- the same distance GEMM on the bf16 matrix pipe, fp32 operands as three bf16 terms (hmx_device.h) -------------
+// A k-step is 32 row floats = 8 pieces of 16 bytes; lane (c16, q) supplies pieces 8 s + 2 q and 8 s + 2 q + 1 of step s
+// (pieces past the row are zero on both sides).  The centroid table sits in LDS as three bf16 planes (h, m, l), rows
+// of 16 NS + 4 registers (the odd multiple of 4 spreads a 16-lane group's 16-byte reads over all 64 banks); the cells' rows
+// are split in registers when their fragments are read -- 9 vector instructions per pair of values, next to six
+// 16-cycle MFMAs per cluster tile and k-step where the f32-input form took eight 32-cycle ones.
+#ifndef HMX_ROUND_BF3
+#define HMX_ROUND_BF3 1
+#endif
+constexpr int bf3_steps(int KS) { return (KS + 7) / 8; }
+constexpr int bf3_ldb(int KS) { return 16 * bf3_steps(KS) + 4; }   // row stride of a plane, in 32-bit words
+// Landing zone of a tile's rows in the BF3 builds: one LDS-DMA request brings WHOLE rows -- 64 / KS of them, lane l the
+// piece l % KS of row l / KS, both fixed per lane -- so that the only per-request work is the row id (one ds_bpermute with an
+// immediate offset) and one 64-bit multiply-add; the dense form (request i brings pieces 64 i .. of the tile's 16 KS) cost
+// ~25 instructions per request, 2.1 k cycles per tile step in front of the first MFMA (profiles/r04_stamps.txt).  A request's
+// rows are contiguous where they land; the requests' bases are 1088 bytes apart (272 words: 16 more than a multiple of 64,
+// so the 16 rows' 16-byte fragment reads of one lane group spread over all banks when a row is 52 words).
+constexpr int zone_rows_per_request(int KS) { return 64 / KS; }
+constexpr int zone_request_floats() { return 272; }
+constexpr int zone_tile_floats(int KS, bool bf3) { return bf3 ? (16 / zone_rows_per_request(KS)) * zone_request_floats() : 16 * 4 * KS; }
+__device__ __forceinline__ int zone_row_offset(int row, int KS) {   // floats from the zone's base to the row
+    return zone_request_floats() * (row / zone_rows_per_request(KS)) + 4 * KS * (row % zone_rows_per_request(KS));
+}
+template <int KS>
+struct RoundZ3 {
+    static constexpr int NS = bf3_steps(KS);
+    u32x4 h[NS], m[NS], l[NS];
+};
+// raw pieces (in the order s, half) -> split fragments
+template <int KS>
+__device__ __forceinline__ void round_split_rows(const f32x4 (&raw)[2 * bf3_steps(KS)], RoundZ3<KS>& Z) {
+    constexpr int NS = bf3_steps(KS);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const f32x4 v = raw[2 * s + hh];
+            unsigned h0, m0, l0, h1, m1, l1;
+            bf16_split3((f32x2){v[0], v[1]}, h0, m0, l0);
+            bf16_split3((f32x2){v[2], v[3]}, h1, m1, l1);
+            Z.h[s][2 * hh] = h0; Z.h[s][2 * hh + 1] = h1;
+            Z.m[s][2 * hh] = m0; Z.m[s][2 * hh + 1] = m1;
+            Z.l[s][2 * hh] = l0; Z.l[s][2 * hh + 1] = l1;
+        }
+}
+template <int KS>
+__device__ __forceinline__ void round_split_step(const f32x4 (&raw)[2 * bf3_steps(KS)], int s, RoundZ3<KS>& Z) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const f32x4 v = raw[2 * s + hh];
+        unsigned h0, m0, l0, h1, m1, l1;
+        bf16_split3((f32x2){v[0], v[1]}, h0, m0, l0);
+        bf16_split3((f32x2){v[2], v[3]}, h1, m1, l1);
+        Z.h[s][2 * hh] = h0; Z.h[s][2 * hh + 1] = h1;
+        Z.m[s][2 * hh] = m0; Z.m[s][2 * hh + 1] = m1;
+        Z.l[s][2 * hh] = l0; Z.l[s][2 * hh + 1] = l1;
+    }
+}
+// the lane's raw pieces of a row at `zr` (LDS landing zone or global memory); reads past the row are clamped and zeroed
+template <int KS>
+__device__ __forceinline__ void round_raw_pieces(const float* zr, int q, f32x4 (&raw)[2 * bf3_steps(KS)]) {
+    constexpr int NS = bf3_steps(KS);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int p = 8 * s + 2 * q + hh;
+            if (8 * s + 7 < KS) {
+                raw[2 * s + hh] = ld4(zr + 4 * p);
+            } else {
+                const f32x4 v = ld4(zr + 4 * min(p, KS - 1));
+                raw[2 * s + hh] = p < KS ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+}
+// Yb: the three planes, K16 x bf3_ldb(KS) words each; nis: the accumulators' start (-c_k), see round_compute<.., true>
+template <int MT, int KS>
+__device__ __forceinline__ void round_compute_bf3(const unsigned* Yb, const float* nis, int c16, int q,
+                                                  const RoundZ3<KS>& Z, RoundTile<MT>& T) {
+    constexpr int NS = bf3_steps(KS), LDB = bf3_ldb(KS), PL = 16 * MT * LDB;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) T.arg[mt] = ld4(nis + 16 * mt + 4 * q);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        // cluster tiles two at a time (three for the odd one out): consecutive MFMAs never share an accumulator
+#pragma unroll
+        for (int g = 0; g < (MT >= 2 ? MT / 2 : 1); ++g) {
+            const int mt0 = 2 * g;
+            const int n = (g == (MT >= 2 ? MT / 2 : 1) - 1) ? MT - mt0 : 2;
+            u32x4 yh[3], ym[3], yl[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (i < n) {
+                    const unsigned* r = Yb + (size_t)(16 * (mt0 + i) + c16) * LDB + 16 * s + 4 * q;
+                    yh[i] = ld4u(r);
+                    ym[i] = ld4u(r + PL);
+                    yl[i] = ld4u(r + 2 * PL);
+                }
+            // smallest terms first
+#pragma unroll
+            for (int i = 0; i < 3; ++i) if (i < n) T.arg[mt0 + i] = MFMA_BF16(yl[i], Z.h[s], T.arg[mt0 + i]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) if (i < n) T.arg[mt0 + i] = MFMA_BF16(yh[i], Z.l[s], T.arg[mt0 + i]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) if (i < n) T.arg[mt0 + i] = MFMA_BF16(ym[i], Z.m[s], T.arg[mt0 + i]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) if (i < n) T.arg[mt0 + i] = MFMA_BF16(ym[i], Z.h[s], T.arg[mt0 + i]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) if (i < n) T.arg[mt0 + i] = MFMA_BF16(yh[i], Z.m[s], T.arg[mt0 + i]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) if (i < n) T.arg[mt0 + i] = MFMA_BF16(yh[i], Z.h[s], T.arg[mt0 + i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one k-step's centroid fragments live at a time
+    }
+}
+
+// two tiles against one read of the centroid fragments (half the LDS traffic per MFMA, and every pair of consecutive
+// MFMAs has different accumulators whatever the number of cluster tiles); `mid()` runs between the k-steps 0 and 1
+template <int MT, int KS, typename F, typename F2>
+__device__ __forceinline__ void round_compute_bf3_pair(const unsigned* Yb, const float* nis, int c16, int q,
+                                                       const f32x4 (&raw0)[2 * bf3_steps(KS)], const f32x4 (&raw1)[2 * bf3_steps(KS)],
+                                                       RoundTile<MT>& T0, RoundTile<MT>& T1, F&& mid, F2&& ready) {
+    constexpr int NS = bf3_steps(KS), LDB = bf3_ldb(KS), PL = 16 * MT * LDB;
+    RoundZ3<KS> Z0, Z1;
+    round_split_step<KS>(raw0, 0, Z0);
+    round_split_step<KS>(raw1, 0, Z1);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) T1.arg[mt] = T0.arg[mt] = ld4(nis + 16 * mt + 4 * q);
+    __builtin_amdgcn_sched_barrier(0);
+    ready();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        // (the split of the next k-step's pieces between this k-step's MFMAs -- sched_group_barrier, the pieces pinned into the
+        // region by empty volatile statements -- measured no different: 302 vs 303 us; the partner wave fills the gaps)
+        if (s + 1 < NS) {
+            round_split_step<KS>(raw0, s + 1, Z0);
+            round_split_step<KS>(raw1, s + 1, Z1);
+        }
+        // centroid fragments one cluster tile ahead of their MFMAs (read in the order of use: l, h, m)
+        u32x4 ya[2][3];
+        auto read_y = [&](int mt, u32x4 (&y)[3]) {
+            const unsigned* r = Yb + (size_t)(16 * mt + c16) * LDB + 16 * s + 4 * q;
+            y[0] = ld4u(r + 2 * PL);
+            y[1] = ld4u(r);
+            y[2] = ld4u(r + PL);
+        };
+        read_y(0, ya[0]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (mt + 1 < MT) read_y(mt + 1, ya[(mt + 1) & 1]);
+            const u32x4 yl = ya[mt & 1][0], yh = ya[mt & 1][1], ym = ya[mt & 1][2];
+            T0.arg[mt] = MFMA_BF16(yl, Z0.h[s], T0.arg[mt]);   // smallest terms first
+            T1.arg[mt] = MFMA_BF16(yl, Z1.h[s], T1.arg[mt]);
+            T0.arg[mt] = MFMA_BF16(yh, Z0.l[s], T0.arg[mt]);
+            T1.arg[mt] = MFMA_BF16(yh, Z1.l[s], T1.arg[mt]);
+            T0.arg[mt] = MFMA_BF16(ym, Z0.m[s], T0.arg[mt]);
+            T1.arg[mt] = MFMA_BF16(ym, Z1.m[s], T1.arg[mt]);
+            T0.arg[mt] = MFMA_BF16(ym, Z0.h[s], T0.arg[mt]);
+            T1.arg[mt] = MFMA_BF16(ym, Z1.h[s], T1.arg[mt]);
+            T0.arg[mt] = MFMA_BF16(yh, Z0.m[s], T0.arg[mt]);
+            T1.arg[mt] = MFMA_BF16(yh, Z1.m[s], T1.arg[mt]);
+            T0.arg[mt] = MFMA_BF16(yh, Z0.h[s], T0.arg[mt]);
+            T1.arg[mt] = MFMA_BF16(yh, Z1.h[s], T1.arg[mt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s == 0) {
+            mid();
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -1265,7 +1439,7 @@ __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_assign_wide2(AssignArgs
     }
 }
 
-template <int MT, int KS>
+template <int MT, int KS, bool BF3T>
 __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     if (a.frozen && *a.frozen) return;   // an earlier sweep of this cluster() call timed out: R, O, the objective block stay as it left them
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1273,12 +1447,16 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     constexpr int NF = KS / 4, NT = KS % 4;
     const int GK = a.G * K16;
     const int LDY = a.ldy_lds;
-    float* Ys0 = reinterpret_cast<float*>(smem);                         // K16 x LDY
+    constexpr bool LOG2 = HMX_ROUND_EXP2 != 0, A2TAB = HMX_ROUND_A2TAB != 0;
+    constexpr bool BF3 = BF3T && LOG2;                                   // distance GEMM on the bf16 pipe (round_compute_bf3)
+    float* Ys0 = reinterpret_cast<float*>(smem);                         // K16 x LDY, or the three bf16 planes of the centroids
+    unsigned* Yb0 = reinterpret_cast<unsigned*>(smem);
     // landing zones of the waves' Z_cos rows (global -> LDS directly): waves x ROUND_TPW tiles x 16 rows x dp floats,
     // 16-byte aligned (LDY is a multiple of 4); a plain offset from the LDS base: a pointer rebuilt from an integer
     // would turn every read of the zones into a flat load, which waits on the memory counter as well
-    float* zbuf = Ys0 + (size_t)K16 * LDY;
-    float* sig0 = zbuf + (size_t)ROUND_WAVES * ROUND_TPW * 16 * (4 * KS);   // K16
+    float* zbuf = Ys0 + (BF3 ? (size_t)3 * K16 * bf3_ldb(KS) : (size_t)K16 * LDY);
+    constexpr int ZTILE = zone_tile_floats(KS, BF3);
+    float* sig0 = zbuf + (size_t)ROUND_WAVES * ROUND_TPW * ZTILE;         // K16
     float* nis0 = sig0 + K16;                                            // K16  -1/sigma (-1e30 for pads)
     float* sig = sig0;
     float* nis = nis0;
@@ -1351,7 +1529,6 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         if (a.V == 1) bgrp[a.group_cols[i]] = i;
     }
     for (int i = tid; i < a.nblk + 3; i += ROUND_THREADS) bs[i] = a.blk_start[min(i, a.nblk)];
-    constexpr bool LOG2 = HMX_ROUND_EXP2 != 0, A2TAB = HMX_ROUND_A2TAB != 0;
     constexpr float TWO_LOG2E = 2.885390081777926814f;
     for (int i = tid; i < K16; i += ROUND_THREADS) {
         const float sgm = (i < a.K) ? a.sigma[i] : 0.f;
@@ -1360,6 +1537,21 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         else nis[i] = (i < a.K) ? -1.0f / sgm : -60.f;               // pads: Y row 0 -> dist 2 -> arg -120 -> exp == 0
     }
     for (int i = tid; i < GK; i += ROUND_THREADS) Ocur[i] = a.O_start[i];
+    if (BF3) {
+        constexpr int NP = 8 * bf3_steps(KS), LDB = bf3_ldb(KS);     // pieces per row incl. the zero ones past the row
+        for (int i = tid; i < K16 * NP; i += ROUND_THREADS) {
+            const int row = i / NP, p = i - row * NP;
+            f32x4 y = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p < KS && row < a.K) y = ld4(a.Y + (size_t)row * a.ldy + 4 * p) * (TWO_LOG2E / a.sigma[row]);
+            unsigned h0, m0, l0, h1, m1, l1;
+            bf16_split3((f32x2){y[0], y[1]}, h0, m0, l0);
+            bf16_split3((f32x2){y[2], y[3]}, h1, m1, l1);
+            unsigned* dst = Yb0 + (size_t)row * LDB + 2 * p;
+            *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
+            *reinterpret_cast<u32x2*>(dst + (size_t)K16 * LDB) = (u32x2){m0, m1};
+            *reinterpret_cast<u32x2*>(dst + (size_t)2 * K16 * LDB) = (u32x2){l0, l1};
+        }
+    } else
     for (int i = tid; i < K16 * KS; i += ROUND_THREADS) {
         const int row = i / KS, c4 = i - row * KS;
         f32x4 y = ld4(a.Y + (size_t)row * a.ldy + 4 * c4);
@@ -1387,7 +1579,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     RoundTile<MT> T[ROUND_TPW];
     float* zb[ROUND_TPW];
 #pragma unroll
-    for (int u = 0; u < ROUND_TPW; ++u) zb[u] = zbuf + (size_t)(wv * ROUND_TPW + u) * 16 * (4 * KS);
+    for (int u = 0; u < ROUND_TPW; ++u) zb[u] = zbuf + (size_t)(wv * ROUND_TPW + u) * ZTILE;
     int cell1[ROUND_TPW], grp1[ROUND_TPW];   // ids of block b+1's tiles (landed)
     int cell2[ROUND_TPW] = {0, 0}, grp2[ROUND_TPW] = {0, 0};   // ids of block b+2's tiles (travelling: raw loads, untouched until they are shifted in)
     bool valid2[ROUND_TPW] = {false, false};
@@ -1410,6 +1602,28 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     // The landing zone is linear in 16-byte pieces: lane l of instruction i brings piece (64 i + l) % KS of row
     // (64 i + l) / KS, so the zone is the tile row-major.  Dead rows (list padding) read cell 0's row.
     auto issue_rows = [&](int cell_c16, float* dst) {
+        if (BF3) {
+            // whole rows per request (zone_row_offset): lane l brings piece l % KS of row RPD it + l / KS
+            constexpr int RPD = zone_rows_per_request(KS), NIT = 16 / RPD;
+            static_assert(16 % RPD == 0, "whole rows per request");
+            const int r_in = lane / KS, piece = lane - r_in * KS;
+            const float* src[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int cell = __builtin_amdgcn_ds_bpermute(4 * (RPD * it + r_in), cell_c16);   // the rows' ids sit in lanes 0..15
+                src[it] = a.Zcos + (size_t)(cell >= 0 ? cell : 0) * (4 * KS) + 4 * piece;
+            }
+            if (lane < RPD * KS) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const unsigned zone = __builtin_amdgcn_readfirstlane(
+                        (unsigned)(size_t)(__attribute__((address_space(3))) void*)(dst + zone_request_floats() * it));
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                                 :: "v"(src[it]), "s"(zone) : "memory", "m0");
+                }
+            }
+            return;
+        }
         constexpr int NCH = 16 * KS, NIT = (NCH + 63) / 64;
         const float* src[NIT];
 #pragma unroll
@@ -1432,6 +1646,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         }
     };
     const float* Ys = Ys0;
+    const unsigned* Yb = Yb0;
     // ---- prologue: block 0 computed, block 1's ids landed ---------------------------------------
 #pragma unroll
     for (int u = 0; u < ROUND_TPW; ++u) {
@@ -1444,15 +1659,26 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     // this phase, the partner wave's MFMAs cover them -- and far from the hand-off: a wave's memory operations return
     // in order, so a request in flight in front of the poll or of the hand-off's loads would be waited for by them.
     // By the next poll these rows have had a whole distance GEMM to land; they are used a block later.
+    int prof_b = -1;   // (profiling build: the block whose record the tile step's stamps go to)
+    (void)prof_b;
     auto tile_step = [&](int blk_ids) {
+        // a wave without a tile in the block it is about to multiply (the last wave of most workgroups, every block) only
+        // keeps its id pipeline going: no rows, no GEMM on dummy operands -- it is the wave that arrives for the workgroup
+        const bool live = j_first < bs[blk_ids - 1] - bs[blk_ids - 2];   // wave-uniform
         RoundZ<KS> Zf[ROUND_TPW];
+        f32x4 raw[ROUND_TPW][2 * bf3_steps(KS)];
+        if (live) {
 #pragma unroll
-        for (int u = 0; u < ROUND_TPW; ++u) round_rows_from_lds<KS>(zb[u], c16, q, Zf[u]);
+        for (int u = 0; u < ROUND_TPW; ++u) {
+            if (BF3) round_raw_pieces<KS>(zb[u] + zone_row_offset(c16, KS), q, raw[u]);
+            else round_rows_from_lds<KS>(zb[u], c16, q, Zf[u]);
+        }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zones are read before they are handed on
         auto request = [&]() {
 #pragma unroll
         for (int u = 0; u < ROUND_TPW; ++u) {
-            issue_rows(cell1[u], zb[u]);
+            if (j_first + u < bs[blk_ids] - bs[blk_ids - 1]) issue_rows(cell1[u], zb[u]);   // (wave-uniform: the tile exists)
             // ids of the block after: clamped loads, the "no such tile" case applied when they are shifted in -- a
             // predicated load or a select here would be waited for at once, and with it every row request above
             const int j = j_first + u;
@@ -1466,8 +1692,19 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         // the two waves of a SIMD stagger the request code: one issues it while the other's first tile keeps the pipe busy
         static_assert(ROUND_TPW == 2, "tile_step is written for two tiles per wave");
         const bool second = wv >= ROUND_WAVES / 2;
+        TSTAMP(11);
         if (!second) request();
         __builtin_amdgcn_sched_barrier(0);
+        TSTAMP(12);
+        if (!live) {
+            if (second) request();
+            return;
+        }
+        if (BF3) {
+            // both tiles against one read of the centroid fragments; the `second` waves' requests ride between the k-steps
+            round_compute_bf3_pair<MT, KS>(Yb, nis, c16, q, raw[0], raw[1], T[0], T[1], [&]() { TSTAMP(14); if (second) request(); }, [&]() { TSTAMP(13); });
+            return;
+        }
         round_compute<MT, KS, LOG2>(Ys, nis, LDY, c16, q, Zf[0], T[0]);
         __builtin_amdgcn_sched_barrier(0);
         if (second) request();
@@ -1489,6 +1726,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             int zero = 0;
             asm volatile("" : "+v"(zero));
             Ys = Ys0 + zero;
+            Yb = Yb0 + zero;
             sig = sig0 + zero;
             nis = nis0 + zero;
             // likewise the lane's own coordinates: everything derived from them (table and row addresses, list
@@ -1625,11 +1863,19 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             for (int u = 0; u < ROUND_TPW; ++u) {
                 if (j + u >= ntl) break;
                 RoundTile<MT> X;
-                RoundZ<KS> XZ;
                 X.cell = a.cells[(size_t)(tb + j + u) * 16 + c16];
                 X.grp = a.tile_grp[tb + j + u];
-                round_issue_z<KS>(a.Zcos, X.cell, q, XZ);
-                round_compute<MT, KS, LOG2>(Ys, nis, LDY, c16, q, XZ, X);
+                if (BF3) {
+                    f32x4 xraw[2 * bf3_steps(KS)];
+                    RoundZ3<KS> XZ3;
+                    round_raw_pieces<KS>(a.Zcos + (size_t)(X.cell >= 0 ? X.cell : 0) * (4 * KS), q, xraw);
+                    round_split_rows<KS>(xraw, XZ3);
+                    round_compute_bf3<MT, KS>(Yb, nis, c16, q, XZ3, X);
+                } else {
+                    RoundZ<KS> XZ;
+                    round_issue_z<KS>(a.Zcos, X.cell, q, XZ);
+                    round_compute<MT, KS, LOG2>(Ys, nis, LDY, c16, q, XZ, X);
+                }
                 float sclx;
                 round_post_pass1<MT, true, LOG2, A2TAB>(sig, rpT, lrpT, q, X, sclx, km_acc, ent_acc);
                 round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, X, sclx, false, X, 0.f);
@@ -1680,6 +1926,10 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         }
         WAIT_VMEM_ALL();   // the sums are performed (and the next operands landed)
         wg_barrier_lds();
+        // (Wave 0 arrives.  Its next vector-memory wait -- the first use of the next tiles' ids, a loop-carried load the
+        // compiler drains the counter for -- therefore covers this add's round trip, ~2 k cycles in front of its distance
+        // GEMM; letting the tile-less last wave arrive instead was SLOWER on one box, 303 vs 296 us per sweep at C3:
+        // profiles/r04_ab_k_round_bf16_pipe.txt)
         if (tid == 0) __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         RSTAMP(4);
@@ -1691,6 +1941,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             cell1[u] = valid2[u] ? cell2[u] : -1;
             grp1[u] = valid2[u] ? grp2[u] : 0;
         }
+        prof_b = b;
         if (b + 1 < a.nblk && !service) tile_step(b + 3);   // rows landed: vmcnt(0) above
         RSTAMP(5);
     }
@@ -3590,11 +3841,12 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
     return 0;
 }
 
-size_t round_lds_bytes(int K16, int dp, int G, int B, int V) {
+size_t round_lds_bytes(int K16, int dp, int G, int B, int V, bool bf3) {
     const size_t GK = (size_t)G * K16;
     // sigma, -1/sigma, rp, lrp, rpc (V > 1) | O, S, T, objective scratch (fp64) | Pr_b, theta, group_cols (V <= 8), bgrp, block offsets | landing zones
-    return ((size_t)K16 * lds_ldy(dp) + 2 * (size_t)K16 + 2 * GK + (V == 1 ? 0 : (size_t)K16 * B)) * 4 + (2 * GK + K16 + 2 * ROUND_WAVES) * 8 +
-           (3 * (size_t)B + (size_t)G * 8 + 64) * 4 + 16 + (size_t)ROUND_WAVES * ROUND_TPW * 16 * dp * 4
+    const size_t ys = bf3 ? (size_t)3 * K16 * bf3_ldb(dp / 4) : (size_t)K16 * lds_ldy(dp);   // centroids: three bf16 planes, or fp32 rows
+    return (ys + 2 * (size_t)K16 + 2 * GK + (V == 1 ? 0 : (size_t)K16 * B)) * 4 + (2 * GK + K16 + 2 * ROUND_WAVES) * 8 +
+           (3 * (size_t)B + (size_t)G * 8 + 64) * 4 + 16 + (size_t)ROUND_WAVES * ROUND_TPW * zone_tile_floats(dp / 4, bf3) * 4
         ;
 }
 
@@ -3665,37 +3917,45 @@ void launch_peer_selftest(double* const* peer_box, double* my_box, int n_ranks, 
 // its rows to the next of these) and 1..7 cluster tiles.
 int round_row_floats(int d) { return d <= 32 ? 32 : d <= 52 ? 52 : d <= 64 ? 64 : 0; }
 
-template <int MT, int KS>
+template <int MT, int KS, bool BF3>
 static void launch_round_t(const RoundArgs& a, int wgs, size_t sm, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_round<MT, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_round<MT, KS, BF3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_round<MT, KS>), dim3(wgs), dim3(ROUND_THREADS), sm, s, a);
+    hipLaunchKernelGGL((k_round<MT, KS, BF3>), dim3(wgs), dim3(ROUND_THREADS), sm, s, a);
 }
-template <int KS>
+template <int KS, bool BF3>
 static void launch_round_ks(const RoundArgs& a, int mt, int wgs, size_t sm, hipStream_t s) {
     switch (mt) {
-        case 1: launch_round_t<1, KS>(a, wgs, sm, s); break;
-        case 2: launch_round_t<2, KS>(a, wgs, sm, s); break;
-        case 3: launch_round_t<3, KS>(a, wgs, sm, s); break;
-        case 4: launch_round_t<4, KS>(a, wgs, sm, s); break;
-        case 5: launch_round_t<5, KS>(a, wgs, sm, s); break;
-        case 6: launch_round_t<6, KS>(a, wgs, sm, s); break;
-        default: launch_round_t<7, KS>(a, wgs, sm, s); break;
+        case 1: launch_round_t<1, KS, BF3>(a, wgs, sm, s); break;
+        case 2: launch_round_t<2, KS, BF3>(a, wgs, sm, s); break;
+        case 3: launch_round_t<3, KS, BF3>(a, wgs, sm, s); break;
+        case 4: launch_round_t<4, KS, BF3>(a, wgs, sm, s); break;
+        case 5: launch_round_t<5, KS, BF3>(a, wgs, sm, s); break;
+        case 6: launch_round_t<6, KS, BF3>(a, wgs, sm, s); break;
+        default: launch_round_t<7, KS, BF3>(a, wgs, sm, s); break;
     }
+}
+// The bf16-pipe form of the distance GEMM (round_compute_bf3) keeps the centroids as three bf16 planes and lands whole rows
+// per request: 41 KB more LDS at K = 100, d = 50 than the f32-input form, whose instances stay for the shapes that need the
+// room for their tables (16 to 30 batch groups at that K) -- and under HMX_ROUND_F32=1, the switch of the A/B runs.
+bool round_uses_bf16_pipe(int K16, int dp, int G, int B, int V) {
+    static const bool forced_f32 = [] { const char* v = getenv("HMX_ROUND_F32"); return v && atoi(v) != 0; }();
+    return HMX_ROUND_BF3 && HMX_ROUND_EXP2 && !forced_f32 && round_lds_bytes(K16, dp, G, B, V, true) <= HMX_ROUND_LDS_LIMIT;
 }
 
 int launch_round(const RoundArgs& a_in, int mt, int wgs, hipStream_t s) {
     RoundArgs a = a_in;
     a.ldy_lds = lds_ldy(a.dp);
-    const size_t sm = round_lds_bytes(a.K16, a.dp, a.G, a.B, a.V);
+    const bool bf3 = round_uses_bf16_pipe(a.K16, a.dp, a.G, a.B, a.V);
+    const size_t sm = round_lds_bytes(a.K16, a.dp, a.G, a.B, a.V, bf3);
     if (mt < 1 || mt > 7 || sm > HMX_ROUND_LDS_LIMIT) return -1;
     switch (a.dp) {
-        case 32: launch_round_ks<8>(a, mt, wgs, sm, s); break;
-        case 52: launch_round_ks<13>(a, mt, wgs, sm, s); break;
-        case 64: launch_round_ks<16>(a, mt, wgs, sm, s); break;
+        case 32: if (bf3) launch_round_ks<8, true>(a, mt, wgs, sm, s); else launch_round_ks<8, false>(a, mt, wgs, sm, s); break;
+        case 52: if (bf3) launch_round_ks<13, true>(a, mt, wgs, sm, s); else launch_round_ks<13, false>(a, mt, wgs, sm, s); break;
+        case 64: if (bf3) launch_round_ks<16, true>(a, mt, wgs, sm, s); else launch_round_ks<16, false>(a, mt, wgs, sm, s); break;
         default: return -1;
     }
     return 0;

@@ -256,7 +256,9 @@ int hmx_set_timing_stride(hmx_engine* e, int stride);
 
 /* Event counters of the engine since hmx_create: out[0] collectives issued (sharded jobs), out[1] rounds whose
  * persistent sweep kernel gave up on a grid-wide wait and were repeated block by block (harmony.py:464-513 has no
- * counterpart: it runs the blocks one torch call at a time), out[2] rounds with a device-side update order, out[3] 0;
+ * counterpart: it runs the blocks one torch call at a time), out[2] rounds with a device-side update order, out[3] sweeps
+ * whose distance GEMM ran on the bf16 matrix pipe (fp32 operands as three bf16 terms; the others
+ * used the f32-input instances: shapes whose tables need the LDS, or HMX_ROUND_F32=1);
  * the grid-wide waits of the persistent sweep kernel (per workgroup and block: the hop every block of a sweep pays, across
  * ranks when cells are sharded): out[4] waits, out[5] polls that found the hand-off incomplete (each followed by an
  * s_sleep of ~64 shader cycles), out[6] the most such polls any single wait took, out[7] 0. */

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of libraries on ONE box: usage gpu_r4_ab.sh "<gate -k expression>" lib1 lib2 ...   ("default" = harmonypy_amd/libhmx.so)
+# A/B of libraries on ONE box: usage gpu_r4_ab.sh "<gate -k expression>" lib1 lib2 ...   ("default" = harmonypy_amd/libhmx.so; "f32" = the same with HMX_ROUND_F32=1: the f32-input instances of k_round)
 # the parity gate runs on the default library first; then `--config c3` and c2 per library, twice, interleaved
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -12,7 +12,8 @@ if [ -n "$GATE" ]; then
 fi
 for rep in 1 2; do
 for lib in "$@"; do
-  if [ "$lib" = default ]; then unset HMX_LIB; else export HMX_LIB=$PWD/$lib; fi
+  unset HMX_ROUND_F32
+  if [ "$lib" = default ]; then unset HMX_LIB; elif [ "$lib" = f32 ]; then unset HMX_LIB; export HMX_ROUND_F32=1; else export HMX_LIB=$PWD/$lib; fi
   for cfg in ${CFGS:-c3 c2}; do
     timeout 300 python bench.py --config $cfg --steps 8 --warmup 2 --cpu-sample 0 --no-convergence --no-lisi > gpurun_out/ab.json 2> gpurun_out/ab.err
     python - "$lib" "$cfg" <<'PY'

@@ -6,6 +6,7 @@ bash scripts/gpu_final.sh
 bash scripts/gpu_pmc.sh
 bash scripts/gpu_pmc_mfma.sh
 bash scripts/gpu_pmc_sq.sh
+if [ -z "$SKIP_C5" ]; then   # (SKIP_C5=1: the configs[4] passes, when the wide kernels have not changed)
 bash scripts/gpu_pmc_sq_c5.sh
 rm -rf gpurun_out/pmc_mfma_c5
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace -d gpurun_out/pmc_mfma_c5 -o p --output-format csv -- python bench.py --config c5 --steps 1 --warmup 1 --cpu-sample 0 --no-roofline --no-convergence > gpurun_out/pmc_mfma_c5.json 2> gpurun_out/pmc_mfma_c5.err
@@ -25,9 +26,12 @@ with open("gpurun_out/pmc_mfma_c5_summary.txt", "w") as out:
 for f in files:
     if os.path.getsize(f) > 4_000_000: os.remove(f)
 PY
+fi
 find gpurun_out -name '*kernel_trace.csv' -size +4M -delete
 HMX_LIB=$PWD/build/libhmx_prof.so timeout 300 python bench.py --steps 4 --warmup 1 --cpu-sample 0 --no-convergence --no-lisi 2>&1 | grep "prof\]" | tee gpurun_out/stamps_c3.txt
-HMX_LIB=$PWD/build/libhmx_prof.so timeout 300 python bench.py --config c5 --steps 2 --warmup 1 --cpu-sample 0 --no-convergence --no-lisi 2>&1 | grep "prof\]" | tee gpurun_out/stamps_c5.txt
+[ -z "$SKIP_C5" ] && HMX_LIB=$PWD/build/libhmx_prof.so timeout 300 python bench.py --config c5 --steps 2 --warmup 1 --cpu-sample 0 --no-convergence --no-lisi 2>&1 | grep "prof\]" | tee gpurun_out/stamps_c5.txt
 timeout 200 python bench.py --config c2 --steps 20 --warmup 5 --cpu-sample 0 --no-convergence --no-lisi > gpurun_out/bench_c2_alone.json 2> gpurun_out/bench_c2_alone.err
 python -c "
 import json; d=json.loads(open('gpurun_out/bench_c2_alone.json').read().splitlines()[0]); print('c2 alone', round(d['value']/1e6,2), 'M', round(d['ms_per_step'],3), 'ms')"
+# the two instances of k_round on this box: distance GEMM on the bf16 pipe (default) and the f32-input form (HMX_ROUND_F32=1)
+CFGS="c3 c2" bash scripts/gpu_r4_ab.sh "" default f32 2>&1 | tee gpurun_out/ab_bf16_pipe.txt
