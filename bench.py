@@ -505,6 +505,10 @@ def main():
                         f"{args.rounds} k-means rounds (block_size 0.05 -> 20 blocks) + 1 ridge correction",
             "cells_per_gpu": N, "pcs": d, "batches": B, "clusters": K, "rounds_per_iteration": args.rounds,
             "update_order": "device (keyed bijection, generated inside the timed region)",
+            # fp32 operands, fp32 accumulators, fp32 results; HOW the sweep multiplies (tests/test_split_gemm.py)
+            "distance_gemm": ("bf16x3: every fp32 operand as the exact sum of three bf16 terms, six bf16 MFMAs per 32 k with fp32 "
+                              "accumulation (as close to float64 as the f32-input MFMA)" if counters.get("sweeps_bf16_pipe", 0) > 0
+                              else "f32-input MFMA"),
             "init": "k-means++ on a 50k-cell subsample, untimed",
             "parallelism": (f"cells sharded over {world} ranks (1 per GPU), transport {transport}: "
                             + ("block sums exchanged inside the sweep kernel through peer boxes (xGMI), 1 all-reduce per "

@@ -634,18 +634,12 @@ __device__ __forceinline__ void round_compute(const float* Ys, const float* nis,
 #endif
 constexpr int bf3_steps(int KS) { return (KS + 7) / 8; }
 constexpr int bf3_ldb(int KS) { return 16 * bf3_steps(KS) + 4; }   // row stride of a plane, in 32-bit words
-// Landing zone of a tile's rows in the BF3 builds: one LDS-DMA request brings WHOLE rows -- 64 / KS of them, lane l the
-// piece l % KS of row l / KS, both fixed per lane -- so that the only per-request work is the row id (one ds_bpermute with an
-// immediate offset) and one 64-bit multiply-add; the dense form (request i brings pieces 64 i .. of the tile's 16 KS) cost
-// ~25 instructions per request, 2.1 k cycles per tile step in front of the first MFMA (profiles/r04_stamps.txt).  A request's
-// rows are contiguous where they land; the requests' bases are 1088 bytes apart (272 words: 16 more than a multiple of 64,
-// so the 16 rows' 16-byte fragment reads of one lane group spread over all banks when a row is 52 words).
+// Row requests of the bf16-pipe instances: one LDS-DMA request brings WHOLE rows -- 64 / KS of them, lane l the piece l % KS
+// of row l / KS, both fixed per lane -- so that the only per-request work is the row id (one ds_bpermute with an immediate
+// offset) and one 64-bit multiply-add; the dense form of the f32-input instances (request i brings pieces 64 i .. of the
+// tile's 16 KS) costs ~25 instructions per request.  Consecutive requests land back to back, so the zone is the tile
+// row-major either way (rows of 52 words: the 16 rows' 16-byte fragment reads of a lane group cover all 64 banks).
 constexpr int zone_rows_per_request(int KS) { return 64 / KS; }
-constexpr int zone_request_floats() { return 272; }
-constexpr int zone_tile_floats(int KS, bool bf3) { return bf3 ? (16 / zone_rows_per_request(KS)) * zone_request_floats() : 16 * 4 * KS; }
-__device__ __forceinline__ int zone_row_offset(int row, int KS) {   // floats from the zone's base to the row
-    return zone_request_floats() * (row / zone_rows_per_request(KS)) + 4 * KS * (row % zone_rows_per_request(KS));
-}
 template <int KS>
 struct RoundZ3 {
     static constexpr int NS = bf3_steps(KS);
@@ -1455,7 +1449,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     // 16-byte aligned (LDY is a multiple of 4); a plain offset from the LDS base: a pointer rebuilt from an integer
     // would turn every read of the zones into a flat load, which waits on the memory counter as well
     float* zbuf = Ys0 + (BF3 ? (size_t)3 * K16 * bf3_ldb(KS) : (size_t)K16 * LDY);
-    constexpr int ZTILE = zone_tile_floats(KS, BF3);
+    constexpr int ZTILE = 16 * (4 * KS);
     float* sig0 = zbuf + (size_t)ROUND_WAVES * ROUND_TPW * ZTILE;         // K16
     float* nis0 = sig0 + K16;                                            // K16  -1/sigma (-1e30 for pads)
     float* sig = sig0;
@@ -1603,7 +1597,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     // (64 i + l) / KS, so the zone is the tile row-major.  Dead rows (list padding) read cell 0's row.
     auto issue_rows = [&](int cell_c16, float* dst) {
         if (BF3) {
-            // whole rows per request (zone_row_offset): lane l brings piece l % KS of row RPD it + l / KS
+            // whole rows per request: lane l brings piece l % KS of row RPD it + l / KS
             constexpr int RPD = zone_rows_per_request(KS), NIT = 16 / RPD;
             static_assert(16 % RPD == 0, "whole rows per request");
             const int r_in = lane / KS, piece = lane - r_in * KS;
@@ -1617,7 +1611,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const unsigned zone = __builtin_amdgcn_readfirstlane(
-                        (unsigned)(size_t)(__attribute__((address_space(3))) void*)(dst + zone_request_floats() * it));
+                        (unsigned)(size_t)(__attribute__((address_space(3))) void*)(dst + RPD * (4 * KS) * it));
                     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                                  :: "v"(src[it]), "s"(zone) : "memory", "m0");
                 }
@@ -1670,7 +1664,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         if (live) {
 #pragma unroll
         for (int u = 0; u < ROUND_TPW; ++u) {
-            if (BF3) round_raw_pieces<KS>(zb[u] + zone_row_offset(c16, KS), q, raw[u]);
+            if (BF3) round_raw_pieces<KS>(zb[u] + c16 * (4 * KS), q, raw[u]);
             else round_rows_from_lds<KS>(zb[u], c16, q, Zf[u]);
         }
         }
@@ -3846,7 +3840,7 @@ size_t round_lds_bytes(int K16, int dp, int G, int B, int V, bool bf3) {
     // sigma, -1/sigma, rp, lrp, rpc (V > 1) | O, S, T, objective scratch (fp64) | Pr_b, theta, group_cols (V <= 8), bgrp, block offsets | landing zones
     const size_t ys = bf3 ? (size_t)3 * K16 * bf3_ldb(dp / 4) : (size_t)K16 * lds_ldy(dp);   // centroids: three bf16 planes, or fp32 rows
     return (ys + 2 * (size_t)K16 + 2 * GK + (V == 1 ? 0 : (size_t)K16 * B)) * 4 + (2 * GK + K16 + 2 * ROUND_WAVES) * 8 +
-           (3 * (size_t)B + (size_t)G * 8 + 64) * 4 + 16 + (size_t)ROUND_WAVES * ROUND_TPW * zone_tile_floats(dp / 4, bf3) * 4
+           (3 * (size_t)B + (size_t)G * 8 + 64) * 4 + 16 + (size_t)ROUND_WAVES * ROUND_TPW * 16 * dp * 4
         ;
 }
 
@@ -3938,9 +3932,9 @@ static void launch_round_ks(const RoundArgs& a, int mt, int wgs, size_t sm, hipS
         default: launch_round_t<7, KS, BF3>(a, wgs, sm, s); break;
     }
 }
-// The bf16-pipe form of the distance GEMM (round_compute_bf3) keeps the centroids as three bf16 planes and lands whole rows
-// per request: 41 KB more LDS at K = 100, d = 50 than the f32-input form, whose instances stay for the shapes that need the
-// room for their tables (16 to 30 batch groups at that K) -- and under HMX_ROUND_F32=1, the switch of the A/B runs.
+// The bf16-pipe form of the distance GEMM (round_compute_bf3) keeps the centroids as three bf16 planes: 25 KB more LDS at
+// K = 100, d = 50 than the f32-input form, whose instances stay for the shapes that need the room for their tables (21 to 30
+// batch groups at that K) -- and under HMX_ROUND_F32=1, the switch of the A/B runs.
 bool round_uses_bf16_pipe(int K16, int dp, int G, int B, int V) {
     static const bool forced_f32 = [] { const char* v = getenv("HMX_ROUND_F32"); return v && atoi(v) != 0; }();
     return HMX_ROUND_BF3 && HMX_ROUND_EXP2 && !forced_f32 && round_lds_bytes(K16, dp, G, B, V, true) <= HMX_ROUND_LDS_LIMIT;
