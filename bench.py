@@ -53,6 +53,9 @@ CONFIGS = {
     # all 10M cells of BASELINE configs[3] on ONE GPU (R = 4.5 GB of the 288 GB)
     "c4x1": (10_000_000, 50, 16, 100),
 }
+if os.environ.get("BENCH_SHAPE"):   # experiments only: "name=N,d,B,K" replaces a configuration's shape (the line then describes that shape)
+    _n, _v = os.environ["BENCH_SHAPE"].split("=")
+    CONFIGS[_n] = tuple(int(x) for x in _v.split(","))
 CONFIG_INDEX = {"c2": 1, "c3": 2, "c4": 3, "c5": 4, "c4x1": 3}
 # cells of the whole job of the configurations BASELINE.json defines over several GPUs (sharded evenly: strong scaling)
 JOB_CELLS = {"c4": 10_000_000, "c5": 10_000_000}

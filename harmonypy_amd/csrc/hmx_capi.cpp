@@ -1216,8 +1216,9 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
             if (prof.reserve((size_t)wgs * e->nblk * 16)) return -1;
             ra.prof = prof.p;
 #endif
-            if (launch_round(ra, e->mt, multi ? wgs + 1 : wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported shape for k_round");
-            if (round_uses_bf16_pipe(ra.K16, ra.dp, ra.G, ra.B, ra.V)) e->n_sweeps_bf16++;
+            const bool extra_tiles = max_upper > 16 * wgs;   // (ROUND_TPW x ROUND_WAVES slots per workgroup)
+            if (launch_round(ra, e->mt, multi ? wgs + 1 : wgs, e->stream, extra_tiles)) return fail(HMX_ERR_ARG, "unsupported shape for k_round");
+            if (round_uses_bf16_pipe(ra.K16, ra.dp, ra.G, ra.B, ra.V, extra_tiles)) e->n_sweeps_bf16++;
 #ifdef HMX_ROUND_PROF
             if (++prof_rounds == 25) {   // one round in steady state: phase durations over workgroups and blocks
                 std::vector<unsigned long long> h((size_t)wgs * e->nblk * 16);

@@ -229,11 +229,11 @@ int sweep_row_floats(int d);
 int sweep_waves();
 int launch_sweep(const SweepArgs& a, int mt, int d, int wgs, hipStream_t s);
 size_t round_lds_bytes(int K16, int dp, int G, int B, int V, bool bf3);
-bool round_uses_bf16_pipe(int K16, int dp, int G, int B, int V);   // which k_round instance launch_round picks
+bool round_uses_bf16_pipe(int K16, int dp, int G, int B, int V, bool extra_tiles);   // which k_round instance launch_round picks
 // k_round has no static LDS and one workgroup per CU: everything the CU has (160 KB), less a small margin
 #define HMX_ROUND_LDS_LIMIT (size_t)(159 * 1024)
 int round_row_floats(int d);
-int launch_round(const RoundArgs& a, int mt, int wgs, hipStream_t s);
+int launch_round(const RoundArgs& a, int mt, int wgs, hipStream_t s, bool extra_tiles);   // extra_tiles: a block holds more tiles than the grid's 16 slots per workgroup
 size_t peer_box_doubles(int n_ranks, size_t GK);
 void launch_peer_selftest(double* const* peer_box, double* my_box, int n_ranks, int rank, size_t GK, unsigned long long token,
                           unsigned* result, hipStream_t s);

@@ -376,6 +376,7 @@ def test_bench_path_parity_blocks_larger_than_the_grid(wgs, monkeypatch):
     ho = _bench_path_case(150_000, 50, 8, 100, monkeypatch, ridge_dtype=np.float64, rounds=(3, 2))
     cnt = ho._engine.counters()
     assert cnt["sweep_waits"] > 0 and cnt["sweep_fallbacks"] == 0, cnt
+    assert cnt["sweeps_bf16_pipe"] == 0, cnt     # such blocks go to the f32-input instances (round_uses_bf16_pipe: the extra-tile loop does not hide the split)
 
 
 def test_bench_path_parity_many_batches(monkeypatch):
