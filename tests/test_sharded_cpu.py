@@ -67,7 +67,7 @@ def test_sharded_oracle_reproduces_reference_golden(case, tmp_path):
     np.testing.assert_array_equal(res[0]["objective_kmeans"], res[1]["objective_kmeans"])
 
 
-@pytest.mark.parametrize("world,case", [(4, "pbmc_short"), (4, "pbmc_two_vars"), (8, "pbmc_default"), (8, "pbmc_short")])
+@pytest.mark.parametrize("world,case", [(4, "pbmc_short"), (4, "pbmc_two_vars"), (4, "pbmc_default"), (8, "pbmc_short")])
 def test_sharded_oracle_world_4_and_8(world, case, tmp_path):
     """The same with 4 and 8 ranks (the C ABI allows 8: hmx_set_ranks): uneven contiguous slices of the donor-sorted
     pbmc cells, so most ranks hold a SINGLE donor (their other batch groups are empty) and no rank sees every level --
