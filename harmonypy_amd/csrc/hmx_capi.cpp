@@ -612,8 +612,12 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
         e->ntasks3 = 0;
         if (contig) {
             std::vector<int> a0, a1, ac0, acend, ag, ast;
-            const int target = std::max(1, 2 * e->n_cus - e->G);
-            const int CH3 = std::max(16, std::min(256, (n_static_tiles + target - 1) / target));
+            // k_rtz3 keeps two workgroups per CU resident, k_rtz3b (four tile buffers per wave) one: as many tasks as fit at once,
+            // or a second round of workgroups pays the prologue, the slab reduction and the tail again (measured: 188 us per
+            // pass with 505 tasks of 31 tiles per wave)
+            const bool one_per_cu = !rtz_wide_ok(e->mt, e->dp) && rtz3b_ok(e->mt, e->dp, e->nblk, e->Kp);
+            const int target = std::max(1, (one_per_cu ? 1 : 2) * e->n_cus - e->G);
+            const int CH3 = std::max(16, std::min(one_per_cu ? 2048 : 256, (n_static_tiles + target - 1) / target));
             // HMX_RTZ3_TASKS=contig: a task is a contiguous run of a group's tiles; default: the m tasks of a group take
             // neighbouring quads of tiles (task j: tiles ts + 4j + w + 4m i) and sweep the group's rows together
             const char* tk = getenv("HMX_RTZ3_TASKS");

@@ -150,6 +150,7 @@ struct Rtz3FinishArgs {
 bool rtz3_ok(int mt, int dp, int nblk, int G);
 int rtz3_ntb(int dp, int nblk);
 int rtz3_slab_floats(int mt, int dp, int nblk);
+bool rtz3b_ok(int mt, int dp, int nblk, int Kp);   // launch_rtz3 takes the bf16-pipe kernel k_rtz3b (one workgroup per CU)
 int launch_rtz3(const Rtz3Args& a, int mt, int dp, int nblk, hipStream_t s);
 void launch_rtz3_finish(const Rtz3FinishArgs& a, hipStream_t s);
 bool rtzw_ok(int mt, int dp, int d, int nblk, int G);
