@@ -338,7 +338,7 @@ class Engine:
         buf = np.zeros(8, np.int64)
         _check(self._lib.hmx_counters(self._h, _ptr(buf)))
         return {"collectives": int(buf[0]), "sweep_fallbacks": int(buf[1]), "seeded_rounds": int(buf[2]), "sweeps_bf16_pipe": int(buf[3]),
-                "sweep_waits": int(buf[4]), "sweep_wait_polls": int(buf[5]), "sweep_wait_polls_max": int(buf[6])}
+                "sweep_waits": int(buf[4]), "sweep_wait_polls": int(buf[5]), "sweep_wait_polls_max": int(buf[6]), "rtz_bf16_pipe": int(buf[7])}
 
     def kernel_times(self):
         """{family: (total_ms, launches)} since timing was enabled."""

@@ -114,6 +114,9 @@ struct hmx_engine {
     int sweep_kernel = 0;        // 0: k_round + R^T.Z pass with the removal sums (faster at C3: DESIGN.md §3), 1: k_sweep (hmx_sweep.hip; HMX_SWEEP=1)
     unsigned spin_limit = 1u << 24;  // polls a grid-wide wait may take (HMX_SPIN_LIMIT; tests shrink it to force the fall-back)
     long n_sweep_fallbacks = 0;  // rounds repeated through the per-block path after a wait timed out
+    long n_rtz_bf16 = 0;         // R^T.Z passes launched on the bf16-pipe instance k_rtz3b
+    bool allow_round_bf16 = true;   // HMX_ROUND_F32=1 at hmx_create: the f32-input instances of k_round (A/B runs and tests)
+    bool allow_rtz_bf16 = true;     // HMX_RTZ3_BF16=0 at hmx_create: k_rtz3 instead of k_rtz3b
     long n_sweeps_bf16 = 0;      // sweeps launched on the bf16-pipe instances of k_round (round_uses_bf16_pipe)
     DevBuf<unsigned long long> wait_stats;   // {waits, incomplete polls, most polls of one wait} of the sweep kernels' grid-wide waits
     DevBuf<double> xch;
@@ -392,6 +395,8 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
                                  "(python -m harmonypy_amd._build -DHMX_WITH_SWEEP)");
     }
 #endif
+    if (const char* rf = getenv("HMX_ROUND_F32")) e->allow_round_bf16 = atoi(rf) == 0;
+    if (const char* rb = getenv("HMX_RTZ3_BF16")) e->allow_rtz_bf16 = atoi(rb) != 0;
     if (const char* rk = getenv("HMX_RTZ")) e->rtz_kernel = atoi(rk) == 2 ? 2 : 3;
     if (const char* fs = getenv("HMX_TEST_FAIL_SWEEP")) e->test_fail_sweep = atol(fs);
     if (const char* sl = getenv("HMX_SPIN_LIMIT")) e->spin_limit = (unsigned)std::max(0L, atol(sl));   // 0: every wait of the persistent kernels gives up at once (tests)
@@ -615,7 +620,7 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
             // k_rtz3 keeps two workgroups per CU resident, k_rtz3b (four tile buffers per wave) one: as many tasks as fit at once,
             // or a second round of workgroups pays the prologue, the slab reduction and the tail again (measured: 188 us per
             // pass with 505 tasks of 31 tiles per wave)
-            const bool one_per_cu = !rtz_wide_ok(e->mt, e->dp) && rtz3b_ok(e->mt, e->dp, e->nblk, e->Kp);
+            const bool one_per_cu = !rtz_wide_ok(e->mt, e->dp) && e->allow_rtz_bf16 && rtz3b_ok(e->mt, e->dp, e->nblk, e->Kp);
             const int target = std::max(1, (one_per_cu ? 1 : 2) * e->n_cus - e->G);
             const int CH3 = std::max(16, std::min(one_per_cu ? 2048 : 256, (n_static_tiles + target - 1) / target));
             // HMX_RTZ3_TASKS=contig: a task is a contiguous run of a group's tiles; default: the m tasks of a group take
@@ -814,11 +819,25 @@ int hmx_kmeans_lloyd(hmx_engine* e, const float* centers_in, int n_iter, float* 
     return HMX_OK;
 }
 
+// An error return in the middle of a cluster() call may leave the sticky time-out word set (a sweep gave up, then a HIP call
+// failed before the replay cleared it): every later kernel would return at once and a "replay" would mix two rounds' state.
+// Called on every error return of hmx_cluster and at the head of hmx_init_cluster: drain, clear the word, forget what was
+// prepared ahead, defer no read-back before a sweep has been seen to complete.
+static void thaw(hmx_engine* e) {
+    (void)hipStreamSynchronize(e->stream);
+    if (e->stream2) (void)hipStreamSynchronize(e->stream2);
+    (void)hipMemsetAsync(e->frozen(), 0, sizeof(unsigned long long), e->stream);
+    e->pre_valid = false;
+    e->pre_outstanding = false;
+    e->clean_sweeps = 0;
+}
+
 int hmx_init_cluster(hmx_engine* e, const float* Y0, double obj_out[4]) {
     if (!e || !Y0 || !obj_out) return fail(HMX_ERR_ARG, "null argument");
     if (!e->uploaded) return fail(HMX_ERR_STATE, "hmx_upload must come first");
     int rc;
     if ((rc = use_device(e))) return rc;
+    thaw(e);
     std::vector<float> y((size_t)e->K16 * e->ldy, 0.f);
     for (int k = 0; k < e->K; ++k) std::memcpy(&y[(size_t)k * e->ldy], Y0 + (size_t)k * e->d, sizeof(float) * e->d);
     HIP_TRY(hipMemcpyAsync(e->Yacc.p, y.data(), y.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
@@ -875,7 +894,9 @@ static int rtz3_pass(hmx_engine* e, int mode, const unsigned char* tile_blk, int
         r.task_t0 = e->t3_t0.p; r.task_t1 = e->t3_t1.p; r.task_stride = e->t3_stride.p; r.task_c0 = e->t3_c0.p; r.task_cend = e->t3_cend.p;
         r.slab = e->slab.p; r.ntasks = e->ntasks3; r.Kp = e->Kp;
         r.frozen = duties ? e->frozen() : nullptr;   // (the fused round of a single engine: the only path whose read-back is deferred)
-        if (wide ? launch_rtzw(r, e->mt, e->dp, e->d, nblk_cols, e->stream) : launch_rtz3(r, e->mt, e->dp, nblk_cols, e->stream))
+        const int lr = wide ? launch_rtzw(r, e->mt, e->dp, e->d, nblk_cols, e->stream) : launch_rtz3(r, e->mt, e->dp, nblk_cols, e->stream, e->allow_rtz_bf16);
+        if (lr > 0) e->n_rtz_bf16++;
+        if (lr < 0)
             return fail(HMX_ERR_ARG, "unsupported shape for the streaming R^T.Z pass");
     }
     Timed t(e, mode == 1 ? F_RIDGE_STATS : F_RTZ_REDUCE);
@@ -1221,8 +1242,8 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
             ra.prof = prof.p;
 #endif
             const bool extra_tiles = max_upper > 16 * wgs;   // (ROUND_TPW x ROUND_WAVES slots per workgroup)
-            if (launch_round(ra, e->mt, multi ? wgs + 1 : wgs, e->stream, extra_tiles)) return fail(HMX_ERR_ARG, "unsupported shape for k_round");
-            if (round_uses_bf16_pipe(ra.K16, ra.dp, ra.G, ra.B, ra.V, extra_tiles)) e->n_sweeps_bf16++;
+            if (launch_round(ra, e->mt, multi ? wgs + 1 : wgs, e->stream, extra_tiles, e->allow_round_bf16)) return fail(HMX_ERR_ARG, "unsupported shape for k_round");
+            if (round_uses_bf16_pipe(ra.K16, ra.dp, ra.G, ra.B, ra.V, extra_tiles, e->allow_round_bf16)) e->n_sweeps_bf16++;
 #ifdef HMX_ROUND_PROF
             if (++prof_rounds == 25) {   // one round in steady state: phase durations over workgroups and blocks
                 std::vector<unsigned long long> h((size_t)wgs * e->nblk * 16);
@@ -1484,7 +1505,7 @@ int hmx_cluster(hmx_engine* e, uint64_t seed, int64_t cells_per_block, int max_r
         const bool may_defer = !(i > window) && i + 1 < n && n_pending < HMX_DEFER_MAX;
         rc = seeded_round(e, HMX_ROUND_ALL, seed, cells_per_block, o,
                           may_defer ? e->obj_defer + (size_t)n_pending * (2 * HMX_OBJ_SLOTS + 2) : nullptr, n_pending > 0);
-        if (rc < 0) return rc;
+        if (rc < 0) { thaw(e); return rc; }
         if (rc == 1) {                                              // deferred
             if (n_pending == 0) first_pending = i;
             ++n_pending;
@@ -1506,7 +1527,10 @@ int hmx_cluster(hmx_engine* e, uint64_t seed, int64_t cells_per_block, int max_r
             e->pre_outstanding = false;
             e->seeded_rounds = counter0 + (uint64_t)failed_round;
             i = failed_round;
-            if ((rc = seeded_round(e, HMX_ROUND_ALL, seed, cells_per_block, obj_out + 4 * (size_t)i, nullptr, false, true))) return rc < 0 ? rc : fail(HMX_ERR_STATE, "replay of round %d failed", i);
+            if ((rc = seeded_round(e, HMX_ROUND_ALL, seed, cells_per_block, obj_out + 4 * (size_t)i, nullptr, false, true))) {
+                thaw(e);
+                return rc < 0 ? rc : fail(HMX_ERR_STATE, "replay of round %d failed", i);
+            }
         }
         for (size_t j = hist.size(); j <= (size_t)i; ++j) {
             const double* oj = obj_out + 4 * j;
@@ -1521,7 +1545,7 @@ int hmx_cluster(hmx_engine* e, uint64_t seed, int64_t cells_per_block, int max_r
             if (std::fabs(obj_old - obj_new) / std::fabs(obj_old) < epsilon) break;
         }
     }
-    if (n_pending > 0) return fail(HMX_ERR_STATE, "internal: %d objective blocks unread at the end of hmx_cluster", n_pending);   // (the last round is always read back)
+    if (n_pending > 0) { thaw(e); return fail(HMX_ERR_STATE, "internal: %d objective blocks unread at the end of hmx_cluster", n_pending); }   // (the last round is always read back)
     *rounds_out = (int)std::max<size_t>(hist.size(), (size_t)*rounds_out);
     return HMX_OK;
 }
@@ -1838,7 +1862,7 @@ int hmx_counters(hmx_engine* e, int64_t out[8]) {
     out[4] = (int64_t)ws[0];
     out[5] = (int64_t)ws[1];
     out[6] = (int64_t)ws[2];
-    out[7] = 0;
+    out[7] = e->n_rtz_bf16;
     return HMX_OK;
 }
 

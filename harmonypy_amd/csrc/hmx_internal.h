@@ -151,7 +151,7 @@ bool rtz3_ok(int mt, int dp, int nblk, int G);
 int rtz3_ntb(int dp, int nblk);
 int rtz3_slab_floats(int mt, int dp, int nblk);
 bool rtz3b_ok(int mt, int dp, int nblk, int Kp);   // launch_rtz3 takes the bf16-pipe kernel k_rtz3b (one workgroup per CU)
-int launch_rtz3(const Rtz3Args& a, int mt, int dp, int nblk, hipStream_t s);
+int launch_rtz3(const Rtz3Args& a, int mt, int dp, int nblk, hipStream_t s, bool allow_bf16);   // returns 1 when the bf16-pipe instance (k_rtz3b) ran, 0 for k_rtz3, -1 unsupported
 void launch_rtz3_finish(const Rtz3FinishArgs& a, hipStream_t s);
 bool rtzw_ok(int mt, int dp, int d, int nblk, int G);
 int rtzw_nt(int dp, int d, int nblk);
@@ -230,11 +230,11 @@ int sweep_row_floats(int d);
 int sweep_waves();
 int launch_sweep(const SweepArgs& a, int mt, int d, int wgs, hipStream_t s);
 size_t round_lds_bytes(int K16, int dp, int G, int B, int V, bool bf3);
-bool round_uses_bf16_pipe(int K16, int dp, int G, int B, int V, bool extra_tiles);   // which k_round instance launch_round picks
+bool round_uses_bf16_pipe(int K16, int dp, int G, int B, int V, bool extra_tiles, bool allow_bf16);   // which k_round instance launch_round picks
 // k_round has no static LDS and one workgroup per CU: everything the CU has (160 KB), less a small margin
 #define HMX_ROUND_LDS_LIMIT (size_t)(159 * 1024)
 int round_row_floats(int d);
-int launch_round(const RoundArgs& a, int mt, int wgs, hipStream_t s, bool extra_tiles);   // extra_tiles: a block holds more tiles than the grid's 16 slots per workgroup
+int launch_round(const RoundArgs& a, int mt, int wgs, hipStream_t s, bool extra_tiles, bool allow_bf16);   // extra_tiles: a block holds more tiles than the grid's 16 slots per workgroup
 size_t peer_box_doubles(int n_ranks, size_t GK);
 void launch_peer_selftest(double* const* peer_box, double* my_box, int n_ranks, int rank, size_t GK, unsigned long long token,
                           unsigned* result, hipStream_t s);

@@ -3936,16 +3936,15 @@ static void launch_round_ks(const RoundArgs& a, int mt, int wgs, size_t sm, hipS
 // K = 100, d = 50 than the f32-input form, whose instances stay for the shapes that need the room for their tables (21 to 30
 // batch groups at that K), for blocks larger than the grid carries (`extra_tiles`: most tiles then go through the unpipelined
 // extra-tile loop, one tile per wave at a time, where the split is not hidden -- all 10 M cells of configs[3] on one GPU:
-// 3.22 ms per sweep against 3.03, profiles/r04_ab_k_round_bf16_pipe.txt) -- and under HMX_ROUND_F32=1, the switch of the A/B runs.
-bool round_uses_bf16_pipe(int K16, int dp, int G, int B, int V, bool extra_tiles) {
-    static const bool forced_f32 = [] { const char* v = getenv("HMX_ROUND_F32"); return v && atoi(v) != 0; }();
-    return HMX_ROUND_BF3 && HMX_ROUND_EXP2 && !forced_f32 && !extra_tiles && round_lds_bytes(K16, dp, G, B, V, true) <= HMX_ROUND_LDS_LIMIT;
+// 3.22 ms per sweep against 3.03, profiles/r04_ab_k_round_bf16_pipe.txt) -- and for engines created under HMX_ROUND_F32=1 (`allow_bf16` false), the switch of the A/B runs and of the direct A/B test.
+bool round_uses_bf16_pipe(int K16, int dp, int G, int B, int V, bool extra_tiles, bool allow_bf16) {
+    return HMX_ROUND_BF3 && HMX_ROUND_EXP2 && allow_bf16 && !extra_tiles && round_lds_bytes(K16, dp, G, B, V, true) <= HMX_ROUND_LDS_LIMIT;
 }
 
-int launch_round(const RoundArgs& a_in, int mt, int wgs, hipStream_t s, bool extra_tiles) {
+int launch_round(const RoundArgs& a_in, int mt, int wgs, hipStream_t s, bool extra_tiles, bool allow_bf16) {
     RoundArgs a = a_in;
     a.ldy_lds = lds_ldy(a.dp);
-    const bool bf3 = round_uses_bf16_pipe(a.K16, a.dp, a.G, a.B, a.V, extra_tiles);
+    const bool bf3 = round_uses_bf16_pipe(a.K16, a.dp, a.G, a.B, a.V, extra_tiles, allow_bf16);
     const size_t sm = round_lds_bytes(a.K16, a.dp, a.G, a.B, a.V, bf3);
     if (mt < 1 || mt > 7 || sm > HMX_ROUND_LDS_LIMIT) return -1;
     switch (a.dp) {

@@ -1115,8 +1115,7 @@ static void launch_rtz3_k(const Rtz3Args& a, int mt, int ntb, size_t sm, hipStre
 // ---- k_rtz3b: at most one extra one-hot tile (140 accumulators), four tile buffers per wave in one CU's LDS
 size_t rtz3b_lds_bytes(int Kp, int dp) { return (size_t)4 * RTZ3_WAVES * (16 * (Kp + dp) + 4) * sizeof(float); }
 bool rtz3b_ok(int mt, int dp, int nblk, int Kp) {
-    static const bool on = [] { const char* v = getenv("HMX_RTZ3_BF16"); return !v || atoi(v) != 0; }();
-    return on && rtz3_ntb(dp, nblk) <= 1 && std::max(rtz3b_lds_bytes(Kp, dp), (size_t)rtz3_slab_floats(mt, dp, nblk) * sizeof(float)) <= 160 * 1024;
+    return rtz3_ntb(dp, nblk) <= 1 && std::max(rtz3b_lds_bytes(Kp, dp), (size_t)rtz3_slab_floats(mt, dp, nblk) * sizeof(float)) <= 160 * 1024;
 }
 template <int MT, int KS, int NTB>
 static void launch_rtz3b_t(const Rtz3Args& a, size_t sm, hipStream_t s) {
@@ -1145,17 +1144,17 @@ static void launch_rtz3b_k(const Rtz3Args& a, int mt, int ntb, size_t sm, hipStr
 }
 
 // `nblk` decides the one-hot columns (1 for the ridge / centroid-only passes: column 0 = the plain column sums)
-int launch_rtz3(const Rtz3Args& a, int mt, int dp, int nblk, hipStream_t s) {
+int launch_rtz3(const Rtz3Args& a, int mt, int dp, int nblk, hipStream_t s, bool allow_bf16) {
     if (!rtz3_ok(mt, dp, nblk, 1) || a.ntasks <= 0) return -1;
     const int ntb = rtz3_ntb(dp, nblk);
-    if (rtz3b_ok(mt, dp, nblk, a.Kp)) {
+    if (allow_bf16 && rtz3b_ok(mt, dp, nblk, a.Kp)) {
         const size_t smb = std::max(rtz3b_lds_bytes(a.Kp, dp), (size_t)rtz3_slab_floats(mt, dp, nblk) * sizeof(float));
         switch (dp) {
             case 32: launch_rtz3b_k<8>(a, mt, ntb, smb, s); break;
             case 52: launch_rtz3b_k<13>(a, mt, ntb, smb, s); break;
             default: launch_rtz3b_k<16>(a, mt, ntb, smb, s); break;
         }
-        return 0;
+        return 1;
     }
     const size_t sm = std::max(rtz3_lds_bytes(a.Kp, dp), (size_t)rtz3_slab_floats(mt, dp, nblk) * sizeof(float));
     switch (dp) {

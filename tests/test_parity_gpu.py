@@ -389,6 +389,72 @@ def test_bench_path_parity_many_batches(monkeypatch):
     assert cnt["sweep_waits"] > 0 and cnt["sweeps_bf16_pipe"] == 0, cnt
 
 
+def _ab_engines(N, d, B, K, monkeypatch, switch, value):
+    """Two engines in ONE process on the same uploaded state, Y0 and seed (device update order): the default instances and
+    the ones an engine created under `switch`=`value` selects (the switches are read by hmx_create, per engine)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import quick_centroids, synthetic_dataset
+    monkeypatch.setenv("HMX_UPDATE_ORDER", "device")
+    Z, meta = synthetic_dataset(N, d, B, K, seed=5)
+    Y0 = quick_centroids(Z, K, seed=5, sample=20_000)
+    monkeypatch.delenv(switch, raising=False)
+    a = _run_engine(Z, meta, ["batch"], Y0=Y0, nclust=K, max_iter_harmony=0, random_state=7)
+    monkeypatch.setenv(switch, value)
+    b = _run_engine(Z, meta, ["batch"], Y0=Y0, nclust=K, max_iter_harmony=0, random_state=7)
+    monkeypatch.delenv(switch, raising=False)
+    return a, b
+
+
+AB_SHAPES = [(150_000, 50, 8, 100), (40_000, 50, 21, 100), (30_000, 17, 2, 7), (60_000, 32, 3, 30), (50_000, 64, 5, 112)]
+
+
+@pytest.mark.parametrize("N,d,B,K", AB_SHAPES)
+def test_bf16_pipe_distance_gemm_against_the_f32_input_instance(N, d, B, K, monkeypatch):
+    """Direct A/B of the sweep's distance GEMM (harmony.py:447) inside one build, on one state: k_round on the bf16 matrix
+    pipe (every fp32 operand as the exact sum of three bf16 terms, six products: hmx_device.h `bf16_split3`) against its
+    f32-input instance (HMX_ROUND_F32=1) -- the C3 shape, the 21-group edge (the most groups whose tables fit next to the
+    bf16 planes), rows of 17 / 32 / 64 PCs.  One seeded round each: the counters say which instance ran, the new R rows
+    differ by <= 4e-6, O by 1e-6 relative to the cluster masses, the three objective terms by 2e-6 relative.  A regression
+    in the split (a dropped term, a wrong plane pairing) shows as 1e-3 .. 1e-5 here, far above the bound."""
+    a, b = _ab_engines(N, d, B, K, monkeypatch, "HMX_ROUND_F32", "1")
+    a.cluster(_rounds=1)
+    b.cluster(_rounds=1)
+    ca, cb = a._engine.counters(), b._engine.counters()
+    assert ca["sweeps_bf16_pipe"] == 1 and cb["sweeps_bf16_pipe"] == 0, (ca, cb)
+    assert ca["sweep_fallbacks"] == 0 and cb["sweep_fallbacks"] == 0
+    Ra, Rb = a.R, b.R
+    dR = float(np.abs(Ra - Rb).max())
+    assert dR <= 4e-6, f"max |R(bf16x3) - R(f32 input)| = {dR:.2e}"
+    assert np.abs(a.O - b.O).max() <= 1e-6 * max(1.0, float(np.abs(b.O).max()))
+    for name in ("objective_kmeans_dist", "objective_kmeans_entropy", "objective_kmeans_cross", "objective_kmeans"):
+        va, vb = getattr(a, name)[-1], getattr(b, name)[-1]
+        assert abs(va - vb) <= 2e-6 * abs(vb), (name, va, vb)
+    print(f"bf16x3 vs f32-input distance GEMM {N}x{d} K={K} B={B}: max|dR|={dR:.2e}")
+
+
+@pytest.mark.parametrize("N,d,B,K", AB_SHAPES)
+def test_bf16_pipe_rtz_pass_against_the_f32_input_kernel(N, d, B, K, monkeypatch):
+    """Direct A/B of the streaming R^T.Z pass (harmony.py:443-444 centroid numerators, :491-492 removal sums, :550, :559-563
+    ridge statistics): k_rtz3b (both operands split in registers, bf16 pipe) against k_rtz3 (f32-input MFMA, engines
+    created under HMX_RTZ3_BF16=0), same shapes as above.  Two seeded rounds (the second round's pass reads the R the first
+    one wrote) + the ridge: Y atol 2e-6, O 1e-6 relative to the masses, R 4e-6, Z_corr 1e-6 relative Frobenius; the counter
+    says which kernel ran."""
+    a, b = _ab_engines(N, d, B, K, monkeypatch, "HMX_RTZ3_BF16", "0")
+    for h in (a, b):
+        h.cluster(_rounds=2)
+        h.moe_correct_ridge()
+    ca, cb = a._engine.counters(), b._engine.counters()
+    assert ca["rtz_bf16_pipe"] >= 3 and cb["rtz_bf16_pipe"] == 0, (ca, cb)
+    np.testing.assert_allclose(a.Y, b.Y, rtol=0, atol=2e-6)
+    assert np.abs(a.O - b.O).max() <= 1e-6 * max(1.0, float(np.abs(b.O).max()))
+    assert float(np.abs(a.R - b.R).max()) <= 4e-6
+    Za, Zb = a.Z_corr, b.Z_corr
+    rel = float(np.linalg.norm(Za - Zb) / np.linalg.norm(Zb))
+    assert rel <= 1e-6, f"Z_corr relF {rel:.2e}"
+    print(f"k_rtz3b vs k_rtz3 {N}x{d} K={K} B={B}: Y {np.abs(a.Y - b.Y).max():.2e}  Z_corr relF {rel:.2e}")
+
+
 def test_bench_path_parity_c5_shape(monkeypatch):
     """BASELINE configs[4]'s exact shape (d=200, K=200, 32 batches: the wide kernels) at 40k cells,
     seeded device-order rounds vs the oracle in its plain fp32 mode (the reference's arithmetic): objectives 2e-5,

@@ -118,3 +118,107 @@ def test_rtz3_round_trip(K, d, nblk):
         if blk[i] < nblk:
             S_ref[blk[i]] += R[i, :K]
     np.testing.assert_allclose(S, S_ref, rtol=1e-12, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------
+# k_rtz3b: the same pass on the bf16 matrix pipe.  A k-step of v_mfma_f32_16x16x32_bf16 is a PAIR of the wave's tiles;
+# lane (c16, q) supplies cells 8 (q & 1) .. + 8 of tile q >> 1 (hmx_device.h: A[i = l & 15][k = 8 (l >> 4) .. + 8]).
+# The split into three bf16 terms is value-preserving (tests/test_split_gemm.py), so the replay multiplies the values.
+# ------------------------------------------------------------------------------------------
+def mfma32(a_lane, b_lane, acc):
+    """v_mfma_f32_16x16x32_bf16: a_lane[l][j] = A[i = l & 15][k = 8 (l >> 4) + j], b_lane likewise B[k][j = l & 15]."""
+    A = np.zeros((16, 32))
+    B = np.zeros((32, 16))
+    for l in range(64):
+        A[l & 15, 8 * (l >> 4): 8 * (l >> 4) + 8] = a_lane[l]
+        B[8 * (l >> 4): 8 * (l >> 4) + 8, l & 15] = b_lane[l]
+    D = A @ B
+    for l in range(64):
+        for r in range(4):
+            acc[l, r] += D[4 * (l >> 4) + r, l & 15]
+
+
+def kernel_pair_b(tiles, MT, KS, NTB, Kp, acc):
+    """One pair of tiles through k_rtz3b's fragment construction.  tiles: two (Rt 16 x Kp, Zt 16 x 4KS, blk 16, n_live);
+    n_live = 0 stands for the missing second tile of an odd count (its buffer holds the first tile again, zeroed, ids 255)."""
+    NT, DP = 4 + NTB, 4 * KS
+    H, REM = MT // 4, MT % 4
+    bufs = []
+    for Rt, Zt, blk, n_live in tiles:
+        Rt, Zt, blk = Rt.copy(), Zt.copy(), blk.copy()
+        Rt[n_live:] = 0.0
+        Zt[n_live:] = 0.0
+        if n_live == 0:
+            blk[:] = 255
+        bufs.append((Rt, Zt, blk))
+    afr = np.zeros((MT, 64, 8))
+    bfr = np.zeros((NT, 64, 8))
+    for lane in range(64):
+        c16, q = lane & 15, lane >> 4
+        Rt, Zt, blk = bufs[q >> 1]
+        for j in range(8):
+            cell = 8 * (q & 1) + j
+            bid = int(blk[cell])
+            zc = 4 * min(c16, KS - 1)
+            for nt in range(4):
+                bfr[nt, lane, j] = Zt[cell, zc + nt] if c16 < KS else (1.0 if bid == 4 * c16 + nt - DP else 0.0)
+            if NTB > 0:
+                bfr[4, lane, j] = 1.0 if bid == (64 - DP) + c16 else 0.0
+            for h in range(H):
+                for jj in range(4):
+                    afr[4 * h + jj, lane, j] = Rt[cell, 64 * h + 4 * c16 + jj]
+            for jj in range(REM):
+                col = 64 * H + REM * c16 + jj
+                afr[4 * H + jj, lane, j] = Rt[cell, col] if col < Kp else 0.0
+    for mt in range(MT):
+        for nt in range(NT):
+            mfma32(afr[mt], bfr[nt], acc[mt][nt])
+
+
+@pytest.mark.parametrize("K,d,nblk,n_tiles,last_live", [
+    (100, 50, 20, 4, 16), (100, 50, 20, 3, 9),      # C3: round pass (one one-hot tile), odd tile count + a group's ragged end
+    (100, 50, 1, 2, 16), (30, 30, 1, 5, 3),         # ridge / centroid-only passes: no block tile at 52 / 32-float rows
+    (64, 64, 1, 2, 16), (112, 64, 16, 3, 16),       # 64-float rows: the one-hot tile carries every block column
+    (30, 30, 20, 2, 16), (17, 33, 8, 1, 5), (5, 3, 1, 1, 16), (48, 17, 28, 4, 1)])
+def test_rtz3b_pair_round_trip(K, d, nblk, n_tiles, last_live):
+    """Every (row length, cluster-tile count, block-tile count) family launch_rtz3 hands to k_rtz3b, with the pair
+    bookkeeping: odd tile counts (the spare buffer requests the first tile again and counts for nothing) and a last tile
+    that runs past the group's end."""
+    rng = np.random.default_rng(K * 977 + d * 31 + nblk)
+    Kp, MT = (K + 3) & ~3, (K + 15) // 16
+    dp = 32 if d <= 32 else 52 if d <= 52 else 64
+    KS = dp // 4
+    NTB = max(0, (nblk - (64 - dp) + 15) // 16)
+    assert NTB <= 1                                          # rtz3b_ok
+    NT = 4 + NTB
+    R = rng.random((16 * n_tiles, Kp))
+    R[:, K:] = 0.0
+    Z = rng.normal(size=(16 * n_tiles, dp))
+    Z[:, d:] = 0.0
+    blk = rng.integers(0, nblk, size=16 * n_tiles)
+    live = [16] * (n_tiles - 1) + [last_live]
+    acc = [[np.zeros((64, 4)) for _ in range(NT)] for _ in range(MT)]
+    for i in range((n_tiles + 1) // 2):
+        pair = []
+        for u in range(2):
+            t = 2 * i + u
+            if t < n_tiles:
+                pair.append((R[16 * t:16 * t + 16], Z[16 * t:16 * t + 16], blk[16 * t:16 * t + 16], live[t]))
+            else:
+                t = 2 * i                                    # request_pair: the first tile again, into the spare buffer
+                pair.append((R[16 * t:16 * t + 16], Z[16 * t:16 * t + 16], blk[16 * t:16 * t + 16], 0))
+        kernel_pair_b(pair, MT, KS, NTB, Kp, acc)
+    slab = np.zeros(MT * NT * 256)
+    for mt in range(MT):
+        for nt in range(NT):
+            for r in range(4):
+                for lane in range(64):
+                    slab[(mt * NT + nt) * 256 + lane * 4 + r] = acc[mt][nt][lane, r]
+    Y, S = finish(slab, MT, KS, NTB, K, d, nblk)
+    keep = np.concatenate([np.arange(16) < n for n in live])
+    Rl, Zl = R[keep], Z[keep]
+    np.testing.assert_allclose(Y, Rl[:, :K].T @ Zl[:, :d], rtol=1e-12, atol=1e-12)
+    S_ref = np.zeros((nblk, K))
+    for i in np.flatnonzero(keep):
+        S_ref[blk[i]] += R[i, :K]
+    np.testing.assert_allclose(S, S_ref, rtol=1e-12, atol=1e-12)
