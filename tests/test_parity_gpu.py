@@ -389,7 +389,7 @@ def test_bench_path_parity_many_batches(monkeypatch):
     assert cnt["sweep_waits"] > 0 and cnt["sweeps_bf16_pipe"] == 0, cnt
 
 
-def _ab_engines(N, d, B, K, monkeypatch, switch, value):
+def _ab_engines(N, d, B, K, monkeypatch, switch, value, **kw):
     """Two engines in ONE process on the same uploaded state, Y0 and seed (device update order): the default instances and
     the ones an engine created under `switch`=`value` selects (the switches are read by hmx_create, per engine)."""
     import os, sys
@@ -399,9 +399,9 @@ def _ab_engines(N, d, B, K, monkeypatch, switch, value):
     Z, meta = synthetic_dataset(N, d, B, K, seed=5)
     Y0 = quick_centroids(Z, K, seed=5, sample=20_000)
     monkeypatch.delenv(switch, raising=False)
-    a = _run_engine(Z, meta, ["batch"], Y0=Y0, nclust=K, max_iter_harmony=0, random_state=7)
+    a = _run_engine(Z, meta, ["batch"], Y0=Y0, nclust=K, max_iter_harmony=0, random_state=7, **kw)
     monkeypatch.setenv(switch, value)
-    b = _run_engine(Z, meta, ["batch"], Y0=Y0, nclust=K, max_iter_harmony=0, random_state=7)
+    b = _run_engine(Z, meta, ["batch"], Y0=Y0, nclust=K, max_iter_harmony=0, random_state=7, **kw)
     monkeypatch.delenv(switch, raising=False)
     return a, b
 
@@ -433,14 +433,16 @@ def test_bf16_pipe_distance_gemm_against_the_f32_input_instance(N, d, B, K, monk
     print(f"bf16x3 vs f32-input distance GEMM {N}x{d} K={K} B={B}: max|dR|={dR:.2e}")
 
 
-@pytest.mark.parametrize("N,d,B,K", AB_SHAPES)
-def test_bf16_pipe_rtz_pass_against_the_f32_input_kernel(N, d, B, K, monkeypatch):
+# (rows of 64 floats: k_rtz3b serves at most one extra one-hot tile = 16 update blocks there, and K <= 64 so that its four
+# tile buffers per wave fit one CU's LDS; the 112-cluster shape of AB_SHAPES stays on k_rtz3 whatever the switch says)
+@pytest.mark.parametrize("N,d,B,K,bs", [s + (0.05,) for s in AB_SHAPES[:4]] + [(50_000, 64, 5, 64, 1.0 / 16)])
+def test_bf16_pipe_rtz_pass_against_the_f32_input_kernel(N, d, B, K, bs, monkeypatch):
     """Direct A/B of the streaming R^T.Z pass (harmony.py:443-444 centroid numerators, :491-492 removal sums, :550, :559-563
     ridge statistics): k_rtz3b (both operands split in registers, bf16 pipe) against k_rtz3 (f32-input MFMA, engines
     created under HMX_RTZ3_BF16=0), same shapes as above.  Two seeded rounds (the second round's pass reads the R the first
     one wrote) + the ridge: Y atol 2e-6, O 1e-6 relative to the masses, R 4e-6, Z_corr 1e-6 relative Frobenius; the counter
     says which kernel ran."""
-    a, b = _ab_engines(N, d, B, K, monkeypatch, "HMX_RTZ3_BF16", "0")
+    a, b = _ab_engines(N, d, B, K, monkeypatch, "HMX_RTZ3_BF16", "0", block_size=bs)
     for h in (a, b):
         h.cluster(_rounds=2)
         h.moe_correct_ridge()
