@@ -332,6 +332,7 @@ AssignArgs assign_args(hmx_engine* e) {
     a.obj = e->objacc;
     a.K = e->K; a.Kp = e->Kp; a.K16 = e->K16; a.mt = e->mt; a.dp = e->dp; a.ldy = e->ldy;
     a.G = e->G; a.tiles_per_wave = e->tiles_per_wave; a.ablate = e->ablate;
+    a.bf16_pipe = e->allow_round_bf16 ? 1 : 0;
     return a;
 }
 
@@ -620,7 +621,7 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
             // k_rtz3 keeps two workgroups per CU resident, k_rtz3b (four tile buffers per wave) one: as many tasks as fit at once,
             // or a second round of workgroups pays the prologue, the slab reduction and the tail again (measured: 188 us per
             // pass with 505 tasks of 31 tiles per wave)
-            const bool one_per_cu = !rtz_wide_ok(e->mt, e->dp) && e->allow_rtz_bf16 && rtz3b_ok(e->mt, e->dp, e->nblk, e->Kp);
+            const bool one_per_cu = e->allow_rtz_bf16 && (rtz_wide_ok(e->mt, e->dp) ? rtzw2b_ok(e->mt, e->dp, e->d, e->nblk) : rtz3b_ok(e->mt, e->dp, e->nblk, e->Kp));
             const int target = std::max(1, (one_per_cu ? 1 : 2) * e->n_cus - e->G);
             const int CH3 = std::max(16, std::min(one_per_cu ? 2048 : 256, (n_static_tiles + target - 1) / target));
             // HMX_RTZ3_TASKS=contig: a task is a contiguous run of a group's tiles; default: the m tasks of a group take
@@ -851,7 +852,7 @@ int hmx_init_cluster(hmx_engine* e, const float* Y0, double obj_out[4]) {
         AssignArgs a = assign_args(e);
         a.cells = e->s_cells.p; a.tile_grp = e->s_tile_grp.p; a.S_out = e->Ogrp.p;  // O = R Phi^T exactly (:389)
         a.tile_begin = 0; a.tile_end = e->n_s_tiles;
-        if (launch_assign(a, false, e->max_wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported cluster count");
+        if (launch_assign(a, false, e->max_wgs, e->stream) < 0) return fail(HMX_ERR_ARG, "unsupported cluster count");
     }
     if ((rc = sum_over_ranks(e, e->Ogrp.p, GK)) || (rc = sum_over_ranks(e, e->objacc, 2 * HMX_OBJ_SLOTS))) return rc;
     {
@@ -894,7 +895,7 @@ static int rtz3_pass(hmx_engine* e, int mode, const unsigned char* tile_blk, int
         r.task_t0 = e->t3_t0.p; r.task_t1 = e->t3_t1.p; r.task_stride = e->t3_stride.p; r.task_c0 = e->t3_c0.p; r.task_cend = e->t3_cend.p;
         r.slab = e->slab.p; r.ntasks = e->ntasks3; r.Kp = e->Kp;
         r.frozen = duties ? e->frozen() : nullptr;   // (the fused round of a single engine: the only path whose read-back is deferred)
-        const int lr = wide ? launch_rtzw(r, e->mt, e->dp, e->d, nblk_cols, e->stream) : launch_rtz3(r, e->mt, e->dp, nblk_cols, e->stream, e->allow_rtz_bf16);
+        const int lr = wide ? launch_rtzw(r, e->mt, e->dp, e->d, nblk_cols, e->stream, e->allow_rtz_bf16) : launch_rtz3(r, e->mt, e->dp, nblk_cols, e->stream, e->allow_rtz_bf16);
         if (lr > 0) e->n_rtz_bf16++;
         if (lr < 0)
             return fail(HMX_ERR_ARG, "unsupported shape for the streaming R^T.Z pass");
@@ -975,7 +976,7 @@ static int lloyd_wide(hmx_engine* e, const float* centers_in, int n_iter, float*
         a.Y = e->Yacc.p; a.hn = e->km_hn.p;
         a.cells = e->s_cells.p; a.tile_grp = e->s_tile_grp.p; a.S_out = e->Ogrp.p;
         a.tile_begin = 0; a.tile_end = e->n_s_tiles;
-        if (launch_assign(a, false, e->max_wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported cluster count");
+        if (launch_assign(a, false, e->max_wgs, e->stream) < 0) return fail(HMX_ERR_ARG, "unsupported cluster count");
         if ((rc = rtz3_pass(e, 2, e->tile_blk_zero.p, 1, false, false))) return rc;
         if ((rc = sum_over_ranks(e, e->Sr, GK * e->ldy + GK))) return rc;   // Sr and Oxr are neighbours
         launch_kmeans_sums_from_stats(e->Sr, e->Oxr, e->G, e->K16, e->ldy, e->d, e->km_sums.p, e->stream);
@@ -1073,6 +1074,7 @@ static int round_sweep(hmx_engine* e, int flags, const std::vector<int>& tiles_u
 static int blocks_loop(hmx_engine* e, int flags, const std::vector<int>& tiles_upper) {
     int rc;
     const size_t GK = (size_t)e->G * e->K16;
+    int bf16_blocks = 0;                                            // blocks assigned by the bf16-pipe instance of the wide kernel
     for (int b = 0; b < e->nblk; ++b) {
         {
             Timed t(e, F_BLOCK_TABLE);
@@ -1090,13 +1092,16 @@ static int blocks_loop(hmx_engine* e, int flags, const std::vector<int>& tiles_u
             a.cells = e->lists[e->cur].cells.p; a.tile_grp = e->lists[e->cur].tile_grp.p; a.S_out = e->Snew + GK * b;
             a.blk_start = e->lists[e->cur].blk_start.p; a.blk = b;
             a.tile_begin = 0; a.tile_end = tiles_upper[b];
-            if (launch_assign(a, true, e->max_wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported cluster count");
+            const int la = launch_assign(a, true, e->max_wgs, e->stream);
+            if (la < 0) return fail(HMX_ERR_ARG, "unsupported cluster count");
+            if (la > 0) bf16_blocks++;
         }
         // the block's new sums (:506-507) over all ranks; the last block takes the two objective
         // sums (:399, :402) along: objacc follows Snew in xch
         const bool last = b == e->nblk - 1;
         if ((rc = sum_over_ranks(e, e->Snew + GK * b, GK + (last ? 2 * HMX_OBJ_SLOTS : 0)))) return rc;
     }
+    if (bf16_blocks > 0) e->n_sweeps_bf16++;
     Timed t(e, F_BLOCK_TABLE);
     TableArgs ta = table_args(e);  // close the round: O, T state and the cross-entropy term
     ta.O_prev = e->Ohist.p + GK * (e->nblk - 1);

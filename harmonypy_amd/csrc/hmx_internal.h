@@ -25,6 +25,7 @@ struct AssignArgs {
     int tile_begin, tile_end;  // host-side range (or an upper bound of its length when blk_start)
     int K, Kp, K16, mt, dp, ldy;
     int G, ldy_lds, tables_in_lds, tiles_per_wave, ablate;
+    int bf16_pipe;         // wide shapes: the bf16-pipe instance k_assign_wide2b (0: engines created under HMX_ROUND_F32=1 keep k_assign_wide2)
     const float* hn;       // k_assign_wide without penalty only: half squared norms of the centres in Y (+inf for pads) -> HARD
                            // assignment of the device k-means (a one-hot row of R per cell) instead of the softmax; null otherwise
 };
@@ -156,7 +157,8 @@ void launch_rtz3_finish(const Rtz3FinishArgs& a, hipStream_t s);
 bool rtzw_ok(int mt, int dp, int d, int nblk, int G);
 int rtzw_nt(int dp, int d, int nblk);
 int rtzw_slab_floats(int mt, int dp, int d, int nblk);
-int launch_rtzw(const Rtz3Args& a, int mt, int dp, int d, int nblk, hipStream_t s);
+bool rtzw2b_ok(int mt, int dp, int d, int nblk);   // launch_rtzw takes the bf16-pipe kernel k_rtzw2b (one workgroup per CU)
+int launch_rtzw(const Rtz3Args& a, int mt, int dp, int d, int nblk, hipStream_t s, bool allow_bf16);   // 1: k_rtzw2b ran, 0: an f32-input kernel, -1 unsupported
 void launch_tile_blocks(const int* cells, const int* tile_grp, const int* blk_start, int nblk, int64_t n_pos_upper, const int* gstart,
                         const int* s_tile_start, unsigned char* tile_blk, hipStream_t s);
 
@@ -298,7 +300,7 @@ void launch_order(const OrderArgs& a, hipStream_t s);
 int order_chunks(int64_t N);
 void launch_normalize_rows(const float* Z, float* Zc, int64_t N, int dp, hipStream_t s);
 void launch_y_normalize(const float* src, float* dst, int K, int K16, int d, int ldy, hipStream_t s);
-int launch_assign(const AssignArgs& a, bool penalty, int max_wgs, hipStream_t s);
+int launch_assign(const AssignArgs& a, bool penalty, int max_wgs, hipStream_t s);   // 1: the bf16-pipe wide instance ran, 0: another kernel, -1 unsupported
 void rtz_geometry(int mt, int ntd, int* nsub, int* slab_per_wave);
 bool rtz2_ok(int mt, int dp);
 bool rtz_wide_ok(int mt, int dp);

@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "hmx_internal.h"
@@ -905,6 +906,236 @@ __global__ __launch_bounds__(64 * RTZW2_WAVES, 2) void k_rtzw2(Rtz3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_rtzw2b: k_rtzw2 on the bf16 matrix pipe (hmx_device.h: every fp32 operand as the exact sum of three bf16 terms, six
+// products, fp32 accumulation).  configs[4] is bound by the f32-input MFMA outright (8 x 32 cycles per 32 cells and output
+// tile; here 6 x 16), so this is where the split moves the BOUND, not only the constant.  The k index runs over cells: a
+// k-step of v_mfma_f32_16x16x32_bf16 is a PAIR of the task's tiles, lane (c16, q) supplies cells 8 (q & 1) .. + 8 of tile
+// q >> 1 (as in k_rtz3b), both operands are split in registers.  Same tasks, same 2 x 2 split of the MT x NT output tiles
+// over four waves, same slabs and finish kernel as k_rtzw2.  What is different besides the multiply:
+//   * one workgroup per CU (512 registers per lane: 196 accumulators + the 84 registers of the column half's B planes);
+//   * the tiles travel global -> registers -> LDS with ORDINARY loads (non-temporal), half a pair at a time, under the
+//     multiply of the pair before: the compiler counts the waits, rows past the group's end (and the missing second tile
+//     of an odd count) are written as zeros -- no live-row factor, no select in the loop -- and an LDS-DMA request's
+//     ~200 cycles of issue (k_rtzw2's stamps: 1.9 k of a tile's 16.4 k) are not paid by a wave that has no partner on its SIMD;
+//   * A values come as 16-byte LDS reads (four cluster tiles of the permuted row map per read);
+//   * every column tile takes the same six products -- a PC tile, the tile whose padding carries the first one-hot block
+//     columns, a pure one-hot tile (its m and l planes are zero) or a tile past NT (all zero): no branch in the multiply.
+// ------------------------------------------------------------------------------------------
+#define RTZWB_WAVES 4
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F& f) {                    // f(integral_constant<int, I>) for I .. N-1, unrolled by construction
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+template <int MT, int NTH>
+__global__ __launch_bounds__(64 * RTZWB_WAVES, 1) void k_rtzw2b(Rtz3Args a) {
+    if (a.frozen && *a.frozen) return;
+    constexpr int MTA = (MT + 1) / 2;
+    constexpr int H = MT / 4, REM = MT % 4;
+    constexpr int NRP = (64 * MT + 255) / 256;                       // 16-byte pieces of an R tile per thread (16 rows x Kp <= 16 MT floats)
+    constexpr int NZP = 4;                                           // ... of a Z tile (dp <= 208: 832 pieces)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* lds = reinterpret_cast<float*>(smem);
+    const int Kp = a.Kp, DP = a.dp, d = a.d, NT = a.nt, NTP = DP >> 4;
+    const int buf_floats = 256 * MT + 16 * DP + 4;                   // R tile (rows at stride Kp, padded to MT KB) | Z tile | 16 block-id bytes
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, c16 = lane & 15, q = lane >> 4;
+    const int task = blockIdx.x;
+    const int t0 = a.task_t0[task], t1 = a.task_t1[task];
+    const int c_first = a.task_c0[task], c_end = a.task_cend[task];
+    const int stride = __builtin_amdgcn_readfirstlane(a.task_stride[task]);
+    const int n_tiles = (t1 - t0 + stride - 1) / stride;
+    const int n_pairs = (n_tiles + 1) / 2;
+    if (n_tiles <= 0) return;                                         // (workgroup-uniform; the slab of such a task is never read: no task is built without a tile)
+    const int rh = wv >> 1, ch = wv & 1;                             // this wave's quarter of the output: row half, column half
+    const int nt_lo = ch * NTH;
+    const int spare = DP - d;
+
+    // ---- staging: tile `ti` of the task (clamped: a missing tile is loaded from the last one and written as zeros) ----
+    f32x4 sr[NRP], sz[NZP], sid;
+    auto load_tile = [&](int ti) {
+        const int tc = min(ti, n_tiles - 1);
+        const size_t cell0 = (size_t)c_first + (size_t)16 * stride * tc;
+        const float* rsrc = a.R + cell0 * Kp;
+        const float* zsrc = a.Z + cell0 * DP;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NRP; ++j) {
+            const int p = tid + 256 * j;
+            sr[j] = (p < 4 * Kp) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rsrc) + p) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < NZP; ++j) {
+            const int p = tid + 256 * j;
+            sz[j] = (p < 4 * DP) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(zsrc) + p) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        sid = (tid == 0) ? *reinterpret_cast<const f32x4*>(a.tile_blk + (size_t)16 * (t0 + (size_t)stride * tc)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto store_tile = [&](int ti, int b) {                            // ... into tile buffer b (0..3)
+        const int cell0 = c_first + 16 * stride * min(ti, n_tiles - 1);
+        const int n_live = ti < n_tiles ? min(16, c_end - cell0) : 0; // rows of the tile inside the group (workgroup-uniform)
+        float* Rt = lds + (size_t)b * buf_floats;
+        float* Zt = Rt + 256 * MT;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NRP; ++j) {
+            const int p = tid + 256 * j;
+            if (p < 4 * Kp) st4(Rt + 4 * p, (4 * p < n_live * Kp) ? sr[j] : (f32x4){0.f, 0.f, 0.f, 0.f});
+        }
+#pragma unroll
+        for (int j = 0; j < NZP; ++j) {
+            const int p = tid + 256 * j;
+            if (p < 4 * DP) st4(Zt + 4 * p, (4 * p < n_live * DP) ? sz[j] : (f32x4){0.f, 0.f, 0.f, 0.f});
+        }
+        if (tid == 0) st4(Zt + 16 * DP, sid);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    auto body = [&](auto rh_c) {
+        constexpr int RH = decltype(rh_c)::value;
+        constexpr int LO = RH * MTA, HI = RH ? MT : MTA;              // this wave's row tiles
+        f32x4 acc[MTA][NTH];
+#pragma unroll
+        for (int t = 0; t < MTA; ++t)
+#pragma unroll
+            for (int u = 0; u < NTH; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        load_tile(0);
+        store_tile(0, 0);
+        load_tile(1);
+        store_tile(1, 1);
+
+        for (int i = 0; i < n_pairs; ++i) {
+            wg_barrier_lds();                                         // pair i is complete in LDS; nobody reads pair i-1 any more
+            const float* pb = lds + (size_t)(2 * (i & 1)) * buf_floats;
+            const int nb = 2 * ((i + 1) & 1);                         // the tile buffers of pair i+1 (pair i-1's)
+            load_tile(2 * i + 2);                                     // travels under the B planes and the first row tiles
+            // lane (c16, q): k slot j <-> cell 8 (q & 1) + j of tile q >> 1 of the pair
+            const float* Rl = pb + (size_t)(q >> 1) * buf_floats + 8 * (q & 1) * Kp;
+            const float* Zl = Rl + 256 * MT - 8 * (q & 1) * Kp + 8 * (q & 1) * DP;
+            const unsigned char* ids = reinterpret_cast<const unsigned char*>(pb + (size_t)(q >> 1) * buf_floats + 256 * MT + 16 * DP) + 8 * (q & 1);
+            int bid[8];
+            {
+                const u32x2 w = *reinterpret_cast<const u32x2*>(ids);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bid[j] = (int)((w[j >> 2] >> (8 * (j & 3))) & 255u);
+            }
+            // ---- B planes of the column half: value = PC column (zero in the row padding) + one-hot of the block column ----
+            u32x4 bh[NTH], bm[NTH], bl[NTH];
+#pragma unroll
+            for (int u = 0; u < NTH; ++u) {
+                const int nt = nt_lo + u;                             // wave-uniform
+                const bool pc = nt < NTP;
+                const float* zr = Zl + 16 * min(nt, NTP - 1) + c16;   // (clamped: an unused read stays inside the tile)
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = zr[j * DP];
+                if (!pc) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = 0.f;
+                }
+                if (nt >= NTP - 1 && nt < NT) {                       // block whose one-hot column this lane's column is (negative: none)
+                    const int blk_col = pc ? 16 * nt + c16 - d : spare + 16 * (nt - NTP) + c16;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] += (bid[j] == blk_col) ? 1.f : 0.f;
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    unsigned h, m, l;
+                    bf16_split3((f32x2){x[2 * p], x[2 * p + 1]}, h, m, l);
+                    bh[u][p] = h; bm[u][p] = m; bl[u][p] = l;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- row tiles, software-pipelined: while the 6 NTH products of tile t are in the matrix pipe, the A values of tile
+            //      t+1 are read (16-byte reads: the four tiles of a group of the permuted row map share them) and split.  One
+            //      scheduling region per tile; the hints ask for one VALU instruction behind every MFMA (a wave without a
+            //      partner on its SIMD hides the split only inside its own instruction stream).  Products: smallest terms
+            //      first, consecutive MFMAs go to different accumulators.
+            f32x4 v[8];
+            u32x4 pa[2][3];                                           // planes (h, m, l) of the current / the next tile
+            auto fetch_split = [&](auto tc, u32x4 (&pl)[3]) {         // tile LO + T of the wave's half -> planes
+                constexpr int T = decltype(tc)::value;
+                constexpr int mt = LO + T;
+                float av[8];
+                if constexpr (mt < 4 * H) {
+                    if constexpr (T == 0 || (mt & 3) == 0) {          // first tile of its group in this half: the group's values
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = ld4(Rl + j * Kp + 64 * (mt >> 2) + 4 * c16);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) av[j] = v[j][mt & 3];
+                } else {
+                    const int col = 64 * H + REM * c16 + (mt - 4 * H);   // clusters past the row do not exist: no read past it
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        av[j] = Rl[j * Kp + min(col, Kp - 1)];
+                        if (col >= Kp) av[j] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    unsigned h, m, l;
+                    bf16_split3((f32x2){av[2 * p], av[2 * p + 1]}, h, m, l);
+                    pl[0][p] = h; pl[1][p] = m; pl[2][p] = l;
+                }
+            };
+            auto products = [&](int t, const u32x4 (&pl)[3]) {
+#pragma unroll
+                for (int u = 0; u < NTH; ++u) acc[t][u] = MFMA_BF16(pl[2], bh[u], acc[t][u]);
+#pragma unroll
+                for (int u = 0; u < NTH; ++u) acc[t][u] = MFMA_BF16(pl[0], bl[u], acc[t][u]);
+#pragma unroll
+                for (int u = 0; u < NTH; ++u) acc[t][u] = MFMA_BF16(pl[1], bm[u], acc[t][u]);
+#pragma unroll
+                for (int u = 0; u < NTH; ++u) acc[t][u] = MFMA_BF16(pl[1], bh[u], acc[t][u]);
+#pragma unroll
+                for (int u = 0; u < NTH; ++u) acc[t][u] = MFMA_BF16(pl[0], bm[u], acc[t][u]);
+#pragma unroll
+                for (int u = 0; u < NTH; ++u) acc[t][u] = MFMA_BF16(pl[0], bh[u], acc[t][u]);
+            };
+            fetch_split(std::integral_constant<int, 0>{}, pa[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            auto tile_step = [&](auto tc) {
+                constexpr int T = decltype(tc)::value;
+                if constexpr (T + 1 < HI - LO) fetch_split(std::integral_constant<int, T + 1>{}, pa[(T + 1) & 1]);
+                products(T, pa[T & 1]);
+                if constexpr (T + 1 < HI - LO) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // the LDS reads of the next tile's values first
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // ... their latency under the first products
+#pragma unroll
+                    for (int r = 0; r < 6 * NTH - 6; ++r) {
+                        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (T + 1 == (HI - LO + 1) / 2) {           // half way: the first tile of pair i+1 has landed
+                    store_tile(2 * i + 2, nb);
+                    load_tile(2 * i + 3);
+                }
+            };
+            static_for<0, HI - LO>(tile_step);
+            store_tile(2 * i + 3, nb + 1);
+        }
+        // every wave stores its own output tiles: slab [mt][nt][lane][r]
+        float* slab = a.slab + (size_t)task * ((size_t)MT * NT * 256);
+#pragma unroll
+        for (int t = 0; t < MTA; ++t)
+#pragma unroll
+            for (int u = 0; u < NTH; ++u) {
+                const int mt = LO + t, nt = nt_lo + u;
+                if (mt < HI && nt < NT) st4(slab + ((size_t)(mt * NT + nt) * 64 + lane) * 4, acc[t][u]);
+            }
+    };
+    if (rh == 0) body(std::integral_constant<int, 0>{}); else body(std::integral_constant<int, 1>{});
+}
+
+// ------------------------------------------------------------------------------------------
 // k_rtz3_finish: the per-task slabs summed in fp64, one workgroup per cluster k; undoes the index maps of k_rtz3.
 //   mode 0 (k-means round): Ysum[k][pc] over all tasks (the centroid numerators, :443), Sold[blk][g][k] over the tasks of
 //          group g (the removal sums, :491-492); with Yout the row is normalised on the spot (:444) -- no collective
@@ -1278,10 +1509,52 @@ static bool launch_rtzw2(const Rtz3Args& a, int mt, hipStream_t s) {
     }
 }
 
-int launch_rtzw(const Rtz3Args& a_in, int mt, int dp, int d, int nblk, hipStream_t s) {
+// ---- k_rtzw2b: the shapes of k_rtzw2 (K > 112, seven to fourteen column tiles), four tile buffers in one CU's LDS
+bool rtzw2b_ok(int mt, int dp, int d, int nblk) {
+    if (!rtzw_ok(mt, dp, d, nblk, 1) || mt < 8 || mt > 13) return false;
+    const int nth = (rtzw_nt(dp, d, nblk) + 1) / 2;
+    return nth >= 4 && nth <= 7 && (size_t)4 * (256 * mt + 16 * dp + 4) * sizeof(float) <= 160 * 1024;
+}
+template <int MT, int NTH>
+static void launch_rtzw2b_t(const Rtz3Args& a, size_t sm, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rtzw2b<MT, NTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_rtzw2b<MT, NTH>), dim3(a.ntasks), dim3(64 * RTZWB_WAVES), sm, s, a);
+}
+template <int MT>
+static void launch_rtzw2b_m(const Rtz3Args& a, int nth, size_t sm, hipStream_t s) {
+    switch (nth) {
+        case 4: launch_rtzw2b_t<MT, 4>(a, sm, s); break;
+        case 5: launch_rtzw2b_t<MT, 5>(a, sm, s); break;
+        case 6: launch_rtzw2b_t<MT, 6>(a, sm, s); break;
+        default: launch_rtzw2b_t<MT, 7>(a, sm, s); break;
+    }
+}
+static void launch_rtzw2b(const Rtz3Args& a, int mt, hipStream_t s) {
+    const int nth = (a.nt + 1) / 2;
+    const size_t sm = (size_t)4 * (256 * mt + 16 * a.dp + 4) * sizeof(float);
+    switch (mt) {
+        case 8: launch_rtzw2b_m<8>(a, nth, sm, s); break;
+        case 9: launch_rtzw2b_m<9>(a, nth, sm, s); break;
+        case 10: launch_rtzw2b_m<10>(a, nth, sm, s); break;
+        case 11: launch_rtzw2b_m<11>(a, nth, sm, s); break;
+        case 12: launch_rtzw2b_m<12>(a, nth, sm, s); break;
+        default: launch_rtzw2b_m<13>(a, nth, sm, s); break;
+    }
+}
+
+// returns 1 when the bf16-pipe kernel (k_rtzw2b) ran, 0 for the f32-input kernels, -1 unsupported
+int launch_rtzw(const Rtz3Args& a_in, int mt, int dp, int d, int nblk, hipStream_t s, bool allow_bf16) {
     if (!rtzw_ok(mt, dp, d, nblk, 1) || a_in.ntasks <= 0) return -1;
     Rtz3Args a = a_in;
     a.dp = dp; a.d = d; a.nt = rtzw_nt(dp, d, nblk);
+    if (allow_bf16 && rtzw2b_ok(mt, dp, d, nblk)) {
+        launch_rtzw2b(a, mt, s);
+        return 1;
+    }
     if (launch_rtzw2(a, mt, s)) return 0;
     const size_t sm = (size_t)RTZW_NBUF * (16 * (a.Kp + dp) + 4) * sizeof(float);
     if (sm > 160 * 1024) return -1;

@@ -457,6 +457,42 @@ def test_bf16_pipe_rtz_pass_against_the_f32_input_kernel(N, d, B, K, bs, monkeyp
     print(f"k_rtz3b vs k_rtz3 {N}x{d} K={K} B={B}: Y {np.abs(a.Y - b.Y).max():.2e}  Z_corr relF {rel:.2e}")
 
 
+WIDE_AB_SHAPES = [(40_000, 200, 32, 200), (30_000, 100, 4, 130), (20_000, 208, 3, 208), (25_000, 72, 5, 100), (20_000, 40, 2, 150)]
+
+
+@pytest.mark.parametrize("N,d,B,K", WIDE_AB_SHAPES)
+@pytest.mark.parametrize("switch,value", [("HMX_ROUND_F32", "1"), ("HMX_RTZ3_BF16", "0")])
+def test_wide_bf16_pipe_kernels_against_the_f32_input_kernels(N, d, B, K, switch, value, monkeypatch):
+    """The wide regime (K > 112 or d > 64: BASELINE configs[4] is K = d = 200) is bound by the f32-input MFMA; its block
+    assignment (k_assign_wide2b, harmony.py:447, 464-513) and its streaming R^T.Z pass (k_rtzw2b, :443-444, :491-492, :550,
+    :559-563) run on the bf16 matrix pipe with every fp32 operand as three exact bf16 terms.  Direct A/B inside one build on
+    one state against the f32-input kernels (engines created under HMX_ROUND_F32=1 / HMX_RTZ3_BF16=0): two seeded rounds +
+    the ridge; R 4e-6, Y 2e-6, O 1e-6 of the masses, objective terms 2e-6 relative, Z_corr 1e-6 relative Frobenius; the
+    counters say which kernels ran (shapes outside k_rtzw2b's -- K <= 112 or fewer than seven column tiles -- keep k_rtzw)."""
+    a, b = _ab_engines(N, d, B, K, monkeypatch, switch, value)
+    assert a._wide_shape()
+    for h in (a, b):
+        h.cluster(_rounds=2)
+        h.moe_correct_ridge()
+    ca, cb = a._engine.counters(), b._engine.counters()
+    if switch == "HMX_ROUND_F32":
+        assert ca["sweeps_bf16_pipe"] == 2 and cb["sweeps_bf16_pipe"] == 0, (ca, cb)
+    else:
+        MT, NT = (K + 15) // 16, ((d + 15) // 16) + max(0, (20 - (((d + 15) & ~15) - d) + 15) // 16)
+        served = 8 <= MT <= 13 and 4 <= (NT + 1) // 2 <= 7
+        assert (ca["rtz_bf16_pipe"] >= 3) == served and cb["rtz_bf16_pipe"] == 0, (ca, cb, served)
+    dR = float(np.abs(a.R - b.R).max())
+    assert dR <= 4e-6, f"max |dR| = {dR:.2e}"
+    np.testing.assert_allclose(a.Y, b.Y, rtol=0, atol=2e-6)
+    assert np.abs(a.O - b.O).max() <= 1e-6 * max(1.0, float(np.abs(b.O).max()))
+    for name in ("objective_kmeans_dist", "objective_kmeans_entropy", "objective_kmeans_cross"):
+        for va, vb in zip(getattr(a, name), getattr(b, name)):
+            assert abs(va - vb) <= 2e-6 * abs(vb), (name, va, vb)
+    rel = float(np.linalg.norm(a.Z_corr - b.Z_corr) / np.linalg.norm(b.Z_corr))
+    assert rel <= 1e-6, f"Z_corr relF {rel:.2e}"
+    print(f"wide bf16 pipe vs f32 input ({switch}) {N}x{d} K={K} B={B}: max|dR|={dR:.2e}  Z_corr relF {rel:.2e}")
+
+
 def test_bench_path_parity_c5_shape(monkeypatch):
     """BASELINE configs[4]'s exact shape (d=200, K=200, 32 batches: the wide kernels) at 40k cells,
     seeded device-order rounds vs the oracle in its plain fp32 mode (the reference's arithmetic): objectives 2e-5,

@@ -222,3 +222,121 @@ def test_rtz3b_pair_round_trip(K, d, nblk, n_tiles, last_live):
     for i in np.flatnonzero(keep):
         S_ref[blk[i]] += R[i, :K]
     np.testing.assert_allclose(S, S_ref, rtol=1e-12, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------
+# k_rtzw2b: the wide streaming pass on the bf16 matrix pipe.  Four waves split the MT x NT output tiles 2 x 2 (row half
+# x column half); a k-step is a pair of the task's tiles with k_rtz3b's k-slot map; plain column tiles (PC tile nt holds
+# columns 16 nt .., the padding columns d .. dp-1 of the last PC tile carry the first one-hot block columns, whole extra
+# tiles the rest); rows past the group's end and the missing tile of an odd count are ZEROS in LDS (store_tile).
+# ------------------------------------------------------------------------------------------
+def finish_wide(slab, MT, NT, K, d, DP, nblk):
+    """k_rtz3_finish's read-out of one slab [mt][nt][lane][r] in its `wide` mode."""
+    Hq, rem = MT // 4, MT % 4
+    spare = DP - d
+    Y = np.zeros((K, d))
+    S = np.zeros((nblk, K))
+    for k in range(K):
+        if k < 64 * Hq:
+            mt, m = 4 * (k // 64) + (k & 3), (k & 63) >> 2
+        else:
+            x = k - 64 * Hq
+            m, mt = x // rem, 4 * Hq + x % rem
+
+        def val(v):
+            nt, n = v >> 4, v & 15
+            return slab[(mt * NT + nt) * 256 + (16 * (m >> 2) + n) * 4 + (m & 3)]
+        for pc in range(d):
+            Y[k, pc] = val(pc)
+        for b in range(nblk):
+            S[b, k] = val(d + b if b < spare else DP + (b - spare))
+    return Y, S
+
+
+def rtzw2b_wave_pair(bufs, wv, MT, NTH, Kp, DP, d, NT, acc):
+    """One pair of tile buffers through one wave of k_rtzw2b (bufs: two (Rt 16 x Kp, Zt 16 x DP, ids 16) images as
+    store_tile leaves them).  acc: dict (mt, nt) -> 64 x 4."""
+    MTA = (MT + 1) // 2
+    H, REM = MT // 4, MT % 4
+    NTP = DP // 16
+    rh, ch = wv >> 1, wv & 1
+    LO, HI = rh * MTA, (MT if rh else MTA)
+    nt_lo = ch * NTH
+    bplanes = []
+    for u in range(NTH):
+        nt = nt_lo + u
+        b = np.zeros((64, 8))
+        for lane in range(64):
+            c16, q = lane & 15, lane >> 4
+            Rt, Zt, ids = bufs[q >> 1]
+            for j in range(8):
+                cell = 8 * (q & 1) + j
+                x = Zt[cell, 16 * min(nt, NTP - 1) + c16] if nt < NTP else 0.0
+                if NTP - 1 <= nt < NT:
+                    blk_col = 16 * nt + c16 - d
+                    x += 1.0 if int(ids[cell]) == blk_col else 0.0
+                b[lane, j] = x
+        bplanes.append(b)
+    for mt in range(LO, HI):
+        a = np.zeros((64, 8))
+        for lane in range(64):
+            c16, q = lane & 15, lane >> 4
+            Rt, Zt, ids = bufs[q >> 1]
+            flat = np.concatenate([Rt.ravel(), np.full(256 * MT - Rt.size, np.nan)])   # the R segment is padded to MT KB: a 16-byte read
+            for j in range(8):                                                          # past a row's end stays inside it (rows of clusters >= Kp: never read out)
+                cell = 8 * (q & 1) + j
+                if mt < 4 * H:
+                    a[lane, j] = flat[cell * Kp + 64 * (mt >> 2) + 4 * c16 + (mt & 3)]
+                else:
+                    col = 64 * H + REM * c16 + (mt - 4 * H)
+                    a[lane, j] = flat[cell * Kp + col] if col < Kp else 0.0
+        for u in range(NTH):
+            nt = nt_lo + u
+            if nt < NT:                                      # (the kernel multiplies zeros there and does not store them)
+                mfma32(a, bplanes[u], acc.setdefault((mt, nt), np.zeros((64, 4))))
+
+
+@pytest.mark.parametrize("K,d,nblk,n_tiles,last_live", [(200, 200, 20, 3, 7), (200, 200, 1, 2, 16), (130, 100, 20, 4, 16),
+                                                         (208, 120, 40, 1, 3), (177, 193, 20, 2, 16)])
+def test_rtzw2b_round_trip(K, d, nblk, n_tiles, last_live):
+    """Shapes launch_rtzw hands to k_rtzw2b (K > 112, seven to fourteen column tiles): configs[4] with its 20 update blocks
+    (8 one-hot columns in the row padding + one extra tile) and as the ridge / k-means pass (one block column), odd tile
+    counts, a ragged last tile, a remainder row tile, a one-hot tile per column half."""
+    rng = np.random.default_rng(K * 131 + d * 7 + nblk)
+    Kp, MT = (K + 3) & ~3, (K + 15) // 16
+    DP = (d + 15) & ~15
+    NT = DP // 16 + max(0, (nblk - (DP - d) + 15) // 16)
+    NTH = (NT + 1) // 2
+    assert 8 <= MT <= 13 and 4 <= NTH <= 7                   # rtzw2b_ok
+    R = rng.random((16 * n_tiles, Kp))
+    R[:, K:] = 0.0
+    Z = rng.normal(size=(16 * n_tiles, DP))
+    Z[:, d:] = 0.0
+    blk = rng.integers(0, nblk, size=16 * n_tiles)
+    live = [16] * (n_tiles - 1) + [last_live]
+
+    def image(ti):                                           # store_tile: the tile as it sits in LDS
+        tc = min(ti, n_tiles - 1)
+        n_live = live[tc] if ti < n_tiles else 0
+        Rt, Zt = R[16 * tc:16 * tc + 16].copy(), Z[16 * tc:16 * tc + 16].copy()
+        Rt[n_live:] = 0.0
+        Zt[n_live:] = 0.0
+        return Rt, Zt, blk[16 * tc:16 * tc + 16]
+    acc = {}
+    for i in range((n_tiles + 1) // 2):
+        bufs = [image(2 * i), image(2 * i + 1)]
+        for wv in range(4):
+            rtzw2b_wave_pair(bufs, wv, MT, NTH, Kp, DP, d, NT, acc)
+    slab = np.zeros(MT * NT * 256)
+    for (mt, nt), a in acc.items():
+        for lane in range(64):
+            for r in range(4):
+                slab[(mt * NT + nt) * 256 + lane * 4 + r] = a[lane, r]
+    assert len(acc) == MT * NT                               # every output tile has exactly one owner
+    Y, S = finish_wide(slab, MT, NT, K, d, DP, nblk)
+    keep = np.concatenate([np.arange(16) < n for n in live])
+    np.testing.assert_allclose(Y, R[keep][:, :K].T @ Z[keep][:, :d], rtol=1e-12, atol=1e-12)
+    S_ref = np.zeros((nblk, K))
+    for i in np.flatnonzero(keep):
+        S_ref[blk[i]] += R[i, :K]
+    np.testing.assert_allclose(S, S_ref, rtol=1e-12, atol=1e-12)
