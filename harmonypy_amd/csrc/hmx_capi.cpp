@@ -154,6 +154,7 @@ struct hmx_engine {
     int ntasks3 = 0;
     DevBuf<int> t3_t0, t3_t1, t3_c0, t3_cend, t3_grp, t3_stride, s_tile_start;
     DevBuf<unsigned char> tile_blk[2], tile_blk_zero;
+    DevBuf<unsigned> Wf;                 // wide shapes: W as bf16 fragments for k_ridge_apply_wideb (launch_w_planes)
     DevBuf<double> Osave;                // O at the start of the round in flight (exact replay after a time-out)
 
     struct Span { hipEvent_t a, b; int fam; };
@@ -478,7 +479,7 @@ void hmx_destroy(hmx_engine* e) {
     if (e->pre_event) (void)hipEventDestroy(e->pre_event);
     e->task_t0.release(); e->task_t1.release();
     e->t3_t0.release(); e->t3_t1.release(); e->t3_stride.release(); e->t3_c0.release(); e->t3_cend.release(); e->t3_grp.release(); e->s_tile_start.release();
-    e->tile_blk[0].release(); e->tile_blk[1].release(); e->tile_blk_zero.release(); e->Osave.release();
+    e->tile_blk[0].release(); e->tile_blk[1].release(); e->tile_blk_zero.release(); e->Osave.release(); e->Wf.release();
     e->task_grp.release(); e->gstart.release(); e->chunk_tab.release(); e->run_count.release(); e->run_start.release();
     e->Ogrp.release(); e->Tmass.release(); e->Ohist.release(); e->xch.release(); e->scratch.release();
     e->global_id.release(); e->wait_stats.release(); e->sync_words.p = nullptr; e->sync_words.n = 0; e->Sslots.release(); e->km_hn.release(); e->km_sums.release();
@@ -1735,6 +1736,11 @@ int hmx_moe_correct_ridge(hmx_engine* e) {
         a.cells = e->s_cells.p; a.tile_grp = e->s_tile_grp.p; a.n_tiles = e->n_s_tiles;
         a.Kp = e->Kp; a.K16 = e->K16; a.dp = e->dp; a.ldw = e->ldy; a.mtd = e->ntd;
         if (rtz2 || rtzw) { a.task_tile0 = e->task_t0.p; a.task_tile1 = e->task_t1.p; a.task_grp = e->task_grp.p; a.ntasks = e->ntasks; }
+        if (rtzw && e->allow_round_bf16) {                           // the correction GEMM on the bf16 pipe: W split once into fragments
+            if ((rc = e->Wf.reserve(w_planes_dwords(e->G, e->K16, e->dp)))) return rc;
+            launch_w_planes(e->W.p, e->G, e->K16, e->ldy, e->dp, e->Wf.p, e->stream);
+            a.Wf = e->Wf.p;
+        }
         if (launch_ridge_apply(a, e->max_wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported n_pcs");
     }
     HIP_TRY(hipGetLastError());

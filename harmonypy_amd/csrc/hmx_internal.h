@@ -196,6 +196,7 @@ struct ApplyArgs {
     const float* R;
     const float* Zorig;
     const float* W;        // G x K16 x ldw
+    const unsigned* Wf;    // wide shapes, bf16 pipe: W as the A fragments of k_ridge_apply_wideb (launch_w_planes), or null
     float* Zcorr;
     float* Zcos;
     const int* cells;
@@ -300,6 +301,8 @@ void launch_order(const OrderArgs& a, hipStream_t s);
 int order_chunks(int64_t N);
 void launch_normalize_rows(const float* Z, float* Zc, int64_t N, int dp, hipStream_t s);
 void launch_y_normalize(const float* src, float* dst, int K, int K16, int d, int ldy, hipStream_t s);
+size_t w_planes_dwords(int G, int K16, int dp);
+void launch_w_planes(const float* W, int G, int K16, int ldw, int dp, unsigned* Wf, hipStream_t s);
 int launch_assign(const AssignArgs& a, bool penalty, int max_wgs, hipStream_t s);   // 1: the bf16-pipe wide instance ran, 0: another kernel, -1 unsupported
 void rtz_geometry(int mt, int ntd, int* nsub, int* slab_per_wave);
 bool rtz2_ok(int mt, int dp);

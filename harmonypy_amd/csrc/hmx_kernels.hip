@@ -3637,6 +3637,172 @@ __global__ __launch_bounds__(64 * WIDE_WAVES, 2) void k_ridge_apply_wide(ApplyAr
 }
 
 // ------------------------------------------------------------------------------------------
+// The wide correction on the bf16 matrix pipe (hmx_device.h: fp32 operands as three exact bf16 terms, six products).
+// k_ridge_apply_wide multiplies with the f32-input MFMA from scalar LDS reads, one tile per wave: 36 % pipe busy and 46 %
+// LDS-conflict cycles in round 4's counters, 2.0 ms per pass at the configs[4] shard against an HBM floor of 0.5 ms.  Here:
+//   * k_w_planes (one small launch behind the ridge solve): W of every group as the A FRAGMENTS of
+//     v_mfma_f32_16x16x32_bf16, split once: Wf[g][step s][plane h, m, l][PC tile mt][lane][8 bf16] -- row i = PC 16 mt + c16,
+//     k slot j of lane (c16, q) = cluster 32 s + 8 q + j (zeros past K16).  A (plane, tile) fragment is 1 KB contiguous:
+//     one LDS-DMA request brings it, one conflict-free 16-byte read per lane hands it to the matrix pipe;
+//   * k_ridge_apply_wideb: one workgroup of eight waves per CU walks a task's tiles sixteen at a time (two per wave: a
+//     fragment read feeds two tiles' products), W steps through a two-slot ring (3 MTD KB per slot), the R values of a step
+//     (two 16-byte loads per tile and lane) are split in registers; one vmcnt(0) + one barrier per step, the requests of
+//     step s+1 go out behind the first PC tile of step s.  Epilogue as in k_ridge_apply_wide (:566, :569).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_w_planes(const float* __restrict__ W, int K16, int ldw, int mtd, int ns, unsigned* __restrict__ Wf) {
+    const int lane = threadIdx.x, c16 = lane & 15, q = lane >> 4;
+    const int s = blockIdx.x / mtd, mt = blockIdx.x - s * mtd, g = blockIdx.y;
+    const float* Wg = W + (size_t)g * K16 * ldw + 16 * mt + c16;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 32 * s + 8 * q + j;
+        x[j] = (k < K16) ? Wg[(size_t)k * ldw] : 0.f;
+    }
+    u32x4 pl[3];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        unsigned h, m, l;
+        bf16_split3((f32x2){x[2 * p], x[2 * p + 1]}, h, m, l);
+        pl[0][p] = h; pl[1][p] = m; pl[2][p] = l;
+    }
+#pragma unroll
+    for (int pn = 0; pn < 3; ++pn)
+        *reinterpret_cast<u32x4*>(Wf + ((((size_t)g * ns + s) * 3 + pn) * mtd + mt) * 256 + 4 * lane) = pl[pn];
+}
+
+#define APPLYB_WAVES 8
+template <int MTD>
+__global__ __launch_bounds__(64 * APPLYB_WAVES, 1) void k_ridge_apply_wideb(ApplyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* ring = reinterpret_cast<unsigned*>(smem);              // 2 slots x 3 planes x MTD tiles x 256 dwords
+    constexpr int SLOT = 3 * MTD * 256;                              // dwords per slot
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, q = lane >> 4;
+    const int task = blockIdx.x;
+    if (task >= a.ntasks) return;
+    const int t0 = a.task_tile0[task], t1 = a.task_tile1[task], g = a.task_grp[task];
+    const int ns = (a.K16 + 31) >> 5;                                // k-steps of 32 clusters
+    auto u64 = [](unsigned long long v) {
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
+               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v);
+    };
+    const unsigned long long wsrc = u64((unsigned long long)(a.Wf + (size_t)g * ns * SLOT));
+    const unsigned ring0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)ring);
+    const unsigned voff = 16u * (unsigned)lane;
+    auto request = [&](int s) {                                      // this wave's fragments of step s: pieces wv, wv + 8, ... of 3 MTD
+        const unsigned long long src0 = wsrc + (unsigned long long)s * (SLOT * 4);
+        const unsigned zone0 = ring0 + (unsigned)(s & 1) * (SLOT * 4);
+#pragma unroll
+        for (int j = 0; j < (3 * MTD + APPLYB_WAVES - 1) / APPLYB_WAVES; ++j) {
+            const int p = wv + APPLYB_WAVES * j;                     // wave-uniform
+            if (p < 3 * MTD) {
+                const unsigned long long src = src0 + 1024ull * p;
+                const unsigned zone = zone0 + 1024u * p;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(zone) : "memory", "m0");
+            }
+        }
+    };
+    for (int base = t0; base < t1; base += 2 * APPLYB_WAVES) {       // workgroup-uniform trip count
+        const int ta = base + 2 * wv;
+        const bool has0 = ta < t1, has1 = ta + 1 < t1;               // wave-uniform
+        const int cell0 = has0 ? a.cells[(size_t)ta * 16 + c16] : -1;
+        const int cell1 = has1 ? a.cells[(size_t)(ta + 1) * 16 + c16] : -1;
+        const bool live0 = cell0 >= 0, live1 = cell1 >= 0;
+        const float* rr0 = a.R + (size_t)(live0 ? cell0 : 0) * a.Kp + 8 * q;
+        const float* rr1 = a.R + (size_t)(live1 ? cell1 : 0) * a.Kp + 8 * q;
+        f32x4 acc0[MTD], acc1[MTD];
+#pragma unroll
+        for (int mt = 0; mt < MTD; ++mt) { acc0[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        f32x4 rv[4];                                                 // raw R values of the coming step (dead once the step has split them)
+        auto load_r = [&](int s) {                                   // ordinary loads, pinned where they are written; clusters past the row are zeros
+            __builtin_amdgcn_sched_barrier(0);
+            const int col = 32 * s + 8 * q;
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            rv[0] = (live0 && col < a.Kp) ? ld4(rr0 + 32 * s) : zero;
+            rv[1] = (live0 && col + 4 < a.Kp) ? ld4(rr0 + 32 * s + 4) : zero;
+            rv[2] = (live1 && col < a.Kp) ? ld4(rr1 + 32 * s) : zero;
+            rv[3] = (live1 && col + 4 < a.Kp) ? ld4(rr1 + 32 * s + 4) : zero;
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        wg_barrier_lds();                                            // nobody reads the ring any more (the pass before)
+        request(0);
+        load_r(0);
+        auto split4 = [&](const f32x4& lo, const f32x4& hi, u32x4 (&pl)[3]) {
+            unsigned h, m, l;
+            bf16_split3((f32x2){lo[0], lo[1]}, h, m, l); pl[0][0] = h; pl[1][0] = m; pl[2][0] = l;
+            bf16_split3((f32x2){lo[2], lo[3]}, h, m, l); pl[0][1] = h; pl[1][1] = m; pl[2][1] = l;
+            bf16_split3((f32x2){hi[0], hi[1]}, h, m, l); pl[0][2] = h; pl[1][2] = m; pl[2][2] = l;
+            bf16_split3((f32x2){hi[2], hi[3]}, h, m, l); pl[0][3] = h; pl[1][3] = m; pl[2][3] = l;
+        };
+#pragma unroll 1
+        for (int s = 0; s < ns; ++s) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's fragments and R values of step s (requested a whole step ago)
+            wg_barrier_lds();                                        // everybody's fragments of step s are in; nobody reads step s-1 any more
+            const unsigned* slot = ring + (size_t)(s & 1) * SLOT + 4 * lane;
+            u32x4 bp0[3], bp1[3];                                    // the two tiles' B planes of this step
+            split4(rv[0], rv[1], bp0);
+            split4(rv[2], rv[3], bp1);
+            u32x4 wp[2][3];                                          // A planes of the current / the next PC tile
+            auto fetch = [&](int mt, u32x4 (&pl)[3]) {
+#pragma unroll
+                for (int pn = 0; pn < 3; ++pn) pl[pn] = ld4u(slot + (pn * MTD + mt) * 256);
+            };
+            auto products = [&](int mt, const u32x4 (&pl)[3]) {      // smallest terms first; the two tiles alternate
+                acc0[mt] = MFMA_BF16(pl[2], bp0[0], acc0[mt]);  acc1[mt] = MFMA_BF16(pl[2], bp1[0], acc1[mt]);
+                acc0[mt] = MFMA_BF16(pl[0], bp0[2], acc0[mt]);  acc1[mt] = MFMA_BF16(pl[0], bp1[2], acc1[mt]);
+                acc0[mt] = MFMA_BF16(pl[1], bp0[1], acc0[mt]);  acc1[mt] = MFMA_BF16(pl[1], bp1[1], acc1[mt]);
+                acc0[mt] = MFMA_BF16(pl[1], bp0[0], acc0[mt]);  acc1[mt] = MFMA_BF16(pl[1], bp1[0], acc1[mt]);
+                acc0[mt] = MFMA_BF16(pl[0], bp0[1], acc0[mt]);  acc1[mt] = MFMA_BF16(pl[0], bp1[1], acc1[mt]);
+                acc0[mt] = MFMA_BF16(pl[0], bp0[0], acc0[mt]);  acc1[mt] = MFMA_BF16(pl[0], bp1[0], acc1[mt]);
+            };
+            fetch(0, wp[0]);
+#pragma unroll
+            for (int mt = 0; mt < MTD; ++mt) {
+                if (mt + 1 < MTD) fetch(mt + 1, wp[(mt + 1) & 1]);
+                products(mt, wp[mt & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (mt == 0 && s + 1 < ns) {                         // behind the first PC tile: slot (s+1) & 1 is free, rv[] is split
+                    request(s + 1);
+                    load_r(s + 1);
+                }
+            }
+        }
+        // ---- Z_corr = Z_orig - W^T (Phi_moe R) (:566), Z_cos = its unit rows (:569) ----
+        auto finish = [&](bool has, bool live, int cell, f32x4 (&acc)[MTD]) {
+            if (!has) return;
+            const size_t row = (size_t)(live ? cell : 0) * a.dp;
+            float ss = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MTD; ++mt) {
+                const int col = 16 * mt + 4 * q;
+                const f32x4 zo = (live && col < a.dp) ? ld4(a.Zorig + row + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc[mt] = zo - acc[mt];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ss += acc[mt][r] * acc[mt][r];
+            }
+            ss = wave_sum_q(ss);
+            const float nrm = sqrtf(ss);
+#pragma unroll
+            for (int mt = 0; mt < MTD; ++mt) {
+                const int col = 16 * mt + 4 * q;
+                if (live && col < a.dp) {
+                    st4(a.Zcorr + row + col, acc[mt]);
+                    f32x4 zc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) zc[r] = acc[mt][r] / nrm;
+                    st4(a.Zcos + row + col, zc);
+                }
+            }
+        };
+        finish(has0, live0, cell0, acc0);
+        finish(has1, live1, cell1, acc1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Device-side update order (replaces torch.randperm + the gather/argsort of harmony.py:471-480,
 // 512-513 when the caller does not supply an order).
 //
@@ -4420,9 +4586,34 @@ void launch_kmeans_seed(const SeedArgs& a, int K, hipStream_t s) {
     }
 }
 
+size_t w_planes_dwords(int G, int K16, int dp) { return (size_t)G * ((K16 + 31) / 32) * 3 * (dp / 16) * 256; }
+void launch_w_planes(const float* W, int G, int K16, int ldw, int dp, unsigned* Wf, hipStream_t s) {
+    const int ns = (K16 + 31) / 32, mtd = dp / 16;
+    hipLaunchKernelGGL(k_w_planes, dim3(ns * mtd, G), dim3(64), 0, s, W, K16, ldw, mtd, ns, Wf);
+}
+
 int launch_ridge_apply(const ApplyArgs& a_in, int max_wgs, hipStream_t s) {
     ApplyArgs a = a_in;
     if (a.n_tiles <= 0) return 0;
+    if (a.task_tile0 && a.Wf && rtz_wide_ok((a.K16 + 15) / 16, a.dp)) {   // the bf16-pipe instance: W comes as fragments (launch_w_planes)
+        const int mtd = a.dp / 16;
+        const size_t sm = (size_t)2 * 3 * mtd * 1024;
+#define HMX_AWB(M)                                                                                                     \
+    case M: {                                                                                                         \
+        static bool attr_done = false;                                                                                \
+        if (!attr_done) {                                                                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ridge_apply_wideb<M>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+            attr_done = true;                                                                                         \
+        }                                                                                                             \
+        hipLaunchKernelGGL((k_ridge_apply_wideb<M>), dim3(a.ntasks), dim3(64 * APPLYB_WAVES), sm, s, a);               \
+    } break;
+        switch (mtd) {
+            HMX_AWB(1) HMX_AWB(2) HMX_AWB(3) HMX_AWB(4) HMX_AWB(5) HMX_AWB(6) HMX_AWB(7) HMX_AWB(8) HMX_AWB(9) HMX_AWB(10) HMX_AWB(11) HMX_AWB(12)
+            default: hipLaunchKernelGGL((k_ridge_apply_wideb<13>), dim3(a.ntasks), dim3(64 * APPLYB_WAVES), sm, s, a); break;
+        }
+#undef HMX_AWB
+        return 0;
+    }
     if (a.task_tile0 && rtz_wide_ok((a.K16 + 15) / 16, a.dp)) {
         const int mtd = a.dp / 16;
         a.ldw_lds = ((16 * mtd + 31) / 32) * 32 + 16;

@@ -4,7 +4,7 @@
 # rocprofv3 kernel statistics of the default run.
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests -m gpu -q -x -k "wide or edge_shapes or repeatable or c5 or large[c5shape] or lloyd or kmeans_initialisation_wide or without_the_streaming" -rP > gpurun_out/wide_gate_full.log 2>&1
+timeout 1200 python -m pytest tests -m gpu -q -k "wide or edge_shapes or repeatable or c5 or large[c5shape] or lloyd or kmeans_initialisation_wide or without_the_streaming" -rP > gpurun_out/wide_gate_full.log 2>&1
 grep -E "passed|failed|error|Error|wide path|wide bf16|configs\[4\] shape|bench path|c5shape" gpurun_out/wide_gate_full.log | tail -40
 grep -B3 -A25 "^E  " gpurun_out/wide_gate_full.log | head -80
 run() {
