@@ -116,6 +116,7 @@ struct hmx_engine {
     long n_sweep_fallbacks = 0;  // rounds repeated through the per-block path after a wait timed out
     long n_rtz_bf16 = 0;         // R^T.Z passes launched on the bf16-pipe instance k_rtz3b
     bool allow_round_bf16 = true;   // HMX_ROUND_F32=1 at hmx_create: the f32-input instances of k_round (A/B runs and tests)
+    bool wide_pre_split = true;     // HMX_WIDE_PRESPLIT=0 at hmx_create: k_assign_wide2b (centroids split in registers) instead of k_assign_wide3
     bool allow_rtz_bf16 = true;     // HMX_RTZ3_BF16=0 at hmx_create: k_rtz3 instead of k_rtz3b
     long n_sweeps_bf16 = 0;      // sweeps launched on the bf16-pipe instances of k_round (round_uses_bf16_pipe)
     DevBuf<unsigned long long> wait_stats;   // {waits, incomplete polls, most polls of one wait} of the sweep kernels' grid-wide waits
@@ -154,6 +155,7 @@ struct hmx_engine {
     int ntasks3 = 0;
     DevBuf<int> t3_t0, t3_t1, t3_c0, t3_cend, t3_grp, t3_stride, s_tile_start;
     DevBuf<unsigned char> tile_blk[2], tile_blk_zero;
+    DevBuf<unsigned> Yf;                 // wide shapes: the round's Y as bf16 fragments for k_assign_wide3 (launch_y_planes)
     DevBuf<unsigned> Wf;                 // wide shapes: W as bf16 fragments for k_ridge_apply_wideb (launch_w_planes)
     DevBuf<double> Osave;                // O at the start of the round in flight (exact replay after a time-out)
 
@@ -399,6 +401,7 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
 #endif
     if (const char* rf = getenv("HMX_ROUND_F32")) e->allow_round_bf16 = atoi(rf) == 0;
     if (const char* rb = getenv("HMX_RTZ3_BF16")) e->allow_rtz_bf16 = atoi(rb) != 0;
+    if (const char* ps = getenv("HMX_WIDE_PRESPLIT")) e->wide_pre_split = atoi(ps) != 0;
     if (const char* rk = getenv("HMX_RTZ")) e->rtz_kernel = atoi(rk) == 2 ? 2 : 3;
     if (const char* fs = getenv("HMX_TEST_FAIL_SWEEP")) e->test_fail_sweep = atol(fs);
     if (const char* sl = getenv("HMX_SPIN_LIMIT")) e->spin_limit = (unsigned)std::max(0L, atol(sl));   // 0: every wait of the persistent kernels gives up at once (tests)
@@ -479,7 +482,7 @@ void hmx_destroy(hmx_engine* e) {
     if (e->pre_event) (void)hipEventDestroy(e->pre_event);
     e->task_t0.release(); e->task_t1.release();
     e->t3_t0.release(); e->t3_t1.release(); e->t3_stride.release(); e->t3_c0.release(); e->t3_cend.release(); e->t3_grp.release(); e->s_tile_start.release();
-    e->tile_blk[0].release(); e->tile_blk[1].release(); e->tile_blk_zero.release(); e->Osave.release(); e->Wf.release();
+    e->tile_blk[0].release(); e->tile_blk[1].release(); e->tile_blk_zero.release(); e->Osave.release(); e->Wf.release(); e->Yf.release();
     e->task_grp.release(); e->gstart.release(); e->chunk_tab.release(); e->run_count.release(); e->run_start.release();
     e->Ogrp.release(); e->Tmass.release(); e->Ohist.release(); e->xch.release(); e->scratch.release();
     e->global_id.release(); e->wait_stats.release(); e->sync_words.p = nullptr; e->sync_words.n = 0; e->Sslots.release(); e->km_hn.release(); e->km_sums.release();
@@ -1076,6 +1079,11 @@ static int blocks_loop(hmx_engine* e, int flags, const std::vector<int>& tiles_u
     int rc;
     const size_t GK = (size_t)e->G * e->K16;
     int bf16_blocks = 0;                                            // blocks assigned by the bf16-pipe instance of the wide kernel
+    const bool y_frags = e->allow_round_bf16 && e->wide_pre_split && rtz_wide_ok(e->mt, e->dp);
+    if (y_frags) {                                                  // Y of this round, split once into the fragments k_assign_wide3 multiplies with
+        if ((rc = e->Yf.reserve(y_planes_dwords(e->K16, e->dp)))) return rc;
+        launch_y_planes(e->Y.p, e->K16, e->ldy, e->dp, e->Yf.p, e->stream);
+    }
     for (int b = 0; b < e->nblk; ++b) {
         {
             Timed t(e, F_BLOCK_TABLE);
@@ -1093,6 +1101,7 @@ static int blocks_loop(hmx_engine* e, int flags, const std::vector<int>& tiles_u
             a.cells = e->lists[e->cur].cells.p; a.tile_grp = e->lists[e->cur].tile_grp.p; a.S_out = e->Snew + GK * b;
             a.blk_start = e->lists[e->cur].blk_start.p; a.blk = b;
             a.tile_begin = 0; a.tile_end = tiles_upper[b];
+            if (y_frags) a.Yf = e->Yf.p;
             const int la = launch_assign(a, true, e->max_wgs, e->stream);
             if (la < 0) return fail(HMX_ERR_ARG, "unsupported cluster count");
             if (la > 0) bf16_blocks++;

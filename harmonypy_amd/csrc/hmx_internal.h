@@ -25,6 +25,7 @@ struct AssignArgs {
     int tile_begin, tile_end;  // host-side range (or an upper bound of its length when blk_start)
     int K, Kp, K16, mt, dp, ldy;
     int G, ldy_lds, tables_in_lds, tiles_per_wave, ablate;
+    const unsigned* Yf;    // wide shapes, bf16 pipe: Y as the A fragments of k_assign_wide3 (launch_y_planes), or null (k_assign_wide2b splits in registers)
     int bf16_pipe;         // wide shapes: the bf16-pipe instance k_assign_wide2b (0: engines created under HMX_ROUND_F32=1 keep k_assign_wide2)
     const float* hn;       // k_assign_wide without penalty only: half squared norms of the centres in Y (+inf for pads) -> HARD
                            // assignment of the device k-means (a one-hot row of R per cell) instead of the softmax; null otherwise
@@ -301,6 +302,8 @@ void launch_order(const OrderArgs& a, hipStream_t s);
 int order_chunks(int64_t N);
 void launch_normalize_rows(const float* Z, float* Zc, int64_t N, int dp, hipStream_t s);
 void launch_y_normalize(const float* src, float* dst, int K, int K16, int d, int ldy, hipStream_t s);
+size_t y_planes_dwords(int K16, int dp);
+void launch_y_planes(const float* Y, int K16, int ldy, int dp, unsigned* Yf, hipStream_t s);
 size_t w_planes_dwords(int G, int K16, int dp);
 void launch_w_planes(const float* W, int G, int K16, int ldw, int dp, unsigned* Wf, hipStream_t s);
 int launch_assign(const AssignArgs& a, bool penalty, int max_wgs, hipStream_t s);   // 1: the bf16-pipe wide instance ran, 0: another kernel, -1 unsupported

@@ -1677,6 +1677,218 @@ __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_assign_wide2b(AssignArg
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_assign_wide3: the wide block assignment with the centroids PRE-SPLIT.  k_assign_wide2b splits the centroid values in
+// registers, per workgroup and k-step: 36 vector instructions for 12 MFMAs -- measured at the configs[4] shard it runs at the
+// vector rate (59 us per block launch against 66 with the f32-input MFMA), not at the matrix pipe's.  But Y changes once
+// per ROUND: k_y_planes (one small launch per round) writes it as the A fragments of v_mfma_f32_16x16x32_bf16, three bf16
+// planes, Yf[step s][plane h, m, l][cluster tile mt][lane][8 bf16] (row i = cluster 16 mt + c16, k slot j of lane (c16, q) =
+// PC 32 s + 8 q + j, zeros past the row).  A (plane, tile) fragment is 1 KB contiguous: one LDS-DMA request brings it, one
+// conflict-free 16-byte read per lane hands it to the matrix pipe, no vector instruction touches it.  What is left to split
+// in registers are the tiles' own Z_cos values, once per step (72 instructions for 156 MFMAs).
+// One workgroup of EIGHT waves per CU (a step of all three planes is 3 MT KB: the two-slot ring takes 78 KB at K16 = 208),
+// two tiles per wave, sixteen per workgroup; table rows and block sums for the groups of those sixteen tiles; finishing
+// passes as in k_assign_wide2 / k_round.  One vmcnt(0) + one barrier per step; the requests of step s+1 go out behind the
+// first cluster tile of step s.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_y_planes(const float* __restrict__ Y, int ldy, int mt_n, unsigned* __restrict__ Yf) {
+    const int lane = threadIdx.x, c16 = lane & 15, q = lane >> 4;
+    const int s = blockIdx.x / mt_n, mt = blockIdx.x - s * mt_n;
+    const float* row = Y + (size_t)(16 * mt + c16) * ldy;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 32 * s + 8 * q + j;
+        x[j] = (k < ldy) ? row[k] : 0.f;
+    }
+    u32x4 pl[3];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        unsigned h, m, l;
+        bf16_split3((f32x2){x[2 * p], x[2 * p + 1]}, h, m, l);
+        pl[0][p] = h; pl[1][p] = m; pl[2][p] = l;
+    }
+#pragma unroll
+    for (int pn = 0; pn < 3; ++pn) *reinterpret_cast<u32x4*>(Yf + (((size_t)s * 3 + pn) * mt_n + mt) * 256 + 4 * lane) = pl[pn];
+}
+
+#define WIDE3_WAVES 8
+#define WIDE3_SLOTS (2 * WIDE3_WAVES)
+template <int MT>
+__global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_assign_wide3(AssignArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int K16 = 16 * MT;
+    constexpr int SLOT = 3 * MT * 256;                                   // dwords of a ring slot (one step, three planes)
+    unsigned* ring = reinterpret_cast<unsigned*>(smem);                  // 2 x SLOT
+    float* sig = reinterpret_cast<float*>(ring + 2 * SLOT);              // K16
+    float* nis = sig + K16;                                              // K16: -2 log2(e) / sigma (-200 for pads)
+    float* rpL = nis + K16;                                              // slots x K16
+    float* lrpL = rpL + WIDE3_SLOTS * K16;
+    double* Sd = reinterpret_cast<double*>(lrpL + WIDE3_SLOTS * K16);    // slots x K16 block sums
+    double* objw = Sd + WIDE3_SLOTS * K16;                               // waves x 2
+    int* tg = reinterpret_cast<int*>(objw + 2 * WIDE3_WAVES);            // group of the workgroup's tile j (-1: no such tile)
+    int* ts = tg + WIDE3_SLOTS;                                          // its slot: tiles of one group share table rows and sums
+    int* sg = ts + WIDE3_SLOTS;                                          // group of a slot
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, c16 = lane & 15, q = lane >> 4;
+    const int ns = (a.dp + 31) >> 5;                                     // k-steps of 32 PCs
+    const int tile_begin = a.blk_start ? a.blk_start[a.blk] : a.tile_begin;
+    const int tile_end = a.blk_start ? a.blk_start[a.blk + 1] : a.tile_end;
+    const int ntiles = tile_end - tile_begin;
+    const int base = blockIdx.x * WIDE3_SLOTS;
+    if (base >= ntiles) return;                                          // (the grid is sized for an upper bound of the block)
+
+    RoundTile<MT> T0, T1;
+    const int j0 = base + 2 * wv;
+    const bool has0 = j0 < ntiles, has1 = j0 + 1 < ntiles;              // wave-uniform
+    T0.cell = has0 ? a.cells[(size_t)(tile_begin + j0) * 16 + c16] : -1;
+    T1.cell = has1 ? a.cells[(size_t)(tile_begin + j0 + 1) * 16 + c16] : -1;
+    const float* zr0 = a.Zcos + (size_t)(T0.cell >= 0 ? T0.cell : 0) * a.dp + 8 * q;
+    const float* zr1 = a.Zcos + (size_t)(T1.cell >= 0 ? T1.cell : 0) * a.dp + 8 * q;
+    auto u64 = [](unsigned long long v) {
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
+               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v);
+    };
+    const unsigned long long ysrc = u64((unsigned long long)a.Yf);
+    const unsigned ring0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)ring);
+    const unsigned voff = 16u * (unsigned)lane;
+    auto request = [&](int s) {                                          // this wave's fragments of step s: pieces wv, wv + 8, ... of 3 MT
+        const unsigned long long src0 = ysrc + (unsigned long long)s * (SLOT * 4);
+        const unsigned zone0 = ring0 + (unsigned)(s & 1) * (SLOT * 4);
+#pragma unroll
+        for (int j = 0; j < (3 * MT + WIDE3_WAVES - 1) / WIDE3_WAVES; ++j) {
+            const int p = wv + WIDE3_WAVES * j;                          // wave-uniform
+            if (p < 3 * MT) {
+                const unsigned long long src = src0 + 1024ull * p;
+                const unsigned zone = zone0 + 1024u * p;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(zone) : "memory", "m0");
+            }
+        }
+    };
+    f32x4 z[4];                                                          // raw Z_cos values of the coming step (dead once the step has split them)
+    auto load_z = [&](int s) {                                           // ordinary loads, pinned where they are written; PCs past the row are zeros
+        __builtin_amdgcn_sched_barrier(0);
+        const bool in_row = 32 * s + 8 * q < a.dp;                       // (dp is a multiple of 16: the lane's eight columns are inside or outside together)
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        z[0] = in_row ? ld4(zr0 + 32 * s) : zero;
+        z[1] = in_row ? ld4(zr0 + 32 * s + 4) : zero;
+        z[2] = in_row ? ld4(zr1 + 32 * s) : zero;
+        z[3] = in_row ? ld4(zr1 + 32 * s + 4) : zero;
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    request(0);
+    load_z(0);
+
+    // ---- set-up: sigma, the groups of the workgroup's tiles, their table rows, zeroed sums (as in k_assign_wide2) ----
+    for (int i = tid; i < K16; i += 64 * WIDE3_WAVES) {
+        const float sgm = (i < a.K) ? a.sigma[i] : 0.f;
+        sig[i] = sgm;
+        nis[i] = (i < a.K) ? -(2.885390081777926814f / sgm) : -200.f;   // -c_k = -2 log2(e) / sigma_k; pads: Y row 0 -> 2^-200 == 0
+    }
+    if (tid < WIDE3_SLOTS) tg[tid] = base + tid < ntiles ? a.tile_grp[tile_begin + base + tid] : -1;
+    for (int i = tid; i < WIDE3_SLOTS * K16; i += 64 * WIDE3_WAVES) Sd[i] = 0.0;
+    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0) only: the requests above stay in flight
+    __builtin_amdgcn_s_barrier();
+    if (tid < WIDE3_SLOTS) {
+        int slot = 0;
+        for (int u = 1; u <= tid; ++u) slot += (tg[u] != tg[u - 1] && tg[u] >= 0) ? 1 : 0;
+        ts[tid] = slot;
+        if (tg[tid] >= 0 && (tid == 0 || tg[tid] != tg[tid - 1])) sg[slot] = tg[tid];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    const int nslots = ts[WIDE3_SLOTS - 1] + 1;
+    for (int i = tid; i < nslots * K16; i += 64 * WIDE3_WAVES) {
+        const int sl = i / K16, k = i - sl * K16;
+        const size_t src = (size_t)sg[sl] * K16 + k;
+        rpL[i] = a.rp[src];
+        lrpL[i] = a.lrp[src];
+    }
+    T0.grp = ts[2 * wv];
+    T1.grp = has1 ? ts[2 * wv + 1] : T0.grp;              // (a missing tile computes on cell 0's row and counts for nothing)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        T0.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        T1.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ---- the k-steps ---------------------------------------------------------------------------------------------------
+    auto split4 = [&](const f32x4& lo, const f32x4& hi, u32x4 (&pl)[3]) {   // 8 values -> three bf16 planes (k slot j <-> value j)
+        unsigned h, m, l;
+        bf16_split3((f32x2){lo[0], lo[1]}, h, m, l); pl[0][0] = h; pl[1][0] = m; pl[2][0] = l;
+        bf16_split3((f32x2){lo[2], lo[3]}, h, m, l); pl[0][1] = h; pl[1][1] = m; pl[2][1] = l;
+        bf16_split3((f32x2){hi[0], hi[1]}, h, m, l); pl[0][2] = h; pl[1][2] = m; pl[2][2] = l;
+        bf16_split3((f32x2){hi[2], hi[3]}, h, m, l); pl[0][3] = h; pl[1][3] = m; pl[2][3] = l;
+    };
+#pragma unroll 1
+    for (int s = 0; s < ns; ++s) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's fragments and Z values of step s (requested a whole step ago)
+        wg_barrier_lds();                                            // everybody's fragments of step s are in; nobody reads step s-1 any more
+        const unsigned* slot = ring + (size_t)(s & 1) * SLOT + 4 * lane;
+        u32x4 zp0[3], zp1[3];                                        // the two tiles' B planes of this step
+        split4(z[0], z[1], zp0);
+        split4(z[2], z[3], zp1);
+        u32x4 yp[2][3];                                              // A planes of the current / the next cluster tile
+        auto fetch = [&](int mt, u32x4 (&pl)[3]) {
+#pragma unroll
+            for (int pn = 0; pn < 3; ++pn) pl[pn] = ld4u(slot + (pn * MT + mt) * 256);
+        };
+        auto products = [&](int mt, const u32x4 (&pl)[3]) {          // smallest terms first; the two tiles alternate
+            T0.arg[mt] = MFMA_BF16(pl[2], zp0[0], T0.arg[mt]);  T1.arg[mt] = MFMA_BF16(pl[2], zp1[0], T1.arg[mt]);
+            T0.arg[mt] = MFMA_BF16(pl[0], zp0[2], T0.arg[mt]);  T1.arg[mt] = MFMA_BF16(pl[0], zp1[2], T1.arg[mt]);
+            T0.arg[mt] = MFMA_BF16(pl[1], zp0[1], T0.arg[mt]);  T1.arg[mt] = MFMA_BF16(pl[1], zp1[1], T1.arg[mt]);
+            T0.arg[mt] = MFMA_BF16(pl[1], zp0[0], T0.arg[mt]);  T1.arg[mt] = MFMA_BF16(pl[1], zp1[0], T1.arg[mt]);
+            T0.arg[mt] = MFMA_BF16(pl[0], zp0[1], T0.arg[mt]);  T1.arg[mt] = MFMA_BF16(pl[0], zp1[1], T1.arg[mt]);
+            T0.arg[mt] = MFMA_BF16(pl[0], zp0[0], T0.arg[mt]);  T1.arg[mt] = MFMA_BF16(pl[0], zp1[0], T1.arg[mt]);
+        };
+        fetch(0, yp[0]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (mt + 1 < MT) fetch(mt + 1, yp[(mt + 1) & 1]);
+            products(mt, yp[mt & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (mt == 0 && s + 1 < ns) {                             // behind the first cluster tile: slot (s+1) & 1 is free, z[] is split
+                request(s + 1);
+                load_z(s + 1);
+            }
+        }
+    }
+
+    // ---- finish: exp, penalty, renormalisation, R rows, block sums, objective terms (k_round's passes) ---------------
+    double km_acc = 0.0, ent_acc = 0.0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const f32x4 ni = ld4(nis + 16 * mt + 4 * q);       // dist = 2 (1 - Y.Z) (:447), arg = -dist / sigma (:466), here in log2 units:
+        T0.arg[mt] = __builtin_elementwise_fma(T0.arg[mt], -ni, ni);   // c_k (y.z - 1), the argument of the hardware exp2 (one fma per entry)
+        T1.arg[mt] = __builtin_elementwise_fma(T1.arg[mt], -ni, ni);
+    }
+    if (has0) {
+        float scl0, scl1 = 0.f;
+        round_post_pass1<MT, true, true, false, (HMX_ROUND_PK != 0 && MT <= 8)>(sig, rpL, lrpL, q, T0, scl0, km_acc, ent_acc);
+        if (has1) round_post_pass1<MT, true, true, false, (HMX_ROUND_PK != 0 && MT <= 8)>(sig, rpL, lrpL, q, T1, scl1, km_acc, ent_acc);
+        round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T0, scl0, has1, T1, scl1);
+    }
+    km_acc = wave_sum_all(km_acc);
+    ent_acc = wave_sum_all(ent_acc);
+    if (lane == 0) {
+        objw[2 * wv] = km_acc;
+        objw[2 * wv + 1] = ent_acc;
+    }
+    __syncthreads();
+    if (tid < 2) {
+        double v = 0.0;
+        for (int w = 0; w < WIDE3_WAVES; ++w) v += objw[2 * w + tid];
+        if (v != 0.0) atomicAdd(&a.obj[2 * (blockIdx.x & (HMX_OBJ_SLOTS - 1)) + tid], v);
+    }
+    for (int i = tid; i < nslots * K16; i += 64 * WIDE3_WAVES) {
+        const double v = Sd[i];
+        const int sl = i / K16;
+        if (v != 0.0) atomicAdd(&a.S_out[(size_t)sg[sl] * K16 + (i - sl * K16)], v);
+    }
+}
+
 template <int MT, int KS, bool BF3T>
 __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     if (a.frozen && *a.frozen) return;   // an earlier sweep of this cluster() call timed out: R, O, the objective block stay as it left them
@@ -4209,6 +4421,27 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
         }                                                                                                             \
         hipLaunchKernelGGL((k_assign_wide2b<M>), dim3(wgs2), dim3(64 * WIDE2_WAVES), sm2b, s, a);                      \
     } break;
+            // ... with the centroids pre-split into fragments (k_assign_wide3: eight waves, one workgroup per CU)
+            const size_t sm3 = (size_t)2 * 3 * a.mt * 1024 + ((size_t)2 * a.K16 + 2 * WIDE3_SLOTS * a.K16) * sizeof(float) +
+                               ((size_t)WIDE3_SLOTS * a.K16 + 2 * WIDE3_WAVES) * sizeof(double) + 3 * WIDE3_SLOTS * sizeof(int);
+            const int wgs3 = cdiv(ntiles, WIDE3_SLOTS);
+#define HMX_WIDE3_CASE(M)                                                                                               \
+    case M: {                                                                                                         \
+        static bool attr_done = false;                                                                                \
+        if (!attr_done) {                                                                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_assign_wide3<M>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_done = true;                                                                                         \
+        }                                                                                                             \
+        hipLaunchKernelGGL((k_assign_wide3<M>), dim3(wgs3), dim3(64 * WIDE3_WAVES), sm3, s, a);                        \
+    } break;
+            if (a.bf16_pipe && a.Yf && sm3 <= 160 * 1024) {
+                switch (a.mt) {
+                    HMX_WIDE3_CASE(1) HMX_WIDE3_CASE(2) HMX_WIDE3_CASE(3) HMX_WIDE3_CASE(4) HMX_WIDE3_CASE(5) HMX_WIDE3_CASE(6) HMX_WIDE3_CASE(7)
+                    HMX_WIDE3_CASE(8) HMX_WIDE3_CASE(9) HMX_WIDE3_CASE(10) HMX_WIDE3_CASE(11) HMX_WIDE3_CASE(12) HMX_WIDE3_CASE(13)
+                }
+                return 1;
+            }
+#undef HMX_WIDE3_CASE
             if (a.bf16_pipe && sm2b <= 80 * 1024) {
                 switch (a.mt) {
                     HMX_WIDE2B_CASE(1) HMX_WIDE2B_CASE(2) HMX_WIDE2B_CASE(3) HMX_WIDE2B_CASE(4) HMX_WIDE2B_CASE(5) HMX_WIDE2B_CASE(6) HMX_WIDE2B_CASE(7)
@@ -4586,6 +4819,11 @@ void launch_kmeans_seed(const SeedArgs& a, int K, hipStream_t s) {
     }
 }
 
+size_t y_planes_dwords(int K16, int dp) { return (size_t)((dp + 31) / 32) * 3 * (K16 / 16) * 256; }
+void launch_y_planes(const float* Y, int K16, int ldy, int dp, unsigned* Yf, hipStream_t s) {
+    const int ns = (dp + 31) / 32, mt = K16 / 16;
+    hipLaunchKernelGGL(k_y_planes, dim3(ns * mt), dim3(64), 0, s, Y, ldy, mt, Yf);
+}
 size_t w_planes_dwords(int G, int K16, int dp) { return (size_t)G * ((K16 + 31) / 32) * 3 * (dp / 16) * 256; }
 void launch_w_planes(const float* W, int G, int K16, int ldw, int dp, unsigned* Wf, hipStream_t s) {
     const int ns = (K16 + 31) / 32, mtd = dp / 16;
