@@ -83,6 +83,8 @@ def resolve_workload(config, gpus):
 TIMED_LAUNCH_STRIDE = 4   # the dominant kernel's launches bracketed with HIP events inside the timed region: every 4th (every 7th left 8 samples per default run: one delayed launch moved the average by 5 %)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense (= the f32 vector rate)
+BF16X3_PEAK_TF = 2500.0 / 6.0   # fp32 products as six bf16 MFMAs on three exact bf16 terms per operand: the dense bf16 peak (~2.5 PFLOP/s) / 6
+REFERENCE_AT_1M_SURVEY = 2.56e4   # harmonypy itself (device='cpu', 8 threads) at configs[2]'s size, cells/s/iteration
 
 
 def synthetic_dataset(N, d, B, K, seed=0, cell_seed=None):
@@ -233,7 +235,14 @@ def newest_pmc(engine_version):
                   + (f" (newest: {os.path.basename(files[0])})" if files else ""))
 
 
-def roofline_block(config, N, d, B, K, ktimes, steps, rounds, wide, ktimes_all=None):
+def mfma_ceiling_tf(bf16_sweep, bf16_rtz):
+    """fp32-exact matrix-pipe ceiling of a round whose two GEMMs (equal flops) ran on the given instructions: harmonic mean."""
+    a = BF16X3_PEAK_TF if bf16_sweep else F32_MFMA_PEAK_TF
+    b = BF16X3_PEAK_TF if bf16_rtz else F32_MFMA_PEAK_TF
+    return 2.0 / (1.0 / a + 1.0 / b)
+
+
+def roofline_block(config, N, d, B, K, ktimes, steps, rounds, wide, ktimes_all=None, bf16_sweep=False, bf16_rtz=False):
     """`roofline` of the dominant kernel of the configuration + per-family kernel milliseconds.
 
     C2 / C3 / C4 (K <= 112, d <= 64): k_round, one persistent launch per update_R sweep (or k_sweep under HMX_SWEEP=1):
@@ -259,9 +268,11 @@ def roofline_block(config, N, d, B, K, ktimes, steps, rounds, wide, ktimes_all=N
     if wide:
         flops = cells_per_launch * 2.0 * d * K
         achieved = flops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": ("k_round_wide (one persistent launch per update_R sweep; K > 112 or d > 64)" if sweep else
-                                            "k_assign_wide2 (one launch per update block; K > 112 or d > 64)"),
-                "achieved": achieved, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TF,
+        peak = BF16X3_PEAK_TF if bf16_sweep else F32_MFMA_PEAK_TF
+        roof = {"bound": "mfma", "kernel": ("k_assign_wide3 (one launch per update block, centroids pre-split into bf16 fragments; K > 112 or d > 64)"
+                                            if bf16_sweep else "k_assign_wide2 (one launch per update block, f32-input MFMA; K > 112 or d > 64)"),
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "peak_note": "fp32-exact ceiling of the instruction that ran: bf16x3 = 2.5 PFLOP/s / 6 products, f32-input MFMA = 157.3",
                 "traffic": None, "traffic_source": "not collected for this configuration",
                 "avg_launch_us": per_launch_ms * 1e3, "launches": cnt, "launches_timed": cnt_timed, "algorithmic_flops_per_launch": flops}
     else:
@@ -282,17 +293,32 @@ def roofline_block(config, N, d, B, K, ktimes, steps, rounds, wide, ktimes_all=N
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_us": per_launch_ms * 1e3, "launches": cnt, "launches_timed": cnt_timed, "algorithmic_bytes_per_launch": alg_bytes}
     round_bytes = N * (4 * d + 8 * K + 8)
+    round_flops = N * 4 * d * K
+    # Which roof: both GEMMs of a round (distance product in the sweep, R^T.Z in the streaming pass) keep fp32 operands and
+    # fp32 accumulators; HOW they multiply decides the matrix-pipe ceiling -- the f32-input MFMA (157.3 TFLOP/s) or six bf16
+    # MFMAs per product on three exact bf16 terms per operand (2.5 PFLOP/s / 6 = 417 TFLOP/s of fp32-exact work).  The
+    # round is priced against the instruction that RAN (the engine's counters say which).
+    ceiling = mfma_ceiling_tf(bf16_sweep, bf16_rtz)
+    t_hbm_us = round_bytes / (HBM_PEAK_GBS * 1e9) * 1e6
+    t_mfma_us = round_flops / (ceiling * 1e12) * 1e6
     roof["round"] = {
         "algorithmic_bytes": round_bytes, "kernel_ms_per_round": t_round_kernels,
         "frac_of_hbm_peak": (round_bytes / (t_round_kernels * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_round_kernels > 0 else 0.0,
-        "mfma_flops": N * 4 * d * K,
-        "frac_of_f32_mfma_peak": (N * 4 * d * K / (t_round_kernels * 1e-3) / (F32_MFMA_PEAK_TF * 1e12)) if t_round_kernels > 0 else 0.0}
+        "mfma_flops": round_flops,
+        "mfma_ceiling_fp32_exact_tf": {"f32_input_mfma": F32_MFMA_PEAK_TF, "bf16x3": BF16X3_PEAK_TF, "this_run": ceiling,
+                                       "instruction": {"sweep": "bf16x3" if bf16_sweep else "f32-input", "rtz": "bf16x3" if bf16_rtz else "f32-input"}},
+        "frac_of_mfma_ceiling": (round_flops / (t_round_kernels * 1e-3) / (ceiling * 1e12)) if t_round_kernels > 0 else 0.0,
+        "frac_of_f32_mfma_peak": (round_flops / (t_round_kernels * 1e-3) / (F32_MFMA_PEAK_TF * 1e12)) if t_round_kernels > 0 else 0.0,
+        "floor_us_per_round": {"hbm_8TBs": t_hbm_us, "hbm_copy_ceiling_6.29TBs": t_hbm_us * 8.0 / 6.29, "mfma_this_run": t_mfma_us},
+        "bound": "hbm" if t_hbm_us >= t_mfma_us else "mfma"}
     roof["engine_version"] = harmonypy_amd.engine_version()
     return roof, fam_ms
 
 
-def side_config(name, rounds, steps, warmup, device):
-    """Throughput of another BASELINE configuration with the same step definition (single GPU)."""
+def side_config(name, rounds, steps, warmup, device, repeats=1, converge=False):
+    """Throughput of another BASELINE configuration with the same step definition (single GPU).  `repeats` timed regions of
+    `steps` steps each: the entry reports their median (and all of them).  `converge`: also a default run to convergence on
+    the same cells (its own initialisation), wall-clock -- the second figure of BASELINE.json's metric."""
     from harmonypy_amd import harmony as H
     N, d, B, K = CONFIGS[name]
     Z, meta = synthetic_dataset(N, d, B, K, seed=0, cell_seed=0)
@@ -305,28 +331,74 @@ def side_config(name, rounds, steps, warmup, device):
         ho.check_convergence(1)
     for _ in range(warmup):
         step()
-    ho._engine.sync()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    ho._engine.sync()
-    dt = time.perf_counter() - t0
+    dts = []
+    for _ in range(max(1, repeats)):
+        ho._engine.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        ho._engine.sync()
+        dts.append(time.perf_counter() - t0)
+    dt = sorted(dts)[len(dts) // 2]
+    counters = ho._engine.counters()
     # whole-step roofline of the side entry from its wall time (no per-kernel events here): a round moves 4d + 8K + 8
     # algorithmic bytes and 4 d K flops per cell (distance product + R^T.Z), the ridge step 8K + 16d + 8 bytes and 4 d K flops
-    # (statistics + correction) -- SURVEY section 8d's per-cell figures; the wide shapes are priced against the f32 MFMA peak
+    # (statistics + correction) -- SURVEY section 8d's per-cell figures; the wide shapes are priced against the fp32-exact
+    # ceiling of the instruction that ran (bf16x3: 417 TFLOP/s; f32-input MFMA: 157.3)
     t_step = dt / steps
     step_bytes = N * (rounds * (4.0 * d + 8 * K + 8) + 8.0 * K + 16 * d + 8)
     step_flops = N * (rounds + 1) * 4.0 * d * K
     wide = K > 112 or d > 64
-    roof = ({"bound": "mfma", "achieved": step_flops / t_step / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-             "frac": step_flops / t_step / 1e12 / F32_MFMA_PEAK_TF} if wide else
+    peak_tf = mfma_ceiling_tf(counters.get("sweeps_bf16_pipe", 0) > 0, counters.get("rtz_bf16_pipe", 0) > 0)
+    roof = ({"bound": "mfma", "achieved": step_flops / t_step / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
+             "frac": step_flops / t_step / 1e12 / peak_tf, "frac_of_f32_mfma_peak": step_flops / t_step / 1e12 / F32_MFMA_PEAK_TF,
+             "peak_note": "fp32-exact ceiling of the instructions that ran (harmonic mean over the round's two GEMMs): bf16x3 = 2.5 PFLOP/s / 6, f32-input MFMA = 157.3"}
+            if wide else
             {"bound": "hbm", "achieved": step_bytes / t_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": step_bytes / t_step / 1e9 / HBM_PEAK_GBS})
     roof["scope"] = "whole step (wall time of the loop, launch gaps included)"
-    return {"workload": f"BASELINE configs[{CONFIG_INDEX[name]}] ({name.upper()}): {N} cells x {d} PCs, "
-                        f"{B} batches, K={K}; step = {rounds} k-means rounds + 1 ridge correction",
-            "value": N * steps / dt, "unit": "cells/sec/Harmony-iteration", "ms_per_step": 1e3 * dt / steps, "steps": steps,
-            "roofline": roof}
+    out = {"workload": f"BASELINE configs[{CONFIG_INDEX[name]}] ({name.upper()}): {N} cells x {d} PCs, "
+                       f"{B} batches, K={K}; step = {rounds} k-means rounds + 1 ridge correction",
+           "value": N * steps / dt, "unit": "cells/sec/Harmony-iteration", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+           "roofline": roof}
+    if len(dts) > 1:
+        out["repeats_ms_per_step"] = [round(1e3 * x / steps, 4) for x in dts]
+        out["value_is"] = f"median of {len(dts)} timed regions of {steps} steps"
+    if converge:
+        del ho
+        t0 = time.perf_counter()
+        ho2 = H.run_harmony(Z, meta, ["batch"], nclust=K, max_iter_harmony=0, verbose=False, random_state=0, device=device)
+        ho2._engine.sync()
+        t_init = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        ho2.harmonize(10, verbose=False)                               # max_iter_harmony default (harmony.py:58)
+        ho2._engine.sync()
+        t_loop = time.perf_counter() - t1
+        out["convergence"] = {"wall_s": t_init + t_loop, "setup_and_init_s": t_init, "harmonize_loop_s": t_loop,
+                              "harmony_iterations": len(ho2.kmeans_rounds), "kmeans_rounds": [int(r) for r in ho2.kmeans_rounds],
+                              "converged": bool(ho2.check_convergence(1)), "cells_total": N,
+                              "setup_breakdown_s": {k: round(v, 4) for k, v in ho2.timing.items() if k != "harmonize"},
+                              "init": "host arrays -> upload (rows regrouped on the GPU) + k-means++ seeds on a 32k-cell subsample (GPU) + 25 Lloyd "
+                                      "iterations over all cells (GPU) + init_cluster, then harmonize() to convergence; wall-clock on ONE GPU"}
+    return out
+
+
+def side_config_fresh_process(name, rounds, steps, warmup, repeats):
+    """The side entry measured in a process of its own (nothing of this process's allocations, LISI buffers or freed engines
+    in front of it): `python bench.py --side NAME ...` prints the entry as one JSON line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--side", name, "--rounds", str(rounds), "--steps", str(steps),
+           "--warmup", str(warmup), "--side-repeats", str(repeats)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        out = json.loads(line)
+        out["measured_in"] = "a fresh process"
+        return out
+    except Exception as ex:   # fall back to this process, say so
+        out = side_config(name, rounds, steps, warmup, "cuda:0", repeats=repeats)
+        out["measured_in"] = f"this process (fresh process failed: {type(ex).__name__})"
+        return out
 
 
 def main():
@@ -343,10 +415,20 @@ def main():
     ap.add_argument("--no-lisi", action="store_true", help="skip the LISI of the embedding before / after the run to convergence")
     ap.add_argument("--lisi-cells", type=int, default=1_000_000, help="cells of the LISI measurement (evenly spaced subsample above that)")
     ap.add_argument("--no-convergence", action="store_true", help="skip the untimed end-to-end run to convergence")
+    ap.add_argument("--side", default=None, choices=sorted(CONFIGS), help="print only the side entry of that configuration (one JSON line)")
+    ap.add_argument("--side-repeats", type=int, default=3)
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
 
+    if args.side:
+        os.environ["HMX_UPDATE_ORDER"] = "device"
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
+        entry = side_config(args.side, args.rounds, args.steps, args.warmup, "cuda:0", repeats=args.side_repeats)
+        os.write(json_fd, (json.dumps(entry) + "\n").encode())
+        return 0
     if args.cpu_only:
         N0, d0, B0, K0 = CONFIGS[args.config or "c3"]
         print(json.dumps(cpu_baseline(d0, B0, K0, args.rounds, min(args.cpu_sample, N0))))
@@ -500,7 +582,7 @@ def main():
         # which machine: the same build measures 5-6 % apart on different boxes of the pool, so a
         # difference between two lines is progress only if their `box` agrees or an A/B on ONE box backs it (profiles/*ab*)
         "box": hashlib.sha256(socket.gethostname().encode()).hexdigest()[:8],
-        "box_to_box_spread_note": "same build: 5-6 % between boxes; gains are claimed from same-box A/B runs (profiles/r04_ab_*.txt)",
+        "box_to_box_spread_note": "same build: 5-6 % between boxes; gains are claimed from same-box A/B runs (profiles/r0*_ab_*.txt)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
@@ -535,7 +617,8 @@ def main():
                         "transports": sorted(set(r["transport"] for r in per_rank)),
                         "collectives_per_rank": sorted(set(r["collectives"] for r in per_rank))}
     if timing:
-        out["roofline"], _ = roofline_block(config, N, d, B, K, ktimes, args.steps, args.rounds, ho_wide, ktimes_all)
+        out["roofline"], _ = roofline_block(config, N, d, B, K, ktimes, args.steps, args.rounds, ho_wide, ktimes_all,
+                                            bf16_sweep=counters.get("sweeps_bf16_pipe", 0) > 0, bf16_rtz=counters.get("rtz_bf16_pipe", 0) > 0)
         out["kernel_ms_per_step"] = {k: round(v[0], 3) for k, v in ktimes_all.items()}
     if conv is not None:
         out["convergence"] = conv
@@ -558,14 +641,20 @@ def main():
         # BASELINE configs[1] (69k cells x 50 PCs, 4 batches, K=30) measured the same way, for reference: it is
         # latency-bound (its working set lives in the L3; 20 sequential hand-offs per round), so the headline
         # figure is quoted on configs[2], the roofline point
-        out["configs_1"] = side_config("c2", args.rounds, steps=20, warmup=5, device=f"cuda:{local_rank}")
-        # all 10M cells of BASELINE configs[3] on this ONE GPU (the N=1 point of the strong-scaling curve `--gpus N`
-        # measures), and the per-GPU shard of configs[4] on 8 GPUs (wide-PC regime)
+        # (in a process of its own, median of three timed regions: inside this process the entry read 15 % low in round 4)
         del Z, meta
-        out["configs_3_on_one_gpu"] = side_config("c4x1", args.rounds, steps=2, warmup=1, device=f"cuda:{local_rank}")
+        out["configs_1"] = side_config_fresh_process("c2", args.rounds, steps=20, warmup=5, repeats=3)
+        # all 10M cells of BASELINE configs[3] on this ONE GPU (the N=1 point of the strong-scaling curve `--gpus N`
+        # measures) incl. the default run to convergence on them (north_star: "10M cells converged in < 10 s"), and the
+        # per-GPU shard of configs[4] on 8 GPUs (wide-PC regime)
+        out["configs_3_on_one_gpu"] = side_config("c4x1", args.rounds, steps=2, warmup=1, device=f"cuda:{local_rank}", converge=True)
         out["configs_4_shard"] = side_config("c5", args.rounds, steps=2, warmup=1, device=f"cuda:{local_rank}")
     if args.cpu_sample > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(d, B, K, args.rounds, min(args.cpu_sample, N))
+        # the survey's own measurement of the reference at the HEADLINE size (the CPU path is super-linear in N: the sample
+        # above flatters it): context beside the in-run figure, never a target
+        out["cpu_baseline"]["reference_at_1M_survey"] = {"value": REFERENCE_AT_1M_SURVEY, "unit": "cells/sec/Harmony-iteration", "cores": 8,
+                                                        "source": "BASELINE.md section 2: harmonypy run_harmony(device='cpu') at 1 M cells x 50 PCs, K=100, measured by the survey (not in this run)"}
     os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
