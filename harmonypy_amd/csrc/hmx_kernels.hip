@@ -1766,24 +1766,19 @@ __global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_assign_wide3(AssignArgs
             }
         }
     };
-    // raw Z_cos values of the steps s (even: za, odd: zb), requested TWO steps ahead: the rows are gathered from HBM (a block's
-    // cells are a random sample), one step of 156 MFMAs per wave is shorter than that round trip -- with one step of
-    // distance the launch ran at the latency of seven dependent gathers (48.6 us per block at the configs[4] shard)
-    f32x4 za[4], zb[4];
-    auto load_z = [&](f32x4 (&z)[4], int s) {                            // ordinary loads, pinned where they are written; PCs past the row are zeros
+    f32x4 z[4];                                                          // raw Z_cos values of the coming step (dead once the step has split them)
+    auto load_z = [&](int s) {                                           // ordinary loads, pinned where they are written; PCs past the row are zeros
         __builtin_amdgcn_sched_barrier(0);
-        const int sc = min(s, ns - 1);                                   // (a step past the last: the last one again, never used -- the request count stays fixed)
-        const bool in_row = 32 * sc + 8 * q < a.dp;                      // (dp is a multiple of 16: the lane's eight columns are inside or outside together)
+        const bool in_row = 32 * s + 8 * q < a.dp;                       // (dp is a multiple of 16: the lane's eight columns are inside or outside together)
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        z[0] = in_row ? ld4(zr0 + 32 * sc) : zero;
-        z[1] = in_row ? ld4(zr0 + 32 * sc + 4) : zero;
-        z[2] = in_row ? ld4(zr1 + 32 * sc) : zero;
-        z[3] = in_row ? ld4(zr1 + 32 * sc + 4) : zero;
+        z[0] = in_row ? ld4(zr0 + 32 * s) : zero;
+        z[1] = in_row ? ld4(zr0 + 32 * s + 4) : zero;
+        z[2] = in_row ? ld4(zr1 + 32 * s) : zero;
+        z[3] = in_row ? ld4(zr1 + 32 * s + 4) : zero;
         __builtin_amdgcn_sched_barrier(0);
     };
-    load_z(za, 0);
     request(0);
-    load_z(zb, 1);
+    load_z(0);
 
     // ---- set-up: sigma, the groups of the workgroup's tiles, their table rows, zeroed sums (as in k_assign_wide2) ----
     for (int i = tid; i < K16; i += 64 * WIDE3_WAVES) {
@@ -1826,13 +1821,10 @@ __global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_assign_wide3(AssignArgs
         bf16_split3((f32x2){hi[0], hi[1]}, h, m, l); pl[0][2] = h; pl[1][2] = m; pl[2][2] = l;
         bf16_split3((f32x2){hi[2], hi[3]}, h, m, l); pl[0][3] = h; pl[1][3] = m; pl[2][3] = l;
     };
-    // Memory operations of a wave retire in order.  Behind the first cluster tile of step s the wave issues: the fragment requests
-    // of step s+1, then the four Z loads of step s+2 (always four: past the last step they repeat it).  At the head of step s
-    // it needs its fragments of step s (issued in step s-1) and the Z values of step s (issued in step s-2, older): the only
-    // younger operations are the four Z loads of step s+1 -> vmcnt(4); nothing of those four is read before the next head.
-    auto step = [&](int s, f32x4 (&z)[4]) {
+#pragma unroll 1
+    for (int s = 0; s < ns; ++s) {
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's fragments and Z values of step s (requested a whole step ago)
         wg_barrier_lds();                                            // everybody's fragments of step s are in; nobody reads step s-1 any more
         const unsigned* slot = ring + (size_t)(s & 1) * SLOT + 4 * lane;
         u32x4 zp0[3], zp1[3];                                        // the two tiles' B planes of this step
@@ -1857,16 +1849,11 @@ __global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_assign_wide3(AssignArgs
             if (mt + 1 < MT) fetch(mt + 1, yp[(mt + 1) & 1]);
             products(mt, yp[mt & 1]);
             __builtin_amdgcn_sched_barrier(0);
-            if (mt == 0) {                                           // behind the first cluster tile: slot (s+1) & 1 is free, z[] is split
-                if (s + 1 < ns) request(s + 1);                      // (wave-uniform; the last step requests nothing, its head count is the same: see below)
-                load_z(z, s + 2);
+            if (mt == 0 && s + 1 < ns) {                             // behind the first cluster tile: slot (s+1) & 1 is free, z[] is split
+                request(s + 1);
+                load_z(s + 1);
             }
         }
-    };
-#pragma unroll 1
-    for (int s = 0; s < ns; s += 2) {
-        step(s, za);
-        if (s + 1 < ns) step(s + 1, zb);
     }
 
     // ---- finish: exp, penalty, renormalisation, R rows, block sums, objective terms (k_round's passes) ---------------
@@ -3940,24 +3927,20 @@ __global__ __launch_bounds__(64 * APPLYB_WAVES, 1) void k_ridge_apply_wideb(Appl
         f32x4 acc0[MTD], acc1[MTD];
 #pragma unroll
         for (int mt = 0; mt < MTD; ++mt) { acc0[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        // raw R values of the steps (even: rva, odd: rvb), requested TWO steps ahead (as the Z values of k_assign_wide3: a step of
-        // 156 MFMAs is shorter than the round trip to HBM).  UNCONDITIONAL loads -- dead lanes and clusters past the row read
-        // valid memory (cell 0's row; R has slack rows behind it) and are zeroed when they are split -- so that every step
-        // issues exactly four of them and the counted wait at a step's head holds.
-        f32x4 rva[4], rvb[4];
-        auto load_r = [&](f32x4 (&rv)[4], int s) {
+        f32x4 rv[4];                                                 // raw R values of the coming step (dead once the step has split them)
+        auto load_r = [&](int s) {                                   // ordinary loads, pinned where they are written; clusters past the row are zeros
             __builtin_amdgcn_sched_barrier(0);
-            const int sc = min(s, ns - 1);
-            rv[0] = ld4(rr0 + 32 * sc);
-            rv[1] = ld4(rr0 + 32 * sc + 4);
-            rv[2] = ld4(rr1 + 32 * sc);
-            rv[3] = ld4(rr1 + 32 * sc + 4);
+            const int col = 32 * s + 8 * q;
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            rv[0] = (live0 && col < a.Kp) ? ld4(rr0 + 32 * s) : zero;
+            rv[1] = (live0 && col + 4 < a.Kp) ? ld4(rr0 + 32 * s + 4) : zero;
+            rv[2] = (live1 && col < a.Kp) ? ld4(rr1 + 32 * s) : zero;
+            rv[3] = (live1 && col + 4 < a.Kp) ? ld4(rr1 + 32 * s + 4) : zero;
             __builtin_amdgcn_sched_barrier(0);
         };
         wg_barrier_lds();                                            // nobody reads the ring any more (the pass before)
-        load_r(rva, 0);
         request(0);
-        load_r(rvb, 1);
+        load_r(0);
         auto split4 = [&](const f32x4& lo, const f32x4& hi, u32x4 (&pl)[3]) {
             unsigned h, m, l;
             bf16_split3((f32x2){lo[0], lo[1]}, h, m, l); pl[0][0] = h; pl[1][0] = m; pl[2][0] = l;
@@ -3965,18 +3948,15 @@ __global__ __launch_bounds__(64 * APPLYB_WAVES, 1) void k_ridge_apply_wideb(Appl
             bf16_split3((f32x2){hi[0], hi[1]}, h, m, l); pl[0][2] = h; pl[1][2] = m; pl[2][2] = l;
             bf16_split3((f32x2){hi[2], hi[3]}, h, m, l); pl[0][3] = h; pl[1][3] = m; pl[2][3] = l;
         };
-        // (waits as in k_assign_wide3: behind the first PC tile of step s go the fragment requests of step s+1, then the four
-        // R loads of step s+2; at the head of a step only the four R loads of the step after it may still travel)
-        auto step = [&](int s, f32x4 (&rv)[4]) {
+#pragma unroll 1
+        for (int s = 0; s < ns; ++s) {
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's fragments and R values of step s (requested a whole step ago)
             wg_barrier_lds();                                        // everybody's fragments of step s are in; nobody reads step s-1 any more
             const unsigned* slot = ring + (size_t)(s & 1) * SLOT + 4 * lane;
-            const int col = 32 * s + 8 * q;
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             u32x4 bp0[3], bp1[3];                                    // the two tiles' B planes of this step
-            split4((live0 && col < a.Kp) ? rv[0] : zero, (live0 && col + 4 < a.Kp) ? rv[1] : zero, bp0);
-            split4((live1 && col < a.Kp) ? rv[2] : zero, (live1 && col + 4 < a.Kp) ? rv[3] : zero, bp1);
+            split4(rv[0], rv[1], bp0);
+            split4(rv[2], rv[3], bp1);
             u32x4 wp[2][3];                                          // A planes of the current / the next PC tile
             auto fetch = [&](int mt, u32x4 (&pl)[3]) {
 #pragma unroll
@@ -3996,16 +3976,11 @@ __global__ __launch_bounds__(64 * APPLYB_WAVES, 1) void k_ridge_apply_wideb(Appl
                 if (mt + 1 < MTD) fetch(mt + 1, wp[(mt + 1) & 1]);
                 products(mt, wp[mt & 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (mt == 0) {                                       // behind the first PC tile: slot (s+1) & 1 is free, rv[] is split
-                    if (s + 1 < ns) request(s + 1);
-                    load_r(rv, s + 2);
+                if (mt == 0 && s + 1 < ns) {                         // behind the first PC tile: slot (s+1) & 1 is free, rv[] is split
+                    request(s + 1);
+                    load_r(s + 1);
                 }
             }
-        };
-#pragma unroll 1
-        for (int s = 0; s < ns; s += 2) {
-            step(s, rva);
-            if (s + 1 < ns) step(s + 1, rvb);
         }
         // ---- Z_corr = Z_orig - W^T (Phi_moe R) (:566), Z_cos = its unit rows (:569) ----
         auto finish = [&](bool has, bool live, int cell, f32x4 (&acc)[MTD]) {
