@@ -245,7 +245,7 @@ def mfma_ceiling_tf(bf16_sweep, bf16_rtz):
 def roofline_block(config, N, d, B, K, ktimes, steps, rounds, wide, ktimes_all=None, bf16_sweep=False, bf16_rtz=False):
     """`roofline` of the dominant kernel of the configuration + per-family kernel milliseconds.
 
-    C2 / C3 / C4 (K <= 112, d <= 64): k_round, one persistent launch per update_R sweep (or k_sweep under HMX_SWEEP=1):
+    C2 / C3 / C4 (K <= 112, d <= 64): k_round, one persistent launch per update_R sweep:
     HBM-bound, algorithmic bytes per cell 4d + 4K + 4 (Z_cos row, R row, list entry).
     C5 (wide shapes): k_assign_wide, one launch per update block: f32-MFMA-bound, 2 d K flop per cell."""
     import harmonypy_amd
@@ -278,7 +278,7 @@ def roofline_block(config, N, d, B, K, ktimes, steps, rounds, wide, ktimes_all=N
     else:
         alg_bytes = cells_per_launch * (4 * d + 4 * K + 4)
         achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
-        sweep_name = "k_sweep" if os.environ.get("HMX_SWEEP", "0") not in ("0", "") else "k_round"
+        sweep_name = "k_round"
         kernel = (f"{sweep_name} (one persistent launch per update_R sweep: all 20 blocks)" if sweep
                   else "k_assign_lds (one launch per update block)")
         traffic, traffic_src = None, None

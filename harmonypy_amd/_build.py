@@ -24,9 +24,6 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhmx.so")
 OBJ_DIR = os.path.join(ROOT, "build", "obj")
 SOURCES = ["hmx_kernels.hip", "hmx_rtz3.hip", "hmx_lisi.hip", "hmx_capi.cpp"]
-# the one-pass study kernel k_sweep (a documented negative result) is compiled only on request:
-# `python -m harmonypy_amd._build -DHMX_WITH_SWEEP` (or HMX_WITH_SWEEP=1 in the environment)
-SWEEP_SOURCE = "hmx_sweep.hip"
 HEADERS = [os.path.join(CSRC, "hmx_internal.h"), os.path.join(CSRC, "hmx_device.h"), os.path.join(ROOT, "include", "hmx.h")]
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 
@@ -38,23 +35,19 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
-def _with_sweep(extra_flags) -> bool:
-    return "-DHMX_WITH_SWEEP" in extra_flags or os.environ.get("HMX_WITH_SWEEP", "0") not in ("0", "")
-
-
 def sources(extra_flags=()) -> list:
-    return SOURCES + ([SWEEP_SOURCE] if _with_sweep(extra_flags) else [])
+    return list(SOURCES)
 
 
 def build_id(extra_flags=()) -> str:
-    """Hash of everything that decides the kernels: csrc/* (all of it, built or not), include/hmx.h, the flags."""
+    """Hash of everything that decides the kernels: csrc/*, include/hmx.h, the flags."""
     h = hashlib.sha256()
     files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h")))
     for p in files + [os.path.join(ROOT, "include", "hmx.h")]:
         h.update(os.path.basename(p).encode())
         with open(p, "rb") as f:
             h.update(f.read())
-    flags = sorted(set(extra_flags) | ({"-DHMX_WITH_SWEEP"} if _with_sweep(extra_flags) else set()))
+    flags = sorted(set(extra_flags))
     h.update(" ".join(BASE_FLAGS + flags).encode())
     return h.hexdigest()[:12]
 
@@ -132,7 +125,7 @@ def _object(src, flags, verbose):
 def _compile(lib, verbose, extra_flags, capi_flags=(), stamp=None):
     os.makedirs(OBJ_DIR, exist_ok=True)
     bid = stamp or build_id(extra_flags)
-    flags = BASE_FLAGS + list(extra_flags) + (["-DHMX_WITH_SWEEP"] if _with_sweep(extra_flags) and "-DHMX_WITH_SWEEP" not in extra_flags else [])
+    flags = BASE_FLAGS + list(extra_flags)
     srcs = sources(extra_flags)
 
     def one(src):

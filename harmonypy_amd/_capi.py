@@ -26,16 +26,24 @@ EXPORTS = [
     "hmx_last_error", "hmx_abi_version", "hmx_create", "hmx_destroy", "hmx_upload", "hmx_init_cluster",
     "hmx_cluster_round", "hmx_cluster_round_seeded", "hmx_moe_correct_ridge", "hmx_get", "hmx_set", "hmx_sync", "hmx_device_ptr",
     "hmx_kernel_times", "hmx_enable_timing", "hmx_counters", "hmx_comm_unique_id", "hmx_comm_init", "hmx_set_host_allreduce",
-    "hmx_build_id", "hmx_has_sweep_kernel", "hmx_cluster", "hmx_set_timing_stride", "hmx_set_timing_families", "hmx_kmeans_lloyd", "hmx_kmeans_seed", "hmx_compute_lisi", "hmx_get_rows", "hmx_set_ranks", "hmx_peer_export", "hmx_peer_attach", "hmx_peer_selftest", "hmx_peer_enable",
+    "hmx_build_id", "hmx_cluster", "hmx_set_timing_stride", "hmx_set_timing_families", "hmx_kmeans_lloyd", "hmx_can_lloyd", "hmx_kmeans_seed", "hmx_compute_lisi", "hmx_get_rows", "hmx_set_ranks", "hmx_peer_export", "hmx_peer_attach", "hmx_peer_selftest", "hmx_peer_enable",
 ]
 HMX_PEER_HANDLE_BYTES = 64
-HMX_ABI_VERSION = 6
+HMX_ABI_VERSION = 7
 HMX_UNIQUE_ID_BYTES = 128
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
 
 
 class HmxError(RuntimeError):
-    pass
+    """A libhmx call returned a negative code.  ``code`` is that return value (HMX_ERR_ARG = -1 bad argument / unsupported
+    shape, HMX_ERR_HIP = -2, HMX_ERR_STATE = -3, HMX_ERR_COMM = -4; None when the library could not be loaded)."""
+
+    def __init__(self, message, code=None):
+        super().__init__(message)
+        self.code = code
+
+
+HMX_ERR_ARG, HMX_ERR_HIP, HMX_ERR_STATE, HMX_ERR_COMM = -1, -2, -3, -4
 
 
 class HmxConfig(C.Structure):
@@ -78,11 +86,11 @@ def load():
     lib.hmx_peer_enable.argtypes = [vp, C.c_int]
     lib.hmx_init_cluster.argtypes = [vp, vp, vp]
     lib.hmx_kmeans_lloyd.argtypes = [vp, vp, C.c_int, vp]
+    lib.hmx_can_lloyd.argtypes = [vp]
     lib.hmx_cluster_round.argtypes = [vp, C.c_int, vp, i64, vp, i32, vp, vp]
     lib.hmx_cluster_round_seeded.argtypes = [vp, C.c_int, C.c_uint64, i64, vp]
     lib.hmx_cluster.argtypes = [vp, C.c_uint64, i64, C.c_int, C.c_int, C.c_int, C.c_double, vp, vp]
     lib.hmx_build_id.argtypes = []
-    lib.hmx_has_sweep_kernel.argtypes = []
     lib.hmx_moe_correct_ridge.argtypes = [vp]
     lib.hmx_get.argtypes = [vp, C.c_int, vp, C.c_size_t]
     lib.hmx_set.argtypes = [vp, C.c_int, vp, C.c_size_t]
@@ -107,14 +115,9 @@ def build_id() -> str:
     return load().hmx_build_id().decode()
 
 
-def has_sweep_kernel() -> bool:
-    """Whether the library carries the opt-in study kernel k_sweep (``python -m harmonypy_amd._build -DHMX_WITH_SWEEP``)."""
-    return bool(load().hmx_has_sweep_kernel())
-
-
 def _check(rc):
     if rc < 0:
-        raise HmxError(f"libhmx: {load().hmx_last_error().decode(errors='replace')} (code {rc})")
+        raise HmxError(f"libhmx: {load().hmx_last_error().decode(errors='replace')} (code {rc})", code=int(rc))
     return rc
 
 
@@ -223,6 +226,10 @@ class Engine:
         chosen = np.empty(self.K, np.int32)
         _check(self._lib.hmx_kmeans_seed(self._h, _ptr(pts), pts.shape[0], int(seed) & (2**64 - 1), _ptr(out), _ptr(chosen)))
         return out, chosen
+
+    def can_lloyd(self) -> bool:
+        """Whether kmeans_lloyd serves this engine's shape and layout (hmx_can_lloyd)."""
+        return bool(_check(self._lib.hmx_can_lloyd(self._h)))
 
     def kmeans_lloyd(self, centers, n_iter=25):
         """Lloyd iterations over all cells of Z_cos on the device; centres K x d in and out."""

@@ -111,12 +111,10 @@ struct hmx_engine {
     int n_cus = 0;
     int rtz_wgs_per_cu = 4;      // k_rtz2 grid (HMX_RTZ_WGS_PER_CU)
     int round_mode = 1;          // 1: persistent sweep kernel when the shape allows it, 0: one launch per block (HMX_ROUND_MODE=blocks)
-    int sweep_kernel = 0;        // 0: k_round + R^T.Z pass with the removal sums (faster at C3: DESIGN.md §3), 1: k_sweep (hmx_sweep.hip; HMX_SWEEP=1)
     unsigned spin_limit = 1u << 24;  // polls a grid-wide wait may take (HMX_SPIN_LIMIT; tests shrink it to force the fall-back)
     long n_sweep_fallbacks = 0;  // rounds repeated through the per-block path after a wait timed out
     long n_rtz_bf16 = 0;         // R^T.Z passes launched on the bf16-pipe instance k_rtz3b
     bool allow_round_bf16 = true;   // HMX_ROUND_F32=1 at hmx_create: the f32-input instances of k_round (A/B runs and tests)
-    bool wide_pre_split = true;     // HMX_WIDE_PRESPLIT=0 at hmx_create: k_assign_wide2b (centroids split in registers) instead of k_assign_wide3
     bool allow_rtz_bf16 = true;     // HMX_RTZ3_BF16=0 at hmx_create: k_rtz3 instead of k_rtz3b
     long n_sweeps_bf16 = 0;      // sweeps launched on the bf16-pipe instances of k_round (round_uses_bf16_pipe)
     DevBuf<unsigned long long> wait_stats;   // {waits, incomplete polls, most polls of one wait} of the sweep kernels' grid-wide waits
@@ -391,17 +389,8 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
     if (const char* rc_ = getenv("HMX_ROUND_WGS")) e->round_wgs_cap = std::max(0, atoi(rc_));
     if (const char* pl = getenv("HMX_PREFETCH_LISTS")) e->prefetch_lists = atoi(pl) != 0;
     if (const char* rm = getenv("HMX_ROUND_MODE")) e->round_mode = (std::string(rm) == "blocks") ? 0 : 1;
-    if (const char* sw = getenv("HMX_SWEEP")) e->sweep_kernel = atoi(sw) != 0;
-#ifndef HMX_WITH_SWEEP
-    if (e->sweep_kernel) {
-        delete e;
-        return fail(HMX_ERR_ARG, "HMX_SWEEP=1 asks for the study kernel k_sweep, which this library was built without "
-                                 "(python -m harmonypy_amd._build -DHMX_WITH_SWEEP)");
-    }
-#endif
     if (const char* rf = getenv("HMX_ROUND_F32")) e->allow_round_bf16 = atoi(rf) == 0;
     if (const char* rb = getenv("HMX_RTZ3_BF16")) e->allow_rtz_bf16 = atoi(rb) != 0;
-    if (const char* ps = getenv("HMX_WIDE_PRESPLIT")) e->wide_pre_split = atoi(ps) != 0;
     if (const char* rk = getenv("HMX_RTZ")) e->rtz_kernel = atoi(rk) == 2 ? 2 : 3;
     if (const char* fs = getenv("HMX_TEST_FAIL_SWEEP")) e->test_fail_sweep = atol(fs);
     if (const char* sl = getenv("HMX_SPIN_LIMIT")) e->spin_limit = (unsigned)std::max(0L, atol(sl));   // 0: every wait of the persistent kernels gives up at once (tests)
@@ -415,7 +404,6 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
         hipError_t se = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
         if (se != hipSuccess) { rc = fail(HMX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se)); break; }
         const size_t N = (size_t)e->N, GK = (size_t)e->G * e->K16;
-        // R: + a trash row behind the last cell for k_sweep's unconditional stores
         // + 16 rows of slack behind Z_orig / Z_cos / R: the streaming pass (k_rtz3) fetches whole 16-cell tiles
         if ((rc = e->Zorig.reserve((N + 16) * e->dp)) || (rc = e->Zcos.reserve((N + 16) * e->dp)) || (rc = e->Zcorr.reserve(N * e->dp)) ||
             (rc = e->R.reserve((N + 16) * e->Kp + e->K16 + 64)) || (rc = e->Osave.reserve(GK)) || (rc = e->Y.reserve((size_t)e->K16 * e->ldy)) ||
@@ -625,7 +613,7 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
             // k_rtz3 keeps two workgroups per CU resident, k_rtz3b (four tile buffers per wave) one: as many tasks as fit at once,
             // or a second round of workgroups pays the prologue, the slab reduction and the tail again (measured: 188 us per
             // pass with 505 tasks of 31 tiles per wave)
-            const bool one_per_cu = e->allow_rtz_bf16 && (rtz_wide_ok(e->mt, e->dp) ? rtzw2b_ok(e->mt, e->dp, e->d, e->nblk) : rtz3b_ok(e->mt, e->dp, e->nblk, e->Kp));
+            const bool one_per_cu = e->allow_rtz_bf16 && (rtz_wide_ok(e->mt, e->dp) ? (rtzw2b_ok(e->mt, e->dp, e->d, e->nblk) || rtzw3b_ok(e->mt, e->dp, e->d, e->nblk, e->Kp)) : rtz3b_ok(e->mt, e->dp, e->nblk, e->Kp));
             const int target = std::max(1, (one_per_cu ? 1 : 2) * e->n_cus - e->G);
             const int CH3 = std::max(16, std::min(one_per_cu ? 2048 : 256, (n_static_tiles + target - 1) / target));
             // HMX_RTZ3_TASKS=contig: a task is a contiguous run of a group's tiles; default: the m tasks of a group take
@@ -792,6 +780,16 @@ int hmx_kmeans_seed(hmx_engine* e, const float* points, int64_t n_points, uint64
 
 static int lloyd_wide(hmx_engine* e, const float* centers_in, int n_iter, float* centers_out);
 
+// 1 when hmx_kmeans_lloyd serves this engine's shape and layout, 0 when it would refuse (wide shapes whose static tiles do not
+// hold consecutive cells, or with more batch groups than the finish kernel of the streaming pass tabulates): a caller --
+// every rank of a sharded job, BEFORE any of them enters the iterations' collectives -- asks first and falls back together.
+int hmx_can_lloyd(hmx_engine* e) {
+    if (!e) return fail(HMX_ERR_ARG, "null argument");
+    if (!e->uploaded) return fail(HMX_ERR_STATE, "hmx_upload must come first");
+    if (e->mt > 7 || e->dp > 64) return (e->static_contig && e->ntasks3 > 0 && rtzw_ok(e->mt, e->dp, e->d, 1, e->G)) ? 1 : 0;
+    return 1;
+}
+
 int hmx_kmeans_lloyd(hmx_engine* e, const float* centers_in, int n_iter, float* centers_out) {
     if (!e || !centers_in || !centers_out) return fail(HMX_ERR_ARG, "null argument");
     if (!e->uploaded) return fail(HMX_ERR_STATE, "hmx_upload must come first");
@@ -890,6 +888,7 @@ struct Rtz3Duties { bool on = false; };
 static int rtz3_pass(hmx_engine* e, int mode, const unsigned char* tile_blk, int nblk_cols, bool normalize, bool duties) {
     int rc;
     const bool wide = !(use_rtz3(e) && rtz3_ok(e->mt, e->dp, nblk_cols, e->G));   // (mode 2 comes here for wide shapes whatever the rounds' kernel is)
+    bool plain_rows = false;
     if ((rc = e->slab.reserve((size_t)e->ntasks3 * (wide ? rtzw_slab_floats(e->mt, e->dp, e->d, nblk_cols) : rtz3_slab_floats(e->mt, e->dp, nblk_cols)))))
         return rc;
     {
@@ -903,12 +902,14 @@ static int rtz3_pass(hmx_engine* e, int mode, const unsigned char* tile_blk, int
         if (lr > 0) e->n_rtz_bf16++;
         if (lr < 0)
             return fail(HMX_ERR_ARG, "unsupported shape for the streaming R^T.Z pass");
+        plain_rows = lr == 2;
     }
     Timed t(e, mode == 1 ? F_RIDGE_STATS : F_RTZ_REDUCE);
     const size_t GK = (size_t)e->G * e->K16;
     Rtz3FinishArgs f{};
     f.slab = e->slab.p; f.task_grp = e->t3_grp.p; f.ntasks = e->ntasks3;
     f.MT = e->mt; f.KS = e->dp / 4; f.NTB = rtz3_ntb(e->dp, nblk_cols);
+    f.plain_rows = plain_rows ? 1 : 0;
     f.wide = wide ? 1 : 0; f.NT = wide ? rtzw_nt(e->dp, e->d, nblk_cols) : 4 + f.NTB;
     f.K = e->K; f.K16 = e->K16; f.d = e->d; f.ld = e->ldy; f.G = e->G; f.nblk = nblk_cols; f.mode = mode == 0 ? 0 : 1;
     f.Ysum = e->Yacc64; f.Yout = normalize ? e->Y.p : nullptr; f.Sold = e->Sold; f.Sr = e->Sr; f.Oxr = e->Oxr;
@@ -923,7 +924,7 @@ static int rtz3_pass(hmx_engine* e, int mode, const unsigned char* tile_blk, int
 }
 
 // Centroid numerators sum_cells R (x) Z_cos (harmony.py:443) of this rank's cells into Yacc64, by a pass over the
-// static list (no removal sums: k_sweep forms those itself).
+// static list (no removal sums).
 static int centroid_pass(hmx_engine* e) {
     if (streaming_rtz(e)) return rtz3_pass(e, 0, e->tile_blk_zero.p, 1, false, false);
     int rc, nsub, spw;
@@ -1006,71 +1007,6 @@ static void note_sweep_timeout(hmx_engine* e) {
     }
 }
 
-#ifdef HMX_WITH_SWEEP
-// (k_sweep, the opt-in study kernel) A grid-wide wait gave up.  k_sweep forms the removal sums inside the launch, so
-// nothing of the failed round can be replayed exactly: take O from R again (every row is still a distribution); the
-// caller then repeats the round block by block.  Every rank comes here together: a rank that timed out poisons its
-// objective sums with NaN, which every rank sees after the all-reduce of those sums.
-static int sweep_timed_out(hmx_engine* e) {
-    const size_t GK = (size_t)e->G * e->K16;
-    note_sweep_timeout(e);
-    HIP_TRY(hipMemsetAsync(e->Ogrp.p, 0, GK * sizeof(double), e->stream));
-    launch_group_sums(e->R.p, e->Kp, e->K, e->K16, e->s_cells.p, e->s_tile_grp.p, e->n_s_tiles, e->Ogrp.p, e->stream);
-    return sum_over_ranks(e, e->Ogrp.p, GK);
-}
-
-static bool sweep_shape_ok(const hmx_engine* e) {
-    return e->mt <= 7 && e->G <= 64 && sweep_row_floats(e->d) == e->dp &&
-           sweep_lds_bytes(e->K16, e->d, e->G, e->B, e->V, e->nblk) <= 156 * 1024;
-}
-
-// One k-means round on k_sweep (hmx_sweep.hip): centroids from a pass over R -> ONE persistent launch (update_R over
-// all blocks with the removal sums formed inside, objective).
-// Returns 1 when a grid-wide wait of the kernel timed out on any rank (the caller repeats the round block by block).
-static int round_sweep(hmx_engine* e, int flags, const std::vector<int>& tiles_upper, double obj_out[4],
-                       const std::function<int()>& before_sweep) {
-    int rc;
-    const size_t GK = (size_t)e->G * e->K16, n_y = (size_t)e->K16 * e->ldy;
-    HIP_TRY(hipMemsetAsync(e->objacc, 0, (2 * HMX_OBJ_SLOTS + 2) * sizeof(double), e->stream));
-    if (flags & HMX_ROUND_CENTROIDS) {
-        if ((rc = centroid_pass(e))) return rc;
-        if ((rc = sum_over_ranks(e, e->Yacc64, n_y))) return rc;
-        Timed t(e, F_RTZ_REDUCE);
-        launch_y_normalize_d(e->Yacc64, e->Y.p, e->K, e->K16, e->d, e->ldy, e->stream);  // :444
-    }
-    if (before_sweep && (rc = before_sweep())) return rc;   // side-stream work that should run beside the sweep
-    HIP_TRY(hipMemsetAsync(e->Sslots.p, 0, (GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 1) * sizeof(double), e->stream));
-    int max_upper = 0;
-    for (int b = 0; b < e->nblk; ++b) max_upper = std::max(max_upper, tiles_upper[b]);
-    const bool multi = e->peers_enabled && e->n_ranks > 1;
-    const int waves = sweep_waves();
-    int wgs_max = std::max(1, e->n_cus - (multi ? 1 : 0) - (e->prefetch_lists ? 12 : 0));
-    if (e->round_wgs_cap > 0) wgs_max = std::min(wgs_max, e->round_wgs_cap);
-    const int per_wave = std::max(1, (max_upper + waves * wgs_max - 1) / (waves * wgs_max));
-    const int wgs = std::max(1, std::min(wgs_max, (max_upper + waves * per_wave - 1) / (waves * per_wave)));
-    {
-        Timed t(e, F_ASSIGN_BLOCK);
-        SweepArgs sa{};
-        sa.Zcos = e->Zcos.p; sa.Y = e->Y.p; sa.sigma = e->sigma.p; sa.R = e->R.p;
-        sa.cells = e->lists[e->cur].cells.p; sa.blk_start = e->lists[e->cur].blk_start.p; sa.gstart = e->gstart.p;
-        sa.O_start = e->Ogrp.p; sa.D_slots = e->Sslots.p; sa.O_out = e->Ogrp.p; sa.T_out = e->Tmass.p;
-        sa.obj = e->objacc; sa.group_cols = e->group_cols.p; sa.Pr_b = e->Pr_b.p; sa.theta = e->theta.p;
-        sa.counter = e->sync_words.p; sa.error = e->sync_words.p + 1; sa.wait_stats = e->wait_stats.p;
-        sa.spin_limit = e->spin_limit; sa.n_cells = e->N;
-        sa.K = e->K; sa.Kp = e->Kp; sa.K16 = e->K16; sa.ldz = e->dp; sa.ldy = e->ldy; sa.G = e->G; sa.B = e->B; sa.V = e->V;
-        sa.nblk = e->nblk; sa.n_ranks = 1;
-        if (multi) {
-            sa.peer_box = e->peer_dev.p; sa.my_box = e->box; sa.n_ranks = e->n_ranks; sa.rank = e->rank;
-            sa.epoch = e->round_epoch;
-            e->round_epoch += 64;
-        }
-        if (launch_sweep(sa, e->mt, e->d, multi ? wgs + 1 : wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported shape for k_sweep");
-    }
-    if (sharded(e) && (rc = sum_over_ranks(e, e->objacc, 2 * HMX_OBJ_SLOTS))) return rc;
-    if ((rc = read_objective(e, obj_out))) return rc;
-    return (obj_out[0] != obj_out[0] || obj_out[1] != obj_out[1]) ? 1 : 0;
-}
-#endif
 
 // update_R block by block (harmony.py:476-507): per block the diversity table (k_block_table), the assignment of the
 // block's tiles (bounded launch) and the block's new sums over all ranks; closes O, T and the cross-entropy term.
@@ -1079,7 +1015,7 @@ static int blocks_loop(hmx_engine* e, int flags, const std::vector<int>& tiles_u
     int rc;
     const size_t GK = (size_t)e->G * e->K16;
     int bf16_blocks = 0;                                            // blocks assigned by the bf16-pipe instance of the wide kernel
-    const bool y_frags = e->allow_round_bf16 && e->wide_pre_split && rtz_wide_ok(e->mt, e->dp);
+    const bool y_frags = e->allow_round_bf16 && rtz_wide_ok(e->mt, e->dp);
     if (y_frags) {                                                  // Y of this round, split once into the fragments k_assign_wide3 multiplies with
         if ((rc = e->Yf.reserve(y_planes_dwords(e->K16, e->dp)))) return rc;
         launch_y_planes(e->Y.p, e->K16, e->ldy, e->dp, e->Yf.p, e->stream);
@@ -1151,18 +1087,6 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
     int rc;
     const size_t GK = (size_t)e->G * e->K16;
     const bool persistent = (flags & HMX_ROUND_UPDATE_R) && e->round_mode == 1 && (!sharded(e) || e->peers_enabled);
-#ifdef HMX_WITH_SWEEP
-    if (persistent && e->sweep_kernel && sweep_shape_ok(e)) {
-        rc = round_sweep(e, flags, tiles_upper, obj_out, before_sweep);
-        if (rc <= 0) return rc;
-        if ((rc = sweep_timed_out(e))) return rc;
-        const int saved = e->round_mode;
-        e->round_mode = 0;
-        rc = round_body(e, flags, n_tiles_upper, tiles_upper, obj_out, nullptr, nullptr);
-        e->round_mode = e->round_mode == 0 && e->n_sweep_fallbacks >= 2 ? 0 : saved;
-        return rc;
-    }
-#endif
     const bool mega = persistent && e->mt <= 7 && round_row_floats(e->d) == e->dp &&
                       round_lds_bytes(e->K16, e->dp, e->G, e->B, e->V, false) <= HMX_ROUND_LDS_LIMIT;
     const bool r3 = streaming_rtz(e);
@@ -1570,14 +1494,6 @@ const char* hmx_build_id(void) {
     return HMX_BUILD_ID;
 #else
     return "unknown";
-#endif
-}
-
-int hmx_has_sweep_kernel(void) {
-#ifdef HMX_WITH_SWEEP
-    return 1;
-#else
-    return 0;
 #endif
 }
 

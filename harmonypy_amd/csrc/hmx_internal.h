@@ -25,8 +25,8 @@ struct AssignArgs {
     int tile_begin, tile_end;  // host-side range (or an upper bound of its length when blk_start)
     int K, Kp, K16, mt, dp, ldy;
     int G, ldy_lds, tables_in_lds, tiles_per_wave, ablate;
-    const unsigned* Yf;    // wide shapes, bf16 pipe: Y as the A fragments of k_assign_wide3 (launch_y_planes), or null (k_assign_wide2b splits in registers)
-    int bf16_pipe;         // wide shapes: the bf16-pipe instance k_assign_wide2b (0: engines created under HMX_ROUND_F32=1 keep k_assign_wide2)
+    const unsigned* Yf;    // wide shapes, bf16 pipe: Y as the A fragments of k_assign_wide3 (launch_y_planes), or null (the f32-input kernel k_assign_wide2)
+    int bf16_pipe;         // wide shapes: the bf16-pipe instance k_assign_wide3 (0: engines created under HMX_ROUND_F32=1 keep k_assign_wide2)
     const float* hn;       // k_assign_wide without penalty only: half squared norms of the centres in Y (+inf for pads) -> HARD
                            // assignment of the device k-means (a one-hot row of R per cell) instead of the softmax; null otherwise
 };
@@ -63,38 +63,6 @@ struct RoundArgs {
     unsigned spin_limit;       // polls a wait may take before it gives up
     int n_ranks, rank;
     int K, Kp, K16, dp, ldy, ldy_lds, G, B, V, nblk;
-};
-
-// One whole update_R sweep (all blocks) in one persistent launch (k_sweep, hmx_sweep.hip): distance product, reassignment,
-// objective sums, and the removal sums of every block (old R rows through LDS-DMA).
-struct SweepArgs {
-    const float* Zcos;       // N x ldz
-    const float* Y;          // K16 x ldy unit rows
-    const float* sigma;      // K16
-    float* R;                // N x Kp, followed by K16 floats the kernel may scribble on
-    const int* cells;        // block-major padded list
-    const int* blk_start;    // nblk+1 tile offsets (device)
-    const int* gstart;       // G+1: first internal cell of every group
-    const double* O_start;   // G x K16: O at the start of the round
-    double* D_slots;         // (nblk+1) x HMX_ROUND_SLOTS x G x K16 hand-off tables, zeroed by the caller
-    double* O_out;           // G x K16: O after the round
-    double* T_out;           // K16: cluster mass after the round
-    double* obj;             // HMX_OBJ_SLOTS x 2 partial sums + cross-entropy term at [2*HMX_OBJ_SLOTS]
-    const int* group_cols;   // G x V
-    const float* Pr_b;
-    const float* theta;
-    unsigned* counter;       // arrivals (zeroed by the caller)
-    unsigned* error;         // set to 1 when a wait gave up (zeroed by the caller)
-    unsigned long long* wait_stats;   // {waits, polls that found the hand-off incomplete, most polls of one wait}: accumulated
-    // cells sharded over ranks: the hand-off tables travel through peer boxes (null / 1: single engine)
-    double* const* peer_box;   // n_ranks box base pointers (own box included), device array
-    double* my_box;
-    unsigned long long epoch;  // flag value of hand-off p in this launch = epoch + p + 1
-    unsigned long long* prof;  // HMX_SWEEP_PROF builds: workgroups x nblk x 16 time stamps (or null)
-    int64_t n_cells;
-    unsigned spin_limit;       // polls a wait may take before it gives up
-    int n_ranks, rank;
-    int K, Kp, K16, ldz, ldy, G, B, V, nblk;
 };
 
 struct RtzArgs {
@@ -134,6 +102,7 @@ struct Rtz3FinishArgs {
     const int* task_grp;
     int ntasks, MT, KS, NTB, K, K16, d, ld, G, nblk;
     int wide, NT;              // k_rtzw's slabs: plain column tiles, NT of them (KS = dp / 4 there too)
+    int plain_rows;            // k_rtzw3b's slabs: row tile mt holds the clusters 16 mt .. 16 mt + 15 (else the permuted map of k_rtz3)
     int mode;                  // 0: k-means round (Ysum, Sold, optional Yout), 1: ridge (Sr, Oxr)
     double* Ysum;              // K16 x ld
     float* Yout;               // K16 x ld unit rows, or null (a collective comes first)
@@ -158,6 +127,7 @@ void launch_rtz3_finish(const Rtz3FinishArgs& a, hipStream_t s);
 bool rtzw_ok(int mt, int dp, int d, int nblk, int G);
 int rtzw_nt(int dp, int d, int nblk);
 int rtzw_slab_floats(int mt, int dp, int d, int nblk);
+bool rtzw3b_ok(int mt, int dp, int d, int nblk, int Kp);   // launch_rtzw takes k_rtzw3b (eight waves, one workgroup per CU; returns 2)
 bool rtzw2b_ok(int mt, int dp, int d, int nblk);   // launch_rtzw takes the bf16-pipe kernel k_rtzw2b (one workgroup per CU)
 int launch_rtzw(const Rtz3Args& a, int mt, int dp, int d, int nblk, hipStream_t s, bool allow_bf16);   // 1: k_rtzw2b ran, 0: an f32-input kernel, -1 unsupported
 void launch_tile_blocks(const int* cells, const int* tile_grp, const int* blk_start, int nblk, int64_t n_pos_upper, const int* gstart,
@@ -232,7 +202,6 @@ struct OrderArgs {
 size_t sweep_lds_bytes(int K16, int d, int G, int B, int V, int nblk);
 int sweep_row_floats(int d);
 int sweep_waves();
-int launch_sweep(const SweepArgs& a, int mt, int d, int wgs, hipStream_t s);
 size_t round_lds_bytes(int K16, int dp, int G, int B, int V, bool bf3);
 bool round_uses_bf16_pipe(int K16, int dp, int G, int B, int V, bool extra_tiles, bool allow_bf16);   // which k_round instance launch_round picks
 // k_round has no static LDS and one workgroup per CU: everything the CU has (160 KB), less a small margin

@@ -1434,254 +1434,12 @@ __global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_assign_wide2(AssignArgs
 }
 
 // ------------------------------------------------------------------------------------------
-// k_assign_wide2b: k_assign_wide2 with the distance GEMM on the bf16 matrix pipe (hmx_device.h: every fp32 operand as the
-// exact sum of three bf16 terms, six products, fp32 accumulation).  The wide shapes are bound by the f32-input MFMA (52
-// k-steps of 32 cycles per cluster tile and cell tile at d = 208; here 7 x 6 of 16), so the split moves the bound.  Same
-// workgroup (four waves, two tiles each, two workgroups per CU), same finishing passes, same LDS-DMA ring of fp32 centroid
-// pieces (16 rows x 16 columns, XOR-swizzled 16-byte chunks) -- but a k-step is 32 columns = TWO ring slots, the ring holds
-// two steps (four slots), and both operands are split in registers: the centroid values per cluster tile (36 vector
-// instructions for 12 MFMAs, pipelined one tile ahead of the products), the tiles' Z_cos values once per step.
-//   * k slot <-> column: lane (c16, q) holds the columns of chunks (q & 1 ? 3, 2 : 0, 1) of ring slot 2 s + (q >> 1): with the
-//     odd lanes' two chunks in that order both 16-byte fragment reads of a 16-lane group touch every bank once (the groups
-//     mix lanes of q = 0 and q = 1; chunk order 2, 3 would put c16 = 4 and c16 = 12 on the same banks);
-//   * waits: everything a step needs was requested during the step before and is drained by ONE vmcnt(0) at its head --
-//     the requests of step s+1 go out behind the first cluster tile of step s (slots of step s-1: free behind the barrier);
-//     no hand-counted partial wait, nothing in flight across a register read (scripts/kernel_audit.py --inflight);
-//   * an odd number of 16-column pieces: the last step's second slot is not requested; its lanes read the first slot again
-//     (finite values) and multiply zeros (the Z side is masked).
-// ------------------------------------------------------------------------------------------
-#define WIDE2B_YSLOTS 4
-template <int MT>
-__global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_assign_wide2b(AssignArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int K16 = 16 * MT;
-    constexpr int NPJ = (MT + WIDE2_WAVES - 1) / WIDE2_WAVES;            // centroid pieces (16 rows x 64 bytes) of a wave per ring slot, at most
-    float* Yring = reinterpret_cast<float*>(smem);                       // WIDE2B_YSLOTS x K16 x 16
-    float* sig = Yring + WIDE2B_YSLOTS * K16 * 16;                       // K16
-    float* nis = sig + K16;                                              // K16: -2 log2(e) / sigma (-200 for pads)
-    float* rpL = nis + K16;                                              // slots x K16
-    float* lrpL = rpL + WIDE2_SLOTS * K16;
-    double* Sd = reinterpret_cast<double*>(lrpL + WIDE2_SLOTS * K16);    // slots x K16 block sums
-    double* objw = Sd + WIDE2_SLOTS * K16;                               // waves x 2
-    int* tg = reinterpret_cast<int*>(objw + 2 * WIDE2_WAVES);            // group of the workgroup's tile j (-1: no such tile)
-    int* ts = tg + WIDE2_SLOTS;                                          // its slot: tiles of one group share table rows and sums
-    int* sg = ts + WIDE2_SLOTS;                                          // group of a slot
-    const int tid = threadIdx.x;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63, c16 = lane & 15, q = lane >> 4;
-    const int nkb = a.dp >> 4;                                           // 16-column pieces of a row
-    const int nks = (nkb + 1) >> 1;                                      // k-steps of 32 columns
-    const int tile_begin = a.blk_start ? a.blk_start[a.blk] : a.tile_begin;
-    const int tile_end = a.blk_start ? a.blk_start[a.blk + 1] : a.tile_end;
-    const int ntiles = tile_end - tile_begin;
-    const int base = blockIdx.x * WIDE2_SLOTS;
-    if (base >= ntiles) return;                                          // (the grid is sized for an upper bound of the block)
-
-    RoundTile<MT> T0, T1;
-    const int j0 = base + 2 * wv;
-    const bool has0 = j0 < ntiles, has1 = j0 + 1 < ntiles;              // wave-uniform
-    T0.cell = has0 ? a.cells[(size_t)(tile_begin + j0) * 16 + c16] : -1;
-    T1.cell = has1 ? a.cells[(size_t)(tile_begin + j0 + 1) * 16 + c16] : -1;
-    // the lane's two 16-byte pieces of a step: columns 32 s + 16 (q >> 1) + 4 chunk, chunk = (q & 1 ? 3, 2 : 0, 1)
-    const int ch0 = (q & 1) ? 3 : 0, ch1 = (q & 1) ? 2 : 1;
-    const int colq = 16 * (q >> 1);
-    const float* zr0 = a.Zcos + (size_t)(T0.cell >= 0 ? T0.cell : 0) * a.dp + colq;
-    const float* zr1 = a.Zcos + (size_t)(T1.cell >= 0 ? T1.cell : 0) * a.dp + colq;
-    // centroid pieces: piece p = 16 rows x 16 columns; lane l brings row l / 4 of the piece, 16-byte chunk (l % 4) ^ (row / 4 % 4)
-    // to LDS position 16 l of the piece -- the zone is row-major with the chunks of a row permuted by its row quad
-    const unsigned yvoff = (unsigned)(((lane >> 2) * a.ldy + 4 * ((lane & 3) ^ ((lane >> 4) & 3))) * 4);
-    const unsigned ring0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)Yring;
-    auto u64 = [](unsigned long long v) {
-        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
-               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v);
-    };
-    // EVERY wave asks for NPJ pieces per slot: wave w owns pieces w, w + 4, ...; a wave that owns fewer asks for the last piece
-    // once more (the same bytes to the same zone) -- as in k_assign_wide2
-    unsigned long long ysrc = u64((unsigned long long)a.Y);             // column block of the next slot to request
-    unsigned ypoff[NPJ], yzoff[NPJ];
-#pragma unroll
-    for (int j = 0; j < NPJ; ++j) {
-        const int pj = min(wv + WIDE2_WAVES * j, MT - 1);
-        ypoff[j] = (unsigned)(64 * pj * a.ldy);
-        yzoff[j] = 1024u * (unsigned)pj;
-    }
-    const unsigned yzone0 = __builtin_amdgcn_readfirstlane(ring0);
-    unsigned yzone = yzone0;
-    int yslot = 0;
-    auto issue_slot = [&]() {                                            // the next 16-column piece set into the next ring slot
-#pragma unroll
-        for (int j = 0; j < NPJ; ++j) {
-            const unsigned long long src = ysrc + ypoff[j];
-            const unsigned zone = yzone + yzoff[j];
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(yvoff), "s"(src), "s"(zone) : "memory", "m0");
-        }
-        ysrc += 64;
-        yzone += (unsigned)(K16 * 64);
-        if (++yslot == WIDE2B_YSLOTS) { yslot = 0; yzone = yzone0; }
-    };
-    auto skip_slot = [&]() {                                             // (a step without a second piece set: the ring position moves on)
-        ysrc += 64;
-        yzone += (unsigned)(K16 * 64);
-        if (++yslot == WIDE2B_YSLOTS) { yslot = 0; yzone = yzone0; }
-    };
-    auto issue_y = [&](int s) {                                          // the pieces of step s: slots 2 s and, if the row has it, 2 s + 1
-        issue_slot();
-        if (2 * s + 1 < nkb) issue_slot(); else skip_slot();
-    };
-    // the tiles' Z_cos values of step s: ordinary loads, pinned where they are written; columns past the row are zeros
-    auto issue_z = [&](f32x4 (&z)[4], int s) {
-        __builtin_amdgcn_sched_barrier(0);
-        const bool in_row = 32 * s + colq < a.dp;                        // (q >> 1 == 1 in the last step of an odd piece count: no such columns)
-        const float* p0 = zr0 + 32 * s, *p1 = zr1 + 32 * s;
-        z[0] = in_row ? ld4(p0 + 4 * ch0) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        z[1] = in_row ? ld4(p0 + 4 * ch1) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        z[2] = in_row ? ld4(p1 + 4 * ch0) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        z[3] = in_row ? ld4(p1 + 4 * ch1) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    f32x4 z[4];                                                          // raw values of the coming step (dead once the step has split them)
-    issue_y(0);
-    issue_z(z, 0);
-
-    // ---- set-up: sigma, the groups of the workgroup's tiles, their table rows, zeroed sums (as in k_assign_wide2) ----
-    for (int i = tid; i < K16; i += 64 * WIDE2_WAVES) {
-        const float sgm = (i < a.K) ? a.sigma[i] : 0.f;
-        sig[i] = sgm;
-        nis[i] = (i < a.K) ? -(2.885390081777926814f / sgm) : -200.f;   // -c_k = -2 log2(e) / sigma_k; pads: Y row 0 -> 2^-200 == 0
-    }
-    if (tid < WIDE2_SLOTS) tg[tid] = base + tid < ntiles ? a.tile_grp[tile_begin + base + tid] : -1;
-    for (int i = tid; i < WIDE2_SLOTS * K16; i += 64 * WIDE2_WAVES) Sd[i] = 0.0;
-    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0) only: the requests above stay in flight
-    __builtin_amdgcn_s_barrier();
-    if (tid < WIDE2_SLOTS) {
-        int slot = 0;
-        for (int u = 1; u <= tid; ++u) slot += (tg[u] != tg[u - 1] && tg[u] >= 0) ? 1 : 0;
-        ts[tid] = slot;
-        if (tg[tid] >= 0 && (tid == 0 || tg[tid] != tg[tid - 1])) sg[slot] = tg[tid];
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_s_barrier();
-    const int nslots = ts[WIDE2_SLOTS - 1] + 1;
-    for (int i = tid; i < nslots * K16; i += 64 * WIDE2_WAVES) {
-        const int sl = i / K16, k = i - sl * K16;
-        const size_t src = (size_t)sg[sl] * K16 + k;
-        rpL[i] = a.rp[src];
-        lrpL[i] = a.lrp[src];
-    }
-    T0.grp = ts[2 * wv];
-    T1.grp = has1 ? ts[2 * wv + 1] : T0.grp;              // (a missing tile computes on cell 0's row and counts for nothing)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        T0.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        T1.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-
-    // ---- the k-steps ---------------------------------------------------------------------------------------------------
-    const int rq = (c16 >> 2) & 3;
-    const int pos0 = 4 * (ch0 ^ rq), pos1 = 4 * (ch1 ^ rq);             // where the lane's two chunks sit in a row of a slot
-    int rslot = 0;                                                       // ring slot of the step's first piece set
-    auto split4 = [&](const f32x4& lo, const f32x4& hi, u32x4 (&pl)[3]) {   // 8 values -> three bf16 planes (k slot j <-> value j)
-        unsigned h, m, l;
-        bf16_split3((f32x2){lo[0], lo[1]}, h, m, l); pl[0][0] = h; pl[1][0] = m; pl[2][0] = l;
-        bf16_split3((f32x2){lo[2], lo[3]}, h, m, l); pl[0][1] = h; pl[1][1] = m; pl[2][1] = l;
-        bf16_split3((f32x2){hi[0], hi[1]}, h, m, l); pl[0][2] = h; pl[1][2] = m; pl[2][2] = l;
-        bf16_split3((f32x2){hi[2], hi[3]}, h, m, l); pl[0][3] = h; pl[1][3] = m; pl[2][3] = l;
-    };
-    auto step = [&](auto more_c, int s) {
-        constexpr bool MORE = decltype(more_c)::value;               // a step follows: its requests go out from here
-        __builtin_amdgcn_sched_barrier(0);
-        wide2_wait<0>();                                             // this wave's pieces and Z values of step s (requested a whole step ago)
-        wg_barrier_lds();                                            // everybody's pieces of step s are in; nobody reads step s-1 any more
-        const int second = (2 * s + 1 < nkb) ? 1 : 0;                // (the lanes of a missing second piece set read the first: finite values x 0)
-        int sl = rslot + ((q >> 1) & second);
-        if (sl >= WIDE2B_YSLOTS) sl -= WIDE2B_YSLOTS;
-        const float* Yst = Yring + (size_t)sl * (K16 * 16) + c16 * 16;
-        rslot += 2;
-        if (rslot >= WIDE2B_YSLOTS) rslot -= WIDE2B_YSLOTS;
-        u32x4 zp0[3], zp1[3];                                        // the two tiles' B planes of this step
-        split4(z[0], z[1], zp0);
-        split4(z[2], z[3], zp1);
-        u32x4 yp[2][3];                                              // A planes of the current / the next cluster tile
-        auto fetch_split = [&](int mt, u32x4 (&pl)[3]) {
-            const f32x4 lo = ld4(Yst + mt * 256 + pos0), hi = ld4(Yst + mt * 256 + pos1);
-            split4(lo, hi, pl);
-        };
-        auto products = [&](int mt, const u32x4 (&pl)[3]) {          // smallest terms first; the two tiles alternate
-            T0.arg[mt] = MFMA_BF16(pl[2], zp0[0], T0.arg[mt]);  T1.arg[mt] = MFMA_BF16(pl[2], zp1[0], T1.arg[mt]);
-            T0.arg[mt] = MFMA_BF16(pl[0], zp0[2], T0.arg[mt]);  T1.arg[mt] = MFMA_BF16(pl[0], zp1[2], T1.arg[mt]);
-            T0.arg[mt] = MFMA_BF16(pl[1], zp0[1], T0.arg[mt]);  T1.arg[mt] = MFMA_BF16(pl[1], zp1[1], T1.arg[mt]);
-            T0.arg[mt] = MFMA_BF16(pl[1], zp0[0], T0.arg[mt]);  T1.arg[mt] = MFMA_BF16(pl[1], zp1[0], T1.arg[mt]);
-            T0.arg[mt] = MFMA_BF16(pl[0], zp0[1], T0.arg[mt]);  T1.arg[mt] = MFMA_BF16(pl[0], zp1[1], T1.arg[mt]);
-            T0.arg[mt] = MFMA_BF16(pl[0], zp0[0], T0.arg[mt]);  T1.arg[mt] = MFMA_BF16(pl[0], zp1[0], T1.arg[mt]);
-        };
-        fetch_split(0, yp[0]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            if (mt + 1 < MT) fetch_split(mt + 1, yp[(mt + 1) & 1]);
-            products(mt, yp[mt & 1]);
-            if (mt + 1 < MT) {                                       // the next tile's two reads, then its split between the products
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-#pragma unroll
-                for (int r = 0; r < 10; ++r) {
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (MORE && mt == 0) {                                   // behind the first cluster tile: the slots of step s-1 are free, z[] is split
-                issue_y(s + 1);
-                issue_z(z, s + 1);
-            }
-        }
-    };
-    {
-        const std::integral_constant<bool, true> MORE;
-        const std::integral_constant<bool, false> LAST;
-#pragma unroll 1
-        for (int s = 0; s + 1 < nks; ++s) step(MORE, s);
-        step(LAST, nks - 1);
-    }
-
-    // ---- finish: exp, penalty, renormalisation, R rows, block sums, objective terms (k_round's passes) ---------------
-    double km_acc = 0.0, ent_acc = 0.0;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const f32x4 ni = ld4(nis + 16 * mt + 4 * q);       // dist = 2 (1 - Y.Z) (:447), arg = -dist / sigma (:466), here in log2 units:
-        T0.arg[mt] = __builtin_elementwise_fma(T0.arg[mt], -ni, ni);   // c_k (y.z - 1), the argument of the hardware exp2 (one fma per entry)
-        T1.arg[mt] = __builtin_elementwise_fma(T1.arg[mt], -ni, ni);
-    }
-    if (has0) {
-        float scl0, scl1 = 0.f;
-        round_post_pass1<MT, true, true, false, (HMX_ROUND_PK != 0 && MT <= 8)>(sig, rpL, lrpL, q, T0, scl0, km_acc, ent_acc);
-        if (has1) round_post_pass1<MT, true, true, false, (HMX_ROUND_PK != 0 && MT <= 8)>(sig, rpL, lrpL, q, T1, scl1, km_acc, ent_acc);
-        round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T0, scl0, has1, T1, scl1);
-    }
-    km_acc = wave_sum_all(km_acc);
-    ent_acc = wave_sum_all(ent_acc);
-    if (lane == 0) {
-        objw[2 * wv] = km_acc;
-        objw[2 * wv + 1] = ent_acc;
-    }
-    __syncthreads();
-    if (tid < 2) {
-        double v = 0.0;
-        for (int w = 0; w < WIDE2_WAVES; ++w) v += objw[2 * w + tid];
-        if (v != 0.0) atomicAdd(&a.obj[2 * (blockIdx.x & (HMX_OBJ_SLOTS - 1)) + tid], v);
-    }
-    for (int i = tid; i < nslots * K16; i += 64 * WIDE2_WAVES) {
-        const double v = Sd[i];
-        const int sl = i / K16;
-        if (v != 0.0) atomicAdd(&a.S_out[(size_t)sg[sl] * K16 + (i - sl * K16)], v);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_assign_wide3: the wide block assignment with the centroids PRE-SPLIT.  k_assign_wide2b splits the centroid values in
-// registers, per workgroup and k-step: 36 vector instructions for 12 MFMAs -- measured at the configs[4] shard it runs at the
-// vector rate (59 us per block launch against 66 with the f32-input MFMA), not at the matrix pipe's.  But Y changes once
-// per ROUND: k_y_planes (one small launch per round) writes it as the A fragments of v_mfma_f32_16x16x32_bf16, three bf16
+// k_assign_wide3: the wide block assignment on the bf16 matrix pipe (hmx_device.h: every fp32 operand as the exact sum of
+// three bf16 terms, six products, fp32 accumulation) with the centroids PRE-SPLIT.  The wide shapes are bound by the f32-input
+// MFMA (52 k-steps of 32 cycles per cluster tile and cell tile at d = 208; here 7 x 6 of 16).  A first cut (round 5,
+// k_assign_wide2b: k_assign_wide2's four-slot fp32 centroid ring, the centroid values split in registers per workgroup and
+// k-step -- 36 vector instructions for 12 MFMAs) ran at the VECTOR rate: 59 us per block launch at the configs[4] shard
+// against 66 with the f32-input MFMA (profiles/r05_ab_wide_bf16_pipe.txt).  But Y changes once per ROUND: k_y_planes (one small launch per round) writes it as the A fragments of v_mfma_f32_16x16x32_bf16, three bf16
 // planes, Yf[step s][plane h, m, l][cluster tile mt][lane][8 bf16] (row i = cluster 16 mt + c16, k slot j of lane (c16, q) =
 // PC 32 s + 8 q + j, zeros past the row).  A (plane, tile) fragment is 1 KB contiguous: one LDS-DMA request brings it, one
 // conflict-free 16-byte read per lane hands it to the matrix pipe, no vector instruction touches it.  What is left to split
@@ -4410,17 +4168,6 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
             const size_t sm2 = ((size_t)WIDE2_YBUF * a.K16 * 16 + 2 * a.K16 + 2 * WIDE2_SLOTS * a.K16) * sizeof(float) +
                                ((size_t)WIDE2_SLOTS * a.K16 + 2 * WIDE2_WAVES) * sizeof(double) + 3 * WIDE2_SLOTS * sizeof(int);
             const int wgs2 = cdiv(ntiles, WIDE2_SLOTS);
-            // ... with the distance GEMM on the bf16 matrix pipe (k_assign_wide2b: a ring of four centroid slots)
-            const size_t sm2b = sm2 + (size_t)(WIDE2B_YSLOTS - WIDE2_YBUF) * a.K16 * 16 * sizeof(float);
-#define HMX_WIDE2B_CASE(M)                                                                                              \
-    case M: {                                                                                                         \
-        static bool attr_done = false;                                                                                \
-        if (!attr_done) {                                                                                             \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_assign_wide2b<M>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
-            attr_done = true;                                                                                         \
-        }                                                                                                             \
-        hipLaunchKernelGGL((k_assign_wide2b<M>), dim3(wgs2), dim3(64 * WIDE2_WAVES), sm2b, s, a);                      \
-    } break;
             // ... with the centroids pre-split into fragments (k_assign_wide3: eight waves, one workgroup per CU)
             const size_t sm3 = (size_t)2 * 3 * a.mt * 1024 + ((size_t)2 * a.K16 + 2 * WIDE3_SLOTS * a.K16) * sizeof(float) +
                                ((size_t)WIDE3_SLOTS * a.K16 + 2 * WIDE3_WAVES) * sizeof(double) + 3 * WIDE3_SLOTS * sizeof(int);
@@ -4442,14 +4189,6 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
                 return 1;
             }
 #undef HMX_WIDE3_CASE
-            if (a.bf16_pipe && sm2b <= 80 * 1024) {
-                switch (a.mt) {
-                    HMX_WIDE2B_CASE(1) HMX_WIDE2B_CASE(2) HMX_WIDE2B_CASE(3) HMX_WIDE2B_CASE(4) HMX_WIDE2B_CASE(5) HMX_WIDE2B_CASE(6) HMX_WIDE2B_CASE(7)
-                    HMX_WIDE2B_CASE(8) HMX_WIDE2B_CASE(9) HMX_WIDE2B_CASE(10) HMX_WIDE2B_CASE(11) HMX_WIDE2B_CASE(12) HMX_WIDE2B_CASE(13)
-                }
-                return 1;
-            }
-#undef HMX_WIDE2B_CASE
 #define HMX_WIDE2_CASE(M)                                                                                               \
     case M: {                                                                                                         \
         static bool attr_done = false;                                                                                \

@@ -1136,6 +1136,187 @@ __global__ __launch_bounds__(64 * RTZWB_WAVES, 1) void k_rtzw2b(Rtz3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_rtzw3b: k_rtzw2b with a partner wave on every SIMD.  k_rtzw2b's four waves (one per SIMD, 7 x 7 output tiles each) split
+// both operands in their own instruction stream: per pair of tiles ~850 vector / LDS / staging instructions beside 294 MFMAs,
+// of which only the A splits ride between MFMAs -- measured 866 us per pass at the configs[4] shard, ~10.4 k cycles per pair for
+// 5 k cycles of matrix pipe.  Here EIGHT waves per workgroup (two per SIMD, 256 registers each) split the MT x NT output
+// tiles 2 x 4 (row half x column quarter: 7 x 4 tiles = 112 accumulators): while one wave of a SIMD builds its B planes or
+// stages the next tiles, the other multiplies.  What else changed:
+//   * the tiles sit in LDS with PADDED rows: row strides = 16 (mod 32) floats, and k slot j of lane (c16, q) is cell
+//     2 j + (q & 1) of tile q >> 1, so the two 16-lane halves of a 32-lane LDS group read neighbouring rows = disjoint bank
+//     halves: every operand read (one float per lane: column 16 t + c16 of a row) is free of bank conflicts;
+//   * PLAIN row map: row tile mt holds the clusters 16 mt .. 16 mt + 15 (k_rtz3_finish: `plain_rows`) -- the permuted map of
+//     k_rtz3 exists for 16-byte A reads, which need the values of four tiles live at once (32 registers);
+//   * staging: thread (row = tid / 32, t = tid % 32) brings the 16-byte chunks t and t + 32 of its row of R and of Z: no
+//     division, coalesced 512-byte runs, zeros for rows past the group's end, for the missing tile of an odd count and for
+//     the padding columns.
+// Same tasks, same slabs [mt][nt][lane][r], same finish kernel.
+// ------------------------------------------------------------------------------------------
+#define RTZW3_WAVES 8
+__host__ __device__ __forceinline__ int rtzw3_ld(int n) { return n + ((16 - (n & 31)) & 31); }   // smallest stride >= n that is 16 (mod 32)
+template <int MT, int NTQ>
+__global__ __launch_bounds__(64 * RTZW3_WAVES, 1) void k_rtzw3b(Rtz3Args a) {
+    if (a.frozen && *a.frozen) return;
+    constexpr int MTA = (MT + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* lds = reinterpret_cast<float*>(smem);
+    const int Kp = a.Kp, DP = a.dp, d = a.d, NT = a.nt, NTP = DP >> 4;
+    const int LDR = rtzw3_ld(Kp), LDZ = rtzw3_ld(DP);
+    const int buf_floats = 16 * (LDR + LDZ) + 4;                     // R tile | Z tile | 16 block-id bytes
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, c16 = lane & 15, q = lane >> 4;
+    const int task = blockIdx.x;
+    const int t0 = a.task_t0[task], t1 = a.task_t1[task];
+    const int c_first = a.task_c0[task], c_end = a.task_cend[task];
+    const int stride = __builtin_amdgcn_readfirstlane(a.task_stride[task]);
+    const int n_tiles = (t1 - t0 + stride - 1) / stride;
+    const int n_pairs = (n_tiles + 1) / 2;
+    if (n_tiles <= 0) return;
+    const int rh = wv >> 2, cq = wv & 3;                             // this wave's eighth of the output: row half, column quarter
+    const int nt_lo = cq * NTQ;
+
+    // ---- staging: tile `ti` of the task (clamped: a missing tile is loaded from the last one and written as zeros) ----
+    const int srow = tid >> 5, st32 = tid & 31;
+    f32x4 sr[2], sz[2], sid;
+    auto load_tile = [&](int ti) {
+        const int tc = min(ti, n_tiles - 1);
+        const size_t cell = (size_t)c_first + (size_t)16 * stride * tc + srow;
+        const f32x4* rsrc = reinterpret_cast<const f32x4*>(a.R + cell * Kp);
+        const f32x4* zsrc = reinterpret_cast<const f32x4*>(a.Z + cell * DP);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = st32 + 32 * j;
+            sr[j] = (4 * c < Kp) ? __builtin_nontemporal_load(rsrc + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            sz[j] = (4 * c < DP) ? __builtin_nontemporal_load(zsrc + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        sid = (tid == 0) ? *reinterpret_cast<const f32x4*>(a.tile_blk + (size_t)16 * (t0 + (size_t)stride * tc)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto store_tile = [&](int ti, int b) {                            // ... into tile buffer b (0..3)
+        const int cell0 = c_first + 16 * stride * min(ti, n_tiles - 1);
+        const int n_live = ti < n_tiles ? min(16, c_end - cell0) : 0; // rows of the tile inside the group (workgroup-uniform)
+        const bool live = srow < n_live;
+        float* Rt = lds + (size_t)b * buf_floats + srow * LDR;
+        float* Zt = lds + (size_t)b * buf_floats + 16 * LDR + srow * LDZ;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = st32 + 32 * j;
+            if (4 * c < LDR) st4(Rt + 4 * c, (live && 4 * c < Kp) ? sr[j] : zero);
+            if (4 * c < LDZ) st4(Zt + 4 * c, (live && 4 * c < DP) ? sz[j] : zero);
+        }
+        if (tid == 0) st4(lds + (size_t)b * buf_floats + 16 * (LDR + LDZ), sid);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    auto body = [&](auto rh_c) {
+        constexpr int RH = decltype(rh_c)::value;
+        constexpr int LO = RH * MTA, HI = RH ? MT : MTA;              // this wave's row tiles
+        f32x4 acc[MTA][NTQ];
+#pragma unroll
+        for (int t = 0; t < MTA; ++t)
+#pragma unroll
+            for (int u = 0; u < NTQ; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        load_tile(0);
+        store_tile(0, 0);
+        load_tile(1);
+        store_tile(1, 1);
+
+        for (int i = 0; i < n_pairs; ++i) {
+            wg_barrier_lds();                                         // pair i is complete in LDS; nobody reads pair i-1 any more
+            const float* pb = lds + (size_t)(2 * (i & 1)) * buf_floats;
+            const int nb = 2 * ((i + 1) & 1);                         // the tile buffers of pair i+1 (pair i-1's)
+            load_tile(2 * i + 2);                                     // travels under the B planes and the first row tiles
+            // lane (c16, q): k slot j <-> cell 2 j + (q & 1) of tile q >> 1 of the pair
+            const float* tb = pb + (size_t)(q >> 1) * buf_floats;
+            const float* Rl = tb + (q & 1) * LDR + c16;
+            const float* Zl = tb + 16 * LDR + (q & 1) * LDZ + c16;
+            int bid[8];
+            {
+                const u32x4 w = *reinterpret_cast<const u32x4*>(tb + 16 * (LDR + LDZ));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bid[j] = (int)((w[j >> 1] >> (8 * (2 * (j & 1) + (q & 1)))) & 255u);
+            }
+            // ---- B planes of the column quarter: value = PC column (zero in the row padding) + one-hot of the block column ----
+            u32x4 bh[NTQ], bm[NTQ], bl[NTQ];
+#pragma unroll
+            for (int u = 0; u < NTQ; ++u) {
+                const int nt = nt_lo + u;                             // wave-uniform
+                const bool pc = nt < NTP;
+                const float* zr = Zl + 16 * min(nt, NTP - 1);         // (clamped: an unused read stays inside the tile)
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = zr[2 * j * LDZ];
+                if (!pc) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = 0.f;
+                }
+                if (nt >= NTP - 1 && nt < NT) {                       // block whose one-hot column this lane's column is (negative: none)
+                    const int blk_col = 16 * nt + c16 - d;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] += (bid[j] == blk_col) ? 1.f : 0.f;
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    unsigned h, m, l;
+                    bf16_split3((f32x2){x[2 * p], x[2 * p + 1]}, h, m, l);
+                    bh[u][p] = h; bm[u][p] = m; bl[u][p] = l;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- row tiles: eight values, three planes, six products with every column tile (smallest terms first; consecutive
+            //      MFMAs go to different accumulators); the SIMD's other wave fills the gaps ----
+#pragma unroll
+            for (int t = 0; t < HI - LO; ++t) {
+                const float* rr = Rl + 16 * (LO + t);
+                float av[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) av[j] = rr[2 * j * LDR];
+                u32x4 ah, am, al;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    unsigned h, m, l;
+                    bf16_split3((f32x2){av[2 * p], av[2 * p + 1]}, h, m, l);
+                    ah[p] = h; am[p] = m; al[p] = l;
+                }
+#pragma unroll
+                for (int u = 0; u < NTQ; ++u) acc[t][u] = MFMA_BF16(al, bh[u], acc[t][u]);
+#pragma unroll
+                for (int u = 0; u < NTQ; ++u) acc[t][u] = MFMA_BF16(ah, bl[u], acc[t][u]);
+#pragma unroll
+                for (int u = 0; u < NTQ; ++u) acc[t][u] = MFMA_BF16(am, bm[u], acc[t][u]);
+#pragma unroll
+                for (int u = 0; u < NTQ; ++u) acc[t][u] = MFMA_BF16(am, bh[u], acc[t][u]);
+#pragma unroll
+                for (int u = 0; u < NTQ; ++u) acc[t][u] = MFMA_BF16(ah, bm[u], acc[t][u]);
+#pragma unroll
+                for (int u = 0; u < NTQ; ++u) acc[t][u] = MFMA_BF16(ah, bh[u], acc[t][u]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 == (HI - LO + 1) / 2) {                     // half way: the first tile of pair i+1 has landed
+                    store_tile(2 * i + 2, nb);
+                    load_tile(2 * i + 3);
+                }
+            }
+            store_tile(2 * i + 3, nb + 1);
+        }
+        // every wave stores its own output tiles: slab [mt][nt][lane][r]
+        float* slab = a.slab + (size_t)task * ((size_t)MT * NT * 256);
+#pragma unroll
+        for (int t = 0; t < MTA; ++t)
+#pragma unroll
+            for (int u = 0; u < NTQ; ++u) {
+                const int mt = LO + t, nt = nt_lo + u;
+                if (mt < HI && nt < NT) st4(slab + ((size_t)(mt * NT + nt) * 64 + lane) * 4, acc[t][u]);
+            }
+    };
+    if (rh == 0) body(std::integral_constant<int, 0>{}); else body(std::integral_constant<int, 1>{});
+}
+
+// ------------------------------------------------------------------------------------------
 // k_rtz3_finish: the per-task slabs summed in fp64, one workgroup per cluster k; undoes the index maps of k_rtz3.
 //   mode 0 (k-means round): Ysum[k][pc] over all tasks (the centroid numerators, :443), Sold[blk][g][k] over the tasks of
 //          group g (the removal sums, :491-492); with Yout the row is normalised on the spot (:444) -- no collective
@@ -1163,7 +1344,8 @@ __global__ __launch_bounds__(RTZ3_FIN_THREADS) void k_rtz3_finish(Rtz3FinishArgs
     // where cluster k sits in a slab: tile mt, row m of the tile
     const int Hq = a.MT / 4, rem = a.MT % 4;
     int mt, m;
-    if (k < 64 * Hq) { mt = 4 * (k / 64) + (k & 3); m = (k & 63) >> 2; }
+    if (a.plain_rows) { mt = k >> 4; m = k & 15; }                  // k_rtzw3b: row tile mt holds the clusters 16 mt .. 16 mt + 15
+    else if (k < 64 * Hq) { mt = 4 * (k / 64) + (k & 3); m = (k & 63) >> 2; }
     else { const int x = k - 64 * Hq; m = x / rem; mt = 4 * Hq + x % rem; }
     const int per = a.MT * NT * 256;
     const int nslice = RTZ3_FIN_THREADS / NV;
@@ -1546,11 +1728,53 @@ static void launch_rtzw2b(const Rtz3Args& a, int mt, hipStream_t s) {
     }
 }
 
-// returns 1 when the bf16-pipe kernel (k_rtzw2b) ran, 0 for the f32-input kernels, -1 unsupported
+// ---- k_rtzw3b: eight waves, 2 x 4 split (K > 112, five to sixteen column tiles), four padded tile buffers in one CU's LDS
+bool rtzw3b_ok(int mt, int dp, int d, int nblk, int Kp) {
+    static const bool on = [] { const char* v = getenv("HMX_RTZW3"); return !v || atoi(v) != 0; }();
+    if (!on || !rtzw_ok(mt, dp, d, nblk, 1) || mt < 8 || mt > 13) return false;
+    const int ntq = (rtzw_nt(dp, d, nblk) + 3) / 4;
+    return ntq >= 2 && ntq <= 4 && (size_t)4 * (16 * (rtzw3_ld(Kp) + rtzw3_ld(dp)) + 4) * sizeof(float) <= 160 * 1024;
+}
+template <int MT, int NTQ>
+static void launch_rtzw3b_t(const Rtz3Args& a, size_t sm, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rtzw3b<MT, NTQ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_rtzw3b<MT, NTQ>), dim3(a.ntasks), dim3(64 * RTZW3_WAVES), sm, s, a);
+}
+template <int MT>
+static void launch_rtzw3b_m(const Rtz3Args& a, int ntq, size_t sm, hipStream_t s) {
+    switch (ntq) {
+        case 2: launch_rtzw3b_t<MT, 2>(a, sm, s); break;
+        case 3: launch_rtzw3b_t<MT, 3>(a, sm, s); break;
+        default: launch_rtzw3b_t<MT, 4>(a, sm, s); break;
+    }
+}
+static void launch_rtzw3b(const Rtz3Args& a, int mt, hipStream_t s) {
+    const int ntq = (a.nt + 3) / 4;
+    const size_t sm = (size_t)4 * (16 * (rtzw3_ld(a.Kp) + rtzw3_ld(a.dp)) + 4) * sizeof(float);
+    switch (mt) {
+        case 8: launch_rtzw3b_m<8>(a, ntq, sm, s); break;
+        case 9: launch_rtzw3b_m<9>(a, ntq, sm, s); break;
+        case 10: launch_rtzw3b_m<10>(a, ntq, sm, s); break;
+        case 11: launch_rtzw3b_m<11>(a, ntq, sm, s); break;
+        case 12: launch_rtzw3b_m<12>(a, ntq, sm, s); break;
+        default: launch_rtzw3b_m<13>(a, ntq, sm, s); break;
+    }
+}
+
+// returns 2 when k_rtzw3b ran (bf16 pipe; its slabs use the PLAIN row map: Rtz3FinishArgs.plain_rows), 1 for k_rtzw2b (bf16 pipe),
+// 0 for the f32-input kernels, -1 unsupported
 int launch_rtzw(const Rtz3Args& a_in, int mt, int dp, int d, int nblk, hipStream_t s, bool allow_bf16) {
     if (!rtzw_ok(mt, dp, d, nblk, 1) || a_in.ntasks <= 0) return -1;
     Rtz3Args a = a_in;
     a.dp = dp; a.d = d; a.nt = rtzw_nt(dp, d, nblk);
+    if (allow_bf16 && rtzw3b_ok(mt, dp, d, nblk, a.Kp)) {
+        launch_rtzw3b(a, mt, s);
+        return 2;
+    }
     if (allow_bf16 && rtzw2b_ok(mt, dp, d, nblk)) {
         launch_rtzw2b(a, mt, s);
         return 1;

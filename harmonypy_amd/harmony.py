@@ -654,16 +654,19 @@ class Harmony:
         self._lap("kmeans_seeds")
         # max_iter=25 (harmony.py:371) Lloyd iterations over ALL cells on the device -- wide shapes (K > 112 or d > 64) too:
         # hard assignment as a one-hot R, member sums as the R^T.Z statistics of it (hmx_kmeans_lloyd)
-        try:
+        # wide shapes only: the device Lloyd needs the streaming R^T.Z pass with one block column (hmx_capi.cpp, lloyd_wide);
+        # more batch groups than its finish kernel tabulates (85 at 200 PCs), or a caller-built layout whose static tiles
+        # do not hold consecutive cells, run the 25 iterations on a subsample on the host instead (sklearn's Lloyd from
+        # the same seeds -- what harmony.py:370-372 does on all cells).  The engine is ASKED first (hmx_can_lloyd) and a
+        # sharded job decides together, before any rank enters the iterations' all-reduces; whatever the call itself
+        # raises afterwards (a HIP error, a bad state) is a failure, not a reason to fall back.
+        can = self._engine.can_lloyd()
+        if self.shard is not None:
+            can = all(self.shard.allgather_object(bool(can)))
+        if can:
             centers = self._engine.kmeans_lloyd(centers, 25)
-        except _capi.HmxError as ex:
-            # wide shapes only: the device Lloyd needs the streaming R^T.Z pass with one block column (hmx_capi.cpp, lloyd_wide);
-            # more batch groups than its finish kernel tabulates (85 at 200 PCs), or a caller-built layout whose static tiles
-            # do not hold consecutive cells, run the 25 iterations on a subsample on the host instead (sklearn's Lloyd from
-            # the same seeds -- what harmony.py:370-372 does on all cells)
-            if not self._wide_shape():
-                raise
-            logger.warning(f"device k-means unavailable for this shape ({ex}); Lloyd iterations on a subsample on the host")
+        else:
+            logger.warning("device k-means unavailable for this shape or layout (hmx_can_lloyd); Lloyd iterations on a subsample on the host")
             centers = self._host_lloyd_on_subsample(centers, random_state)
         self._lap("kmeans_lloyd")
         if self.verbose:

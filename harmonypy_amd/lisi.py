@@ -72,5 +72,5 @@ def compute_lisi(
         msg = lib.hmx_last_error().decode(errors="replace")
         if "n_neighbors" in msg or msg.startswith("perplexity"):
             raise ValueError(msg)                                               # what sklearn raises for the reference / this build's limit
-        raise _capi.HmxError(f"libhmx: {msg} (code {rc})")
+        raise _capi.HmxError(f"libhmx: {msg} (code {rc})", code=int(rc))
     return (out, kd, ki) if return_neighbors else out

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HMX_ABI_VERSION 6
+#define HMX_ABI_VERSION 7
 #define HMX_TILE 16 /* cells per tile */
 /* limits of this build, checked by hmx_create (the reference has none: harmony.py:123-124 caps only the default K) */
 #define HMX_MAX_CLUSTERS 208
@@ -86,8 +86,6 @@ int hmx_abi_version(void);
 /* Identity of the kernel set in this library: 12 hex digits of the SHA-256 over csrc/ and this header, computed by
  * harmonypy_amd/_build.py at build time.  Profiles and counter files name the build they were collected on. */
 const char* hmx_build_id(void);
-/* 1 when the library was built with the opt-in one-pass study kernel k_sweep (-DHMX_WITH_SWEEP). */
-int hmx_has_sweep_kernel(void);
 
 /* Allocate the device state of one `Harmony` object (harmony.py:230-278, 357-364). */
 int hmx_create(const hmx_config* cfg, hmx_engine** out);
@@ -187,6 +185,11 @@ int hmx_kmeans_seed(hmx_engine* e, const float* points, int64_t n_points, uint64
  * scratch (hard assignment as a one-hot R, member sums as the R^T.Z statistics of it): an assignment the engine
  * held is void afterwards, hmx_init_cluster must follow. */
 int hmx_kmeans_lloyd(hmx_engine* e, const float* centers_in, int n_iter, float* centers_out);
+/* 1 when hmx_kmeans_lloyd serves this engine's shape and layout, 0 when it would return HMX_ERR_ARG (K > 112 or d > 64 with
+ * static tiles that do not hold consecutive cells, or more batch groups than its statistics pass tabulates: 85 at 200 PCs).
+ * Every rank of a sharded job asks BEFORE the call and all fall back together (the iterations contain all-reduces).  No
+ * reference counterpart (harmony.py:369-373 always runs sklearn's Lloyd on the host). */
+int hmx_can_lloyd(hmx_engine* e);
 
 /* One pass of the loop body harmony.py:443-453.
  *   flags: HMX_ROUND_* bits; the reference's round is all three.

@@ -12,7 +12,7 @@ static const char* kSymbols[] = {
     "hmx_cluster_round", "hmx_cluster_round_seeded", "hmx_moe_correct_ridge", "hmx_get", "hmx_get_rows", "hmx_set",
     "hmx_sync", "hmx_device_ptr", "hmx_kernel_times", "hmx_enable_timing", "hmx_counters", "hmx_comm_unique_id", "hmx_comm_init",
     "hmx_set_host_allreduce", "hmx_set_ranks", "hmx_peer_export", "hmx_peer_attach", "hmx_peer_selftest",
-    "hmx_peer_enable", "hmx_kmeans_seed", "hmx_kmeans_lloyd", "hmx_compute_lisi", "hmx_build_id", "hmx_has_sweep_kernel", "hmx_cluster", "hmx_set_timing_stride",
+    "hmx_peer_enable", "hmx_kmeans_seed", "hmx_kmeans_lloyd", "hmx_can_lloyd", "hmx_compute_lisi", "hmx_build_id", "hmx_cluster", "hmx_set_timing_stride",
     "hmx_set_timing_families",
 };
 

@@ -464,11 +464,11 @@ WIDE_AB_SHAPES = [(40_000, 200, 32, 200), (30_000, 100, 4, 130), (20_000, 208, 3
 @pytest.mark.parametrize("switch,value", [("HMX_ROUND_F32", "1"), ("HMX_RTZ3_BF16", "0")])
 def test_wide_bf16_pipe_kernels_against_the_f32_input_kernels(N, d, B, K, switch, value, monkeypatch):
     """The wide regime (K > 112 or d > 64: BASELINE configs[4] is K = d = 200) is bound by the f32-input MFMA; its block
-    assignment (k_assign_wide2b, harmony.py:447, 464-513) and its streaming R^T.Z pass (k_rtzw2b, :443-444, :491-492, :550,
+    assignment (k_assign_wide3, harmony.py:447, 464-513) and its streaming R^T.Z pass (k_rtzw2b, :443-444, :491-492, :550,
     :559-563) run on the bf16 matrix pipe with every fp32 operand as three exact bf16 terms.  Direct A/B inside one build on
     one state against the f32-input kernels (engines created under HMX_ROUND_F32=1 / HMX_RTZ3_BF16=0): two seeded rounds +
     the ridge; R 4e-6, Y 2e-6, O 1e-6 of the masses, objective terms 2e-6 relative, Z_corr 1e-6 relative Frobenius; the
-    counters say which kernels ran (shapes outside k_rtzw2b's -- K <= 112 or fewer than seven column tiles -- keep k_rtzw)."""
+    counters say which kernels ran (shapes outside k_rtzw3b's -- K <= 112 or fewer than five column tiles -- keep k_rtzw)."""
     a, b = _ab_engines(N, d, B, K, monkeypatch, switch, value)
     assert a._wide_shape()
     for h in (a, b):
@@ -481,7 +481,7 @@ def test_wide_bf16_pipe_kernels_against_the_f32_input_kernels(N, d, B, K, switch
         assert ca["sweeps_bf16_pipe"] == (2 if served else 0) and cb["sweeps_bf16_pipe"] == 0, (ca, cb)
     else:
         MT, NT = (K + 15) // 16, ((d + 15) // 16) + max(0, (20 - (((d + 15) & ~15) - d) + 15) // 16)
-        served = 8 <= MT <= 13 and 4 <= (NT + 1) // 2 <= 7
+        served = 8 <= MT <= 13 and (2 <= (NT + 3) // 4 <= 4 or 4 <= (NT + 1) // 2 <= 7)      # k_rtzw3b (2 x 4 split) or k_rtzw2b (2 x 2)
         assert (ca["rtz_bf16_pipe"] >= 3) == served and cb["rtz_bf16_pipe"] == 0, (ca, cb, served)
     # (bounds: an R entry moves by c_k = 2 log2(e) / sigma = 28.9 times the rounding of its fp32 dot product of d terms; at
     # d = 200 two summation orders of the f32-input MFMA itself differ by that much -- measured here: 9.9e-6 / 3.5e-6 relative Frobenius)
@@ -509,40 +509,16 @@ def test_bench_path_parity_c5_shape(monkeypatch):
 
 
 # ------------------------------------------------------------------------------------------
-# the two persistent sweep kernels: opt-in k_sweep, and what happens when a grid-wide wait gives up
+# the persistent sweep kernel: what happens when a grid-wide wait gives up
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("case", ["pbmc_default", "pbmc_two_vars", "pbmc_theta_tau", "synth_small_default"])
-def test_k_sweep_path_vs_reference_golden(case, monkeypatch):
-    """HMX_SWEEP=1 (hmx_sweep.hip: removal sums formed inside the sweep, old R rows through LDS-DMA) replays the
-    reference's schedule to the same 1e-4 as the default k_round path."""
-    from harmonypy_amd import _capi
-    if not _capi.has_sweep_kernel():
-        pytest.skip("libhmx.so was built without the study kernel (python -m harmonypy_amd._build -DHMX_WITH_SWEEP)")
-    monkeypatch.setenv("HMX_SWEEP", "1")
-    data, meta, vars_use, kw, g = load_case(case)
-    rounds = [int(r) for r in g["kmeans_rounds"]]
-    ho = _run_engine(data, meta, vars_use, Y0=g["Y0"], forced_rounds=rounds, **kw)
-    rel_f, max_rel = assert_z_close(ho.Z_corr, g["Z_corr"])
-    print(f"{case} (k_sweep): relF={rel_f:.2e} max={max_rel:.2e}")
-    np.testing.assert_allclose(ho.objective_kmeans, g["objective_kmeans"], rtol=2e-5)
-    np.testing.assert_allclose(ho.O, g["O"], rtol=3e-4, atol=3e-4)
-
-
-@pytest.mark.parametrize("sweep", ["0", "1"])
-def test_sweep_timeout_falls_back_to_blocks(sweep, monkeypatch, capfd):
+def test_sweep_timeout_falls_back_to_blocks(monkeypatch, capfd):
     """HMX_SPIN_LIMIT=0 makes every grid-wide wait of the persistent kernel give up at once: the engine must notice
-    and repeat the round with one bounded launch per block.  With k_round (sweep 0) the replay is EXACT: it starts from
-    the round's own start -- O as it was, the removal sums and centroids the failed launch used, the round's own lists --
-    and a new row of R depends on Z_cos, Y and its block's table, never on the old row, so rows the failed launch had
-    already replaced are simply computed again: Z_corr within 1e-4 of the undisturbed run, same round schedule.  (The
-    study kernel k_sweep, sweep 1, forms the removal sums inside the launch and can only rebuild O from R: close, not equal.)
-    After the second time-out the engine stays on the per-block path."""
-    from scipy.stats import pearsonr
-    from harmonypy_amd import _capi
-    if sweep == "1" and not _capi.has_sweep_kernel():
-        pytest.skip("libhmx.so was built without the study kernel (python -m harmonypy_amd._build -DHMX_WITH_SWEEP)")
+    and repeat the round with one bounded launch per block.  The replay is EXACT: it starts from the round's own start
+    -- O as it was, the removal sums and centroids the failed launch used, the round's own lists -- and a new row of R
+    depends on Z_cos, Y and its block's table, never on the old row, so rows the failed launch had already replaced are
+    simply computed again: Z_corr within 1e-4 of the undisturbed run, same round schedule.  After the second time-out the
+    engine stays on the per-block path."""
     data, meta, vars_use, kw, g = load_case("pbmc_default")
-    monkeypatch.setenv("HMX_SWEEP", sweep)
     monkeypatch.setenv("HMX_SPIN_LIMIT", "0")
     ho = _run_engine(data, meta, vars_use, Y0=g["Y0"], **dict(kw, max_iter_harmony=3))
     cnt = ho._engine.counters()
@@ -557,15 +533,11 @@ def test_sweep_timeout_falls_back_to_blocks(sweep, monkeypatch, capfd):
     monkeypatch.delenv("HMX_SPIN_LIMIT")
     ok = _run_engine(data, meta, vars_use, Y0=g["Y0"], **dict(kw, max_iter_harmony=3))    # the undisturbed run
     assert ok._engine.counters()["sweep_fallbacks"] == 0
-    if sweep == "0":
-        assert cnt["sweep_fallbacks"] == 2, cnt                 # then the engine stops launching the persistent kernel
-        assert ho.kmeans_rounds == ok.kmeans_rounds
-        rel_f, max_rel = assert_z_close(ho.Z_corr, ok.Z_corr, what="Z_corr after replayed rounds vs the undisturbed run")
-        print(f"time-out replay: relF={rel_f:.2e} max={max_rel:.2e}")
-        np.testing.assert_allclose(ho.objective_kmeans, ok.objective_kmeans, rtol=2e-5)
-    else:
-        cors = [pearsonr(ho.Z_corr[:, j], ok.Z_corr[:, j])[0] for j in range(ho.d)]
-        assert min(cors) > 0.99, min(cors)
+    assert cnt["sweep_fallbacks"] == 2, cnt                 # then the engine stops launching the persistent kernel
+    assert ho.kmeans_rounds == ok.kmeans_rounds
+    rel_f, max_rel = assert_z_close(ho.Z_corr, ok.Z_corr, what="Z_corr after replayed rounds vs the undisturbed run")
+    print(f"time-out replay: relF={rel_f:.2e} max={max_rel:.2e}")
+    np.testing.assert_allclose(ho.objective_kmeans, ok.objective_kmeans, rtol=2e-5)
 
 
 @pytest.mark.parametrize("fail_at", [2, 4, 1])
