@@ -913,7 +913,7 @@ __global__ __launch_bounds__(64 * RTZW2_WAVES, 2) void k_rtzw2(Rtz3Args a) {
 // q >> 1 (as in k_rtz3b), both operands are split in registers.  Same tasks, same 2 x 2 split of the MT x NT output tiles
 // over four waves, same slabs and finish kernel as k_rtzw2.  What is different besides the multiply:
 //   * one workgroup per CU (512 registers per lane: 196 accumulators + the 84 registers of the column half's B planes);
-//   * the tiles travel global -> registers -> LDS with ORDINARY loads (non-temporal), a whole pair (72 registers) under the
+//   * the tiles travel global -> registers -> LDS with ORDINARY loads (non-temporal), half a pair at a time, under the
 //     multiply of the pair before: the compiler counts the waits, rows past the group's end (and the missing second tile
 //     of an odd count) are written as zeros -- no live-row factor, no select in the loop -- and an LDS-DMA request's
 //     ~200 cycles of issue (k_rtzw2's stamps: 1.9 k of a tile's 16.4 k) are not paid by a wave that has no partner on its SIMD;
@@ -955,10 +955,8 @@ __global__ __launch_bounds__(64 * RTZWB_WAVES, 1) void k_rtzw2b(Rtz3Args a) {
     const int spare = DP - d;
 
     // ---- staging: tile `ti` of the task (clamped: a missing tile is loaded from the last one and written as zeros) ----
-    // two register sets: BOTH tiles of the pair after next travel while a pair is multiplied (a whole pair-step of distance; with
-    // half a pair at a time a pair cost two HBM round trips: 866 us per pass at the configs[4] shard)
-    f32x4 sr[2][NRP], sz[2][NZP], sid[2];
-    auto load_tile = [&](int ti, int set) {
+    f32x4 sr[NRP], sz[NZP], sid;
+    auto load_tile = [&](int ti) {
         const int tc = min(ti, n_tiles - 1);
         const size_t cell0 = (size_t)c_first + (size_t)16 * stride * tc;
         const float* rsrc = a.R + cell0 * Kp;
@@ -967,17 +965,17 @@ __global__ __launch_bounds__(64 * RTZWB_WAVES, 1) void k_rtzw2b(Rtz3Args a) {
 #pragma unroll
         for (int j = 0; j < NRP; ++j) {
             const int p = tid + 256 * j;
-            sr[set][j] = (p < 4 * Kp) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rsrc) + p) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            sr[j] = (p < 4 * Kp) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rsrc) + p) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int j = 0; j < NZP; ++j) {
             const int p = tid + 256 * j;
-            sz[set][j] = (p < 4 * DP) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(zsrc) + p) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            sz[j] = (p < 4 * DP) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(zsrc) + p) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        sid[set] = (tid == 0) ? *reinterpret_cast<const f32x4*>(a.tile_blk + (size_t)16 * (t0 + (size_t)stride * tc)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        sid = (tid == 0) ? *reinterpret_cast<const f32x4*>(a.tile_blk + (size_t)16 * (t0 + (size_t)stride * tc)) : (f32x4){0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto store_tile = [&](int ti, int b, int set) {                   // ... into tile buffer b (0..3)
+    auto store_tile = [&](int ti, int b) {                            // ... into tile buffer b (0..3)
         const int cell0 = c_first + 16 * stride * min(ti, n_tiles - 1);
         const int n_live = ti < n_tiles ? min(16, c_end - cell0) : 0; // rows of the tile inside the group (workgroup-uniform)
         float* Rt = lds + (size_t)b * buf_floats;
@@ -986,14 +984,14 @@ __global__ __launch_bounds__(64 * RTZWB_WAVES, 1) void k_rtzw2b(Rtz3Args a) {
 #pragma unroll
         for (int j = 0; j < NRP; ++j) {
             const int p = tid + 256 * j;
-            if (p < 4 * Kp) st4(Rt + 4 * p, (4 * p < n_live * Kp) ? sr[set][j] : (f32x4){0.f, 0.f, 0.f, 0.f});
+            if (p < 4 * Kp) st4(Rt + 4 * p, (4 * p < n_live * Kp) ? sr[j] : (f32x4){0.f, 0.f, 0.f, 0.f});
         }
 #pragma unroll
         for (int j = 0; j < NZP; ++j) {
             const int p = tid + 256 * j;
-            if (p < 4 * DP) st4(Zt + 4 * p, (4 * p < n_live * DP) ? sz[set][j] : (f32x4){0.f, 0.f, 0.f, 0.f});
+            if (p < 4 * DP) st4(Zt + 4 * p, (4 * p < n_live * DP) ? sz[j] : (f32x4){0.f, 0.f, 0.f, 0.f});
         }
-        if (tid == 0) st4(Zt + 16 * DP, sid[set]);
+        if (tid == 0) st4(Zt + 16 * DP, sid);
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -1006,21 +1004,16 @@ __global__ __launch_bounds__(64 * RTZWB_WAVES, 1) void k_rtzw2b(Rtz3Args a) {
 #pragma unroll
             for (int u = 0; u < NTH; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        load_tile(0, 0);
-        load_tile(1, 1);
-        store_tile(0, 0, 0);
-        store_tile(1, 1, 1);
-        load_tile(2, 0);                                              // pair 1 travels while pair 0 is multiplied
-        load_tile(3, 1);
+        load_tile(0);
+        store_tile(0, 0);
+        load_tile(1);
+        store_tile(1, 1);
 
         for (int i = 0; i < n_pairs; ++i) {
             wg_barrier_lds();                                         // pair i is complete in LDS; nobody reads pair i-1 any more
             const float* pb = lds + (size_t)(2 * (i & 1)) * buf_floats;
             const int nb = 2 * ((i + 1) & 1);                         // the tile buffers of pair i+1 (pair i-1's)
-            store_tile(2 * i + 2, nb, 0);                             // pair i+1 (requested a whole pair-step ago) into the buffers pair i-1 left
-            store_tile(2 * i + 3, nb + 1, 1);
-            load_tile(2 * i + 4, 0);                                  // pair i+2 travels under this pair's products
-            load_tile(2 * i + 5, 1);
+            load_tile(2 * i + 2);                                     // travels under the B planes and the first row tiles
             // lane (c16, q): k slot j <-> cell 8 (q & 1) + j of tile q >> 1 of the pair
             const float* Rl = pb + (size_t)(q >> 1) * buf_floats + 8 * (q & 1) * Kp;
             const float* Zl = Rl + 256 * MT - 8 * (q & 1) * Kp + 8 * (q & 1) * DP;
@@ -1121,8 +1114,13 @@ __global__ __launch_bounds__(64 * RTZWB_WAVES, 1) void k_rtzw2b(Rtz3Args a) {
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (T + 1 == (HI - LO + 1) / 2) {           // half way: the first tile of pair i+1 has landed
+                    store_tile(2 * i + 2, nb);
+                    load_tile(2 * i + 3);
+                }
             };
             static_for<0, HI - LO>(tile_step);
+            store_tile(2 * i + 3, nb + 1);
         }
         // every wave stores its own output tiles: slab [mt][nt][lane][r]
         float* slab = a.slab + (size_t)task * ((size_t)MT * NT * 256);
@@ -1151,7 +1149,7 @@ __global__ __launch_bounds__(64 * RTZWB_WAVES, 1) void k_rtzw2b(Rtz3Args a) {
 //     k_rtz3 exists for 16-byte A reads, which need the values of four tiles live at once (32 registers);
 //   * staging: thread (row = tid / 32, t = tid % 32) brings the 16-byte chunks t and t + 32 of its row of R and of Z: no
 //     division, coalesced 512-byte runs, zeros for rows past the group's end, for the missing tile of an odd count and for
-//     the padding columns; a WHOLE pair travels in registers (40 per lane) while the pair before it is multiplied.
+//     the padding columns.
 // Same tasks, same slabs [mt][nt][lane][r], same finish kernel.
 // ------------------------------------------------------------------------------------------
 #define RTZW3_WAVES 8
@@ -1180,10 +1178,8 @@ __global__ __launch_bounds__(64 * RTZW3_WAVES, 1) void k_rtzw3b(Rtz3Args a) {
 
     // ---- staging: tile `ti` of the task (clamped: a missing tile is loaded from the last one and written as zeros) ----
     const int srow = tid >> 5, st32 = tid & 31;
-    // two register sets: BOTH tiles of the pair after next travel while a pair is multiplied (a whole pair-step of distance: with
-    // half a pair at a time -- the first cut -- a pair cost two HBM round trips, ~10 k cycles, whatever the waves did meanwhile)
-    f32x4 sr[2][2], sz[2][2], sid[2];
-    auto load_tile = [&](int ti, int set) {
+    f32x4 sr[2], sz[2], sid;
+    auto load_tile = [&](int ti) {
         const int tc = min(ti, n_tiles - 1);
         const size_t cell = (size_t)c_first + (size_t)16 * stride * tc + srow;
         const f32x4* rsrc = reinterpret_cast<const f32x4*>(a.R + cell * Kp);
@@ -1192,13 +1188,13 @@ __global__ __launch_bounds__(64 * RTZW3_WAVES, 1) void k_rtzw3b(Rtz3Args a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int c = st32 + 32 * j;
-            sr[set][j] = (4 * c < Kp) ? __builtin_nontemporal_load(rsrc + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            sz[set][j] = (4 * c < DP) ? __builtin_nontemporal_load(zsrc + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            sr[j] = (4 * c < Kp) ? __builtin_nontemporal_load(rsrc + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            sz[j] = (4 * c < DP) ? __builtin_nontemporal_load(zsrc + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        sid[set] = (tid == 0) ? *reinterpret_cast<const f32x4*>(a.tile_blk + (size_t)16 * (t0 + (size_t)stride * tc)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        sid = (tid == 0) ? *reinterpret_cast<const f32x4*>(a.tile_blk + (size_t)16 * (t0 + (size_t)stride * tc)) : (f32x4){0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto store_tile = [&](int ti, int b, int set) {                   // ... into tile buffer b (0..3)
+    auto store_tile = [&](int ti, int b) {                            // ... into tile buffer b (0..3)
         const int cell0 = c_first + 16 * stride * min(ti, n_tiles - 1);
         const int n_live = ti < n_tiles ? min(16, c_end - cell0) : 0; // rows of the tile inside the group (workgroup-uniform)
         const bool live = srow < n_live;
@@ -1209,10 +1205,10 @@ __global__ __launch_bounds__(64 * RTZW3_WAVES, 1) void k_rtzw3b(Rtz3Args a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int c = st32 + 32 * j;
-            if (4 * c < LDR) st4(Rt + 4 * c, (live && 4 * c < Kp) ? sr[set][j] : zero);
-            if (4 * c < LDZ) st4(Zt + 4 * c, (live && 4 * c < DP) ? sz[set][j] : zero);
+            if (4 * c < LDR) st4(Rt + 4 * c, (live && 4 * c < Kp) ? sr[j] : zero);
+            if (4 * c < LDZ) st4(Zt + 4 * c, (live && 4 * c < DP) ? sz[j] : zero);
         }
-        if (tid == 0) st4(lds + (size_t)b * buf_floats + 16 * (LDR + LDZ), sid[set]);
+        if (tid == 0) st4(lds + (size_t)b * buf_floats + 16 * (LDR + LDZ), sid);
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -1225,21 +1221,16 @@ __global__ __launch_bounds__(64 * RTZW3_WAVES, 1) void k_rtzw3b(Rtz3Args a) {
 #pragma unroll
             for (int u = 0; u < NTQ; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        load_tile(0, 0);
-        load_tile(1, 1);
-        store_tile(0, 0, 0);
-        store_tile(1, 1, 1);
-        load_tile(2, 0);                                              // pair 1 travels while pair 0 is multiplied
-        load_tile(3, 1);
+        load_tile(0);
+        store_tile(0, 0);
+        load_tile(1);
+        store_tile(1, 1);
 
         for (int i = 0; i < n_pairs; ++i) {
             wg_barrier_lds();                                         // pair i is complete in LDS; nobody reads pair i-1 any more
             const float* pb = lds + (size_t)(2 * (i & 1)) * buf_floats;
             const int nb = 2 * ((i + 1) & 1);                         // the tile buffers of pair i+1 (pair i-1's)
-            store_tile(2 * i + 2, nb, 0);                             // pair i+1 (requested a whole pair-step ago) into the buffers pair i-1 left
-            store_tile(2 * i + 3, nb + 1, 1);
-            load_tile(2 * i + 4, 0);                                  // pair i+2 travels under this pair's products
-            load_tile(2 * i + 5, 1);
+            load_tile(2 * i + 2);                                     // travels under the B planes and the first row tiles
             // lane (c16, q): k slot j <-> cell 2 j + (q & 1) of tile q >> 1 of the pair
             const float* tb = pb + (size_t)(q >> 1) * buf_floats;
             const float* Rl = tb + (q & 1) * LDR + c16;
@@ -1305,7 +1296,12 @@ __global__ __launch_bounds__(64 * RTZW3_WAVES, 1) void k_rtzw3b(Rtz3Args a) {
 #pragma unroll
                 for (int u = 0; u < NTQ; ++u) acc[t][u] = MFMA_BF16(ah, bh[u], acc[t][u]);
                 __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 == (HI - LO + 1) / 2) {                     // half way: the first tile of pair i+1 has landed
+                    store_tile(2 * i + 2, nb);
+                    load_tile(2 * i + 3);
+                }
             }
+            store_tile(2 * i + 3, nb + 1);
         }
         // every wave stores its own output tiles: slab [mt][nt][lane][r]
         float* slab = a.slab + (size_t)task * ((size_t)MT * NT * 256);
