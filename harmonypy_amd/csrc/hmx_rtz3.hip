@@ -1730,7 +1730,7 @@ static void launch_rtzw2b(const Rtz3Args& a, int mt, hipStream_t s) {
 
 // ---- k_rtzw3b: eight waves, 2 x 4 split (K > 112, five to sixteen column tiles), four padded tile buffers in one CU's LDS
 bool rtzw3b_ok(int mt, int dp, int d, int nblk, int Kp) {
-    static const bool on = [] { const char* v = getenv("HMX_RTZW3"); return !v || atoi(v) != 0; }();
+    static const bool on = [] { const char* v = getenv("HMX_RTZW3"); return v && atoi(v) != 0; }();   // (measured slower than k_rtzw2b: opt-in)
     if (!on || !rtzw_ok(mt, dp, d, nblk, 1) || mt < 8 || mt > 13) return false;
     const int ntq = (rtzw_nt(dp, d, nblk) + 3) / 4;
     return ntq >= 2 && ntq <= 4 && (size_t)4 * (16 * (rtzw3_ld(Kp) + rtzw3_ld(dp)) + 4) * sizeof(float) <= 160 * 1024;
