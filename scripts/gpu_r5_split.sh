@@ -3,11 +3,11 @@
 # -DHMX_SPLIT_PK=1), same box: parity gate of the bf16-pipe A/B tests, then C3 / configs[1] / configs[4] shard timed twice each.
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -q -k "bf16_pipe or split or c3_shape or c5_shape" -rP > gpurun_out/split_gate_full.log 2>&1
+[ -z "$SKIP_GATE" ] && timeout 900 python -m pytest tests -m gpu -q -k "bf16_pipe or split or c3_shape or c5_shape" -rP > gpurun_out/split_gate_full.log 2>&1
 grep -E "passed|failed|error|Error" gpurun_out/split_gate_full.log | tail -5
 grep -B3 -A25 "^E  " gpurun_out/split_gate_full.log | head -60
 run() {
-  label=$1; cfg=$2; steps=$3; shift 3
+  local label=$1 cfg=$2 steps=$3; shift 3
   env "$@" timeout 300 python bench.py --config $cfg --steps $steps --warmup 2 --cpu-sample 0 --no-convergence --no-lisi > gpurun_out/w.json 2> gpurun_out/w.err
   python - "$label" "$cfg" <<'PY'
 import json, sys
@@ -19,8 +19,8 @@ except Exception as ex:
 PY
 }
 for rep in 1 2; do
-  for cfg in c3:10 c2:40 c5:3; do
-    run single_subs ${cfg%%:*} ${cfg##*:} X=1
-    run packed_subs ${cfg%%:*} ${cfg##*:} HMX_LIB=$PWD/build/libhmx_splitpk.so
+  for cs in c3:10 c2:40 c5:3; do
+    run single_subs ${cs%%:*} ${cs##*:} X=1
+    run packed_subs ${cs%%:*} ${cs##*:} HMX_LIB=$PWD/build/libhmx_splitpk.so
   done
 done 2>&1 | tee gpurun_out/ab_split_subs.txt
