@@ -613,7 +613,7 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
             // k_rtz3 keeps two workgroups per CU resident, k_rtz3b (four tile buffers per wave) one: as many tasks as fit at once,
             // or a second round of workgroups pays the prologue, the slab reduction and the tail again (measured: 188 us per
             // pass with 505 tasks of 31 tiles per wave)
-            const bool one_per_cu = e->allow_rtz_bf16 && (rtz_wide_ok(e->mt, e->dp) ? (rtzw2b_ok(e->mt, e->dp, e->d, e->nblk) || rtzw3b_ok(e->mt, e->dp, e->d, e->nblk, e->Kp)) : rtz3b_ok(e->mt, e->dp, e->nblk, e->Kp));
+            const bool one_per_cu = e->allow_rtz_bf16 && (rtz_wide_ok(e->mt, e->dp) ? rtzw2b_ok(e->mt, e->dp, e->d, e->nblk) : rtz3b_ok(e->mt, e->dp, e->nblk, e->Kp));
             const int target = std::max(1, (one_per_cu ? 1 : 2) * e->n_cus - e->G);
             const int CH3 = std::max(16, std::min(one_per_cu ? 2048 : 256, (n_static_tiles + target - 1) / target));
             // HMX_RTZ3_TASKS=contig: a task is a contiguous run of a group's tiles; default: the m tasks of a group take
@@ -888,7 +888,6 @@ struct Rtz3Duties { bool on = false; };
 static int rtz3_pass(hmx_engine* e, int mode, const unsigned char* tile_blk, int nblk_cols, bool normalize, bool duties) {
     int rc;
     const bool wide = !(use_rtz3(e) && rtz3_ok(e->mt, e->dp, nblk_cols, e->G));   // (mode 2 comes here for wide shapes whatever the rounds' kernel is)
-    bool plain_rows = false;
     if ((rc = e->slab.reserve((size_t)e->ntasks3 * (wide ? rtzw_slab_floats(e->mt, e->dp, e->d, nblk_cols) : rtz3_slab_floats(e->mt, e->dp, nblk_cols)))))
         return rc;
     {
@@ -902,14 +901,12 @@ static int rtz3_pass(hmx_engine* e, int mode, const unsigned char* tile_blk, int
         if (lr > 0) e->n_rtz_bf16++;
         if (lr < 0)
             return fail(HMX_ERR_ARG, "unsupported shape for the streaming R^T.Z pass");
-        plain_rows = lr == 2;
     }
     Timed t(e, mode == 1 ? F_RIDGE_STATS : F_RTZ_REDUCE);
     const size_t GK = (size_t)e->G * e->K16;
     Rtz3FinishArgs f{};
     f.slab = e->slab.p; f.task_grp = e->t3_grp.p; f.ntasks = e->ntasks3;
     f.MT = e->mt; f.KS = e->dp / 4; f.NTB = rtz3_ntb(e->dp, nblk_cols);
-    f.plain_rows = plain_rows ? 1 : 0;
     f.wide = wide ? 1 : 0; f.NT = wide ? rtzw_nt(e->dp, e->d, nblk_cols) : 4 + f.NTB;
     f.K = e->K; f.K16 = e->K16; f.d = e->d; f.ld = e->ldy; f.G = e->G; f.nblk = nblk_cols; f.mode = mode == 0 ? 0 : 1;
     f.Ysum = e->Yacc64; f.Yout = normalize ? e->Y.p : nullptr; f.Sold = e->Sold; f.Sr = e->Sr; f.Oxr = e->Oxr;

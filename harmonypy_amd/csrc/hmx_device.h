@@ -1,4 +1,4 @@
-// hmx_device.h -- device-side helpers shared by the kernel files (hmx_kernels.hip, hmx_sweep.hip).
+// hmx_device.h -- device-side helpers shared by the kernel files (hmx_kernels.hip, hmx_rtz3.hip).
 //
 // Fragment conventions of v_mfma_f32_16x16x4_f32 (cdna_hip_programming.md §3):
 //   A operand: lane l holds A[i = l&15][k = l>>4]
@@ -72,36 +72,14 @@ __device__ __forceinline__ f32x2 bf16_widen(unsigned p) {
     r.y = __uint_as_float(p & 0xffff0000u);
     return r;
 }
-// x = h + m + l exactly (pairs: 3 conversions, 4 subtractions, 4 shifts / masks).  The subtractions are pinned as four
-// SINGLE v_sub_f32: written on the pair the compiler emits v_pk_add_f32, and a packed fp32 instruction beside MFMAs costs
-// more than the two single ones it replaces (MI355X_MICROARCH.md: "2 v_pk_add_f32 per gap +26 cyc vs 2 v_fma_f32 -- an
-// anti-lever beside MFMAs, including when the compiler SLP-packs adjacent scalar f32 adds"); HMX_SPLIT_PK=1 keeps the pair form.
-#ifndef HMX_SPLIT_PK
-#define HMX_SPLIT_PK 0
-#endif
-__device__ __forceinline__ float sub_f32_single(float a, float b) {
-    float r;
-    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
+// x = h + m + l exactly (pairs: 3 conversions, 2 packed subtractions, 4 shifts / masks).  (Four single v_sub_f32 instead of
+// the two v_pk_add_f32 were measured in round 5 -- packed fp32 instructions are dear beside MFMAs -- and lost: C3 191.6 vs
+// 194.8 M cells/s/iteration on one box, profiles/r05_ab_split_single_subs.txt.)
 __device__ __forceinline__ void bf16_split3(f32x2 x, unsigned& h, unsigned& m, unsigned& l) {
     h = bf16_pack(x);
-#if HMX_SPLIT_PK
     const f32x2 r1 = x - bf16_widen(h);
     m = bf16_pack(r1);
     l = bf16_pack(r1 - bf16_widen(m));
-#else
-    const f32x2 wh = bf16_widen(h);
-    f32x2 r1;
-    r1.x = sub_f32_single(x.x, wh.x);
-    r1.y = sub_f32_single(x.y, wh.y);
-    m = bf16_pack(r1);
-    const f32x2 wm = bf16_widen(m);
-    f32x2 r2;
-    r2.x = sub_f32_single(r1.x, wm.x);
-    r2.y = sub_f32_single(r1.y, wm.y);
-    l = bf16_pack(r2);
-#endif
 }
 
 // sum over the 16 lanes of a DPP row (the lanes that share q); every lane of the row gets the total

@@ -25,8 +25,8 @@ struct AssignArgs {
     int tile_begin, tile_end;  // host-side range (or an upper bound of its length when blk_start)
     int K, Kp, K16, mt, dp, ldy;
     int G, ldy_lds, tables_in_lds, tiles_per_wave, ablate;
-    const unsigned* Yf;    // wide shapes, bf16 pipe: Y as the A fragments of k_assign_wide3 (launch_y_planes), or null (the f32-input kernel k_assign_wide2)
-    int bf16_pipe;         // wide shapes: the bf16-pipe instance k_assign_wide3 (0: engines created under HMX_ROUND_F32=1 keep k_assign_wide2)
+    const unsigned* Yf;    // wide shapes, bf16 pipe: Y as the A fragments of k_assign_wide3 (launch_y_planes), or null (the f32-input kernel k_assign_wide)
+    int bf16_pipe;         // wide shapes: the bf16-pipe instance k_assign_wide3 (0: engines created under HMX_ROUND_F32=1 keep k_assign_wide)
     const float* hn;       // k_assign_wide without penalty only: half squared norms of the centres in Y (+inf for pads) -> HARD
                            // assignment of the device k-means (a one-hot row of R per cell) instead of the softmax; null otherwise
 };
@@ -102,7 +102,6 @@ struct Rtz3FinishArgs {
     const int* task_grp;
     int ntasks, MT, KS, NTB, K, K16, d, ld, G, nblk;
     int wide, NT;              // k_rtzw's slabs: plain column tiles, NT of them (KS = dp / 4 there too)
-    int plain_rows;            // k_rtzw3b's slabs: row tile mt holds the clusters 16 mt .. 16 mt + 15 (else the permuted map of k_rtz3)
     int mode;                  // 0: k-means round (Ysum, Sold, optional Yout), 1: ridge (Sr, Oxr)
     double* Ysum;              // K16 x ld
     float* Yout;               // K16 x ld unit rows, or null (a collective comes first)
@@ -127,7 +126,6 @@ void launch_rtz3_finish(const Rtz3FinishArgs& a, hipStream_t s);
 bool rtzw_ok(int mt, int dp, int d, int nblk, int G);
 int rtzw_nt(int dp, int d, int nblk);
 int rtzw_slab_floats(int mt, int dp, int d, int nblk);
-bool rtzw3b_ok(int mt, int dp, int d, int nblk, int Kp);   // launch_rtzw takes k_rtzw3b (eight waves, one workgroup per CU; returns 2)
 bool rtzw2b_ok(int mt, int dp, int d, int nblk);   // launch_rtzw takes the bf16-pipe kernel k_rtzw2b (one workgroup per CU)
 int launch_rtzw(const Rtz3Args& a, int mt, int dp, int d, int nblk, hipStream_t s, bool allow_bf16);   // 1: k_rtzw2b ran, 0: an f32-input kernel, -1 unsupported
 void launch_tile_blocks(const int* cells, const int* tile_grp, const int* blk_start, int nblk, int64_t n_pos_upper, const int* gstart,

@@ -1193,260 +1193,19 @@ __global__ __launch_bounds__(64 * WIDE_WAVES, 2) void k_assign_wide(AssignArgs a
 }
 
 // ------------------------------------------------------------------------------------------
-// k_assign_wide2: the penalised assignment of one update block for the wide shapes, second cut.
-// k_assign_wide (8 waves, one tile per wave, a workgroup barrier per 16-column k-step) has 52 MFMAs per wave between two
-// barriers and keeps the block sums of ALL groups in LDS.  Here: FOUR waves per workgroup (one per SIMD), TWO workgroups
-// per CU, TWO tiles per wave: a centroid fragment read from LDS feeds 8 MFMAs instead of 4, 104 MFMAs per wave between two
-// barriers.  A k-step's centroid columns (K16 x 16 floats) travel global -> LDS directly (three-deep ring, XOR-swizzled
-// 16-byte pieces: the requests write linearly, the fragment reads stay free of bank conflicts), the tiles' Z_cos pieces
-// global -> registers one k-step ahead, both with hand-counted waits.  The workgroup keeps table rows and block sums only
-// for the groups of its own eight tiles (a block's list is sorted by group): 68 KB of LDS at K16 = 208 whatever the number
-// of batches.  Measured at the configs[4] shard (62.5 k cells per block, K = d = 200): 74 -> 70 us per block launch incl.
-// the launch gap -- the restructuring buys 5 %; the finishing passes (two tiles per wave after the last k-step, matrix
-// pipe idle) and the per-launch ramp are what is left.
-// ------------------------------------------------------------------------------------------
-#define WIDE2_WAVES 4
-#define WIDE2_YBUF 3
-#define WIDE2_SLOTS (2 * WIDE2_WAVES)
-// The tiles' Z_cos pieces are ORDINARY loads (the compiler sees them and waits for them itself); only the centroid pieces,
-// which have no destination registers, are inline-assembly LDS-DMA requests with a hand-counted wait in front of the
-// barrier.  Rounds 2-3 issued the Z pieces from inline assembly too (global_load_dwordx4 with an "=&v" result) and released
-// them with asm("s_waitcnt vmcnt(N)" : "+v"(z0), "+v"(z1)) "so that their uses stay behind the wait".  The compiler knows
-// nothing of a load it cannot see: a tied ("+v") operand is lowered as `COPY out = in` in FRONT of the statement, and the
-// copies that resolve a loop-carried value may land anywhere between the load and the wait -- the shipped code read the
-// load destinations (4 x v_mov_b64) BEFORE the s_waitcnt on every rung of the wait ladder but one, i.e. in flight.  With
-// 13 cluster tiles a k-step lasts 3 k cycles and the loads, issued two steps ahead, had always landed; with two cluster
-// tiles (K = 20) a step is 16 MFMAs and waves 2, 3 copied stale registers in some runs: "a few dozen rows of R off by more
-// than 1e-4" = one wave's tile pair (round-3 DESIGN section 8 item 4; the same statement served the tile pass of round 3's
-// persistent wide sweep, whose small-block failures have the same signature).  scripts/kernel_audit.py --inflight now follows
-// every register a vector-memory load writes through the BUILT code of every kernel and fails if anything touches it before
-// a wait has retired the load (tests/test_kernel_audit.py).
-template <int N>
-__device__ __forceinline__ void wide2_wait() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-template <int MT>
-__global__ __launch_bounds__(64 * WIDE2_WAVES, 2) void k_assign_wide2(AssignArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int K16 = 16 * MT;
-    constexpr int NPJ = (MT + WIDE2_WAVES - 1) / WIDE2_WAVES;            // centroid pieces (16 rows x 64 bytes) of a wave per k-step, at most
-    float* Yring = reinterpret_cast<float*>(smem);                       // WIDE2_YBUF x K16 x 16
-    float* sig = Yring + WIDE2_YBUF * K16 * 16;                          // K16
-    float* nis = sig + K16;                                              // K16: -2 log2(e) / sigma (-200 for pads)
-    float* rpL = nis + K16;                                              // slots x K16
-    float* lrpL = rpL + WIDE2_SLOTS * K16;
-    double* Sd = reinterpret_cast<double*>(lrpL + WIDE2_SLOTS * K16);    // slots x K16 block sums
-    double* objw = Sd + WIDE2_SLOTS * K16;                               // waves x 2
-    int* tg = reinterpret_cast<int*>(objw + 2 * WIDE2_WAVES);            // group of the workgroup's tile j (-1: no such tile)
-    int* ts = tg + WIDE2_SLOTS;                                          // its slot: tiles of one group share table rows and sums
-    int* sg = ts + WIDE2_SLOTS;                                          // group of a slot
-    const int tid = threadIdx.x;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63, c16 = lane & 15, q = lane >> 4;
-    const int nkb = a.dp >> 4;
-    const int tile_begin = a.blk_start ? a.blk_start[a.blk] : a.tile_begin;
-    const int tile_end = a.blk_start ? a.blk_start[a.blk + 1] : a.tile_end;
-    const int ntiles = tile_end - tile_begin;
-    const int base = blockIdx.x * WIDE2_SLOTS;
-    if (base >= ntiles) return;                                          // (the grid is sized for an upper bound of the block)
-
-    // ---- requests of k-step 0 and 1 first: their latency runs under the set-up below --------------------------------
-    RoundTile<MT> T0, T1;
-    const int j0 = base + 2 * wv;
-    const bool has0 = j0 < ntiles, has1 = j0 + 1 < ntiles;              // wave-uniform
-    T0.cell = has0 ? a.cells[(size_t)(tile_begin + j0) * 16 + c16] : -1;
-    T1.cell = has1 ? a.cells[(size_t)(tile_begin + j0 + 1) * 16 + c16] : -1;
-    const float* zr0 = a.Zcos + (size_t)(T0.cell >= 0 ? T0.cell : 0) * a.dp + 4 * q;
-    const float* zr1 = a.Zcos + (size_t)(T1.cell >= 0 ? T1.cell : 0) * a.dp + 4 * q;
-    // centroid pieces: piece p = 16 rows x 16 columns; lane l brings row l / 4 of the piece, 16-byte chunk (l % 4) ^ (row / 4 % 4)
-    // to LDS position 16 l of the piece -- the zone is row-major with the chunks of a row permuted by its row quad
-    const unsigned yvoff = (unsigned)(((lane >> 2) * a.ldy + 4 * ((lane & 3) ^ ((lane >> 4) & 3))) * 4);
-    const unsigned ring0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)Yring;
-    auto u64 = [](unsigned long long v) {
-        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
-               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v);
-    };
-    // EVERY wave asks for NPJ pieces per k-step: wave w owns pieces w, w + 4, ...; a wave that owns fewer (K16 not a multiple
-    // of 64) asks for the last piece of the step once more -- the same bytes to the same zone, harmless -- so that the number
-    // of requests in flight is a compile-time constant and the waits below need no per-wave case distinction
-    unsigned long long ysrc = u64((unsigned long long)a.Y);             // column block of the next k-step to request
-    unsigned ypoff[NPJ], yzoff[NPJ];                                    // (wave-uniform) the wave's pieces: byte offset in Y, zone offset in a ring slot
-#pragma unroll
-    for (int j = 0; j < NPJ; ++j) {
-        const int pj = min(wv + WIDE2_WAVES * j, MT - 1);
-        ypoff[j] = (unsigned)(64 * pj * a.ldy);
-        yzoff[j] = 1024u * (unsigned)pj;
-    }
-    const unsigned yzone0 = __builtin_amdgcn_readfirstlane(ring0);
-    unsigned yzone = yzone0;
-    int yslot = 0;
-    auto issue_y = [&]() {
-#pragma unroll
-        for (int j = 0; j < NPJ; ++j) {
-            const unsigned long long src = ysrc + ypoff[j];
-            const unsigned zone = yzone + yzoff[j];
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(yvoff), "s"(src), "s"(zone) : "memory", "m0");
-        }
-        ysrc += 64;                                                      // next k-step: 16 columns on
-        yzone += (unsigned)(K16 * 64);
-        if (++yslot == WIDE2_YBUF) { yslot = 0; yzone = yzone0; }
-    };
-    auto issue_z = [&](f32x4& z0, f32x4& z1, int kb) {   // ordinary loads, pinned where they are written
-        __builtin_amdgcn_sched_barrier(0);
-        z0 = ld4(zr0 + 16 * kb);
-        z1 = ld4(zr1 + 16 * kb);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    f32x4 za0, za1, zb0, zb1;
-    // (pieces before Z values, as in the steps below; with an odd number of k-steps > 1 the B registers take step 0)
-    const bool b_first = nkb > 1 && (nkb & 1);
-    issue_y();
-    if (b_first) issue_z(zb0, zb1, 0); else issue_z(za0, za1, 0);
-    if (nkb > 1) {
-        issue_y();
-        if (b_first) issue_z(za0, za1, 1); else issue_z(zb0, zb1, 1);
-    }
-
-    // ---- set-up: sigma, the groups of the workgroup's tiles, their table rows, zeroed sums --------------------------
-    for (int i = tid; i < K16; i += 64 * WIDE2_WAVES) {
-        const float sgm = (i < a.K) ? a.sigma[i] : 0.f;
-        sig[i] = sgm;
-        nis[i] = (i < a.K) ? -(2.885390081777926814f / sgm) : -200.f;   // -c_k = -2 log2(e) / sigma_k; pads: Y row 0 -> 2^-200 == 0
-    }
-    if (tid < WIDE2_SLOTS) tg[tid] = base + tid < ntiles ? a.tile_grp[tile_begin + base + tid] : -1;
-    for (int i = tid; i < WIDE2_SLOTS * K16; i += 64 * WIDE2_WAVES) Sd[i] = 0.0;
-    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0) only: the requests above stay in flight
-    __builtin_amdgcn_s_barrier();
-    if (tid < WIDE2_SLOTS) {
-        int slot = 0;
-        for (int u = 1; u <= tid; ++u) slot += (tg[u] != tg[u - 1] && tg[u] >= 0) ? 1 : 0;
-        ts[tid] = slot;
-        if (tg[tid] >= 0 && (tid == 0 || tg[tid] != tg[tid - 1])) sg[slot] = tg[tid];
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_s_barrier();
-    const int nslots = ts[WIDE2_SLOTS - 1] + 1;
-    for (int i = tid; i < nslots * K16; i += 64 * WIDE2_WAVES) {
-        const int sl = i / K16, k = i - sl * K16;
-        const size_t src = (size_t)sg[sl] * K16 + k;
-        rpL[i] = a.rp[src];
-        lrpL[i] = a.lrp[src];
-    }
-    T0.grp = ts[2 * wv];
-    T1.grp = has1 ? ts[2 * wv + 1] : T0.grp;              // (a missing tile computes on cell 0's row and counts for nothing)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        T0.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        T1.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-
-    // ---- the k-steps -------------------------------------------------------------------------------------------------
-    // Memory operations return in order.  At the top of step kb the workgroup needs everybody's centroid pieces of step kb;
-    // younger than a wave's own are only the requests of step kb+1 (NPJ pieces + 2 loads), issued one step ago.  The Z values
-    // of step kb are waited for by the compiler, in front of their first use (it counts only its own loads, i.e. it waits
-    // for a little more than it must: the pieces of step kb+1, a whole step old by then).
-    // Three kinds of step, so that no load is issued under a condition inside the main loop (the compiler's wait insertion
-    // joins the paths of a conditional issue conservatively -- it then drains the counter before every step):
-    //   F  multiply, request step kb + 2      (kb + 2 < nkb)
-    //   N  multiply                           (kb + 2 == nkb: step kb + 1 is still in flight)
-    //   L  wait for everything, multiply      (the last step)
-    const int swz = 4 * (q ^ ((c16 >> 2) & 3));
-    int rslot = 0;
-    auto mfma_tile = [&](const float* Yst, int mt, const f32x4& z0, const f32x4& z1) {
-        const f32x4 ya = ld4(Yst + (16 * mt + c16) * 16 + swz);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            T0.arg[mt] = MFMA16(ya[i], z0[i], T0.arg[mt]);
-            T1.arg[mt] = MFMA16(ya[i], z1[i], T1.arg[mt]);
-        }
-    };
-    auto step = [&](auto kind, int kb, f32x4& z0, f32x4& z1) {
-        constexpr int KIND = decltype(kind)::value;
-        __builtin_amdgcn_sched_barrier(0);
-        // this wave's pieces of step kb have landed: younger are z(kb) x 2, the pieces of step kb+1 and z(kb+1) x 2
-        if constexpr (KIND == 2) wide2_wait<0>(); else wide2_wait<NPJ + 4>();
-        wg_barrier_lds();                                // everybody's pieces of step kb are in; nobody reads step kb-1 any more
-        const float* Yst = Yring + (size_t)rslot * (K16 * 16);
-        if (++rslot == WIDE2_YBUF) rslot = 0;
-        // The first cluster tile is where the compiler waits for z(kb) -- counting its own loads only: "all but z(kb+1) x 2".
-        // The requests of step kb+2 go out BEHIND that wait (in front of it they would be the youngest operations in flight
-        // and the wait would drain z(kb+1), issued a moment ago); the pieces of step kb+1 are older than z(kb+1): no loss.
-        mfma_tile(Yst, 0, z0, z1);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (KIND == 0) issue_y();              // into the ring slot of step kb-1
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mt = 1; mt < MT; ++mt) mfma_tile(Yst, mt, z0, z1);
-        if constexpr (KIND == 0) issue_z(z0, z1, kb + 2);   // into the registers this step has consumed
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    {
-        const std::integral_constant<int, 0> F;
-        const std::integral_constant<int, 1> N;
-        const std::integral_constant<int, 2> L;
-        if (nkb == 1) {
-            step(L, 0, za0, za1);
-        } else {
-            // an odd number of steps starts on the B registers (see the first requests above), so that every sequence ends
-            // with the same two steps: ... F(A) F(B) | N(A) L(B)
-            int kb = 0;
-            if (nkb & 1) { step(F, 0, zb0, zb1); kb = 1; }
-            for (; kb + 3 < nkb; kb += 2) {
-                step(F, kb, za0, za1);
-                step(F, kb + 1, zb0, zb1);
-            }
-            step(N, kb, za0, za1);
-            step(L, kb + 1, zb0, zb1);
-        }
-    }
-
-    // ---- finish: exp, penalty, renormalisation, R rows, block sums, objective terms (k_round's passes) ---------------
-    double km_acc = 0.0, ent_acc = 0.0;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const f32x4 ni = ld4(nis + 16 * mt + 4 * q);       // dist = 2 (1 - Y.Z) (:447), arg = -dist / sigma (:466), here in log2 units:
-        T0.arg[mt] = __builtin_elementwise_fma(T0.arg[mt], -ni, ni);   // c_k (y.z - 1), the argument of the hardware exp2 (one fma per entry)
-        T1.arg[mt] = __builtin_elementwise_fma(T1.arg[mt], -ni, ni);
-    }
-    if (has0) {
-        float scl0, scl1 = 0.f;
-        round_post_pass1<MT, true, true, false, (HMX_ROUND_PK != 0 && MT <= 8)>(sig, rpL, lrpL, q, T0, scl0, km_acc, ent_acc);
-        if (has1) round_post_pass1<MT, true, true, false, (HMX_ROUND_PK != 0 && MT <= 8)>(sig, rpL, lrpL, q, T1, scl1, km_acc, ent_acc);
-        round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T0, scl0, has1, T1, scl1);
-    }
-    km_acc = wave_sum_all(km_acc);
-    ent_acc = wave_sum_all(ent_acc);
-    if (lane == 0) {
-        objw[2 * wv] = km_acc;
-        objw[2 * wv + 1] = ent_acc;
-    }
-    __syncthreads();
-    if (tid < 2) {
-        double v = 0.0;
-        for (int w = 0; w < WIDE2_WAVES; ++w) v += objw[2 * w + tid];
-        if (v != 0.0) atomicAdd(&a.obj[2 * (blockIdx.x & (HMX_OBJ_SLOTS - 1)) + tid], v);
-    }
-    for (int i = tid; i < nslots * K16; i += 64 * WIDE2_WAVES) {
-        const double v = Sd[i];
-        const int sl = i / K16;
-        if (v != 0.0) atomicAdd(&a.S_out[(size_t)sg[sl] * K16 + (i - sl * K16)], v);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // k_assign_wide3: the wide block assignment on the bf16 matrix pipe (hmx_device.h: every fp32 operand as the exact sum of
 // three bf16 terms, six products, fp32 accumulation) with the centroids PRE-SPLIT.  The wide shapes are bound by the f32-input
-// MFMA (52 k-steps of 32 cycles per cluster tile and cell tile at d = 208; here 7 x 6 of 16).  A first cut (round 5,
-// k_assign_wide2b: k_assign_wide2's four-slot fp32 centroid ring, the centroid values split in registers per workgroup and
-// k-step -- 36 vector instructions for 12 MFMAs) ran at the VECTOR rate: 59 us per block launch at the configs[4] shard
-// against 66 with the f32-input MFMA (profiles/r05_ab_wide_bf16_pipe.txt).  But Y changes once per ROUND: k_y_planes (one small launch per round) writes it as the A fragments of v_mfma_f32_16x16x32_bf16, three bf16
+// MFMA (52 k-steps of 32 cycles per cluster tile and cell tile at d = 208; here 7 x 6 of 16).  A first cut of round 5 kept an
+// fp32 centroid ring and split the centroid values in registers, per workgroup and k-step -- 36 vector instructions for 12
+// MFMAs: it ran at the VECTOR rate, 59 us per block launch at the configs[4] shard against 66 with the f32-input MFMA
+// (profiles/r05_ab_wide_bf16_pipe.txt; NOTES.md).  But Y changes once per ROUND: k_y_planes (one small launch per round) writes it as the A fragments of v_mfma_f32_16x16x32_bf16, three bf16
 // planes, Yf[step s][plane h, m, l][cluster tile mt][lane][8 bf16] (row i = cluster 16 mt + c16, k slot j of lane (c16, q) =
 // PC 32 s + 8 q + j, zeros past the row).  A (plane, tile) fragment is 1 KB contiguous: one LDS-DMA request brings it, one
 // conflict-free 16-byte read per lane hands it to the matrix pipe, no vector instruction touches it.  What is left to split
 // in registers are the tiles' own Z_cos values, once per step (72 instructions for 156 MFMAs).
 // One workgroup of EIGHT waves per CU (a step of all three planes is 3 MT KB: the two-slot ring takes 78 KB at K16 = 208),
-// two tiles per wave, sixteen per workgroup; table rows and block sums for the groups of those sixteen tiles; finishing
-// passes as in k_assign_wide2 / k_round.  One vmcnt(0) + one barrier per step; the requests of step s+1 go out behind the
+// two tiles per wave, sixteen per workgroup; table rows and block sums for the groups of those sixteen tiles (a block's list is
+// sorted by group); finishing passes as in k_round.  One vmcnt(0) + one barrier per step; the requests of step s+1 go out behind the
 // first cluster tile of step s.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_y_planes(const float* __restrict__ Y, int ldy, int mt_n, unsigned* __restrict__ Yf) {
@@ -1538,7 +1297,7 @@ __global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_assign_wide3(AssignArgs
     request(0);
     load_z(0);
 
-    // ---- set-up: sigma, the groups of the workgroup's tiles, their table rows, zeroed sums (as in k_assign_wide2) ----
+    // ---- set-up: sigma, the groups of the workgroup's tiles, their table rows, zeroed sums ----
     for (int i = tid; i < K16; i += 64 * WIDE3_WAVES) {
         const float sgm = (i < a.K) ? a.sigma[i] : 0.f;
         sig[i] = sgm;
@@ -4162,13 +3921,10 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
         const size_t gk_bytes = (size_t)a.G * a.K16 * sizeof(double);
         a.tables_in_lds = gk_bytes <= 64 * 1024 ? 1 : 0;
         const size_t sm = ((size_t)2 * a.K16 * 20 + 2 * a.K16) * sizeof(float) + (a.tables_in_lds ? gk_bytes : 0) + 2 * WIDE_WAVES * sizeof(double);
-        // the penalised block assignment of the round loop: two tiles per wave, two workgroups per CU (k_assign_wide2)
-        static const int wide_mode = [] { const char* v = getenv("HMX_WIDE_ASSIGN"); return v ? atoi(v) : 2; }();
-        if (penalty && !a.hn && wide_mode == 2 && a.mt >= 1 && a.mt <= 13) {
-            const size_t sm2 = ((size_t)WIDE2_YBUF * a.K16 * 16 + 2 * a.K16 + 2 * WIDE2_SLOTS * a.K16) * sizeof(float) +
-                               ((size_t)WIDE2_SLOTS * a.K16 + 2 * WIDE2_WAVES) * sizeof(double) + 3 * WIDE2_SLOTS * sizeof(int);
-            const int wgs2 = cdiv(ntiles, WIDE2_SLOTS);
-            // ... with the centroids pre-split into fragments (k_assign_wide3: eight waves, one workgroup per CU)
+        // the penalised block assignment of the round loop on the bf16 matrix pipe, centroids pre-split into fragments
+        // (k_assign_wide3: eight waves, two tiles each, one workgroup per CU); engines created under HMX_ROUND_F32=1 and the
+        // assignments without a penalty (init_cluster, the device Lloyd) take the f32-input kernel k_assign_wide below
+        if (penalty && !a.hn && a.bf16_pipe && a.Yf) {
             const size_t sm3 = (size_t)2 * 3 * a.mt * 1024 + ((size_t)2 * a.K16 + 2 * WIDE3_SLOTS * a.K16) * sizeof(float) +
                                ((size_t)WIDE3_SLOTS * a.K16 + 2 * WIDE3_WAVES) * sizeof(double) + 3 * WIDE3_SLOTS * sizeof(int);
             const int wgs3 = cdiv(ntiles, WIDE3_SLOTS);
@@ -4181,7 +3937,7 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
         }                                                                                                             \
         hipLaunchKernelGGL((k_assign_wide3<M>), dim3(wgs3), dim3(64 * WIDE3_WAVES), sm3, s, a);                        \
     } break;
-            if (a.bf16_pipe && a.Yf && sm3 <= 160 * 1024) {
+            if (sm3 <= 160 * 1024) {
                 switch (a.mt) {
                     HMX_WIDE3_CASE(1) HMX_WIDE3_CASE(2) HMX_WIDE3_CASE(3) HMX_WIDE3_CASE(4) HMX_WIDE3_CASE(5) HMX_WIDE3_CASE(6) HMX_WIDE3_CASE(7)
                     HMX_WIDE3_CASE(8) HMX_WIDE3_CASE(9) HMX_WIDE3_CASE(10) HMX_WIDE3_CASE(11) HMX_WIDE3_CASE(12) HMX_WIDE3_CASE(13)
@@ -4189,23 +3945,6 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
                 return 1;
             }
 #undef HMX_WIDE3_CASE
-#define HMX_WIDE2_CASE(M)                                                                                               \
-    case M: {                                                                                                         \
-        static bool attr_done = false;                                                                                \
-        if (!attr_done) {                                                                                             \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_assign_wide2<M>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
-            attr_done = true;                                                                                         \
-        }                                                                                                             \
-        hipLaunchKernelGGL((k_assign_wide2<M>), dim3(wgs2), dim3(64 * WIDE2_WAVES), sm2, s, a);                        \
-    } break;
-            if (sm2 <= 80 * 1024) {
-                switch (a.mt) {
-                    HMX_WIDE2_CASE(1) HMX_WIDE2_CASE(2) HMX_WIDE2_CASE(3) HMX_WIDE2_CASE(4) HMX_WIDE2_CASE(5) HMX_WIDE2_CASE(6) HMX_WIDE2_CASE(7)
-                    HMX_WIDE2_CASE(8) HMX_WIDE2_CASE(9) HMX_WIDE2_CASE(10) HMX_WIDE2_CASE(11) HMX_WIDE2_CASE(12) HMX_WIDE2_CASE(13)
-                }
-                return 0;
-            }
-#undef HMX_WIDE2_CASE
         }
         const int wgs = std::max(1, std::min(2 * 256, cdiv(ntiles, WIDE_WAVES)));
 #define HMX_WIDE_CASE(M)                                                                                          \

@@ -38,7 +38,7 @@
 #define HMX_RTZ3_NT 1    /* the rows are read once per pass: non-temporal requests (micro-benchmark of this very pattern: 6.2 -> 6.9 TB/s) */
 #endif
 // (defined in FRONT of dma16: behind it -- where it stood until round 4 -- `#if HMX_RTZ3_NT` read an undefined macro, i.e. 0, and
-// every request of k_rtz3 / k_rtzw / k_rtzw2 went out without the hint)
+// every request of the streaming kernels went out without the hint)
 namespace {
 
 // one 1 KB piece global -> LDS: lane l brings the 16 bytes at `base` + `voff` (= 16 l) to LDS byte address `zone` + 16 l.
@@ -744,182 +744,24 @@ __global__ __launch_bounds__(64 * RTZW_WAVES, 1) void k_rtzw(Rtz3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// k_rtzw2: the wide streaming pass, second cut (K > 112, seven or more column tiles).  k_rtzw's eight waves share one tile:
-// 104 MFMAs per wave between two barriers, and every wave reads all of the R tile from LDS.  Here a workgroup is FOUR
-// waves -- one per SIMD -- and two workgroups share a CU; the MT x NT output tiles are split 2 x 2 over the waves (row half
-// x column half: up to 7 x 7 tiles = 196 accumulator registers), which doubles the MFMAs between two barriers (196) and
-// halves the LDS operand reads per MFMA.  Ring of three tiles per workgroup (80 KB at K = d = 208).  Same tasks, same
-// slabs, same finish kernel as k_rtzw.  Measured at the configs[4] shard (1.25 M cells x 200, K = 200): 1.30 -> 1.12 ms per
-// pass; cycle stamps per tile and wave: 16.4 k (ideal 12.5 k = 2 waves x 196 MFMAs x 32) of which requests 1.9 k (nine
-// LDS-DMA instructions at ~200 cycles of issue each), barrier 1.4 k, wait for the own pieces 0.4 k.  Starting the CU's
-// second workgroup half a tile late (so that one wave of a SIMD multiplies while the other requests) changed nothing.
-// ------------------------------------------------------------------------------------------
-#define RTZW2_WAVES 4
-#define RTZW2_NBUF 3
-template <int MT, int NTH>
-__global__ __launch_bounds__(64 * RTZW2_WAVES, 2) void k_rtzw2(Rtz3Args a) {
-    constexpr int MTA = (MT + 1) / 2;
-    constexpr int H = MT / 4, REM = MT % 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* lds = reinterpret_cast<float*>(smem);
-    const int Kp = a.Kp, DP = a.dp, d = a.d, NT = a.nt, NTP = DP >> 4;
-    const int buf_floats = 256 * MT + 16 * DP + 4;                // R segment (MT whole pieces) | Z tile | 16 block-id bytes
-    const int tid = threadIdx.x;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63, c16 = lane & 15, q = lane >> 4;
-    const int lane16 = 16 * lane;
-    const int task = blockIdx.x;
-    const int t0 = a.task_t0[task], t1 = a.task_t1[task];
-    const int c_first = a.task_c0[task], c_end = a.task_cend[task];
-    const int stride = __builtin_amdgcn_readfirstlane(a.task_stride[task]);
-    const int n_tiles = (t1 - t0 + stride - 1) / stride;
-    const int rh = wv >> 1, ch = wv & 1;                          // this wave's quarter of the output: row tiles mt_lo.., column tiles nt_lo..
-    const int mt_lo = rh * MTA, nt_lo = ch * NTH;
-
-    f32x4 acc[MTA][NTH];
-#pragma unroll
-    for (int i = 0; i < MTA; ++i)
-#pragma unroll
-        for (int u = 0; u < NTH; ++u) acc[i][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // where the lane's A value of row tile mt sits in an R row (the index map of k_rtz3: cluster 64h + 4 c16 + j for tile
-    // 4h + j, cluster 64H + REM c16 + j for the remaining tiles): a wave-uniform constant plus 4 c16 or REM c16.  Formed
-    // per k-step from the lane's c16 (which passes through an empty asm there): seven offsets kept across the loop would
-    // push the 196 accumulators into scratch.  A tile past MT reads column 0 and counts for nothing.
-    auto a_const = [&](int mt) { return mt >= MT ? 0 : mt < 4 * H ? 64 * (mt >> 2) + (mt & 3) : 64 * H + (mt - 4 * H); };   // wave-uniform
-    auto a_mul = [&](int mt) { return mt >= MT ? 0 : mt < 4 * H ? 4 : REM; };
-    // Requests.  The R segment of a buffer is padded to MT whole 1 KB pieces (the last piece runs into the next tile's rows
-    // -- or the slack rows behind R -- and its tail lands in the padding), a Z segment is NTP whole pieces: every request
-    // is a full, unmasked wave instruction.  Piece p of a segment belongs to wave p % 4; the wave's three streams are running
-    // scalar pointers advanced by a constant per tile, the LDS zone rotates through the ring -- a handful of scalar adds per
-    // tile.  (First version: piece loop with per-piece bounds tests and addresses re-formed from the tile index: 300 scalar
-    // instructions, 5.5 k of the 18.5 k cycles of a tile.)
-    constexpr int NRJ = (MT + 3) / 4;                               // R pieces of a wave, at most
-    const unsigned buf_bytes = (unsigned)buf_floats * 4u;
-    const unsigned zone0 = lds_addr(lds);
-    auto uniform64 = [](unsigned long long v) {
-        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
-               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v);
-    };
-    unsigned long long rs = uniform64((unsigned long long)(a.R + (size_t)c_first * Kp) + 1024ull * wv);
-    unsigned long long zs = uniform64((unsigned long long)(a.Z + (size_t)c_first * DP) + 1024ull * wv);
-    unsigned long long bs = uniform64((unsigned long long)(a.tile_blk + (size_t)16 * t0));
-    const unsigned long long r_step = (unsigned long long)64 * Kp * stride, z_step = (unsigned long long)64 * DP * stride, b_step = (unsigned long long)16 * stride;
-    unsigned zone_next = zone0 + 1024u * wv;
-    int slot_next = 0;
-    const int nrw = (MT - wv + 3) / 4, nzw = (NTP - wv + 3) / 4;    // this wave's pieces of R and of Z (wave-uniform)
-    const int npw = nrw + nzw + (wv == RTZW2_WAVES - 1 ? 1 : 0);
-    auto issue_next = [&]() {                                       // this wave's pieces of the next tile not yet requested
-#pragma unroll
-        for (int j = 0; j < NRJ; ++j)
-            if (j < nrw) dma16((const void*)rs, lane16 + 4096 * j, zone_next + 4096u * j);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (j < nzw) dma16((const void*)zs, lane16 + 4096 * j, zone_next + 1024u * MT + 4096u * j);
-        if (wv == RTZW2_WAVES - 1 && lane == 0) dma16((const void*)bs, 0u, zone_next - 1024u * wv + 1024u * MT + 64u * DP);
-        rs += r_step; zs += z_step; bs += b_step;
-        zone_next += buf_bytes;
-        if (++slot_next == RTZW2_NBUF) { slot_next = 0; zone_next = zone0 + 1024u * wv; }
-    };
-    R3STAMP8(0);
-    for (int i = 0; i < RTZW2_NBUF - 1 && i < n_tiles; ++i) issue_next();
-    R3STAMP8(1);
-
-    for (int i = 0; i < n_tiles; ++i) {
-#ifdef HMX_RTZ3_PROF
-        const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
-#endif
-        // tile i complete (this wave's pieces: all but those of the one younger tile in flight; everybody's: the barrier),
-        // and nobody reads tile i-1 any more: its buffer takes tile i+2
-        asm volatile("" ::: "memory");
-        if (i + 1 < n_tiles) {
-            if (npw >= 8) wait_vmcnt<8>(); else if (npw == 7) wait_vmcnt<7>(); else if (npw == 6) wait_vmcnt<6>(); else if (npw == 5) wait_vmcnt<5>();
-            else if (npw == 4) wait_vmcnt<4>(); else if (npw == 3) wait_vmcnt<3>(); else if (npw == 2) wait_vmcnt<2>(); else wait_vmcnt<1>();
-        } else {
-            wait_vmcnt<0>();
-        }
-#ifdef HMX_RTZ3_PROF
-        const unsigned long long w1_ = __builtin_amdgcn_s_memtime();
-        R3ACC8(4, w1_ - w0_);
-        wg_barrier_lds();
-        const unsigned long long w2_ = __builtin_amdgcn_s_memtime();
-        R3ACC8(6, w2_ - w1_);
-#else
-        wg_barrier_lds();
-#endif
-        asm volatile("" ::: "memory");
-        if (i + RTZW2_NBUF - 1 < n_tiles) issue_next();
-#ifdef HMX_RTZ3_PROF
-        R3ACC8(7, __builtin_amdgcn_s_memtime() - w2_);
-#endif
-        const float* Rt = lds + (size_t)(i % RTZW2_NBUF) * buf_floats;
-        const float* Zt = Rt + 256 * MT;
-        const i32x4 bw4 = *reinterpret_cast<const i32x4*>(Zt + 16 * DP);            // the sixteen block ids of the tile
-        const int rows_live = c_end - (c_first + 16 * stride * i);                   // cells of this tile inside the group
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            __builtin_amdgcn_sched_barrier(0);                      // one k-step's operands live at a time
-            int c = c16, qq = q;
-            asm volatile("" : "+v"(c), "+v"(qq));                   // (addresses are re-formed here, not carried through the loop)
-            // k index (ks, q) <-> cell 4 ks + q: the four rows a k-step reads are NEIGHBOURS.  (With cell 4 q + ks, as in
-            // k_rtz3, they are four rows apart: 4 x 208 floats = 13 x 64 banks at this width, so the four 16-lane groups of a
-            // wave read the same 16 banks -- round 3's counters: 65 % of this kernel's LDS cycles were bank conflicts.  Rows one
-            // apart are 208 = 3 x 64 + 16 floats apart: the groups take four different bank quarters.)
-            const int cell = 4 * ks + qq;
-            const float lm = cell < rows_live ? 1.f : 0.f;          // rows past the group's end belong to the next group: a factor on A
-            const float* rr = Rt + (size_t)cell * Kp;
-            const float* zr = Zt + (size_t)cell * DP + 16 * nt_lo + c;
-            float am[MTA], bm[NTH];
-            // (A values as single reads: the 196 accumulators of the 7 x 7 instance leave no room for 16-byte tuples -- tried in
-            // round 4: 98 spilled registers.  With neighbouring rows their 16-byte stride over c16 and the 200-float row stride
-            // spread the four 16-lane groups over all banks as well.)
-#pragma unroll
-            for (int i2 = 0; i2 < MTA; ++i2) am[i2] = rr[a_const(mt_lo + i2) + a_mul(mt_lo + i2) * c];
-#pragma unroll
-            for (int u = 0; u < NTH; ++u) bm[u] = zr[16 * u];       // (a read past the PC tiles stays inside the ring and is not used)
-            // == 16 u: this lane's column of tile u (column 16 nt + c16, the one-hot of block 16 nt + c16 - d) is the cell's block
-            const int diff = (int)(((unsigned)bw4[ks] >> (8 * qq)) & 255u) - (16 * nt_lo + c - d);
-#pragma unroll
-            for (int i2 = 0; i2 < MTA; ++i2) am[i2] *= (mt_lo + i2 < MT) ? lm : 0.f;
-#pragma unroll
-            for (int u = 0; u < NTH; ++u) {
-                const bool pc = nt_lo + u < NTP;                    // wave-uniform: a PC column tile (its padding columns hold zeros) or a one-hot tile
-                bm[u] = (pc ? bm[u] : 0.f) + ((diff == 16 * u && nt_lo + u < NT) ? 1.f : 0.f);
-            }
-#pragma unroll
-            for (int i2 = 0; i2 < MTA; ++i2)
-#pragma unroll
-                for (int u = 0; u < NTH; ++u) acc[i2][u] = MFMA16(am[i2], bm[u], acc[i2][u]);
-        }
-    }
-    R3STAMP8(2);
-    R3ACC8(5, (unsigned long long)n_tiles);
-    // every wave stores its own output tiles: slab [mt][nt][lane][r]
-    float* slab = a.slab + (size_t)task * ((size_t)MT * NT * 256);
-#pragma unroll
-    for (int i = 0; i < MTA; ++i)
-#pragma unroll
-        for (int u = 0; u < NTH; ++u) {
-            const int mt = mt_lo + i, nt = nt_lo + u;
-            if (mt < MT && nt < NT) st4(slab + ((size_t)(mt * NT + nt) * 64 + lane) * 4, acc[i][u]);
-        }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_rtzw2b: k_rtzw2 on the bf16 matrix pipe (hmx_device.h: every fp32 operand as the exact sum of three bf16 terms, six
-// products, fp32 accumulation).  configs[4] is bound by the f32-input MFMA outright (8 x 32 cycles per 32 cells and output
-// tile; here 6 x 16), so this is where the split moves the BOUND, not only the constant.  The k index runs over cells: a
-// k-step of v_mfma_f32_16x16x32_bf16 is a PAIR of the task's tiles, lane (c16, q) supplies cells 8 (q & 1) .. + 8 of tile
-// q >> 1 (as in k_rtz3b), both operands are split in registers.  Same tasks, same 2 x 2 split of the MT x NT output tiles
-// over four waves, same slabs and finish kernel as k_rtzw2.  What is different besides the multiply:
+// k_rtzw2b: the wide streaming pass (K > 112, seven to fourteen column tiles) on the bf16 matrix pipe (hmx_device.h: every fp32
+// operand as the exact sum of three bf16 terms, six products, fp32 accumulation).  configs[4] is bound by the f32-input MFMA
+// outright (8 x 32 cycles per 32 cells and output tile; here 6 x 16), so this is where the split moves the BOUND, not only
+// the constant.  The k index runs over cells: a k-step of v_mfma_f32_16x16x32_bf16 is a PAIR of the task's tiles, lane (c16, q)
+// supplies cells 8 (q & 1) .. + 8 of tile q >> 1 (as in k_rtz3b), both operands are split in registers.  Tasks, slabs
+// [mt][nt][lane][r] and finish kernel are k_rtzw's; the MT x NT output tiles are split 2 x 2 over FOUR waves (row half x
+// column half: up to 7 x 7 tiles = 196 accumulators; k_rtzw's eight waves share one tile and hold 2 x MT).  Further:
 //   * one workgroup per CU (512 registers per lane: 196 accumulators + the 84 registers of the column half's B planes);
 //   * the tiles travel global -> registers -> LDS with ORDINARY loads (non-temporal), half a pair at a time, under the
 //     multiply of the pair before: the compiler counts the waits, rows past the group's end (and the missing second tile
 //     of an odd count) are written as zeros -- no live-row factor, no select in the loop -- and an LDS-DMA request's
-//     ~200 cycles of issue (k_rtzw2's stamps: 1.9 k of a tile's 16.4 k) are not paid by a wave that has no partner on its SIMD;
+//     ~200 cycles of issue are not paid by a wave that has no partner on its SIMD;
 //   * A values come as 16-byte LDS reads (four cluster tiles of the permuted row map per read);
 //   * every column tile takes the same six products -- a PC tile, the tile whose padding carries the first one-hot block
 //     columns, a pure one-hot tile (its m and l planes are zero) or a tile past NT (all zero): no branch in the multiply.
+// Measured at the configs[4] shard: 866 us per pass (f32-input kernels: 1 144); the pass issues ~2 500 instructions per pair
+// of tiles and wave beside its 294 MFMAs (splits, staging predicates, waits) -- that count, not the matrix pipe, HBM or the
+// staging distance, is what bounds it (NOTES.md, round 5: an eight-wave 2 x 4 version and a deeper staging were slower).
 // ------------------------------------------------------------------------------------------
 #define RTZWB_WAVES 4
 template <int I, int N, typename F>
@@ -1136,187 +978,6 @@ __global__ __launch_bounds__(64 * RTZWB_WAVES, 1) void k_rtzw2b(Rtz3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// k_rtzw3b: k_rtzw2b with a partner wave on every SIMD.  k_rtzw2b's four waves (one per SIMD, 7 x 7 output tiles each) split
-// both operands in their own instruction stream: per pair of tiles ~850 vector / LDS / staging instructions beside 294 MFMAs,
-// of which only the A splits ride between MFMAs -- measured 866 us per pass at the configs[4] shard, ~10.4 k cycles per pair for
-// 5 k cycles of matrix pipe.  Here EIGHT waves per workgroup (two per SIMD, 256 registers each) split the MT x NT output
-// tiles 2 x 4 (row half x column quarter: 7 x 4 tiles = 112 accumulators): while one wave of a SIMD builds its B planes or
-// stages the next tiles, the other multiplies.  What else changed:
-//   * the tiles sit in LDS with PADDED rows: row strides = 16 (mod 32) floats, and k slot j of lane (c16, q) is cell
-//     2 j + (q & 1) of tile q >> 1, so the two 16-lane halves of a 32-lane LDS group read neighbouring rows = disjoint bank
-//     halves: every operand read (one float per lane: column 16 t + c16 of a row) is free of bank conflicts;
-//   * PLAIN row map: row tile mt holds the clusters 16 mt .. 16 mt + 15 (k_rtz3_finish: `plain_rows`) -- the permuted map of
-//     k_rtz3 exists for 16-byte A reads, which need the values of four tiles live at once (32 registers);
-//   * staging: thread (row = tid / 32, t = tid % 32) brings the 16-byte chunks t and t + 32 of its row of R and of Z: no
-//     division, coalesced 512-byte runs, zeros for rows past the group's end, for the missing tile of an odd count and for
-//     the padding columns.
-// Same tasks, same slabs [mt][nt][lane][r], same finish kernel.
-// ------------------------------------------------------------------------------------------
-#define RTZW3_WAVES 8
-__host__ __device__ __forceinline__ int rtzw3_ld(int n) { return n + ((16 - (n & 31)) & 31); }   // smallest stride >= n that is 16 (mod 32)
-template <int MT, int NTQ>
-__global__ __launch_bounds__(64 * RTZW3_WAVES, 1) void k_rtzw3b(Rtz3Args a) {
-    if (a.frozen && *a.frozen) return;
-    constexpr int MTA = (MT + 1) / 2;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* lds = reinterpret_cast<float*>(smem);
-    const int Kp = a.Kp, DP = a.dp, d = a.d, NT = a.nt, NTP = DP >> 4;
-    const int LDR = rtzw3_ld(Kp), LDZ = rtzw3_ld(DP);
-    const int buf_floats = 16 * (LDR + LDZ) + 4;                     // R tile | Z tile | 16 block-id bytes
-    const int tid = threadIdx.x;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63, c16 = lane & 15, q = lane >> 4;
-    const int task = blockIdx.x;
-    const int t0 = a.task_t0[task], t1 = a.task_t1[task];
-    const int c_first = a.task_c0[task], c_end = a.task_cend[task];
-    const int stride = __builtin_amdgcn_readfirstlane(a.task_stride[task]);
-    const int n_tiles = (t1 - t0 + stride - 1) / stride;
-    const int n_pairs = (n_tiles + 1) / 2;
-    if (n_tiles <= 0) return;
-    const int rh = wv >> 2, cq = wv & 3;                             // this wave's eighth of the output: row half, column quarter
-    const int nt_lo = cq * NTQ;
-
-    // ---- staging: tile `ti` of the task (clamped: a missing tile is loaded from the last one and written as zeros) ----
-    const int srow = tid >> 5, st32 = tid & 31;
-    f32x4 sr[2], sz[2], sid;
-    auto load_tile = [&](int ti) {
-        const int tc = min(ti, n_tiles - 1);
-        const size_t cell = (size_t)c_first + (size_t)16 * stride * tc + srow;
-        const f32x4* rsrc = reinterpret_cast<const f32x4*>(a.R + cell * Kp);
-        const f32x4* zsrc = reinterpret_cast<const f32x4*>(a.Z + cell * DP);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c = st32 + 32 * j;
-            sr[j] = (4 * c < Kp) ? __builtin_nontemporal_load(rsrc + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            sz[j] = (4 * c < DP) ? __builtin_nontemporal_load(zsrc + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        sid = (tid == 0) ? *reinterpret_cast<const f32x4*>(a.tile_blk + (size_t)16 * (t0 + (size_t)stride * tc)) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto store_tile = [&](int ti, int b) {                            // ... into tile buffer b (0..3)
-        const int cell0 = c_first + 16 * stride * min(ti, n_tiles - 1);
-        const int n_live = ti < n_tiles ? min(16, c_end - cell0) : 0; // rows of the tile inside the group (workgroup-uniform)
-        const bool live = srow < n_live;
-        float* Rt = lds + (size_t)b * buf_floats + srow * LDR;
-        float* Zt = lds + (size_t)b * buf_floats + 16 * LDR + srow * LDZ;
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c = st32 + 32 * j;
-            if (4 * c < LDR) st4(Rt + 4 * c, (live && 4 * c < Kp) ? sr[j] : zero);
-            if (4 * c < LDZ) st4(Zt + 4 * c, (live && 4 * c < DP) ? sz[j] : zero);
-        }
-        if (tid == 0) st4(lds + (size_t)b * buf_floats + 16 * (LDR + LDZ), sid);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    auto body = [&](auto rh_c) {
-        constexpr int RH = decltype(rh_c)::value;
-        constexpr int LO = RH * MTA, HI = RH ? MT : MTA;              // this wave's row tiles
-        f32x4 acc[MTA][NTQ];
-#pragma unroll
-        for (int t = 0; t < MTA; ++t)
-#pragma unroll
-            for (int u = 0; u < NTQ; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-        load_tile(0);
-        store_tile(0, 0);
-        load_tile(1);
-        store_tile(1, 1);
-
-        for (int i = 0; i < n_pairs; ++i) {
-            wg_barrier_lds();                                         // pair i is complete in LDS; nobody reads pair i-1 any more
-            const float* pb = lds + (size_t)(2 * (i & 1)) * buf_floats;
-            const int nb = 2 * ((i + 1) & 1);                         // the tile buffers of pair i+1 (pair i-1's)
-            load_tile(2 * i + 2);                                     // travels under the B planes and the first row tiles
-            // lane (c16, q): k slot j <-> cell 2 j + (q & 1) of tile q >> 1 of the pair
-            const float* tb = pb + (size_t)(q >> 1) * buf_floats;
-            const float* Rl = tb + (q & 1) * LDR + c16;
-            const float* Zl = tb + 16 * LDR + (q & 1) * LDZ + c16;
-            int bid[8];
-            {
-                const u32x4 w = *reinterpret_cast<const u32x4*>(tb + 16 * (LDR + LDZ));
-#pragma unroll
-                for (int j = 0; j < 8; ++j) bid[j] = (int)((w[j >> 1] >> (8 * (2 * (j & 1) + (q & 1)))) & 255u);
-            }
-            // ---- B planes of the column quarter: value = PC column (zero in the row padding) + one-hot of the block column ----
-            u32x4 bh[NTQ], bm[NTQ], bl[NTQ];
-#pragma unroll
-            for (int u = 0; u < NTQ; ++u) {
-                const int nt = nt_lo + u;                             // wave-uniform
-                const bool pc = nt < NTP;
-                const float* zr = Zl + 16 * min(nt, NTP - 1);         // (clamped: an unused read stays inside the tile)
-                float x[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = zr[2 * j * LDZ];
-                if (!pc) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) x[j] = 0.f;
-                }
-                if (nt >= NTP - 1 && nt < NT) {                       // block whose one-hot column this lane's column is (negative: none)
-                    const int blk_col = 16 * nt + c16 - d;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) x[j] += (bid[j] == blk_col) ? 1.f : 0.f;
-                }
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    unsigned h, m, l;
-                    bf16_split3((f32x2){x[2 * p], x[2 * p + 1]}, h, m, l);
-                    bh[u][p] = h; bm[u][p] = m; bl[u][p] = l;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- row tiles: eight values, three planes, six products with every column tile (smallest terms first; consecutive
-            //      MFMAs go to different accumulators); the SIMD's other wave fills the gaps ----
-#pragma unroll
-            for (int t = 0; t < HI - LO; ++t) {
-                const float* rr = Rl + 16 * (LO + t);
-                float av[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) av[j] = rr[2 * j * LDR];
-                u32x4 ah, am, al;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    unsigned h, m, l;
-                    bf16_split3((f32x2){av[2 * p], av[2 * p + 1]}, h, m, l);
-                    ah[p] = h; am[p] = m; al[p] = l;
-                }
-#pragma unroll
-                for (int u = 0; u < NTQ; ++u) acc[t][u] = MFMA_BF16(al, bh[u], acc[t][u]);
-#pragma unroll
-                for (int u = 0; u < NTQ; ++u) acc[t][u] = MFMA_BF16(ah, bl[u], acc[t][u]);
-#pragma unroll
-                for (int u = 0; u < NTQ; ++u) acc[t][u] = MFMA_BF16(am, bm[u], acc[t][u]);
-#pragma unroll
-                for (int u = 0; u < NTQ; ++u) acc[t][u] = MFMA_BF16(am, bh[u], acc[t][u]);
-#pragma unroll
-                for (int u = 0; u < NTQ; ++u) acc[t][u] = MFMA_BF16(ah, bm[u], acc[t][u]);
-#pragma unroll
-                for (int u = 0; u < NTQ; ++u) acc[t][u] = MFMA_BF16(ah, bh[u], acc[t][u]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (t + 1 == (HI - LO + 1) / 2) {                     // half way: the first tile of pair i+1 has landed
-                    store_tile(2 * i + 2, nb);
-                    load_tile(2 * i + 3);
-                }
-            }
-            store_tile(2 * i + 3, nb + 1);
-        }
-        // every wave stores its own output tiles: slab [mt][nt][lane][r]
-        float* slab = a.slab + (size_t)task * ((size_t)MT * NT * 256);
-#pragma unroll
-        for (int t = 0; t < MTA; ++t)
-#pragma unroll
-            for (int u = 0; u < NTQ; ++u) {
-                const int mt = LO + t, nt = nt_lo + u;
-                if (mt < HI && nt < NT) st4(slab + ((size_t)(mt * NT + nt) * 64 + lane) * 4, acc[t][u]);
-            }
-    };
-    if (rh == 0) body(std::integral_constant<int, 0>{}); else body(std::integral_constant<int, 1>{});
-}
-
-// ------------------------------------------------------------------------------------------
 // k_rtz3_finish: the per-task slabs summed in fp64, one workgroup per cluster k; undoes the index maps of k_rtz3.
 //   mode 0 (k-means round): Ysum[k][pc] over all tasks (the centroid numerators, :443), Sold[blk][g][k] over the tasks of
 //          group g (the removal sums, :491-492); with Yout the row is normalised on the spot (:444) -- no collective
@@ -1344,8 +1005,7 @@ __global__ __launch_bounds__(RTZ3_FIN_THREADS) void k_rtz3_finish(Rtz3FinishArgs
     // where cluster k sits in a slab: tile mt, row m of the tile
     const int Hq = a.MT / 4, rem = a.MT % 4;
     int mt, m;
-    if (a.plain_rows) { mt = k >> 4; m = k & 15; }                  // k_rtzw3b: row tile mt holds the clusters 16 mt .. 16 mt + 15
-    else if (k < 64 * Hq) { mt = 4 * (k / 64) + (k & 3); m = (k & 63) >> 2; }
+    if (k < 64 * Hq) { mt = 4 * (k / 64) + (k & 3); m = (k & 63) >> 2; }
     else { const int x = k - 64 * Hq; m = x / rem; mt = 4 * Hq + x % rem; }
     const int per = a.MT * NT * 256;
     const int nslice = RTZ3_FIN_THREADS / NV;
@@ -1629,69 +1289,7 @@ static void launch_rtzw_t(const Rtz3Args& a, size_t sm, hipStream_t s) {
     hipLaunchKernelGGL((k_rtzw<MT>), dim3(a.ntasks), dim3(64 * RTZW_WAVES), sm, s, a);
 }
 
-template <int MT, int NTH>
-static void launch_rtzw2_t(const Rtz3Args& a, size_t sm, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rtzw2<MT, NTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        attr_done = true;
-    }
-#ifdef HMX_RTZ3_PROF
-    static unsigned long long* prof = nullptr;
-    static int calls = 0;
-    Rtz3Args b = a;
-    if (!prof) (void)hipMalloc(reinterpret_cast<void**>(&prof), (size_t)4096 * 8 * 8 * 8);
-    (void)hipMemsetAsync(prof, 0, (size_t)a.ntasks * 8 * 8 * 8, s);
-    b.prof = prof;
-    hipLaunchKernelGGL((k_rtzw2<MT, NTH>), dim3(a.ntasks), dim3(64 * RTZW2_WAVES), sm, s, b);
-    if (++calls == 12) {
-        std::vector<unsigned long long> h((size_t)a.ntasks * 8 * 8);
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpy(h.data(), prof, h.size() * 8, hipMemcpyDeviceToHost);
-        double pro = 0, loop = 0, wait = 0, bar = 0, iss = 0, tiles = 0, tmin = 1e30, tmax = 0;
-        size_t nw = 0;
-        for (int t = 0; t < a.ntasks; ++t)
-            for (int w = 0; w < RTZW2_WAVES; ++w) {
-                const unsigned long long* r = &h[((size_t)t * 8 + w) * 8];
-                pro += (double)(r[1] - r[0]); loop += (double)(r[2] - r[1]); wait += (double)r[4]; bar += (double)r[6]; iss += (double)r[7]; tiles += (double)r[5];
-                tmin = std::min(tmin, (double)r[0]); tmax = std::max(tmax, (double)r[2]);
-                ++nw;
-            }
-        fprintf(stderr, "[k_rtzw2 prof] <%d,%d> %d tasks: per wave: prologue %.0f, loop %.0f (%.0f per tile, %.1f tiles); per tile: own pieces %.0f, barrier %.0f, requests %.0f; first start to last end %.0f\n",
-                MT, NTH, a.ntasks, pro / nw, loop / nw, loop / tiles, tiles / nw, wait / tiles, bar / tiles, iss / tiles, tmax - tmin);
-    }
-    return;
-#endif
-    hipLaunchKernelGGL((k_rtzw2<MT, NTH>), dim3(a.ntasks), dim3(64 * RTZW2_WAVES), sm, s, a);
-}
-template <int MT>
-static bool launch_rtzw2_m(const Rtz3Args& a, int nth, size_t sm, hipStream_t s) {
-    switch (nth) {
-        case 4: launch_rtzw2_t<MT, 4>(a, sm, s); return true;
-        case 5: launch_rtzw2_t<MT, 5>(a, sm, s); return true;
-        case 6: launch_rtzw2_t<MT, 6>(a, sm, s); return true;
-        case 7: launch_rtzw2_t<MT, 7>(a, sm, s); return true;
-        default: return false;
-    }
-}
-// the 2 x 2 split pays where the quarter is large: K > 112 and at least seven column tiles; the ring must fit half a CU's LDS
-static bool launch_rtzw2(const Rtz3Args& a, int mt, hipStream_t s) {
-    static const int mode = [] { const char* v = getenv("HMX_RTZW"); return v ? atoi(v) : 2; }();
-    if (mode != 2 || mt < 8 || mt > 13) return false;
-    const int nth = (a.nt + 1) / 2;
-    const size_t sm = (size_t)RTZW2_NBUF * (256 * mt + 16 * a.dp + 4) * sizeof(float);
-    if (nth < 4 || nth > 7 || sm > 80 * 1024 || a.dp / 16 > 16) return false;
-    switch (mt) {
-        case 8: return launch_rtzw2_m<8>(a, nth, sm, s);
-        case 9: return launch_rtzw2_m<9>(a, nth, sm, s);
-        case 10: return launch_rtzw2_m<10>(a, nth, sm, s);
-        case 11: return launch_rtzw2_m<11>(a, nth, sm, s);
-        case 12: return launch_rtzw2_m<12>(a, nth, sm, s);
-        default: return launch_rtzw2_m<13>(a, nth, sm, s);
-    }
-}
-
-// ---- k_rtzw2b: the shapes of k_rtzw2 (K > 112, seven to fourteen column tiles), four tile buffers in one CU's LDS
+// ---- k_rtzw2b: K > 112, seven to fourteen column tiles; four tile buffers in one CU's LDS
 bool rtzw2b_ok(int mt, int dp, int d, int nblk) {
     if (!rtzw_ok(mt, dp, d, nblk, 1) || mt < 8 || mt > 13) return false;
     const int nth = (rtzw_nt(dp, d, nblk) + 1) / 2;
@@ -1728,58 +1326,15 @@ static void launch_rtzw2b(const Rtz3Args& a, int mt, hipStream_t s) {
     }
 }
 
-// ---- k_rtzw3b: eight waves, 2 x 4 split (K > 112, five to sixteen column tiles), four padded tile buffers in one CU's LDS
-bool rtzw3b_ok(int mt, int dp, int d, int nblk, int Kp) {
-    static const bool on = [] { const char* v = getenv("HMX_RTZW3"); return v && atoi(v) != 0; }();   // (measured slower than k_rtzw2b: opt-in)
-    if (!on || !rtzw_ok(mt, dp, d, nblk, 1) || mt < 8 || mt > 13) return false;
-    const int ntq = (rtzw_nt(dp, d, nblk) + 3) / 4;
-    return ntq >= 2 && ntq <= 4 && (size_t)4 * (16 * (rtzw3_ld(Kp) + rtzw3_ld(dp)) + 4) * sizeof(float) <= 160 * 1024;
-}
-template <int MT, int NTQ>
-static void launch_rtzw3b_t(const Rtz3Args& a, size_t sm, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rtzw3b<MT, NTQ>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((k_rtzw3b<MT, NTQ>), dim3(a.ntasks), dim3(64 * RTZW3_WAVES), sm, s, a);
-}
-template <int MT>
-static void launch_rtzw3b_m(const Rtz3Args& a, int ntq, size_t sm, hipStream_t s) {
-    switch (ntq) {
-        case 2: launch_rtzw3b_t<MT, 2>(a, sm, s); break;
-        case 3: launch_rtzw3b_t<MT, 3>(a, sm, s); break;
-        default: launch_rtzw3b_t<MT, 4>(a, sm, s); break;
-    }
-}
-static void launch_rtzw3b(const Rtz3Args& a, int mt, hipStream_t s) {
-    const int ntq = (a.nt + 3) / 4;
-    const size_t sm = (size_t)4 * (16 * (rtzw3_ld(a.Kp) + rtzw3_ld(a.dp)) + 4) * sizeof(float);
-    switch (mt) {
-        case 8: launch_rtzw3b_m<8>(a, ntq, sm, s); break;
-        case 9: launch_rtzw3b_m<9>(a, ntq, sm, s); break;
-        case 10: launch_rtzw3b_m<10>(a, ntq, sm, s); break;
-        case 11: launch_rtzw3b_m<11>(a, ntq, sm, s); break;
-        case 12: launch_rtzw3b_m<12>(a, ntq, sm, s); break;
-        default: launch_rtzw3b_m<13>(a, ntq, sm, s); break;
-    }
-}
-
-// returns 2 when k_rtzw3b ran (bf16 pipe; its slabs use the PLAIN row map: Rtz3FinishArgs.plain_rows), 1 for k_rtzw2b (bf16 pipe),
-// 0 for the f32-input kernels, -1 unsupported
+// returns 1 when the bf16-pipe kernel (k_rtzw2b) ran, 0 for the f32-input kernel k_rtzw, -1 unsupported
 int launch_rtzw(const Rtz3Args& a_in, int mt, int dp, int d, int nblk, hipStream_t s, bool allow_bf16) {
     if (!rtzw_ok(mt, dp, d, nblk, 1) || a_in.ntasks <= 0) return -1;
     Rtz3Args a = a_in;
     a.dp = dp; a.d = d; a.nt = rtzw_nt(dp, d, nblk);
-    if (allow_bf16 && rtzw3b_ok(mt, dp, d, nblk, a.Kp)) {
-        launch_rtzw3b(a, mt, s);
-        return 2;
-    }
     if (allow_bf16 && rtzw2b_ok(mt, dp, d, nblk)) {
         launch_rtzw2b(a, mt, s);
         return 1;
     }
-    if (launch_rtzw2(a, mt, s)) return 0;
     const size_t sm = (size_t)RTZW_NBUF * (16 * (a.Kp + dp) + 4) * sizeof(float);
     if (sm > 160 * 1024) return -1;
     switch (mt) {

@@ -21,7 +21,6 @@ PY
 }
 for rep in 1 2; do
   run default X=1
-  run rtz_four_waves_2x2 HMX_RTZW3=0
   run assign_f32 HMX_ROUND_F32=1
   run rtz_f32 HMX_RTZ3_BF16=0
   run both_f32 HMX_ROUND_F32=1 HMX_RTZ3_BF16=0

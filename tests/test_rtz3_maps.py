@@ -341,110 +341,3 @@ def test_rtzw2b_round_trip(K, d, nblk, n_tiles, last_live):
         S_ref[blk[i]] += R[i, :K]
     np.testing.assert_allclose(S, S_ref, rtol=1e-12, atol=1e-12)
 
-
-# ------------------------------------------------------------------------------------------
-# k_rtzw3b: eight waves split the MT x NT output tiles 2 x 4 (row half x column quarter); k slot j of lane (c16, q) is cell
-# 2 j + (q & 1) of tile q >> 1; PLAIN row map (row tile mt = clusters 16 mt ..: k_rtz3_finish's `plain_rows`); the tiles sit in
-# LDS with padded rows (stride = 16 mod 32 floats; padding columns and dead rows are zeros).
-# ------------------------------------------------------------------------------------------
-def rtzw3_ld(n):
-    return n + ((16 - (n & 31)) & 31)
-
-
-def finish_wide_plain(slab, MT, NT, K, d, DP, nblk):
-    spare = DP - d
-    Y = np.zeros((K, d))
-    S = np.zeros((nblk, K))
-    for k in range(K):
-        mt, m = k >> 4, k & 15
-
-        def val(v):
-            nt, n = v >> 4, v & 15
-            return slab[(mt * NT + nt) * 256 + (16 * (m >> 2) + n) * 4 + (m & 3)]
-        for pc in range(d):
-            Y[k, pc] = val(pc)
-        for b in range(nblk):
-            S[b, k] = val(d + b if b < spare else DP + (b - spare))
-    return Y, S
-
-
-def rtzw3b_wave_pair(bufs, wv, MT, NTQ, LDR, LDZ, DP, d, NT, acc):
-    """One pair of tile buffers (images as store_tile leaves them: Rt 16 x LDR, Zt 16 x LDZ, ids 16) through one wave."""
-    MTA = (MT + 1) // 2
-    NTP = DP // 16
-    rh, cq = wv >> 2, wv & 3
-    LO, HI = rh * MTA, (MT if rh else MTA)
-    nt_lo = cq * NTQ
-    bplanes = []
-    for u in range(NTQ):
-        nt = nt_lo + u
-        b = np.zeros((64, 8))
-        for lane in range(64):
-            c16, q = lane & 15, lane >> 4
-            Rt, Zt, ids = bufs[q >> 1]
-            for j in range(8):
-                cell = 2 * j + (q & 1)
-                x = Zt[cell, 16 * min(nt, NTP - 1) + c16] if nt < NTP else 0.0
-                if NTP - 1 <= nt < NT:
-                    x += 1.0 if int(ids[cell]) == 16 * nt + c16 - d else 0.0
-                b[lane, j] = x
-        bplanes.append(b)
-    for mt in range(LO, HI):
-        a = np.zeros((64, 8))
-        for lane in range(64):
-            c16, q = lane & 15, lane >> 4
-            Rt, Zt, ids = bufs[q >> 1]
-            for j in range(8):
-                a[lane, j] = Rt[2 * j + (q & 1), 16 * mt + c16]
-        for u in range(NTQ):
-            nt = nt_lo + u
-            if nt < NT:
-                mfma32(a, bplanes[u], acc.setdefault((mt, nt), np.zeros((64, 4))))
-
-
-@pytest.mark.parametrize("K,d,nblk,n_tiles,last_live", [(200, 200, 20, 3, 7), (200, 200, 1, 2, 16), (130, 100, 20, 4, 16),
-                                                         (208, 120, 40, 1, 3), (177, 193, 20, 2, 16), (190, 60, 20, 2, 11), (208, 208, 20, 2, 16)])
-def test_rtzw3b_round_trip(K, d, nblk, n_tiles, last_live):
-    """Shapes launch_rtzw hands to k_rtzw3b (K > 112, five to sixteen column tiles): configs[4] as the round pass and as the
-    ridge / k-means pass, odd tile counts, ragged last tiles, row strides that need padding (K = 190: 192 -> 208) and that do
-    not (K = 200: 200 -> 208 too; d = 208), a column quarter that is all one-hot tiles, one with tiles past NT."""
-    rng = np.random.default_rng(K * 17 + d * 5 + nblk)
-    Kp, MT = (K + 3) & ~3, (K + 15) // 16
-    DP = (d + 15) & ~15
-    NT = DP // 16 + max(0, (nblk - (DP - d) + 15) // 16)
-    NTQ = (NT + 3) // 4
-    assert 8 <= MT <= 13 and 2 <= NTQ <= 4                   # rtzw3b_ok
-    LDR, LDZ = rtzw3_ld(Kp), rtzw3_ld(DP)
-    assert LDR % 32 == 16 and LDZ % 32 == 16 and LDR >= 16 * MT and LDZ >= DP
-    R = rng.random((16 * n_tiles, Kp))
-    R[:, K:] = 0.0
-    Z = rng.normal(size=(16 * n_tiles, DP))
-    Z[:, d:] = 0.0
-    blk = rng.integers(0, nblk, size=16 * n_tiles)
-    live = [16] * (n_tiles - 1) + [last_live]
-
-    def image(ti):                                           # store_tile: the tile as it sits in LDS (padded rows, zeros elsewhere)
-        tc = min(ti, n_tiles - 1)
-        n_live = live[tc] if ti < n_tiles else 0
-        Rt, Zt = np.zeros((16, LDR)), np.zeros((16, LDZ))
-        Rt[:n_live, :Kp] = R[16 * tc:16 * tc + n_live]
-        Zt[:n_live, :DP] = Z[16 * tc:16 * tc + n_live]
-        return Rt, Zt, blk[16 * tc:16 * tc + 16]
-    acc = {}
-    for i in range((n_tiles + 1) // 2):
-        bufs = [image(2 * i), image(2 * i + 1)]
-        for wv in range(8):
-            rtzw3b_wave_pair(bufs, wv, MT, NTQ, LDR, LDZ, DP, d, NT, acc)
-    assert len(acc) == MT * NT                               # every output tile has exactly one owner
-    slab = np.zeros(MT * NT * 256)
-    for (mt, nt), a in acc.items():
-        for lane in range(64):
-            for r in range(4):
-                slab[(mt * NT + nt) * 256 + lane * 4 + r] = a[lane, r]
-    Y, S = finish_wide_plain(slab, MT, NT, K, d, DP, nblk)
-    keep = np.concatenate([np.arange(16) < n for n in live])
-    np.testing.assert_allclose(Y, R[keep][:, :K].T @ Z[keep][:, :d], rtol=1e-12, atol=1e-12)
-    S_ref = np.zeros((nblk, K))
-    for i in np.flatnonzero(keep):
-        S_ref[blk[i]] += R[i, :K]
-    np.testing.assert_allclose(S, S_ref, rtol=1e-12, atol=1e-12)
