@@ -140,7 +140,7 @@ def run_harmony(
     and of ``bench.py`` -- ``_y0`` is a d x K matrix of initial centroids used instead of the
     k-means initialisation (harmony.py:369-373), ``_schedule`` a list of k-means round counts,
     one per Harmony iteration, replayed instead of the objective thresholds of harmony.py:455-458
-    (which the reference decides on a few fp32 ulps).
+    (which the reference decides on a few fp32 ulps, NOTES.md section 5).
     """
     _validate_arguments(nclust, block_size, meta_data, vars_use)
     p = _prepare_inputs(data_mat, meta_data, vars_use, theta, lamb, sigma, nclust, tau, shard=shard)

@@ -245,7 +245,7 @@ def test_object_api_surface():
 
 @pytest.mark.parametrize("N,d,K,B,bs", [(37, 5, 3, 2, 0.05), (16, 4, 2, 1, 0.3), (1000, 33, 17, 5, 0.13),
                                         (2049, 64, 30, 4, 0.05), (900, 100, 150, 3, 0.05), (1500, 70, 20, 2, 0.1),
-                                        (640, 20, 120, 2, 0.05)])
+                                        (640, 20, 120, 2, 0.05), (800, 40, 130, 2, 0.1)])   # last: K > 112 with 52-float rows: the generic kernels
 def test_edge_shapes_against_oracle(N, d, K, B, bs):
     """Ragged sizes: N below a block/tile, a single batch, K and d off the tile sizes, and shapes
     beyond the LDS-resident kernels (K > 112 or d > 64: the generic kernels, BASELINE config 5's regime)."""
@@ -415,7 +415,7 @@ def test_bf16_pipe_distance_gemm_against_the_f32_input_instance(N, d, B, K, monk
     pipe (every fp32 operand as the exact sum of three bf16 terms, six products: hmx_device.h `bf16_split3`) against its
     f32-input instance (HMX_ROUND_F32=1) -- the C3 shape, the 21-group edge (the most groups whose tables fit next to the
     bf16 planes), rows of 17 / 32 / 64 PCs.  One seeded round each: the counters say which instance ran, the new R rows
-    differ by <= 4e-6, O by 1e-6 relative to the cluster masses, the three objective terms by 2e-6 relative.  A regression
+    differ by <= 4e-6, O by 2e-6 relative to the cluster masses, the three objective terms by 2e-6 relative.  A regression
     in the split (a dropped term, a wrong plane pairing) shows as 1e-3 .. 1e-5 here, far above the bound."""
     a, b = _ab_engines(N, d, B, K, monkeypatch, "HMX_ROUND_F32", "1")
     a.cluster(_rounds=1)
@@ -426,7 +426,7 @@ def test_bf16_pipe_distance_gemm_against_the_f32_input_instance(N, d, B, K, monk
     Ra, Rb = a.R, b.R
     dR = float(np.abs(Ra - Rb).max())
     assert dR <= 4e-6, f"max |R(bf16x3) - R(f32 input)| = {dR:.2e}"
-    assert np.abs(a.O - b.O).max() <= 1e-6 * max(1.0, float(np.abs(b.O).max()))
+    assert np.abs(a.O - b.O).max() <= 2e-6 * max(1.0, float(np.abs(b.O).max()))     # (1e-6 was met within 5 % in one run of the 21-group shape: the order of the fp64 slot adds differs run to run)
     for name in ("objective_kmeans_dist", "objective_kmeans_entropy", "objective_kmeans_cross", "objective_kmeans"):
         va, vb = getattr(a, name)[-1], getattr(b, name)[-1]
         assert abs(va - vb) <= 2e-6 * abs(vb), (name, va, vb)
@@ -440,7 +440,7 @@ def test_bf16_pipe_rtz_pass_against_the_f32_input_kernel(N, d, B, K, bs, monkeyp
     """Direct A/B of the streaming R^T.Z pass (harmony.py:443-444 centroid numerators, :491-492 removal sums, :550, :559-563
     ridge statistics): k_rtz3b (both operands split in registers, bf16 pipe) against k_rtz3 (f32-input MFMA, engines
     created under HMX_RTZ3_BF16=0), same shapes as above.  Two seeded rounds (the second round's pass reads the R the first
-    one wrote) + the ridge: Y atol 2e-6, O 1e-6 relative to the masses, R 4e-6, Z_corr 1e-6 relative Frobenius; the counter
+    one wrote) + the ridge: Y atol 2e-6, O 2e-6 relative to the masses, R 4e-6, Z_corr 1e-6 relative Frobenius; the counter
     says which kernel ran."""
     a, b = _ab_engines(N, d, B, K, monkeypatch, "HMX_RTZ3_BF16", "0", block_size=bs)
     for h in (a, b):
@@ -449,7 +449,7 @@ def test_bf16_pipe_rtz_pass_against_the_f32_input_kernel(N, d, B, K, bs, monkeyp
     ca, cb = a._engine.counters(), b._engine.counters()
     assert ca["rtz_bf16_pipe"] >= 3 and cb["rtz_bf16_pipe"] == 0, (ca, cb)
     np.testing.assert_allclose(a.Y, b.Y, rtol=0, atol=2e-6)
-    assert np.abs(a.O - b.O).max() <= 1e-6 * max(1.0, float(np.abs(b.O).max()))
+    assert np.abs(a.O - b.O).max() <= 2e-6 * max(1.0, float(np.abs(b.O).max()))     # (1e-6 was met within 5 % in one run of the 21-group shape: the order of the fp64 slot adds differs run to run)
     assert float(np.abs(a.R - b.R).max()) <= 4e-6
     Za, Zb = a.Z_corr, b.Z_corr
     rel = float(np.linalg.norm(Za - Zb) / np.linalg.norm(Zb))
@@ -467,7 +467,7 @@ def test_wide_bf16_pipe_kernels_against_the_f32_input_kernels(N, d, B, K, switch
     assignment (k_assign_wide3, harmony.py:447, 464-513) and its streaming R^T.Z pass (k_rtzw2b, :443-444, :491-492, :550,
     :559-563) run on the bf16 matrix pipe with every fp32 operand as three exact bf16 terms.  Direct A/B inside one build on
     one state against the f32-input kernels (engines created under HMX_ROUND_F32=1 / HMX_RTZ3_BF16=0): two seeded rounds +
-    the ridge; R 4e-6, Y 2e-6, O 1e-6 of the masses, objective terms 2e-6 relative, Z_corr 1e-6 relative Frobenius; the
+    the ridge; R 4e-6, Y 2e-6, O 2e-6 of the masses, objective terms 2e-6 relative, Z_corr 1e-6 relative Frobenius; the
     counters say which kernels ran (shapes outside k_rtzw2b's -- K <= 112, fewer than seven or more than fourteen column tiles -- keep k_rtzw)."""
     a, b = _ab_engines(N, d, B, K, monkeypatch, switch, value)
     assert a._wide_shape()
