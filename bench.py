@@ -53,9 +53,18 @@ CONFIGS = {
     # all 10M cells of BASELINE configs[3] on ONE GPU (R = 4.5 GB of the 288 GB)
     "c4x1": (10_000_000, 50, 16, 100),
 }
-if os.environ.get("BENCH_SHAPE"):   # experiments only: "name=N,d,B,K" replaces a configuration's shape (the line then describes that shape)
+CUSTOM_SHAPES = set()
+if os.environ.get("BENCH_SHAPE"):   # experiments only: "name=N,d,B,K" replaces a configuration's shape (the line then says so: no BASELINE label)
     _n, _v = os.environ["BENCH_SHAPE"].split("=")
     CONFIGS[_n] = tuple(int(x) for x in _v.split(","))
+    CUSTOM_SHAPES.add(_n)
+
+
+def config_label(name):
+    """`BASELINE configs[i] (NAME)`, or an explicit note when BENCH_SHAPE replaced the configuration's shape."""
+    if name in CUSTOM_SHAPES:
+        return f"EXPERIMENT SHAPE (BENCH_SHAPE, not a BASELINE configuration; slot {name.upper()})"
+    return f"BASELINE configs[{CONFIG_INDEX[name]}] ({name.upper()})"
 CONFIG_INDEX = {"c2": 1, "c3": 2, "c4": 3, "c5": 4, "c4x1": 3}
 # cells of the whole job of the configurations BASELINE.json defines over several GPUs (sharded evenly: strong scaling)
 JOB_CELLS = {"c4": 10_000_000, "c5": 10_000_000}
@@ -357,7 +366,7 @@ def side_config(name, rounds, steps, warmup, device, repeats=1, converge=False):
             {"bound": "hbm", "achieved": step_bytes / t_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": step_bytes / t_step / 1e9 / HBM_PEAK_GBS})
     roof["scope"] = "whole step (wall time of the loop, launch gaps included)"
-    out = {"workload": f"BASELINE configs[{CONFIG_INDEX[name]}] ({name.upper()}): {N} cells x {d} PCs, "
+    out = {"workload": f"{config_label(name)}: {N} cells x {d} PCs, "
                        f"{B} batches, K={K}; step = {rounds} k-means rounds + 1 ridge correction",
            "value": N * steps / dt, "unit": "cells/sec/Harmony-iteration", "ms_per_step": 1e3 * dt / steps, "steps": steps,
            "roofline": roof}
@@ -572,7 +581,7 @@ def main():
         return 0
     ms_per_step = 1e3 * dt / args.steps
     value = N * world * args.steps / dt
-    job = (f"BASELINE configs[{CONFIG_INDEX[config]}] ({config.upper()}): " +
+    job = (f"{config_label(config)}: " +
            (f"{N * world} cells x {d} PCs, {B} batches, K={K} sharded over {world} GPUs ({N} cells per GPU)" if scaling == "strong"
             else f"{N} cells x {d} PCs, {B} batches, K={K} per GPU"))
     import hashlib
