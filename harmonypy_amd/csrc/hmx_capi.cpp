@@ -115,6 +115,7 @@ struct hmx_engine {
     long n_sweep_fallbacks = 0;  // rounds repeated through the per-block path after a wait timed out
     long n_rtz_bf16 = 0;         // R^T.Z passes launched on the bf16-pipe instance k_rtz3b
     bool allow_round_bf16 = true;   // HMX_ROUND_F32=1 at hmx_create: the f32-input instances of k_round (A/B runs and tests)
+    int rtz3_quad = 4;              // tiles a workgroup of the narrow streaming pass takes side by side (8: the tasks are cut for k_rtz3c)
     bool allow_rtz_bf16 = true;     // HMX_RTZ3_BF16=0 at hmx_create: k_rtz3 instead of k_rtz3b
     long n_sweeps_bf16 = 0;      // sweeps launched on the bf16-pipe instances of k_round (round_uses_bf16_pipe)
     DevBuf<unsigned long long> wait_stats;   // {waits, incomplete polls, most polls of one wait} of the sweep kernels' grid-wide waits
@@ -620,8 +621,9 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
             // neighbouring quads of tiles (task j: tiles ts + 4j + w + 4m i) and sweep the group's rows together
             const char* tk = getenv("HMX_RTZ3_TASKS");
             const bool interleave = !(tk && std::string(tk) == "contig");
-            // tiles a workgroup takes side by side: k_rtz3's four waves own a tile each, k_rtzw's eight share one
-            const int quad = rtz_wide_ok(e->mt, e->dp) ? 1 : 4;
+            // tiles a workgroup takes side by side: k_rtz3's / k_rtz3b's four waves own a tile each, k_rtz3c's eight; k_rtzw's waves share one
+            e->rtz3_quad = rtz3_quad(e->mt, e->dp, e->nblk, e->Kp, e->allow_rtz_bf16);
+            const int quad = rtz_wide_ok(e->mt, e->dp) ? 1 : e->rtz3_quad;
             for (int g = 0; g < e->G; ++g) {
                 const int ts = tstart[g], te = tstart[g + 1];
                 if (te <= ts) continue;
@@ -897,7 +899,7 @@ static int rtz3_pass(hmx_engine* e, int mode, const unsigned char* tile_blk, int
         r.task_t0 = e->t3_t0.p; r.task_t1 = e->t3_t1.p; r.task_stride = e->t3_stride.p; r.task_c0 = e->t3_c0.p; r.task_cend = e->t3_cend.p;
         r.slab = e->slab.p; r.ntasks = e->ntasks3; r.Kp = e->Kp;
         r.frozen = duties ? e->frozen() : nullptr;   // (the fused round of a single engine: the only path whose read-back is deferred)
-        const int lr = wide ? launch_rtzw(r, e->mt, e->dp, e->d, nblk_cols, e->stream, e->allow_rtz_bf16) : launch_rtz3(r, e->mt, e->dp, nblk_cols, e->stream, e->allow_rtz_bf16);
+        const int lr = wide ? launch_rtzw(r, e->mt, e->dp, e->d, nblk_cols, e->stream, e->allow_rtz_bf16) : launch_rtz3(r, e->mt, e->dp, nblk_cols, e->stream, e->allow_rtz_bf16, e->rtz3_quad);
         if (lr > 0) e->n_rtz_bf16++;
         if (lr < 0)
             return fail(HMX_ERR_ARG, "unsupported shape for the streaming R^T.Z pass");
