@@ -113,10 +113,10 @@ struct hmx_engine {
     int round_mode = 1;          // 1: persistent sweep kernel when the shape allows it, 0: one launch per block (HMX_ROUND_MODE=blocks)
     unsigned spin_limit = 1u << 24;  // polls a grid-wide wait may take (HMX_SPIN_LIMIT; tests shrink it to force the fall-back)
     long n_sweep_fallbacks = 0;  // rounds repeated through the per-block path after a wait timed out
-    long n_rtz_bf16 = 0;         // R^T.Z passes launched on the bf16-pipe instance k_rtz3b
+    long n_rtz_bf16 = 0;         // R^T.Z passes launched on the bf16-pipe instance k_rtz3c
     bool allow_round_bf16 = true;   // HMX_ROUND_F32=1 at hmx_create: the f32-input instances of k_round (A/B runs and tests)
     int rtz3_quad = 4;              // tiles a workgroup of the narrow streaming pass takes side by side (8: the tasks are cut for k_rtz3c)
-    bool allow_rtz_bf16 = true;     // HMX_RTZ3_BF16=0 at hmx_create: k_rtz3 instead of k_rtz3b
+    bool allow_rtz_bf16 = true;     // HMX_RTZ3_BF16=0 at hmx_create: k_rtz3 instead of k_rtz3c
     long n_sweeps_bf16 = 0;      // sweeps launched on the bf16-pipe instances of k_round (round_uses_bf16_pipe)
     DevBuf<unsigned long long> wait_stats;   // {waits, incomplete polls, most polls of one wait} of the sweep kernels' grid-wide waits
     DevBuf<double> xch;
@@ -611,7 +611,7 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
         e->ntasks3 = 0;
         if (contig) {
             std::vector<int> a0, a1, ac0, acend, ag, ast;
-            // k_rtz3 keeps two workgroups per CU resident, k_rtz3b (four tile buffers per wave) one: as many tasks as fit at once,
+            // k_rtz3 keeps two workgroups per CU resident, k_rtz3c (sixteen tile buffers) one: as many tasks as fit at once,
             // or a second round of workgroups pays the prologue, the slab reduction and the tail again (measured: 188 us per
             // pass with 505 tasks of 31 tiles per wave)
             const bool one_per_cu = e->allow_rtz_bf16 && (rtz_wide_ok(e->mt, e->dp) ? rtzw2b_ok(e->mt, e->dp, e->d, e->nblk) : rtz3b_ok(e->mt, e->dp, e->nblk, e->Kp));
@@ -621,7 +621,7 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
             // neighbouring quads of tiles (task j: tiles ts + 4j + w + 4m i) and sweep the group's rows together
             const char* tk = getenv("HMX_RTZ3_TASKS");
             const bool interleave = !(tk && std::string(tk) == "contig");
-            // tiles a workgroup takes side by side: k_rtz3's / k_rtz3b's four waves own a tile each, k_rtz3c's eight; k_rtzw's waves share one
+            // tiles a workgroup takes side by side: k_rtz3's four waves own a tile each, k_rtz3c's eight; k_rtzw's waves share one
             e->rtz3_quad = rtz3_quad(e->mt, e->dp, e->nblk, e->Kp, e->allow_rtz_bf16);
             const int quad = rtz_wide_ok(e->mt, e->dp) ? 1 : e->rtz3_quad;
             for (int g = 0; g < e->G; ++g) {

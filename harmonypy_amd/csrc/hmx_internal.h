@@ -120,9 +120,9 @@ struct Rtz3FinishArgs {
 bool rtz3_ok(int mt, int dp, int nblk, int G);
 int rtz3_ntb(int dp, int nblk);
 int rtz3_slab_floats(int mt, int dp, int nblk);
-bool rtz3b_ok(int mt, int dp, int nblk, int Kp);   // launch_rtz3 takes the bf16-pipe kernel k_rtz3b (one workgroup per CU)
-int rtz3_quad(int mt, int dp, int nblk, int Kp, bool allow_bf16);   // 8: the tasks are cut for k_rtz3c's eight waves, 4: for k_rtz3b / k_rtz3
-int launch_rtz3(const Rtz3Args& a, int mt, int dp, int nblk, hipStream_t s, bool allow_bf16, int quad);   // returns 1 when the bf16-pipe instance (k_rtz3b) ran, 0 for k_rtz3, -1 unsupported
+bool rtz3b_ok(int mt, int dp, int nblk, int Kp);   // launch_rtz3 takes the bf16-pipe kernel k_rtz3c (one workgroup per CU)
+int rtz3_quad(int mt, int dp, int nblk, int Kp, bool allow_bf16);   // 8: the tasks are cut for k_rtz3c's eight waves, 4: for k_rtz3c / k_rtz3
+int launch_rtz3(const Rtz3Args& a, int mt, int dp, int nblk, hipStream_t s, bool allow_bf16, int quad);   // returns 1 when the bf16-pipe instance (k_rtz3c) ran, 0 for k_rtz3, -1 unsupported
 void launch_rtz3_finish(const Rtz3FinishArgs& a, hipStream_t s);
 bool rtzw_ok(int mt, int dp, int d, int nblk, int G);
 int rtzw_nt(int dp, int d, int nblk);

@@ -366,216 +366,19 @@ __global__ __launch_bounds__(64 * RTZ3_WAVES, 2) void k_rtz3(Rtz3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// k_rtz3b: k_rtz3 on the bf16 matrix pipe (hmx_device.h: every fp32 operand as the exact sum of three bf16 terms).  The k index
-// runs over cells, so BOTH operands stream and both are split in registers; a k-step of v_mfma_f32_16x16x32_bf16 is 32
-// cells = a PAIR of the wave's tiles (any two of them: each keeps its own LDS buffer, four buffers per wave = two pairs, one
-// travelling while the other is multiplied), lane (c16, q) supplies the cells 8 (q & 1) .. + 8 of tile q >> 1.  Per pair and
-// wave MT x (4 x 6 + 3 NTB) MFMAs of 16 cycles (the one-hot block columns are exact in bf16: one plane, three products)
-// where k_rtz3 issues 2 x 4 x MT x (4 + NTB) of 32.  Same tasks, same requests per tile, same slabs and finish kernel as
-// k_rtz3; one workgroup per CU (the buffers take 156 KB at K = 100, d = 50).  Developed and float64-checked as a standalone
-// kernel first: scripts/micro/rtz_bf3_tasks.hip (137-140 us for the 1 M-cell pass of C3; k_rtz3: 168-180).
-// ------------------------------------------------------------------------------------------
-template <int MT, int KS, int NTB>
-__global__ __launch_bounds__(64 * RTZ3_WAVES, 1) void k_rtz3b(Rtz3Args a) {
-    if (a.frozen && *a.frozen) return;
-    constexpr int NT = 4 + NTB, DP = 4 * KS;
-    constexpr int NR = MT, NZ = (KS + 3) / 4, NI = NR + NZ + 1;     // VMEM operations per tile: R pieces, Z pieces, block ids
-    constexpr int H = MT / 4, REM = MT % 4;
-    static_assert(NTB <= 1 && KS <= 16 && 4 * NI < 64, "shape");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* lds = reinterpret_cast<float*>(smem);
-    const int Kp = a.Kp;
-    const int buf_floats = 16 * (Kp + DP) + 4;                     // R tile | Z tile | 16 block-id bytes
-    const int tid = threadIdx.x;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63, c16 = lane & 15, q = lane >> 4;
-    const int lane16 = 16 * lane;
-    const int task = blockIdx.x;
-    const int t0 = a.task_t0[task], t1 = a.task_t1[task];
-    const int c_first = a.task_c0[task], c_end = a.task_cend[task];
-    const int stride = __builtin_amdgcn_readfirstlane(a.task_stride[task]);
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int n_tiles = (t1 - t0 - wv + stride - 1) / stride;      // this wave's tiles: t0 + wv + stride i (< t1)
-    const int n_mine = n_tiles > 0 ? (n_tiles + 1) / 2 : 0;        // ... taken two at a time
-    const int c_mine = c_first + 16 * wv;
-    const unsigned zone0 = lds_addr(lds + (size_t)(4 * wv) * buf_floats);
-    const unsigned buf_bytes = __builtin_amdgcn_readfirstlane((unsigned)buf_floats * 4u);
-    const unsigned r_bytes = __builtin_amdgcn_readfirstlane(64u * (unsigned)Kp);
-    // the NI requests of the wave's tile `ti` into its buffer `b` (0..3)
-    auto request = [&](int ti, int b) {
-        const size_t cell0 = (size_t)c_mine + (size_t)16 * stride * ti;
-        const unsigned char* r = reinterpret_cast<const unsigned char*>(a.R + cell0 * Kp);
-        const unsigned char* z = reinterpret_cast<const unsigned char*>(a.Z + cell0 * DP);
-        const unsigned char* id = a.tile_blk + (size_t)16 * (t0 + wv + (size_t)stride * ti);
-        const unsigned zb = zone0 + (unsigned)b * buf_bytes;
-#pragma unroll
-        for (int p = 0; p < NR; ++p)
-            if (p + 1 < NR || 1024 * p + lane16 < 64 * Kp) dma16(r + 1024 * p, lane16, zb + 1024u * p);
-#pragma unroll
-        for (int it = 0; it < NZ; ++it)
-            if (1024 * (it + 1) <= 64 * DP || 1024 * it + lane16 < 64 * DP) dma16(z + 1024 * it, lane16, zb + r_bytes + 1024u * it);
-        if (lane == 0) dma16(id, lane16, zb + r_bytes + 64u * DP);
-    };
-    // a pair's requests are always 2 NI instructions: a missing second tile requests the first one again (into the spare
-    // buffer; never read), so that the counted waits do not depend on the parity of the wave's tile count
-    auto request_pair = [&](int i, int par) {
-        request(2 * i, 2 * par);
-        request(2 * i + 1 < n_tiles ? 2 * i + 1 : 2 * i, 2 * par + 1);
-    };
-    if (n_mine > 0) request_pair(0, 0);
-    if (n_mine > 1) request_pair(1, 1);
-
-    for (int i = 0; i < n_mine; ++i) {
-        asm volatile("" ::: "memory");
-        if (i + 1 < n_mine) wait_vmcnt<2 * NI>(); else wait_vmcnt<0>();   // pair i has landed (pair i+1 may travel on)
-        asm volatile("" ::: "memory");
-        const bool has2 = 2 * i + 1 < n_tiles;                      // wave-uniform
-        float* pb = lds + (size_t)(4 * wv + 2 * (i & 1)) * buf_floats;
-        // rows past the group's end hold other cells (or the slack behind the arrays): they count for nothing
-#pragma unroll 1
-        for (int u = 0; u < 2; ++u) {
-            const int c0 = c_mine + 16 * stride * (2 * i + u);
-            const int n_live = (u == 0 || has2) ? min(16, c_end - c0) : 0;
-            if (n_live < 16) {
-                float* Rt = pb + (size_t)u * buf_floats;
-                float* Zt = Rt + 16 * Kp;
-                for (int j = n_live * Kp + lane; j < 16 * Kp; j += 64) Rt[j] = 0.f;
-                for (int j = n_live * DP + lane; j < 16 * DP; j += 64) Zt[j] = 0.f;
-                if (n_live == 0 && lane < 4) reinterpret_cast<unsigned*>(Zt + 16 * DP)[lane] = 0xFFFFFFFFu;   // no block
-            }
-        }
-        // lane (c16, q): k slot j <-> cell 8 (q & 1) + j of tile q >> 1 of the pair
-        const float* R = pb + (size_t)(q >> 1) * buf_floats + 8 * (q & 1) * Kp;
-        const float* Z = pb + (size_t)(q >> 1) * buf_floats + 16 * Kp + 8 * (q & 1) * DP;
-        const unsigned char* ids = reinterpret_cast<const unsigned char*>(pb + (size_t)(q >> 1) * buf_floats + 16 * (Kp + DP)) + 8 * (q & 1);
-        u32x4 bh[4], bm[4], bl[4], oh = {0u, 0u, 0u, 0u};           // B planes of the four PC-column tiles, the one-hot tile's only plane
-        {
-            int bid[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) bid[j] = ids[j];
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {                  // two column tiles at a time: 8-byte reads, 16 raw registers live
-                f32x2 z[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) z[j] = *reinterpret_cast<const f32x2*>(Z + j * DP + 4 * min(c16, KS - 1) + 2 * half);
-#pragma unroll
-                for (int n2 = 0; n2 < 2; ++n2) {
-                    const int nt = 2 * half + n2;
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        f32x2 x;
-                        x.x = (c16 < KS) ? z[2 * p][n2] : ((bid[2 * p] == 4 * c16 + nt - DP) ? 1.f : 0.f);
-                        x.y = (c16 < KS) ? z[2 * p + 1][n2] : ((bid[2 * p + 1] == 4 * c16 + nt - DP) ? 1.f : 0.f);
-                        unsigned h, m, l;
-                        bf16_split3(x, h, m, l);
-                        bh[nt][p] = h; bm[nt][p] = m; bl[nt][p] = l;
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (NTB > 0) {
-#pragma unroll
-                for (int p = 0; p < 4; ++p)                          // bf16(1.0) = 0x3F80
-                    oh[p] = ((bid[2 * p] == (64 - DP) + c16) ? 0x3F80u : 0u) | ((bid[2 * p + 1] == (64 - DP) + c16) ? 0x3F800000u : 0u);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        auto one_mt = [&](int mt, const float (&av)[8]) {
-            u32x4 ah, am, al;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                unsigned h, m, l;
-                bf16_split3((f32x2){av[2 * p], av[2 * p + 1]}, h, m, l);
-                ah[p] = h; am[p] = m; al[p] = l;
-            }
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {                         // smallest terms first
-                acc[mt][nt] = MFMA_BF16(al, bh[nt], acc[mt][nt]);
-                acc[mt][nt] = MFMA_BF16(ah, bl[nt], acc[mt][nt]);
-                acc[mt][nt] = MFMA_BF16(am, bm[nt], acc[mt][nt]);
-                acc[mt][nt] = MFMA_BF16(am, bh[nt], acc[mt][nt]);
-                acc[mt][nt] = MFMA_BF16(ah, bm[nt], acc[mt][nt]);
-                acc[mt][nt] = MFMA_BF16(ah, bh[nt], acc[mt][nt]);
-            }
-            if (NTB > 0) {
-                acc[mt][NT - 1] = MFMA_BF16(al, oh, acc[mt][NT - 1]);
-                acc[mt][NT - 1] = MFMA_BF16(am, oh, acc[mt][NT - 1]);
-                acc[mt][NT - 1] = MFMA_BF16(ah, oh, acc[mt][NT - 1]);
-            }
-        };
-#pragma unroll
-        for (int h = 0; h < H; ++h)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {                  // k_rtz3's groups of four cluster tiles, two at a time (8-byte reads)
-                f32x2 v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x2*>(R + j * Kp + 64 * h + 4 * c16 + 2 * half);
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    float av[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) av[j] = v[j][jj];
-                    one_mt(4 * h + 2 * half + jj, av);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-#pragma unroll
-        for (int jj = 0; jj < REM; ++jj) {
-            float av[8];
-            const int col = 64 * H + REM * c16 + jj;                 // clusters past the row do not exist: no read past it
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                av[j] = R[j * Kp + min(col, Kp - 1)];
-                if (col >= Kp) av[j] = 0.f;
-            }
-            one_mt(4 * H + jj, av);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // the pair's buffers are in registers: hand them to the pair after next
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (i + 2 < n_mine) request_pair(i + 2, i & 1);
-    }
-
-    // ---- the four waves' accumulators meet in the task's slab (as in k_rtz3) ----------------------------------------------------
-    __syncthreads();                                                // every wave is done with its buffers (all requests landed)
-    constexpr int PER = MT * NT * 256;
-    const int nreg = (2 * PER <= 4 * RTZ3_WAVES * buf_floats) ? 2 : 1;   // workgroup-uniform
-    float* slab = a.slab + (size_t)task * PER;
-#pragma unroll 1
-    for (int r0 = 0; r0 < RTZ3_WAVES; r0 += nreg) {
-        if (wv >= r0 && wv < r0 + nreg) {
-            float* reg = lds + (size_t)(wv - r0) * PER + 4 * lane;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) st4(reg + (mt * NT + nt) * 256, acc[mt][nt]);
-        }
-        __syncthreads();
-        for (int j = tid; j < PER / 4; j += 64 * RTZ3_WAVES) {
-            f32x4 v = ld4(lds + 4 * j);
-            if (nreg == 2) v += ld4(lds + PER + 4 * j);
-            if (r0 > 0) v += ld4(slab + 4 * j);
-            st4(slab + 4 * j, v);
-        }
-        __syncthreads();
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_rtz3c: k_rtz3b with a PARTNER wave on every SIMD.  k_rtz3b's wave is alone on its SIMD (four tile buffers per wave fill the
-// LDS): while it issues the 24 LDS-DMA requests of the pair after next (~125 cycles each: 3 k of a pair's 9 k cycles) and
-// while it splits operands, the SIMD's matrix pipe idles -- stream alone 87-98 us, arithmetic alone 82-87 us, together 135-142
-// (profiles/r04_micro_rtz_bf16_pipe.txt).  Here EIGHT waves per workgroup, two per SIMD, TWO tile buffers (one pair) each: the
-// same LDS.  A wave requests a pair, waits for it, multiplies it, and only then requests its next pair -- no double buffering
-// inside the wave; the overlap comes from the SIMD's other wave, which multiplies while this one requests and waits.  The
-// tiles of a task are dealt to the eight waves as k_rtz3b deals them to four (tile t0 + w + stride i; the host cuts the tasks
-// with quads of eight), fragment maps, slabs and finish kernel are unchanged.
+// k_rtz3c: k_rtz3 on the bf16 matrix pipe (hmx_device.h: every fp32 operand as the exact sum of three bf16 terms).  The k index
+// runs over cells, so BOTH operands stream and both are split in registers; a k-step of v_mfma_f32_16x16x32_bf16 is 32 cells =
+// a PAIR of the wave's tiles (any two of them), lane (c16, q) supplies the cells 8 (q & 1) .. + 8 of tile q >> 1.  Per pair and
+// wave MT x (4 x 6 + 3 NTB) MFMAs of 16 cycles (the one-hot block columns are exact in bf16: one plane, three products) where
+// k_rtz3 issues 2 x 4 x MT x (4 + NTB) of 32.  Same requests per tile, same slabs and finish kernel as k_rtz3.
+// EIGHT waves per workgroup, two per SIMD, TWO tile buffers (one pair) each -- one workgroup per CU (156 KB at K = 100, d = 50).
+// A wave requests a pair, waits for it, multiplies it, and only then requests its next pair: no double buffering inside the
+// wave; the overlap comes from the SIMD's other wave, which multiplies while this one requests (24 LDS-DMA instructions of
+// ~125 cycles of issue each) and waits.  The first cut of round 5 (k_rtz3b: four waves, two pair buffers each, a wave alone
+// on its SIMD) left the matrix pipe idle during exactly those phases: 141.8 us per 1 M-cell pass at C3 against 127.5 here
+// (stream alone 87-98 us, arithmetic alone 82-87 us: profiles/r04_micro_rtz_bf16_pipe.txt, r05_ab_rtz3c_eight_waves.txt).
+// The tiles of a task are dealt to the eight waves as tile t0 + w + stride i (the host cuts the tasks with quads of eight:
+// rtz3_quad).  Developed and float64-checked as a standalone kernel first: scripts/micro/rtz_bf3_tasks.hip.
 // ------------------------------------------------------------------------------------------
 #define RTZ3C_WAVES 8
 template <int MT, int KS, int NTB>
@@ -962,7 +765,7 @@ __global__ __launch_bounds__(64 * RTZW_WAVES, 1) void k_rtzw(Rtz3Args a) {
 // operand as the exact sum of three bf16 terms, six products, fp32 accumulation).  configs[4] is bound by the f32-input MFMA
 // outright (8 x 32 cycles per 32 cells and output tile; here 6 x 16), so this is where the split moves the BOUND, not only
 // the constant.  The k index runs over cells: a k-step of v_mfma_f32_16x16x32_bf16 is a PAIR of the task's tiles, lane (c16, q)
-// supplies cells 8 (q & 1) .. + 8 of tile q >> 1 (as in k_rtz3b), both operands are split in registers.  Tasks, slabs
+// supplies cells 8 (q & 1) .. + 8 of tile q >> 1 (as in k_rtz3c), both operands are split in registers.  Tasks, slabs
 // [mt][nt][lane][r] and finish kernel are k_rtzw's; the MT x NT output tiles are split 2 x 2 over FOUR waves (row half x
 // column half: up to 7 x 7 tiles = 196 accumulators; k_rtzw's eight waves share one tile and hold 2 x MT).  Further:
 //   * one workgroup per CU (512 registers per lane: 196 accumulators + the 84 registers of the column half's B planes);
@@ -1399,40 +1202,13 @@ static void launch_rtz3_k(const Rtz3Args& a, int mt, int ntb, size_t sm, hipStre
     }
 }
 
-// ---- k_rtz3b: at most one extra one-hot tile (140 accumulators), four tile buffers per wave in one CU's LDS
+// ---- k_rtz3c (bf16 pipe): at most one extra one-hot tile (140 accumulators), sixteen tile buffers in one CU's LDS
 size_t rtz3b_lds_bytes(int Kp, int dp) { return (size_t)4 * RTZ3_WAVES * (16 * (Kp + dp) + 4) * sizeof(float); }
 bool rtz3b_ok(int mt, int dp, int nblk, int Kp) {
     return rtz3_ntb(dp, nblk) <= 1 && std::max(rtz3b_lds_bytes(Kp, dp), (size_t)rtz3_slab_floats(mt, dp, nblk) * sizeof(float)) <= 160 * 1024;
 }
-template <int MT, int KS, int NTB>
-static void launch_rtz3b_t(const Rtz3Args& a, size_t sm, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rtz3b<MT, KS, NTB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((k_rtz3b<MT, KS, NTB>), dim3(a.ntasks), dim3(64 * RTZ3_WAVES), sm, s, a);
-}
-template <int KS, int NTB>
-static void launch_rtz3b_m(const Rtz3Args& a, int mt, size_t sm, hipStream_t s) {
-    switch (mt) {
-        case 1: launch_rtz3b_t<1, KS, NTB>(a, sm, s); break;
-        case 2: launch_rtz3b_t<2, KS, NTB>(a, sm, s); break;
-        case 3: launch_rtz3b_t<3, KS, NTB>(a, sm, s); break;
-        case 4: launch_rtz3b_t<4, KS, NTB>(a, sm, s); break;
-        case 5: launch_rtz3b_t<5, KS, NTB>(a, sm, s); break;
-        case 6: launch_rtz3b_t<6, KS, NTB>(a, sm, s); break;
-        default: launch_rtz3b_t<7, KS, NTB>(a, sm, s); break;
-    }
-}
-template <int KS>
-static void launch_rtz3b_k(const Rtz3Args& a, int mt, int ntb, size_t sm, hipStream_t s) {
-    if (ntb == 0) launch_rtz3b_m<KS, 0>(a, mt, sm, s); else launch_rtz3b_m<KS, 1>(a, mt, sm, s);
-}
-// ---- k_rtz3c: eight waves, one pair buffer each (the same LDS as k_rtz3b); HMX_RTZ3_WAVES=4 keeps k_rtz3b
-int rtz3_quad(int mt, int dp, int nblk, int Kp, bool allow_bf16) {   // tiles a workgroup takes side by side (the host cuts the tasks with it)
-    static const int waves = [] { const char* v = getenv("HMX_RTZ3_WAVES"); return v ? atoi(v) : 8; }();
-    return (allow_bf16 && waves == 8 && rtz3b_ok(mt, dp, nblk, Kp)) ? 8 : 4;
+int rtz3_quad(int mt, int dp, int nblk, int Kp, bool allow_bf16) {   // tiles a workgroup takes side by side (the host cuts the tasks with it): k_rtz3c's eight waves, k_rtz3's four
+    return (allow_bf16 && rtz3b_ok(mt, dp, nblk, Kp)) ? 8 : 4;
 }
 template <int MT, int KS, int NTB>
 static void launch_rtz3c_t(const Rtz3Args& a, size_t sm, hipStream_t s) {
@@ -1473,15 +1249,7 @@ int launch_rtz3(const Rtz3Args& a, int mt, int dp, int nblk, hipStream_t s, bool
         }
         return 1;
     }
-    if (allow_bf16 && quad == 4 && rtz3b_ok(mt, dp, nblk, a.Kp)) {
-        const size_t smb = std::max(rtz3b_lds_bytes(a.Kp, dp), (size_t)rtz3_slab_floats(mt, dp, nblk) * sizeof(float));
-        switch (dp) {
-            case 32: launch_rtz3b_k<8>(a, mt, ntb, smb, s); break;
-            case 52: launch_rtz3b_k<13>(a, mt, ntb, smb, s); break;
-            default: launch_rtz3b_k<16>(a, mt, ntb, smb, s); break;
-        }
-        return 1;
-    }
+    if (quad != 4) return -1;                                       // (tasks cut for eight waves cannot run on k_rtz3's four)
     const size_t sm = std::max(rtz3_lds_bytes(a.Kp, dp), (size_t)rtz3_slab_floats(mt, dp, nblk) * sizeof(float));
     switch (dp) {
         case 32: launch_rtz3_k<8>(a, mt, ntb, sm, s); break;

@@ -265,7 +265,7 @@ int hmx_set_timing_stride(hmx_engine* e, int stride);
  * the grid-wide waits of the persistent sweep kernel (per workgroup and block: the hop every block of a sweep pays, across
  * ranks when cells are sharded): out[4] waits, out[5] polls that found the hand-off incomplete (each followed by an
  * s_sleep of ~64 shader cycles), out[6] the most such polls any single wait took, out[7] streaming R^T.Z passes
- * (centroid numerators + removal sums, ridge statistics) that ran on the bf16 matrix pipe (k_rtz3b; engines created under
+ * (centroid numerators + removal sums, ridge statistics) that ran on the bf16 matrix pipe (k_rtz3c; engines created under
  * HMX_RTZ3_BF16=0 keep the f32-input kernel k_rtz3). */
 int hmx_counters(hmx_engine* e, int64_t out[8]);
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Where the waves of the round kernels (k_round, k_rtz3b) spend their cycles: SQ wait / issue / active counters (own pass; no trace domains besides --kernel-trace)
+# Where the waves of the round kernels (k_round, k_rtz3c) spend their cycles: SQ wait / issue / active counters (own pass; no trace domains besides --kernel-trace)
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 rm -rf gpurun_out/pmc_sq

@@ -433,12 +433,12 @@ def test_bf16_pipe_distance_gemm_against_the_f32_input_instance(N, d, B, K, monk
     print(f"bf16x3 vs f32-input distance GEMM {N}x{d} K={K} B={B}: max|dR|={dR:.2e}")
 
 
-# (rows of 64 floats: k_rtz3b serves at most one extra one-hot tile = 16 update blocks there, and K <= 64 so that its four
+# (rows of 64 floats: k_rtz3c serves at most one extra one-hot tile = 16 update blocks there, and K <= 64 so that its four
 # tile buffers per wave fit one CU's LDS; the 112-cluster shape of AB_SHAPES stays on k_rtz3 whatever the switch says)
 @pytest.mark.parametrize("N,d,B,K,bs", [s + (0.05,) for s in AB_SHAPES[:4]] + [(50_000, 64, 5, 64, 1.0 / 16)])
 def test_bf16_pipe_rtz_pass_against_the_f32_input_kernel(N, d, B, K, bs, monkeypatch):
     """Direct A/B of the streaming R^T.Z pass (harmony.py:443-444 centroid numerators, :491-492 removal sums, :550, :559-563
-    ridge statistics): k_rtz3b (both operands split in registers, bf16 pipe) against k_rtz3 (f32-input MFMA, engines
+    ridge statistics): k_rtz3c (both operands split in registers, bf16 pipe) against k_rtz3 (f32-input MFMA, engines
     created under HMX_RTZ3_BF16=0), same shapes as above.  Two seeded rounds (the second round's pass reads the R the first
     one wrote) + the ridge: Y atol 2e-6, O 2e-6 relative to the masses, R 4e-6, Z_corr 1e-6 relative Frobenius; the counter
     says which kernel ran."""
@@ -454,7 +454,7 @@ def test_bf16_pipe_rtz_pass_against_the_f32_input_kernel(N, d, B, K, bs, monkeyp
     Za, Zb = a.Z_corr, b.Z_corr
     rel = float(np.linalg.norm(Za - Zb) / np.linalg.norm(Zb))
     assert rel <= 1e-6, f"Z_corr relF {rel:.2e}"
-    print(f"k_rtz3b vs k_rtz3 {N}x{d} K={K} B={B}: Y {np.abs(a.Y - b.Y).max():.2e}  Z_corr relF {rel:.2e}")
+    print(f"k_rtz3c vs k_rtz3 {N}x{d} K={K} B={B}: Y {np.abs(a.Y - b.Y).max():.2e}  Z_corr relF {rel:.2e}")
 
 
 WIDE_AB_SHAPES = [(40_000, 200, 32, 200), (30_000, 100, 4, 130), (20_000, 208, 3, 208), (25_000, 72, 5, 100), (20_000, 40, 2, 150)]

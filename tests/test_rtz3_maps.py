@@ -121,7 +121,7 @@ def test_rtz3_round_trip(K, d, nblk):
 
 
 # ------------------------------------------------------------------------------------------
-# k_rtz3b: the same pass on the bf16 matrix pipe.  A k-step of v_mfma_f32_16x16x32_bf16 is a PAIR of the wave's tiles;
+# k_rtz3c (round 5's first cut was k_rtz3b: same maps, four waves): the same pass on the bf16 matrix pipe.  A k-step of v_mfma_f32_16x16x32_bf16 is a PAIR of the wave's tiles;
 # lane (c16, q) supplies cells 8 (q & 1) .. + 8 of tile q >> 1 (hmx_device.h: A[i = l & 15][k = 8 (l >> 4) .. + 8]).
 # The split into three bf16 terms is value-preserving (tests/test_split_gemm.py), so the replay multiplies the values.
 # ------------------------------------------------------------------------------------------
@@ -139,7 +139,7 @@ def mfma32(a_lane, b_lane, acc):
 
 
 def kernel_pair_b(tiles, MT, KS, NTB, Kp, acc):
-    """One pair of tiles through k_rtz3b's fragment construction.  tiles: two (Rt 16 x Kp, Zt 16 x 4KS, blk 16, n_live);
+    """One pair of tiles through k_rtz3c's fragment construction.  tiles: two (Rt 16 x Kp, Zt 16 x 4KS, blk 16, n_live);
     n_live = 0 stands for the missing second tile of an odd count (its buffer holds the first tile again, zeroed, ids 255)."""
     NT, DP = 4 + NTB, 4 * KS
     H, REM = MT // 4, MT % 4
@@ -181,7 +181,7 @@ def kernel_pair_b(tiles, MT, KS, NTB, Kp, acc):
     (64, 64, 1, 2, 16), (112, 64, 16, 3, 16),       # 64-float rows: the one-hot tile carries every block column
     (30, 30, 20, 2, 16), (17, 33, 8, 1, 5), (5, 3, 1, 1, 16), (48, 17, 28, 4, 1)])
 def test_rtz3b_pair_round_trip(K, d, nblk, n_tiles, last_live):
-    """Every (row length, cluster-tile count, block-tile count) family launch_rtz3 hands to k_rtz3b, with the pair
+    """Every (row length, cluster-tile count, block-tile count) family launch_rtz3 hands to k_rtz3c, with the pair
     bookkeeping: odd tile counts (the spare buffer requests the first tile again and counts for nothing) and a last tile
     that runs past the group's end."""
     rng = np.random.default_rng(K * 977 + d * 31 + nblk)
@@ -226,7 +226,7 @@ def test_rtz3b_pair_round_trip(K, d, nblk, n_tiles, last_live):
 
 # ------------------------------------------------------------------------------------------
 # k_rtzw2b: the wide streaming pass on the bf16 matrix pipe.  Four waves split the MT x NT output tiles 2 x 2 (row half
-# x column half); a k-step is a pair of the task's tiles with k_rtz3b's k-slot map; plain column tiles (PC tile nt holds
+# x column half); a k-step is a pair of the task's tiles with k_rtz3c's k-slot map; plain column tiles (PC tile nt holds
 # columns 16 nt .., the padding columns d .. dp-1 of the last PC tile carry the first one-hot block columns, whole extra
 # tiles the rest); rows past the group's end and the missing tile of an odd count are ZEROS in LDS (store_tile).
 # ------------------------------------------------------------------------------------------
