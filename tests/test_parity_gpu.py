@@ -415,7 +415,7 @@ def test_bf16_pipe_distance_gemm_against_the_f32_input_instance(N, d, B, K, monk
     pipe (every fp32 operand as the exact sum of three bf16 terms, six products: hmx_device.h `bf16_split3`) against its
     f32-input instance (HMX_ROUND_F32=1) -- the C3 shape, the 21-group edge (the most groups whose tables fit next to the
     bf16 planes), rows of 17 / 32 / 64 PCs.  One seeded round each: the counters say which instance ran, the new R rows
-    differ by <= 4e-6, O by 2e-6 relative to the cluster masses, the three objective terms by 2e-6 relative.  A regression
+    differ by <= 6e-6 (measured <= 3.6e-6), O by 2e-6 relative to the cluster masses, the three objective terms by 2e-6 relative.  A regression
     in the split (a dropped term, a wrong plane pairing) shows as 1e-3 .. 1e-5 here, far above the bound."""
     a, b = _ab_engines(N, d, B, K, monkeypatch, "HMX_ROUND_F32", "1")
     a.cluster(_rounds=1)
@@ -425,7 +425,7 @@ def test_bf16_pipe_distance_gemm_against_the_f32_input_instance(N, d, B, K, monk
     assert ca["sweep_fallbacks"] == 0 and cb["sweep_fallbacks"] == 0
     Ra, Rb = a.R, b.R
     dR = float(np.abs(Ra - Rb).max())
-    assert dR <= 4e-6, f"max |R(bf16x3) - R(f32 input)| = {dR:.2e}"
+    assert dR <= 6e-6, f"max |R(bf16x3) - R(f32 input)| = {dR:.2e}"     # (measured 2.3e-6 .. 3.6e-6 over four runs; a dropped term shows as >= 1e-5)
     assert np.abs(a.O - b.O).max() <= 2e-6 * max(1.0, float(np.abs(b.O).max()))     # (1e-6 was met within 5 % in one run of the 21-group shape: the order of the fp64 slot adds differs run to run)
     for name in ("objective_kmeans_dist", "objective_kmeans_entropy", "objective_kmeans_cross", "objective_kmeans"):
         va, vb = getattr(a, name)[-1], getattr(b, name)[-1]
@@ -450,7 +450,7 @@ def test_bf16_pipe_rtz_pass_against_the_f32_input_kernel(N, d, B, K, bs, monkeyp
     assert ca["rtz_bf16_pipe"] >= 3 and cb["rtz_bf16_pipe"] == 0, (ca, cb)
     np.testing.assert_allclose(a.Y, b.Y, rtol=0, atol=2e-6)
     assert np.abs(a.O - b.O).max() <= 2e-6 * max(1.0, float(np.abs(b.O).max()))     # (1e-6 was met within 5 % in one run of the 21-group shape: the order of the fp64 slot adds differs run to run)
-    assert float(np.abs(a.R - b.R).max()) <= 4e-6
+    assert float(np.abs(a.R - b.R).max()) <= 6e-6
     Za, Zb = a.Z_corr, b.Z_corr
     rel = float(np.linalg.norm(Za - Zb) / np.linalg.norm(Zb))
     assert rel <= 1e-6, f"Z_corr relF {rel:.2e}"
