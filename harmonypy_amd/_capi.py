@@ -29,7 +29,7 @@ EXPORTS = [
     "hmx_build_id", "hmx_cluster", "hmx_set_timing_stride", "hmx_set_timing_families", "hmx_kmeans_lloyd", "hmx_can_lloyd", "hmx_kmeans_seed", "hmx_compute_lisi", "hmx_get_rows", "hmx_set_ranks", "hmx_peer_export", "hmx_peer_attach", "hmx_peer_selftest", "hmx_peer_enable",
 ]
 HMX_PEER_HANDLE_BYTES = 64
-HMX_ABI_VERSION = 7
+HMX_ABI_VERSION = 8
 HMX_UNIQUE_ID_BYTES = 128
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
 
@@ -342,10 +342,11 @@ class Engine:
 
     def counters(self):
         """dict of the engine's event counters (hmx_counters)."""
-        buf = np.zeros(8, np.int64)
+        buf = np.zeros(16, np.int64)
         _check(self._lib.hmx_counters(self._h, _ptr(buf)))
         return {"collectives": int(buf[0]), "sweep_fallbacks": int(buf[1]), "seeded_rounds": int(buf[2]), "sweeps_bf16_pipe": int(buf[3]),
-                "sweep_waits": int(buf[4]), "sweep_wait_polls": int(buf[5]), "sweep_wait_polls_max": int(buf[6]), "rtz_bf16_pipe": int(buf[7])}
+                "sweep_waits": int(buf[4]), "sweep_wait_polls": int(buf[5]), "sweep_wait_polls_max": int(buf[6]), "rtz_bf16_pipe": int(buf[7]),
+                "sweeps_group_affine": int(buf[8]), "sweep_group_affine_wgs": int(buf[9])}
 
     def kernel_times(self):
         """{family: (total_ms, launches)} since timing was enabled."""

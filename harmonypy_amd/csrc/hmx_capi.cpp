@@ -87,7 +87,7 @@ struct hmx_engine {
     DevBuf<int> group_cols, s_cells, s_tile_grp, task_t0, task_t1, task_grp;
     // Update-order lists of a round, double buffered: while round r runs, the lists of round r+1 (a function of
     // seed and round counter only) are built on a second stream -- the persistent sweep kernel leaves a few CUs idle.
-    struct Lists { DevBuf<int> cells, tile_grp, blk_start; };
+    struct Lists { DevBuf<int> cells, tile_grp, blk_start, run_tiles; bool runs_ok = false; };   // run_tiles: nblk*G + 1 first tiles of the (block, group) runs (k_round's group-affine map), valid when runs_ok
     Lists lists[2];
     int cur = 0;                         // lists of the round in progress / last round
     hipStream_t stream2 = nullptr;
@@ -105,7 +105,7 @@ struct hmx_engine {
     //   Sold [nblk][G][K16] | Yacc64 [K16][ldy] | Snew [nblk][G][K16] | objacc [2*SLOTS+2] | Sr [G][K16][ldy] | Oxr [G][K16]
     DevBuf<float> km_hn;         // device k-means: half squared norms of the centres
     DevBuf<double> km_sums;      // device k-means: K16 x (d+1) member sums and counts
-    DevBuf<double> Sslots;       // k_round: nblk x HMX_ROUND_SLOTS x G x K16
+    DevBuf<double> Sslots;       // k_round: (nblk + 1) x HMX_ROUND_SLOTS x (G + 1) x K16 (row G of a slot table: the cluster masses, group-affine map)
     DevBuf<unsigned> sync_words; // k_round: {arrival counter, error flag}
     unsigned* sync_host = nullptr;  // pinned copy of sync_words
     int n_cus = 0;
@@ -118,6 +118,14 @@ struct hmx_engine {
     int rtz3_quad = 4;              // tiles a workgroup of the narrow streaming pass takes side by side (8: the tasks are cut for k_rtz3c)
     bool allow_rtz_bf16 = true;     // HMX_RTZ3_BF16=0 at hmx_create: k_rtz3 instead of k_rtz3c
     long n_sweeps_bf16 = 0;      // sweeps launched on the bf16-pipe instances of k_round (round_uses_bf16_pipe)
+    long n_sweeps_ga = 0;        // sweeps launched with the group-affine tile map
+    bool allow_round_ga = true;  // HMX_ROUND_GA=0 at hmx_create: the classic tile map everywhere (A/B runs and tests)
+    std::vector<int> gsize;      // cells of every batch group on this rank (host copy)
+    DevBuf<int> ga_map;          // k_round's group-affine map: per compute workgroup {group, rank in group, workgroups of the group}
+    int ga_nwg = 0;              // workgroups of that map (0: none planned)
+    int64_t ga_key_block = -1;   // ... planned for this largest block size and this cap
+    int ga_key_cap = -1;
+    bool ga_extra = false;       // ... some group's run may exceed 14 tiles per workgroup (the extra-tile loop will run)
     DevBuf<unsigned long long> wait_stats;   // {waits, incomplete polls, most polls of one wait} of the sweep kernels' grid-wide waits
     DevBuf<double> xch;
     double *Sold = nullptr, *Yacc64 = nullptr, *Snew = nullptr, *objacc = nullptr, *Sr = nullptr, *Oxr = nullptr;
@@ -391,6 +399,7 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
     if (const char* pl = getenv("HMX_PREFETCH_LISTS")) e->prefetch_lists = atoi(pl) != 0;
     if (const char* rm = getenv("HMX_ROUND_MODE")) e->round_mode = (std::string(rm) == "blocks") ? 0 : 1;
     if (const char* rf = getenv("HMX_ROUND_F32")) e->allow_round_bf16 = atoi(rf) == 0;
+    if (const char* rg = getenv("HMX_ROUND_GA")) e->allow_round_ga = atoi(rg) != 0;
     if (const char* rb = getenv("HMX_RTZ3_BF16")) e->allow_rtz_bf16 = atoi(rb) != 0;
     if (const char* rk = getenv("HMX_RTZ")) e->rtz_kernel = atoi(rk) == 2 ? 2 : 3;
     if (const char* fs = getenv("HMX_TEST_FAIL_SWEEP")) e->test_fail_sweep = atol(fs);
@@ -404,7 +413,7 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
         (void)hipEventCreateWithFlags(&e->pre_event, hipEventDisableTiming);
         hipError_t se = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
         if (se != hipSuccess) { rc = fail(HMX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se)); break; }
-        const size_t N = (size_t)e->N, GK = (size_t)e->G * e->K16;
+        const size_t N = (size_t)e->N, GK = (size_t)e->G * e->K16, GKs = GK + e->K16;
         // + 16 rows of slack behind Z_orig / Z_cos / R: the streaming pass (k_rtz3) fetches whole 16-cell tiles
         if ((rc = e->Zorig.reserve((N + 16) * e->dp)) || (rc = e->Zcos.reserve((N + 16) * e->dp)) || (rc = e->Zcorr.reserve(N * e->dp)) ||
             (rc = e->R.reserve((N + 16) * e->Kp + e->K16 + 64)) || (rc = e->Osave.reserve(GK)) || (rc = e->Y.reserve((size_t)e->K16 * e->ldy)) ||
@@ -413,7 +422,8 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
             (rc = e->rp.reserve(2 * GK * e->nblk)) || (rc = e->lrp.reserve(GK)) || (rc = e->group_cols.reserve((size_t)e->G * e->V)) ||
             (rc = e->Ogrp.reserve(GK)) || (rc = e->Tmass.reserve(e->K16)) || (rc = e->Ohist.reserve(GK * e->nblk)) ||
             (rc = e->W.reserve(GK * e->ldy)) || (rc = e->lists[0].blk_start.reserve(e->nblk + 1)) ||
-            (rc = e->lists[1].blk_start.reserve(e->nblk + 1)))
+            (rc = e->lists[1].blk_start.reserve(e->nblk + 1)) ||
+            (rc = e->lists[0].run_tiles.reserve((size_t)e->nblk * e->G + 1)) || (rc = e->lists[1].run_tiles.reserve((size_t)e->nblk * e->G + 1)))
             break;
         {
             const size_t n_sold = GK * e->nblk, n_y = (size_t)e->K16 * e->ldy, n_obj = 2 * HMX_OBJ_SLOTS + 2;
@@ -425,9 +435,9 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
             e->Sr = e->objacc + n_obj;
             e->Oxr = e->Sr + GK * e->ldy;
         }
-        if ((rc = e->Sslots.reserve(GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 1 + 256)) || (rc = e->wait_stats.reserve(8))) break;   // + slack: the per-round fill is rounded up to 1 KB
+        if ((rc = e->Sslots.reserve(GKs * (e->nblk + 1) * HMX_ROUND_SLOTS + 1 + 160 + 256)) || (rc = e->wait_stats.reserve(8))) break;   // + slack: the per-round fill is rounded up to 1 KB
         (void)hipMemsetAsync(e->wait_stats.p, 0, 8 * sizeof(unsigned long long), e->stream);
-        e->sync_words.p = reinterpret_cast<unsigned*>(e->Sslots.p + GK * (e->nblk + 1) * HMX_ROUND_SLOTS);   // borrowed tail
+        e->sync_words.p = reinterpret_cast<unsigned*>(e->Sslots.p + GKs * (e->nblk + 1) * HMX_ROUND_SLOTS);   // borrowed tail
         e->sync_words.n = 2;
         if (hipHostMalloc(reinterpret_cast<void**>(&e->sync_host), 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
             rc = fail(HMX_ERR_HIP, "hipHostMalloc failed");
@@ -466,7 +476,8 @@ void hmx_destroy(hmx_engine* e) {
     e->Zorig.release(); e->Zcos.release(); e->Zcorr.release(); e->R.release(); e->Y.release(); e->Yacc.release();
     e->sigma.release(); e->theta.release(); e->Pr_b.release(); e->lamb.release(); e->rp.release(); e->lrp.release();
     e->slab.release(); e->W.release(); e->group_cols.release(); e->s_cells.release(); e->s_tile_grp.release();
-    for (auto& L : e->lists) { L.cells.release(); L.tile_grp.release(); L.blk_start.release(); }
+    for (auto& L : e->lists) { L.cells.release(); L.tile_grp.release(); L.blk_start.release(); L.run_tiles.release(); }
+    e->ga_map.release();
     if (e->stream2) { (void)hipStreamSynchronize(e->stream2); (void)hipStreamDestroy(e->stream2); }
     if (e->pre_event) (void)hipEventDestroy(e->pre_event);
     e->task_t0.release(); e->task_t1.release();
@@ -557,6 +568,8 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
                 if (static_cells[(size_t)t * HMX_TILE + i] >= 0) gcount[static_tile_group[t]]++;
         for (int g = 0; g < e->G; ++g) gs[g + 1] = gs[g] + gcount[g];
         if (gs[e->G] != e->N) return fail(HMX_ERR_ARG, "static list must hold every cell exactly once");
+        e->gsize = gcount;
+        e->ga_nwg = 0; e->ga_key_block = -1;
         if ((rc = e->gstart.reserve(e->G + 1))) return rc;
         HIP_TRY(hipMemcpyAsync(e->gstart.p, gs.data(), gs.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
@@ -914,7 +927,7 @@ static int rtz3_pass(hmx_engine* e, int mode, const unsigned char* tile_blk, int
     f.Ysum = e->Yacc64; f.Yout = normalize ? e->Y.p : nullptr; f.Sold = e->Sold; f.Sr = e->Sr; f.Oxr = e->Oxr;
     if (duties) {
         f.frozen = e->frozen();
-        f.zero_p = e->Sslots.p; f.zero_n = GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 1;   // slot tables + the two sync words
+        f.zero_p = e->Sslots.p; f.zero_n = (GK + e->K16) * (e->nblk + 1) * HMX_ROUND_SLOTS + 1 + 160;   // slot tables + the two sync words + the flag replicas behind them (k_round, group-affine map)
         f.zero2_p = e->objacc; f.zero2_n = 2 * HMX_OBJ_SLOTS + 2;
         f.copy_src = e->Ogrp.p; f.copy_dst = e->Osave.p; f.copy_n = (int)GK;
     }
@@ -1078,6 +1091,48 @@ static int replay_round(hmx_engine* e, int flags, const std::vector<int>& tiles_
     return read_objective(e, obj_out);
 }
 
+// The group-affine tile map of k_round (one batch variable, at most `cap` compute workgroups): workgroup w owns ONE batch
+// group; a group gets workgroups in proportion to the largest run of tiles it is expected to have in any block -- its share
+// of the rank's largest block (`max_tiles` tiles) + 5 sigma of that count, padded to whole tiles -- at HMX_ROUND_GA_WAVES x 2
+// = 14 tiles per workgroup and block.  When the grid cannot carry that (blocks larger than the grid), all `cap` workgroups
+// are dealt out so that the largest per-workgroup share is as small as possible and the kernel's extra-tile loop takes
+// the rest (*extra).  A run that exceeds the estimate is served by the same loop: the map decides speed, never results.
+// The map depends on the group sizes, the block size and the cap only, so it is planned once and kept on the device.
+static bool plan_ga(hmx_engine* e, int max_tiles, int cap) {
+    if (!e->allow_round_ga || e->V != 1 || e->G > cap || (int)e->gsize.size() != e->G || e->N <= 0) return false;
+    if (e->ga_nwg > 0 && e->ga_key_block == max_tiles && e->ga_key_cap == cap) return true;
+    const int G = e->G, per_wg = 2 * HMX_ROUND_GA_WAVES;
+    const double block_cells = 16.0 * std::max(1, max_tiles - G);      // the rank's cells in its largest block (upper estimate)
+    std::vector<double> est(G);
+    std::vector<int> ng(G);
+    int total = 0;
+    for (int g = 0; g < G; ++g) {
+        const double mean = block_cells * (double)e->gsize[g] / (double)e->N;
+        est[g] = std::ceil((mean + 5.0 * std::sqrt(mean)) / 16.0) + (e->gsize[g] > 0 ? 1.0 : 0.0);
+        ng[g] = std::max(1, (int)std::ceil(est[g] / per_wg));
+        total += ng[g];
+    }
+    e->ga_extra = total > cap;
+    if (e->ga_extra) {                                                  // min-max: one more workgroup to the most loaded group
+        std::fill(ng.begin(), ng.end(), 1);
+        for (total = G; total < cap; ++total) {
+            int best = 0;
+            for (int g = 1; g < G; ++g)
+                if (est[g] / ng[g] > est[best] / ng[best]) best = g;
+            ng[best]++;
+        }
+    }
+    std::vector<int> map;
+    map.reserve(3 * (size_t)total);
+    for (int g = 0; g < G; ++g)
+        for (int r = 0; r < ng[g]; ++r) { map.push_back(g); map.push_back(r); map.push_back(ng[g]); }
+    if (e->ga_map.reserve(map.size())) return false;
+    if (hipMemcpyAsync(e->ga_map.p, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice, e->stream) != hipSuccess) return false;
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return false;   // (the vector goes out of scope)
+    e->ga_nwg = total; e->ga_key_block = max_tiles; e->ga_key_cap = cap;
+    return true;
+}
+
 // Kernel sequence of one round; the lists (cells, tile groups, block_tile_start) and, for the streaming R^T.Z pass, the
 // block ids in static tile order (tile_blk) are already in device memory.  tiles_upper[b] bounds the tile count of block b
 // (grid sizing only).
@@ -1086,8 +1141,16 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
     int rc;
     const size_t GK = (size_t)e->G * e->K16;
     const bool persistent = (flags & HMX_ROUND_UPDATE_R) && e->round_mode == 1 && (!sharded(e) || e->peers_enabled);
+    // the sweep's tile map: group-affine when the shape allows it and the lists carry their run offsets (decided from
+    // job-wide properties only -- every rank of a sharded job takes the same decision: the peer boxes carry different rows)
+    int max_upper = 0;
+    for (int b = 0; b < e->nblk; ++b) max_upper = std::max(max_upper, tiles_upper[b]);
+    const bool multi = e->peers_enabled && e->n_ranks > 1;
+    int ga_cap = e->n_cus - (multi ? 1 : 0);
+    if (e->round_wgs_cap > 0) ga_cap = std::min(ga_cap, e->round_wgs_cap);
+    const bool ga = persistent && e->mt <= 7 && round_row_floats(e->d) == e->dp && e->lists[e->cur].runs_ok && plan_ga(e, max_upper, ga_cap);
     const bool mega = persistent && e->mt <= 7 && round_row_floats(e->d) == e->dp &&
-                      round_lds_bytes(e->K16, e->dp, e->G, e->B, e->V, false) <= HMX_ROUND_LDS_LIMIT;
+                      round_lds_bytes(e->K16, e->dp, e->G, e->B, e->V, false, ga, e->nblk) <= HMX_ROUND_LDS_LIMIT;
     const bool r3 = streaming_rtz(e);
     // a single engine on the persistent sweep: k_rtz3_finish normalises the centroids itself (no collective is due in
     // between) and does the sweep kernel's fills -- three launches per round
@@ -1147,15 +1210,13 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
             // the slot tables and the two sync words (carved from the same allocation): one fill (size rounded up to 1 KB
             // inside the allocation: an odd size makes the runtime launch a second fill kernel for the tail); O at the
             // start of the round is kept for an exact replay
-            HIP_TRY(hipMemsetAsync(e->Sslots.p, 0, (((GK * (e->nblk + 1) * HMX_ROUND_SLOTS + 2 + HMX_MAX_BLOCKS / 2) * sizeof(double) + 1023) / 1024) * 1024, e->stream));
+            HIP_TRY(hipMemsetAsync(e->Sslots.p, 0, ((((GK + e->K16) * (e->nblk + 1) * HMX_ROUND_SLOTS + 2 + 160) * sizeof(double) + 1023) / 1024) * 1024, e->stream));
             HIP_TRY(hipMemcpyAsync(e->Osave.p, e->Ogrp.p, GK * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
         }
-        int max_upper = 0;
-        for (int b = 0; b < e->nblk; ++b) max_upper = std::max(max_upper, tiles_upper[b]);
-        const bool multi = e->peers_enabled && e->n_ranks > 1;
         int wgs = std::min(e->n_cus - (multi ? 1 : 0), std::max(1, (max_upper + 13) / 14));   // ~14 of a workgroup's 16 tile slots: 224 of 256 CUs at C3, the rest serve the second stream
         // (sharded: every rank sizes its grid from its own share; the grid only decides how this rank's tiles are dealt out)
         if (e->round_wgs_cap > 0) wgs = std::min(wgs, e->round_wgs_cap);
+        if (ga) wgs = e->ga_nwg;
         {
             Timed t(e, F_ASSIGN_BLOCK);
             RoundArgs ra{};
@@ -1167,6 +1228,7 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
             ra.K = e->K; ra.Kp = e->Kp; ra.K16 = e->K16; ra.dp = e->dp; ra.ldy = e->ldy; ra.G = e->G; ra.B = e->B; ra.V = e->V;
             ra.nblk = e->nblk; ra.spin_limit = e->spin_limit;
             ra.frozen = e->frozen();
+            if (ga) { ra.ga = 1; if (const char* go = getenv("HMX_ROUND_GA_OPTS")) ra.ga_opts = atoi(go); ra.run_start = e->lists[e->cur].run_tiles.p; ra.wg_map = e->ga_map.p; e->n_sweeps_ga++; }
             if (e->n_sweep_launches++ == e->test_fail_sweep) ra.spin_limit = 0;
             if (multi) {
                 ra.peer_box = e->peer_dev.p; ra.my_box = e->box; ra.n_ranks = e->n_ranks; ra.rank = e->rank;
@@ -1176,15 +1238,16 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
 #ifdef HMX_ROUND_PROF
             static DevBuf<unsigned long long> prof;
             static int prof_rounds = 0;
-            if (prof.reserve((size_t)wgs * e->nblk * 16)) return -1;
+            if (prof.reserve((size_t)wgs * e->nblk * 32)) return -1;
+            (void)hipMemsetAsync(prof.p, 0, (size_t)wgs * e->nblk * 32 * 8, e->stream);
             ra.prof = prof.p;
 #endif
-            const bool extra_tiles = max_upper > 16 * wgs;   // (ROUND_TPW x ROUND_WAVES slots per workgroup)
+            const bool extra_tiles = ga ? e->ga_extra : max_upper > 16 * wgs;   // (ROUND_TPW x ROUND_WAVES slots per workgroup; group-affine: 14 per workgroup of the run's group)
             if (launch_round(ra, e->mt, multi ? wgs + 1 : wgs, e->stream, extra_tiles, e->allow_round_bf16)) return fail(HMX_ERR_ARG, "unsupported shape for k_round");
-            if (round_uses_bf16_pipe(ra.K16, ra.dp, ra.G, ra.B, ra.V, extra_tiles, e->allow_round_bf16)) e->n_sweeps_bf16++;
+            if (round_uses_bf16_pipe(ra.K16, ra.dp, ra.G, ra.B, ra.V, extra_tiles, e->allow_round_bf16, ga, e->nblk)) e->n_sweeps_bf16++;
 #ifdef HMX_ROUND_PROF
             if (++prof_rounds == 25) {   // one round in steady state: phase durations over workgroups and blocks
-                std::vector<unsigned long long> h((size_t)wgs * e->nblk * 16);
+                std::vector<unsigned long long> h((size_t)wgs * e->nblk * 32);
                 (void)hipStreamSynchronize(e->stream);
                 (void)hipMemcpy(h.data(), prof.p, h.size() * 8, hipMemcpyDeviceToHost);
                 const char* names[5] = {"wait", "table", "post", "flush+arrive", "pre(next)"};
@@ -1192,18 +1255,18 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
                     double sum = 0, mx = 0;
                     for (int w = 0; w < wgs; ++w)
                         for (int b = 0; b < e->nblk; ++b) {
-                            const double dtk = (double)(h[((size_t)w * e->nblk + b) * 16 + ph + 1] - h[((size_t)w * e->nblk + b) * 16 + ph]);
+                            const double dtk = (double)(h[((size_t)w * e->nblk + b) * 32 + ph + 1] - h[((size_t)w * e->nblk + b) * 32 + ph]);
                             sum += dtk; mx = std::max(mx, dtk);
                         }
                     fprintf(stderr, "[k_round prof] %-14s mean %.0f ticks  max %.0f\n", names[ph], sum / (wgs * e->nblk), mx);
                 }
                 double tot = 0;
-                for (int w = 0; w < wgs; ++w) tot += (double)(h[((size_t)w * e->nblk + e->nblk - 1) * 16 + 5] - h[(size_t)w * e->nblk * 16]);
+                for (int w = 0; w < wgs; ++w) tot += (double)(h[((size_t)w * e->nblk + e->nblk - 1) * 32 + 5] - h[(size_t)w * e->nblk * 32]);
                 {
                     double s1 = 0, s2 = 0, s3 = 0;
                     for (int w = 0; w < wgs; ++w)
                         for (int b = 0; b < e->nblk; ++b) {
-                            const unsigned long long* r = &h[((size_t)w * e->nblk + b) * 16];
+                            const unsigned long long* r = &h[((size_t)w * e->nblk + b) * 32];
                             s1 += (double)(r[6] - r[1]); s2 += (double)(r[7] - r[6]); s3 += (double)(r[2] - r[7]);
                         }
                     fprintf(stderr, "[k_round prof] table split: O update %.0f, pow %.0f, rp/log %.0f\n", s1 / (wgs * e->nblk), s2 / (wgs * e->nblk), s3 / (wgs * e->nblk));
@@ -1212,7 +1275,7 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
                     double s1 = 0, s2 = 0, s3 = 0, sp = 0;
                     for (int w = 0; w < wgs; ++w)
                         for (int b = 1; b < e->nblk; ++b) {
-                            const unsigned long long* r = &h[((size_t)w * e->nblk + b) * 16];
+                            const unsigned long long* r = &h[((size_t)w * e->nblk + b) * 32];
                             s1 += (double)(r[8] - r[0]); s2 += (double)(r[9] - r[8]); s3 += (double)(r[1] - r[9]); sp += (double)r[10];
                         }
                     const double n = (double)wgs * (e->nblk - 1);
@@ -1222,13 +1285,27 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
                     double s[5] = {0, 0, 0, 0, 0};
                     for (int w = 0; w < wgs; ++w)
                         for (int b = 0; b + 1 < e->nblk; ++b) {
-                            const unsigned long long* r = &h[((size_t)w * e->nblk + b) * 16];
+                            const unsigned long long* r = &h[((size_t)w * e->nblk + b) * 32];
                             if (!r[11] || !r[13]) continue;
                             s[0] += (double)(r[11] - r[4]); s[1] += (double)(r[12] - r[11]); s[2] += (double)(r[13] - r[12]);
                             s[3] += (double)(r[14] - r[13]); s[4] += (double)(r[5] - r[14]);
                         }
                     const double n = (double)wgs * (e->nblk - 1);
                     fprintf(stderr, "[k_round prof] pre(next) split: fragments %.0f, requests %.0f, split %.0f, k-step 0 %.0f, rest %.0f\n", s[0] / n, s[1] / n, s[2] / n, s[3] / n, s[4] / n);
+                }
+                if (ga) {   // the chain wave: publish, poll, table (block b's publish .. block b+1's table), and when it ends relative to wave 0's GEMM
+                    double s[4] = {0, 0, 0, 0};
+                    double n = 0;
+                    for (int w = 0; w < wgs; ++w)
+                        for (int b = 0; b + 1 < e->nblk; ++b) {
+                            const unsigned long long* r = &h[((size_t)w * e->nblk + b) * 32];
+                            if (!r[16] || !r[19]) continue;
+                            s[0] += (double)(r[17] - r[16]); s[1] += (double)(r[18] - r[17]); s[2] += (double)(r[19] - r[18]);
+                            s[3] += (double)r[19] - (double)r[5];   // > 0: the table came after wave 0's GEMM had ended
+                            n += 1;
+                        }
+                    fprintf(stderr, "[k_round prof] chain wave: publish %.0f, poll %.0f, table %.0f; table ready %.0f ticks after wave 0's GEMM ended\n",
+                            s[0] / n, s[1] / n, s[2] / n, s[3] / n);
                 }
                 fprintf(stderr, "[k_round prof] whole sweep mean %.0f ticks over %d workgroups\n", tot / wgs, wgs);
             }
@@ -1302,6 +1379,21 @@ int hmx_cluster_round(hmx_engine* e, int flags, const int32_t* cells, int64_t n_
     }
     e->pre_valid = false;   // caller-provided lists: whatever was prepared ahead is void
     if ((rc = e->lists[e->cur].cells.reserve(n_pos)) || (rc = e->lists[e->cur].tile_grp.reserve(n_tiles))) return rc;
+    {   // first tile of every (block, group) run, when every block's tiles are sorted by group (what harmonypy_amd builds):
+        // k_round's group-affine map takes a workgroup's tiles from its group's run
+        std::vector<int> runs((size_t)e->nblk * e->G + 1, n_tiles);
+        bool sorted = true;
+        for (int b = 0; b < e->nblk && sorted; ++b) {
+            int t = block_tile_start[b];
+            for (int g = 0; g < e->G; ++g) {
+                runs[(size_t)b * e->G + g] = t;
+                while (t < block_tile_start[b + 1] && tile_group[t] == g) ++t;
+            }
+            sorted = t == block_tile_start[b + 1];
+        }
+        e->lists[e->cur].runs_ok = sorted;
+        if (sorted) HIP_TRY(hipMemcpyAsync(e->lists[e->cur].run_tiles.p, runs.data(), runs.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    }
     HIP_TRY(hipMemcpyAsync(e->lists[e->cur].cells.p, cells, n_pos * sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(e->lists[e->cur].tile_grp.p, tile_group, n_tiles * sizeof(int), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(e->lists[e->cur].blk_start.p, block_tile_start, (e->nblk + 1) * sizeof(int), hipMemcpyHostToDevice, e->stream));
@@ -1341,6 +1433,7 @@ static int seeded_round(hmx_engine* e, int flags, uint64_t seed, int64_t cells_p
         o.key0 = (uint32_t)z; o.key1 = (uint32_t)(z >> 32) | 1u;
         o.gstart = e->gstart.p; o.chunk_tab = e->chunk_tab.p; o.run_count = e->run_count.p; o.run_start = e->run_start.p;
         o.blk_start = e->lists[which].blk_start.p; o.cells = e->lists[which].cells.p; o.tile_grp = e->lists[which].tile_grp.p;
+        o.run_tiles = e->lists[which].run_tiles.p; e->lists[which].runs_ok = true;
         if (streaming_rtz(e)) { o.tile_blk = e->tile_blk[which].p; o.s_tile_start = e->s_tile_start.p; }   // block ids in static tile order, by the way
         o.frozen = e->frozen();
         launch_order(o, s);
@@ -1542,8 +1635,8 @@ int hmx_peer_export(hmx_engine* e, void* out_handle) {
     int rc;
     if ((rc = use_device(e))) return rc;
     peer_release(e);
-    const size_t GK = (size_t)e->G * e->K16;
-    e->box_doubles = peer_box_doubles(e->n_ranks, GK);
+    const size_t GKs = (size_t)(e->G + 1) * e->K16;   // a rank's share: the G group rows + the cluster-mass row of k_round's slot tables
+    e->box_doubles = peer_box_doubles(e->n_ranks, GKs);
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->box), e->box_doubles * sizeof(double)));
     HIP_TRY(hipMemset(e->box, 0, e->box_doubles * sizeof(double)));
     HIP_TRY(hipDeviceSynchronize());
@@ -1584,7 +1677,7 @@ int hmx_peer_selftest(hmx_engine* e) {
     if ((rc = use_device(e))) return rc;
     HIP_TRY(hipMemsetAsync(e->sync_words.p, 0, 2 * sizeof(unsigned), e->stream));
     e->selftest_token += 1;
-    launch_peer_selftest(e->peer_dev.p, e->box, e->n_ranks, e->rank, (size_t)e->G * e->K16, e->selftest_token, e->sync_words.p, e->stream);
+    launch_peer_selftest(e->peer_dev.p, e->box, e->n_ranks, e->rank, (size_t)(e->G + 1) * e->K16, e->selftest_token, e->sync_words.p, e->stream);
     HIP_TRY(hipMemcpyAsync(e->sync_host, e->sync_words.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipGetLastError());
@@ -1783,7 +1876,7 @@ int hmx_device_ptr(hmx_engine* e, int which, void** d_ptr, size_t* bytes) {
     return HMX_OK;
 }
 
-int hmx_counters(hmx_engine* e, int64_t out[8]) {
+int hmx_counters(hmx_engine* e, int64_t out[HMX_N_COUNTERS]) {
     if (!e || !out) return fail(HMX_ERR_ARG, "null argument");
     int rc;
     if ((rc = use_device(e))) return rc;
@@ -1798,6 +1891,9 @@ int hmx_counters(hmx_engine* e, int64_t out[8]) {
     out[5] = (int64_t)ws[1];
     out[6] = (int64_t)ws[2];
     out[7] = e->n_rtz_bf16;
+    out[8] = e->n_sweeps_ga;
+    out[9] = e->n_sweeps_ga > 0 ? e->ga_nwg : 0;
+    for (int i = 10; i < HMX_N_COUNTERS; ++i) out[i] = 0;
     return HMX_OK;
 }
 

@@ -44,7 +44,7 @@ struct RoundArgs {
     const int* blk_start;    // nblk+1 tile offsets (device)
     const double* O_start;   // G x K16: O at the start of the round
     const double* S_old;     // nblk x G x K16: removal sums of every block (from the old R)
-    double* S_new;           // nblk x HMX_ROUND_SLOTS x G x K16, zeroed by the caller
+    double* S_new;           // nblk x HMX_ROUND_SLOTS x (G + 1) x K16, zeroed by the caller (row G: cluster mass, group-affine map only)
     double* O_out;           // G x K16: O after the round
     double* T_out;           // K16: cluster mass after the round
     double* obj;             // HMX_OBJ_SLOTS x 2 partial sums + cross-entropy term at [2*HMX_OBJ_SLOTS]
@@ -63,6 +63,12 @@ struct RoundArgs {
     unsigned spin_limit;       // polls a wait may take before it gives up
     int n_ranks, rank;
     int K, Kp, K16, dp, ldy, ldy_lds, G, B, V, nblk;
+    // group-affine tile map (one batch variable): every compute workgroup owns ONE batch group and takes its tiles from that
+    // group's run inside each block; the hand-off then carries K16 entries of the group + K16 cluster masses instead of G x K16
+    int ga;                    // 1: group-affine map, 0: classic (tile pairs dealt round-robin over all workgroups)
+    int ga_opts;               // timing experiments (HMX_ROUND_GA_OPTS): 1 the chain starts behind the distance GEMM, 2 long sleeps between polls
+    const int* run_start;      // ga: nblk * G + 1 tile offsets of the (block, group) runs of the list, key = block * G + group
+    const int* wg_map;         // ga: per compute workgroup {group, rank among the group's workgroups, workgroups of the group}
 };
 
 struct RtzArgs {
@@ -189,6 +195,7 @@ struct OrderArgs {
     int* run_count;        // nblk*G
     int* run_start;        // nblk*G (padded positions)
     int* blk_start;        // nblk+1 (tiles)
+    int* run_tiles;        // nblk*G + 1: first tile of every (block, group) run, then the tile count (or null)
     int* cells;            // padded list
     int* tile_grp;
     // for the streaming R^T.Z pass (k_rtz3): every cell's block id in STATIC tile order, written by the histogram pass
@@ -198,11 +205,9 @@ struct OrderArgs {
     const unsigned* frozen;  // non-zero: leave the lists alone (they may be the lists of a round that is about to be replayed), or null
 };
 
-size_t sweep_lds_bytes(int K16, int d, int G, int B, int V, int nblk);
-int sweep_row_floats(int d);
-int sweep_waves();
-size_t round_lds_bytes(int K16, int dp, int G, int B, int V, bool bf3);
-bool round_uses_bf16_pipe(int K16, int dp, int G, int B, int V, bool extra_tiles, bool allow_bf16);   // which k_round instance launch_round picks
+size_t round_lds_bytes(int K16, int dp, int G, int B, int V, bool bf3, bool ga, int nblk);
+bool round_uses_bf16_pipe(int K16, int dp, int G, int B, int V, bool extra_tiles, bool allow_bf16, bool ga, int nblk);   // which k_round instance launch_round picks
+#define HMX_ROUND_GA_WAVES 7   /* tile-carrying waves of a workgroup under the group-affine map (the eighth runs the hand-off) */
 // k_round has no static LDS and one workgroup per CU: everything the CU has (160 KB), less a small margin
 #define HMX_ROUND_LDS_LIMIT (size_t)(159 * 1024)
 int round_row_floats(int d);

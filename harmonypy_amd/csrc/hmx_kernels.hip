@@ -540,16 +540,20 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES, 4) void k_assign_lds(AssignArgs 
 #define HMX_RABL 0   /* timing experiments only: 1 no block sums, 2 no R store, 4 no exp in round_post */
 #endif
 #ifdef HMX_ROUND_PROF   /* timing experiments only: per-workgroup phase stamps (s_memtime) */
-#define RSTAMP(slot) do { if (tid == 0 && a.prof) a.prof[((size_t)wg * a.nblk + b) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define TSTAMP(slot) do { if (tid == 0 && a.prof && prof_b >= 0) a.prof[((size_t)wg * a.nblk + prof_b) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define RSTAMP(slot) do { if (tid == 0 && a.prof) a.prof[((size_t)wg * a.nblk + b) * 32 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TSTAMP(slot) do { if (tid == 0 && a.prof && prof_b >= 0) a.prof[((size_t)wg * a.nblk + prof_b) * 32 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+/* the chain wave of the group-affine map (lane 0 of the last wave), slots 16.. of block `blk` */
+#define CSTAMP(blk, slot) do { if (lane == 0 && a.prof) a.prof[((size_t)wg * a.nblk + (blk)) * 32 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define RSTAMP(slot) do { } while (0)
 #define TSTAMP(slot) do { } while (0)
+#define CSTAMP(blk, slot) do { } while (0)
 #endif
 // s_waitcnt vmcnt(0) as the builtin (gfx9 encoding: vmcnt 0, expcnt 7, lgkmcnt 15), so that the compiler's own wait
 // insertion knows nothing is outstanding afterwards; as inline assembly it is invisible to it and every later
 // wait it computes assumes the older operations are still in flight
 #define WAIT_VMEM_ALL() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); } while (0)
+#define ROUND_FLAGS 8   /* group-affine map: replicas of the "block complete" flag, one 128-byte line each, behind the arrival counter */
 #define ROUND_WAVES 8   /* 2 waves per SIMD: 256 registers per lane, two tiles in flight per wave */
 #define ROUND_TPW 2     /* tiles a wave carries across the hand-off */
 #define ROUND_THREADS (64 * ROUND_WAVES)
@@ -949,7 +953,10 @@ __device__ __forceinline__ void block_sums_rs(const f32x4 (&sm)[NM], double* sd,
     if (i < 4 * NM) atomicAdd(sd + 16 * (i >> 2) + 4 * q + (i & 3), (double)tot);   // value i = cluster tile i / 4 of the group, register i % 4
 }
 
-template <int MT>
+// WHAT = 3: rows out and block sums (one pass); 1: block sums only, 2: rows only -- k_round's group-affine map runs the two
+// halves on either side of the workgroup barrier, so that the hand-off's atomics enter the CU's memory pipeline in FRONT of
+// the block's row stores instead of queueing behind them
+template <int MT, int WHAT = 3>
 __device__ __forceinline__ void round_post_pass2(float* R, int Kp, double* Sd, int c16, int q, const RoundTile<MT>& T0,
                                                  float scl0, bool has1, const RoundTile<MT>& T1, float scl1) {
     constexpr int K16 = 16 * MT;
@@ -971,10 +978,11 @@ __device__ __forceinline__ void round_post_pass2(float* R, int Kp, double* Sd, i
             rv0[m] = T0.arg[mt] * scl0;                    // :503
             rv1[m] = T1.arg[mt] * scl1;
 #if !(HMX_RABL & 2)
-            if (live0 && col < Kp) st4(row0 + col, rv0[m]);
-            if (live1 && col < Kp) st4(row1 + col, rv1[m]);
+            if ((WHAT & 2) && live0 && col < Kp) st4(row0 + col, rv0[m]);
+            if ((WHAT & 2) && live1 && col < Kp) st4(row1 + col, rv1[m]);
 #endif
         }
+        if (!(WHAT & 1)) return;
 #if !(HMX_RABL & 1)
         if (joint || !has1) {                              // one table row for both tiles (scl1 == 0 without a second tile)
 #pragma unroll
@@ -1412,7 +1420,20 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int K16 = 16 * MT;
     constexpr int NF = KS / 4, NT = KS % 4;
-    const int GK = a.G * K16;
+    // Two ways of dealing a block's tiles out.  CLASSIC: tile pair p goes to workgroup p % nwg -- a workgroup's tiles are
+    // spread over the whole group-sorted block, so it keeps the diversity table of ALL groups (G x K16 entries) and publishes
+    // sums for all of them.  GROUP-AFFINE (a.ga; one batch variable): workgroup w owns ONE group g(w) (host table wg_map,
+    // workgroup counts in proportion to the groups' sizes) and takes its tiles from that group's run inside every block
+    // (run_start), so the per-block hand-off shrinks from G x K16 entries to K16 of its own group plus the K16 cluster masses
+    // T_k = sum_g O[g][k] (:491), which travel as row G of the slot tables: fold 4 x 2 K16 agent loads instead of 4 G K16,
+    // K16 powers instead of G K16, 2 K16 returning adds instead of G K16.  With the table that small the whole hand-off chain
+    // (publish, arrive, poll, fold, power table) is run by the workgroup's LAST wave alone (it carries no tiles) UNDER the
+    // other seven waves' distance GEMM of the next block.
+    const bool ga = a.ga != 0;
+    const int Gl = ga ? 1 : a.G;                       // rows of the workgroup's LDS tables
+    const int GK = Gl * K16;                           // entries of the LDS tables
+    const int GKg = a.G * K16;                         // entries of the global tables O_start, S_old, O_out
+    const int GKs = (a.G + 1) * K16;                   // stride of a slot table / of a rank's share of a peer box (row G: cluster mass, GA only)
     const int LDY = a.ldy_lds;
     constexpr bool LOG2 = HMX_ROUND_EXP2 != 0, A2TAB = HMX_ROUND_A2TAB != 0;
     constexpr bool BF3 = BF3T && LOG2;                                   // distance GEMM on the bf16 pipe (round_compute_bf3)
@@ -1427,18 +1448,20 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     float* nis0 = sig0 + K16;                                            // K16  -1/sigma (-1e30 for pads)
     float* sig = sig0;
     float* nis = nis0;
-    float* rpT = nis + K16;                                              // G x K16
-    float* lrpT = rpT + GK;                                              // G x K16
+    float* rpT = nis + K16;                                              // Gl x K16
+    float* lrpT = rpT + GK;                                              // Gl x K16
     float* rpc = lrpT + GK;                                              // B x K16 powered ratios (several batch variables only)
-    double* Ocur = reinterpret_cast<double*>(rpc + (a.V == 1 ? 0 : (size_t)K16 * a.B));   // G x K16 (all offsets so far are even)
-    double* Sd = Ocur + GK;                                              // G x K16 this block's new sums
+    double* Ocur = reinterpret_cast<double*>(rpc + (a.V == 1 ? 0 : (size_t)K16 * a.B));   // Gl x K16 (all offsets so far are even)
+    double* Sd = Ocur + GK;                                              // Gl x K16 this block's new sums
     double* Tm = Sd + GK;                                                // K16 cluster mass
     double* objw = Tm + K16;                                             // waves x 2
     float* prb = reinterpret_cast<float*>(objw + 2 * ROUND_WAVES);       // B
     float* tht = prb + a.B;                                              // B
     int* gcol = reinterpret_cast<int*>(tht + a.B);                       // G x V
     int* bgrp = gcol + a.G * a.V;                                        // B: the group holding batch b (V == 1)
-    int* bs = bgrp + a.B;                                                // nblk + 3 tile offsets (two sentinels)
+    int* bsS = bgrp + a.B;                                               // nblk + 3: first tile of the workgroup's run in block b (two sentinels)
+    int* bsN = bsS + a.nblk + 3;                                         // nblk + 3: tiles of that run (classic: the whole block)
+    int* wgfail = bsN + a.nblk + 3;                                      // GA: a grid-wide wait of the chain wave gave up
 
     int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the wave's landing zones and roles are wave-uniform
@@ -1446,7 +1469,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     int c16 = lane & 15, q = lane >> 4;   // (refreshed per block, see the sweep loop)
     const bool multi = a.n_ranks > 1;
     const int wg = blockIdx.x, nwg = multi ? gridDim.x - 1 : gridDim.x;   // compute workgroups
-    unsigned long long* my_flags = multi ? reinterpret_cast<unsigned long long*>(a.my_box + box_flags(a.n_ranks, GK)) : nullptr;
+    unsigned long long* my_flags = multi ? reinterpret_cast<unsigned long long*>(a.my_box + box_flags(a.n_ranks, GKs)) : nullptr;
 
     if (multi && wg == nwg) {
         // ---- gateway workgroup: once every local workgroup has added its sums of block b, write the
@@ -1462,21 +1485,22 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                 }
             }
             __syncthreads();
-            for (int i = tid; i < GK; i += ROUND_THREADS) {
-                const double* sn = a.S_new + (size_t)b * HMX_ROUND_SLOTS * GK + i;
+            const int nfw = ga ? GKs : GKg;   // group-affine: the cluster-mass row travels too
+            for (int i = tid; i < nfw; i += ROUND_THREADS) {
+                const double* sn = a.S_new + (size_t)b * HMX_ROUND_SLOTS * GKs + i;
                 double v = 0.0;
 #pragma unroll
-                for (int s = 0; s < HMX_ROUND_SLOTS; ++s) v += ld_agent(sn + (size_t)s * GK);
+                for (int s = 0; s < HMX_ROUND_SLOTS; ++s) v += ld_agent(sn + (size_t)s * GKs);
 #if HMX_ROUND_RETURNING
-                for (int r = 0; r < a.n_ranks; ++r) xchg_sys(a.peer_box[r] + box_data(a.n_ranks, GK, b & 1, a.rank) + i, v);
+                for (int r = 0; r < a.n_ranks; ++r) xchg_sys(a.peer_box[r] + box_data(a.n_ranks, GKs, b & 1, a.rank) + i, v);
 #else
-                for (int r = 0; r < a.n_ranks; ++r) st_sys(a.peer_box[r] + box_data(a.n_ranks, GK, b & 1, a.rank) + i, v);
+                for (int r = 0; r < a.n_ranks; ++r) st_sys(a.peer_box[r] + box_data(a.n_ranks, GKs, b & 1, a.rank) + i, v);
 #endif
             }
             WAIT_VMEM_ALL();
             __syncthreads();
             if (tid < a.n_ranks)
-                st_sys(reinterpret_cast<unsigned long long*>(a.peer_box[tid] + box_flags(a.n_ranks, GK)) + (size_t)(b & 1) * a.n_ranks + a.rank,
+                st_sys(reinterpret_cast<unsigned long long*>(a.peer_box[tid] + box_flags(a.n_ranks, GKs)) + (size_t)(b & 1) * a.n_ranks + a.rank,
                        a.epoch + (unsigned long long)b + 1ull);
         }
         if (gfail && tid == 0) {
@@ -1495,7 +1519,17 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         gcol[i] = a.group_cols[i];
         if (a.V == 1) bgrp[a.group_cols[i]] = i;
     }
-    for (int i = tid; i < a.nblk + 3; i += ROUND_THREADS) bs[i] = a.blk_start[min(i, a.nblk)];
+    // the workgroup's map: group-affine (its group, its rank among the group's workgroups, their number) or classic
+    const int g_own = ga ? a.wg_map[3 * wg] : 0;
+    const int wl = ga ? a.wg_map[3 * wg + 1] : wg;
+    const int ng = ga ? a.wg_map[3 * wg + 2] : nwg;
+    const int n_tiles_all = a.blk_start[a.nblk];
+    for (int i = tid; i < a.nblk + 3; i += ROUND_THREADS) {
+        if (i >= a.nblk) { bsS[i] = n_tiles_all; bsN[i] = 0; }
+        else if (ga) { bsS[i] = a.run_start[i * a.G + g_own]; bsN[i] = a.run_start[i * a.G + g_own + 1] - bsS[i]; }
+        else { bsS[i] = a.blk_start[i]; bsN[i] = a.blk_start[i + 1] - bsS[i]; }
+    }
+    if (tid == 0) *wgfail = 0;
     constexpr float TWO_LOG2E = 2.885390081777926814f;
     for (int i = tid; i < K16; i += ROUND_THREADS) {
         const float sgm = (i < a.K) ? a.sigma[i] : 0.f;
@@ -1503,7 +1537,16 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         if (LOG2) nis[i] = (i < a.K) ? -(TWO_LOG2E / sgm) : -200.f;   // the accumulators start here; pads: Y row 0 -> 2^-200 == 0
         else nis[i] = (i < a.K) ? -1.0f / sgm : -60.f;               // pads: Y row 0 -> dist 2 -> arg -120 -> exp == 0
     }
-    for (int i = tid; i < GK; i += ROUND_THREADS) Ocur[i] = a.O_start[i];
+    for (int i = tid; i < GK; i += ROUND_THREADS) {
+        Ocur[i] = a.O_start[(ga ? g_own * K16 : 0) + i];
+        Sd[i] = 0.0;
+    }
+    if (ga)
+        for (int k = tid; k < K16; k += ROUND_THREADS) {
+            double t = 0.0;
+            for (int g = 0; g < a.G; ++g) t += a.O_start[(size_t)g * K16 + k];
+            Tm[k] = t;
+        }
     if (BF3) {
         constexpr int NP = 8 * bf3_steps(KS), LDB = bf3_ldb(KS);     // pieces per row incl. the zero ones past the row
         for (int i = tid; i < K16 * NP; i += ROUND_THREADS) {
@@ -1536,12 +1579,15 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     // configs[1] (G K16 = 128) 129.5-131.8 -> 126.7 us per sweep, but C3 (896 entries: 14 adds per lane from ONE wave, behind
     // the other waves' row stores in the CU's memory pipeline) 322 -> 390 us -- there everybody publishes as before.
     bool pubwave = false;
-    if (HMX_ROUND_PUBWAVE && GK <= 256) {
+    if (HMX_ROUND_PUBWAVE && GK <= 256 && !ga) {
         int max_ntl = 0;
-        for (int bb = 0; bb < a.nblk; ++bb) max_ntl = max(max_ntl, bs[bb + 1] - bs[bb]);
+        for (int bb = 0; bb < a.nblk; ++bb) max_ntl = max(max_ntl, bsN[bb]);
         pubwave = ROUND_TPW * (blockIdx.x + (multi ? (int)gridDim.x - 1 : (int)gridDim.x) * (ROUND_WAVES - 1)) >= max_ntl;
     }
-    const bool service = pubwave && wv == ROUND_WAVES - 1;        // wave-uniform
+    // group-affine: the last wave carries no tile by construction (seven tile-carrying waves) and runs the hand-off chain
+    const bool nochain = ga && (a.ga_opts & 128);   // (experiment: eight tile-carrying waves, the hand-off by one wave between GEMM and finishing pass)
+    const bool service = (pubwave || (ga && !nochain)) && wv == ROUND_WAVES - 1;        // wave-uniform
+    const bool chain = ga && !nochain && wv == ROUND_WAVES - 1;
 
     RoundTile<MT> T[ROUND_TPW];
     float* zb[ROUND_TPW];
@@ -1552,16 +1598,17 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     bool valid2[ROUND_TPW] = {false, false};
     double km_acc = 0.0, ent_acc = 0.0;
     bool failed = false;
-    unsigned ws_n = 0, ws_sum = 0, ws_max = 0;   // this workgroup's grid-wide waits (wave 0)
-    // tiles 2p, 2p+1 of a block go to workgroup p % nwg, wave (p / nwg) % WAVES (pass p / nwg / WAVES)
-    const int j_first = ROUND_TPW * (wg + nwg * wv);
-    const int j_slot = ROUND_TPW * nwg * ROUND_WAVES;
-    auto load_ids = [&](int blk, int u, int& cell, int& grp) {   // blk may run past the last block: bs[] has sentinels
+    unsigned ws_n = 0, ws_sum = 0, ws_max = 0;   // this workgroup's grid-wide waits (wave 0; group-affine: the chain wave)
+    // classic: tiles 2p, 2p+1 of a block go to workgroup p % nwg, wave (p / nwg) % WAVES (pass p / nwg / WAVES);
+    // group-affine: the same deal among the ng workgroups of the group over its run, seven waves per workgroup
+    const int cwaves = (ga && !nochain) ? ROUND_WAVES - 1 : ROUND_WAVES;
+    const int j_first = chain ? (1 << 28) : ROUND_TPW * (wl + ng * wv);
+    const int j_slot = ROUND_TPW * ng * cwaves;
+    auto load_ids = [&](int blk, int u, int& cell, int& grp) {   // blk may run past the last block: bsS / bsN have sentinels
         const int j = j_first + u;
-        const int t0 = bs[blk], t1 = bs[blk + 1];
-        const bool valid = j < t1 - t0;
-        cell = valid ? a.cells[(size_t)(t0 + j) * 16 + c16] : -1;
-        grp = valid ? a.tile_grp[t0 + j] : 0;
+        const bool valid = j < bsN[blk];
+        cell = valid ? a.cells[(size_t)(bsS[blk] + j) * 16 + c16] : -1;
+        grp = (valid && !ga) ? a.tile_grp[bsS[blk] + j] : 0;    // (group-affine: the LDS tables hold the workgroup's own group only)
     };
 
     // A tile's 16 Z_cos rows travel global -> LDS directly (no destination registers: held in VGPRs across the finishing
@@ -1631,7 +1678,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     auto tile_step = [&](int blk_ids) {
         // a wave without a tile in the block it is about to multiply (the last wave of most workgroups, every block) only
         // keeps its id pipeline going: no rows, no GEMM on dummy operands -- it is the wave that arrives for the workgroup
-        const bool live = j_first < bs[blk_ids - 1] - bs[blk_ids - 2];   // wave-uniform
+        const bool live = j_first < bsN[blk_ids - 2];   // wave-uniform
         RoundZ<KS> Zf[ROUND_TPW];
         f32x4 raw[ROUND_TPW][2 * bf3_steps(KS)];
         if (live) {
@@ -1645,13 +1692,13 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         auto request = [&]() {
 #pragma unroll
         for (int u = 0; u < ROUND_TPW; ++u) {
-            if (j_first + u < bs[blk_ids] - bs[blk_ids - 1]) issue_rows(cell1[u], zb[u]);   // (wave-uniform: the tile exists)
+            if (j_first + u < bsN[blk_ids - 1]) issue_rows(cell1[u], zb[u]);   // (wave-uniform: the tile exists)
             // ids of the block after: clamped loads, the "no such tile" case applied when they are shifted in -- a
             // predicated load or a select here would be waited for at once, and with it every row request above
             const int j = j_first + u;
-            const int t0 = bs[blk_ids], t1 = bs[blk_ids + 1];
-            valid2[u] = j < t1 - t0;
-            const int tl = max(min(t0 + j, bs[a.nblk] - 1), 0);   // (a shard may hold no tile at all)
+            const int t0 = bsS[blk_ids];
+            valid2[u] = j < bsN[blk_ids];
+            const int tl = max(min(t0 + j, n_tiles_all - 1), 0);   // (a shard may hold no tile at all)
             cell2[u] = a.cells[(size_t)tl * 16 + c16];
             grp2[u] = a.tile_grp[tl];
         }
@@ -1679,15 +1726,205 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         round_compute<MT, KS, LOG2>(Ys, nis, LDY, c16, q, Zf[1], T[1]);
         __builtin_amdgcn_sched_barrier(0);
     };
+    // ---- grid-wide wait: every workgroup has added its sums of block `bdone` (one wave; its lanes are all active) --------
+    auto wait_block = [&](int bdone) {
+        if (failed) return;          // (a wait that gave up is not repeated block after block: the launch is lost)
+        unsigned spins = 0;
+        if (a.spin_limit == 0) failed = true;   // test knob: give up without looking
+        if (failed) {
+        } else if (!multi && ga && (a.ga_opts & 16)) {
+            // the workgroup that arrived LAST has raised the block's flag in every replica: the pollers read a line that carries
+            // no read-modify-writes, a few of them per line
+            const unsigned* fl = a.counter + 32 * (1 + (wg & (ROUND_FLAGS - 1)));
+            while (ld_agent(fl) < (unsigned)(bdone + 1)) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > a.spin_limit) { failed = true; break; }
+            }
+        } else if (!multi) {
+            const unsigned want = (unsigned)(bdone + 1) * (unsigned)nwg;
+            while (ld_agent(a.counter) < want) {
+                if (a.ga_opts & 2) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(1);
+                if (++spins > a.spin_limit) { failed = true; break; }
+            }
+        } else {   // every rank's total of the block has landed in this rank's box
+            const unsigned long long want = a.epoch + (unsigned long long)bdone + 1ull;
+            const unsigned long long* fl = my_flags + (size_t)(bdone & 1) * a.n_ranks;
+            while (true) {
+                const bool ok = lane >= a.n_ranks || ld_sys(fl + lane) >= want;
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > a.spin_limit) { failed = true; break; }
+            }
+        }
+        ws_n += 1; ws_sum += spins; ws_max = max(ws_max, spins);
+#ifdef HMX_ROUND_PROF
+        if (lane == 0 && a.prof) a.prof[((size_t)wg * a.nblk + bdone + 1) * 32 + 10] = spins;
+#endif
+    };
+    // ---- group-affine hand-off, run by the chain wave alone; a lane owns the table entries k = lane and lane + 64 ---------
+    // O of the own group and the cluster mass T without block b's old sums and with block b-1's new ones (:491-492,
+    // 506-507), then ratio ** theta and its log for block b (:495-499): one round trip of loads, one power chain.
+    // the sums all workgroups (all ranks) added for block bp, per own entry: own group's row ao[n][], cluster-mass row at[n][]
+    const bool fx = ga && !multi && (a.ga_opts & 32);
+    constexpr unsigned long long FX_MASK = (1ull << 55) - 1ull;
+    auto ga_fetch = [&](int bp, double (&ao)[2][8], double (&at)[2][8]) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) ao[n][s] = at[n][s] = 0.0;
+        if (bp < 0) return;
+        if (fx) {
+            // self-validating entries: every workgroup adds (1 << 55) + its sum in 2^-32 fixed point to every entry of its two
+            // rows, so an entry whose count field has reached the number of contributors IS complete -- no arrival counter, no
+            // flag, no ordering between addresses, and the poll that succeeds has brought the data along
+            unsigned long long wo[2][HMX_ROUND_SLOTS], wt[2][HMX_ROUND_SLOTS];
+            unsigned spins = 0;
+            if (a.spin_limit == 0) failed = true;
+            while (true) {
+                bool ok = true;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int k = min(lane + 64 * n, K16 - 1);
+                    const unsigned long long* sn = reinterpret_cast<const unsigned long long*>(a.S_new) + (size_t)bp * HMX_ROUND_SLOTS * GKs + k;
+#pragma unroll
+                    for (int s = 0; s < HMX_ROUND_SLOTS; ++s) {
+                        wo[n][s] = __hip_atomic_load(sn + (size_t)s * GKs + (size_t)g_own * K16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        wt[n][s] = __hip_atomic_load(sn + (size_t)s * GKs + (size_t)a.G * K16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    unsigned co = 0, ct = 0;
+#pragma unroll
+                    for (int s = 0; s < HMX_ROUND_SLOTS; ++s) { co += (unsigned)(wo[n][s] >> 55); ct += (unsigned)(wt[n][s] >> 55); }
+                    ok = ok && co == (unsigned)ng && ct == (unsigned)nwg;
+                }
+                if (__all(ok) || failed) break;
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > a.spin_limit) { failed = true; break; }
+            }
+            ws_n += 1; ws_sum += spins; ws_max = max(ws_max, spins);
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int s = 0; s < HMX_ROUND_SLOTS; ++s) {
+                    ao[n][s] = (double)(long long)(wo[n][s] & FX_MASK) * 0x1p-32;
+                    at[n][s] = (double)(long long)(wt[n][s] & FX_MASK) * 0x1p-32;
+                }
+            return;
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int k = min(lane + 64 * n, K16 - 1);                   // clamped, not predicated
+            if (!multi) {
+                const double* sn = a.S_new + (size_t)bp * HMX_ROUND_SLOTS * GKs + k;
+#pragma unroll
+                for (int s = 0; s < HMX_ROUND_SLOTS; ++s) {      // independent loads, all in flight together
+                    ao[n][s] = ld_agent(sn + (size_t)s * GKs + (size_t)g_own * K16);
+                    at[n][s] = ld_agent(sn + (size_t)s * GKs + (size_t)a.G * K16);
+                }
+            } else {
+                const double* bx = a.my_box + box_data(a.n_ranks, GKs, bp & 1, 0) + k;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    ao[n][s] = ld_sys(bx + (size_t)min(s, a.n_ranks - 1) * GKs + (size_t)g_own * K16);
+                    at[n][s] = ld_sys(bx + (size_t)min(s, a.n_ranks - 1) * GKs + (size_t)a.G * K16);
+                }
+            }
+        }
+    };
+    auto ga_table = [&](int b) {
+        double so[2], st[2], ao[2][8], at[2][8];
+        ga_fetch(b - 1, ao, at);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int k = min(lane + 64 * n, K16 - 1);                   // clamped, not predicated
+            const double* sold = a.S_old + (size_t)b * GKg + k;         // constant during the launch: plain loads
+            so[n] = sold[(size_t)g_own * K16];
+            double t = 0.0;
+            for (int g0 = 0; g0 < a.G; g0 += 8) {                       // eight loads in flight at a time
+                double v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = sold[(size_t)min(g0 + j, a.G - 1) * K16];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t += (g0 + j < a.G) ? v[j] : 0.0;
+            }
+            st[n] = t;
+        }
+        const int bo = gcol[g_own];                                      // the group's batch (one batch variable)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int k = lane + 64 * n;
+            if (k < K16) {
+                double o = Ocur[k] - so[n], t = Tm[k] - st[n];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const bool use = !multi ? s < HMX_ROUND_SLOTS : s < a.n_ranks;
+                    o += use ? ao[n][s] : 0.0;
+                    t += use ? at[n][s] : 0.0;
+                }
+                Ocur[k] = o;
+                Tm[k] = t;
+                const float O = (float)o;
+                const float E = (float)t * prb[bo];                         // :491 (E kept as mass T)
+                const float oe = fmaxf(O + E, 1e-8f);                       // :495-496
+                const float ratio = fminf(fmaxf(E / oe, 1e-8f), 1.0f);      // :497-498
+                const float rp = pow_unit(ratio, tht[bo]);                  // :499
+                rpT[k] = rp;
+                lrpT[k] = __builtin_amdgcn_logf(rp) * 0.693147182464599609375f;   // v_log_f32 (log2, 1 ulp) * ln 2
+            }
+        }
+    };
+    // the workgroup's sums of block b into its group's row and into the cluster-mass row of one slot table, then arrive
+    auto ga_publish = [&](int b) {
+        double* dst = a.S_new + ((size_t)b * HMX_ROUND_SLOTS + (wg % HMX_ROUND_SLOTS)) * GKs;
+        double a2s = 0.0;
+        double olds[4] = {0.0, 0.0, 0.0, 0.0};   // returning adds, all in flight together: behind the wave's vmcnt(0) they are PERFORMED
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int k = lane + 64 * n;
+            if (k < K16) {
+                const double v = Sd[k];
+                Sd[k] = 0.0;
+                if (A2TAB) a2s += v * (double)(lrpT[k] * sig[k]);       // (:402), see round_post_pass1
+                if (fx) {   // count + fixed-point sum in one word, fire and forget (see ga_fetch)
+                    const unsigned long long w = (1ull << 55) + (unsigned long long)__double2ll_rn(v * 4294967296.0);
+                    unsigned long long* du = reinterpret_cast<unsigned long long*>(dst);
+                    __hip_atomic_fetch_add(du + (size_t)g_own * K16 + k, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(du + (size_t)a.G * K16 + k, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (v != 0.0) {
+                    olds[2 * n] = atomicAdd(dst + (size_t)g_own * K16 + k, v);
+                    olds[2 * n + 1] = atomicAdd(dst + (size_t)a.G * K16 + k, v);
+                }
+            }
+        }
+        if (A2TAB) ent_acc += a2s;
+        if (fx) return;
+        WAIT_VMEM_ALL();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(olds[t]));
+        if (!multi && (a.ga_opts & 16)) {
+            unsigned old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old + 1u == (unsigned)(b + 1) * (unsigned)nwg && lane < ROUND_FLAGS)   // the last arrival of the block raises the flags
+                __hip_atomic_store(a.counter + 32 * (1 + lane), (unsigned)(b + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (lane == 0) __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+
     if (!service) {
 #pragma unroll
         for (int u = 0; u < ROUND_TPW; ++u) issue_rows(T[u].cell, zb[u]);
         WAIT_VMEM_ALL();   // landed (nothing else orders an LDS read behind an LDS-DMA)
         tile_step(2);
     }
+    if (chain) ga_table(0);
+    if (nochain && wv == ROUND_WAVES - 1) ga_table(0);
 
+    const bool split_store = ga && !(a.ga_opts & 64);
+    float sclk0 = 0.f, sclk1 = 0.f;
     for (int b = 0; b < a.nblk; ++b) {
-        const int tb = bs[b], ntl = bs[b + 1] - tb;
+        const int tb = bsS[b], ntl = bsN[b];
         {   // the tables do not change, but re-reading them every block is cheaper than the ~150
             // registers the compiler would spend keeping their fragments live across the sweep
             int zero = 0;
@@ -1702,32 +1939,11 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         }
         RSTAMP(0);
         RSTAMP(8);
+        if (ga) { RSTAMP(9); RSTAMP(1); RSTAMP(6); RSTAMP(7); }
+        if (nochain && b > 0 && wv == ROUND_WAVES - 1) ga_table(b);
+        if (!ga) {
         // ---- wait until every workgroup has added its sums of block b-1 ---------------------
-        if (b > 0 && wv == 0 && !failed) {   // (a wait that gave up is not repeated block after block: the launch is lost)
-            unsigned spins = 0;
-            if (a.spin_limit == 0) failed = true;   // test knob: give up without looking
-            if (failed) {
-            } else if (!multi) {
-                const unsigned want = (unsigned)b * (unsigned)nwg;
-                while (ld_agent(a.counter) < want) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > a.spin_limit) { failed = true; break; }
-                }
-            } else {   // every rank's total of block b-1 has landed in this rank's box
-                const unsigned long long want = a.epoch + (unsigned long long)b;
-                const unsigned long long* fl = my_flags + (size_t)((b - 1) & 1) * a.n_ranks;
-                while (true) {
-                    const bool ok = lane >= a.n_ranks || ld_sys(fl + lane) >= want;
-                    if (__all(ok)) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > a.spin_limit) { failed = true; break; }
-                }
-            }
-            ws_n += 1; ws_sum += spins; ws_max = max(ws_max, spins);
-#ifdef HMX_ROUND_PROF
-            if (tid == 0 && a.prof) a.prof[((size_t)wg * a.nblk + b) * 16 + 10] = spins;
-#endif
-        }
+        if (b > 0 && wv == 0) wait_block(b - 1);
         RSTAMP(9);
         wg_barrier_lds();
         RSTAMP(1);
@@ -1739,16 +1955,16 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                 const int i = min(base + n * ROUND_THREADS, GK - 1);    // clamped, not predicated
 #pragma unroll
                 for (int s = 0; s < 8; ++s) add[n][s] = 0.0;
-                so[n] = a.S_old[(size_t)b * GK + i];
+                so[n] = a.S_old[(size_t)b * GKg + i];
                 if (b > 0 && !(HMX_RABL & 8)) {
                     if (!multi) {
-                        const double* sn = a.S_new + (size_t)(b - 1) * HMX_ROUND_SLOTS * GK + i;
+                        const double* sn = a.S_new + (size_t)(b - 1) * HMX_ROUND_SLOTS * GKs + i;
 #pragma unroll
-                        for (int s = 0; s < HMX_ROUND_SLOTS; ++s) add[n][s] = ld_agent(sn + (size_t)s * GK);   // independent loads
+                        for (int s = 0; s < HMX_ROUND_SLOTS; ++s) add[n][s] = ld_agent(sn + (size_t)s * GKs);   // independent loads
                     } else {
-                        const double* bx = a.my_box + box_data(a.n_ranks, GK, (b - 1) & 1, 0) + i;
+                        const double* bx = a.my_box + box_data(a.n_ranks, GKs, (b - 1) & 1, 0) + i;
 #pragma unroll
-                        for (int s = 0; s < 8; ++s) add[n][s] = ld_sys(bx + (size_t)min(s, a.n_ranks - 1) * GK);
+                        for (int s = 0; s < 8; ++s) add[n][s] = ld_sys(bx + (size_t)min(s, a.n_ranks - 1) * GKs);
                     }
                 }
             }
@@ -1813,6 +2029,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             lrpT[i] = __builtin_amdgcn_logf(s) * 0.693147182464599609375f;   // v_log_f32 (log2, 1 ulp) * ln 2
         }
         }
+        }   // (!ga: the chain wave built block b's table behind the previous block's publish)
         wg_barrier_lds();
         RSTAMP(2);
         // ---- finish this block's tiles --------------------------------------------------------
@@ -1823,7 +2040,8 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             if (has1) round_post_pass1<MT, true, LOG2, A2TAB>(sig, rpT, lrpT, q, T[1], scl1, km_acc, ent_acc);
             __builtin_amdgcn_sched_barrier(0);
-            round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T[0], scl0, has1, T[1], scl1);
+            if (split_store) { round_post_pass2<MT, 1>(a.R, a.Kp, Sd, c16, q, T[0], scl0, has1, T[1], scl1); sclk0 = scl0; sclk1 = scl1; }
+            else round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T[0], scl0, has1, T[1], scl1);
         }
         for (int j = j_first + j_slot; j < ntl; j += j_slot) {   // blocks larger than the grid carries
 #pragma unroll 1
@@ -1831,7 +2049,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                 if (j + u >= ntl) break;
                 RoundTile<MT> X;
                 X.cell = a.cells[(size_t)(tb + j + u) * 16 + c16];
-                X.grp = a.tile_grp[tb + j + u];
+                X.grp = ga ? 0 : a.tile_grp[tb + j + u];
                 if (BF3) {
                     f32x4 xraw[2 * bf3_steps(KS)];
                     RoundZ3<KS> XZ3;
@@ -1851,9 +2069,36 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         wg_barrier_lds();
         RSTAMP(3);
         // ---- publish the block's new sums, then arrive ---------------------------------------
-        if (pubwave) {
+        if (nochain) {
+            if (split_store && j_first < ntl)
+                round_post_pass2<MT, 2>(a.R, a.Kp, Sd, c16, q, T[0], sclk0, j_first + 1 < ntl, T[1], sclk1);
+            if (wv == ROUND_WAVES - 1) ga_publish(b);
+            WAIT_VMEM_ALL();
+        } else if (ga) {
+            if (chain) {
+                CSTAMP(b, 16);
+                ga_publish(b);
+                CSTAMP(b, 17);
+                if (a.ga_opts & 1) wg_barrier_lds();   // (experiment: the chain waits for the other waves' distance GEMM)
+                if (a.ga_opts & 4) { for (int z = 0; z < (a.ga_opts >> 8); ++z) __builtin_amdgcn_s_sleep(16); }   // (experiment: sleep (opts >> 8) k cycles before the first poll)
+                if (a.ga_opts & 8) {   // (experiment: poll a word nobody writes for (opts >> 8) polls: a load in flight, no hot line)
+                    for (int z = 0; z < (a.ga_opts >> 8); ++z) { const unsigned v = ld_agent(a.counter + 64 + wg); asm volatile("" ::"v"(v)); __builtin_amdgcn_s_sleep(1); }
+                }
+                if (b + 1 < a.nblk) {   // straight on to the next block's table, under the other waves' distance GEMM
+                    if (!fx) wait_block(b);
+                    CSTAMP(b, 18);
+                    ga_table(b + 1);
+                    CSTAMP(b, 19);
+                }
+            } else {
+                // the rows go out BEHIND the barrier: the chain wave's adds are in the memory pipeline first
+                if (split_store && j_first < ntl)
+                    round_post_pass2<MT, 2>(a.R, a.Kp, Sd, c16, q, T[0], sclk0, j_first + 1 < ntl, T[1], sclk1);
+                WAIT_VMEM_ALL();   // this wave's row stores (and the next operands landed); nobody waits for it
+            }
+        } else if (pubwave) {
             if (service) {
-                double* dst = a.S_new + ((size_t)b * HMX_ROUND_SLOTS + (wg % HMX_ROUND_SLOTS)) * GK;
+                double* dst = a.S_new + ((size_t)b * HMX_ROUND_SLOTS + (wg % HMX_ROUND_SLOTS)) * GKs;
                 double a2s = 0.0;
                 // all adds in flight together (each one's old value is only looked at behind the last: one round trip, not
                 // four); returning, so that behind the wave's vmcnt(0) they are PERFORMED
@@ -1878,7 +2123,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             }
         } else {
         {
-            double* dst = a.S_new + ((size_t)b * HMX_ROUND_SLOTS + (wg % HMX_ROUND_SLOTS)) * GK;
+            double* dst = a.S_new + ((size_t)b * HMX_ROUND_SLOTS + (wg % HMX_ROUND_SLOTS)) * GKs;
             double a2s = 0.0;
             for (int i = tid; i < GK; i += ROUND_THREADS) {
                 double v = Sd[i];
@@ -1906,18 +2151,20 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             T[u].cell = cell1[u];
             T[u].grp = grp1[u];
             cell1[u] = valid2[u] ? cell2[u] : -1;
-            grp1[u] = valid2[u] ? grp2[u] : 0;
+            grp1[u] = (valid2[u] && !ga) ? grp2[u] : 0;
         }
         prof_b = b;
         if (b + 1 < a.nblk && !service) tile_step(b + 3);   // rows landed: vmcnt(0) above
         RSTAMP(5);
+        if (ga && (a.ga_opts & 1) && !chain) wg_barrier_lds();
     }
 
-    if (tid == 0 && a.wait_stats) {
+    if (lane == 0 && wv == (ga ? ROUND_WAVES - 1 : 0) && a.wait_stats) {   // (the wave that waits)
         atomicAdd(a.wait_stats, (unsigned long long)ws_n);
         atomicAdd(a.wait_stats + 1, (unsigned long long)ws_sum);
         atomicMax(a.wait_stats + 2, (unsigned long long)ws_max);
     }
+    if (ga && wv == ROUND_WAVES - 1 && failed && lane == 0) *wgfail = 1;
     // ---- objective partial sums (:399, :402) ----------------------------------------------------
     km_acc = wave_sum_all(km_acc);
     ent_acc = wave_sum_all(ent_acc);
@@ -1931,21 +2178,21 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         for (int w = 0; w < ROUND_WAVES; ++w) v += objw[2 * w + tid];
         if (v != 0.0) atomicAdd(&a.obj[2 * (wg & (HMX_OBJ_SLOTS - 1)) + tid], v);
     }
-    if (failed && tid == 0) {
+    if (tid == 0 && (failed || (ga && *wgfail))) {
         atomicExch(a.error, 1u); if (a.frozen) atomicExch(a.frozen, 1u);
         atomicAdd(&a.obj[0], __builtin_nan(""));
         atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS + 1], 1.0);   // the host (every rank's, after the all-reduce) replays the round block by block
     }
-    if (wg != 0) return;
-
-    // ---- workgroup 0 closes the sweep: O, cluster mass, cross-entropy term (:405-411) -----------
-    if (wv == 0) {
+    auto give_up = [&]() {
+        if (lane == 0) { atomicExch(a.error, 1u); if (a.frozen) atomicExch(a.frozen, 1u); atomicAdd(&a.obj[0], __builtin_nan("")); atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS + 1], 1.0); }
+    };
+    auto wait_last = [&]() {   // one wave: every workgroup (every rank) has added its sums of the last block
         unsigned spins = 0;
         if (!multi) {
             const unsigned want = (unsigned)a.nblk * (unsigned)nwg;
             while (ld_agent(a.counter) < want) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > a.spin_limit) { if (lane == 0) { atomicExch(a.error, 1u); if (a.frozen) atomicExch(a.frozen, 1u); atomicAdd(&a.obj[0], __builtin_nan("")); atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS + 1], 1.0); } break; }
+                if (++spins > a.spin_limit) { give_up(); break; }
             }
         } else {
             const unsigned long long want = a.epoch + (unsigned long long)a.nblk;
@@ -1954,20 +2201,61 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                 const bool ok = lane >= a.n_ranks || ld_sys(fl + lane) >= want;
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > a.spin_limit) { if (lane == 0) { atomicExch(a.error, 1u); if (a.frozen) atomicExch(a.frozen, 1u); atomicAdd(&a.obj[0], __builtin_nan("")); atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS + 1], 1.0); } break; }
+                if (++spins > a.spin_limit) { give_up(); break; }
             }
         }
+    };
+    if (ga) {
+        // ---- group-affine: the first workgroup of every group closes its group's row of O, its share of the
+        //      cross-entropy term (:405-411) and -- group 0's -- the cluster mass
+        if (wl != 0 || wv != ROUND_WAVES - 1) return;
+        if (!fx) wait_last();
+        const int bo = gcol[g_own];
+        double part = 0.0;
+        double ao[2][8], at[2][8];
+        const bool failed_before = failed;
+        ga_fetch(a.nblk - 1, ao, at);
+        if (fx && failed && !failed_before) give_up();
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int k = min(lane + 64 * n, K16 - 1);
+            double o = Ocur[k], t = Tm[k];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const bool use = !multi ? s < HMX_ROUND_SLOTS : s < a.n_ranks;
+                o += use ? ao[n][s] : 0.0;
+                t += use ? at[n][s] : 0.0;
+            }
+            if (lane + 64 * n < K16) {
+                a.O_out[(size_t)g_own * K16 + k] = o;
+                if (g_own == 0) a.T_out[k] = t;
+                const float O = (float)o;
+                const float Oc = fmaxf(O, 1e-8f);                               // :407
+                const float Ec = fmaxf((float)t * prb[bo], 1e-8f);              // :408
+                const float tl = tht[bo] * logf((Oc + Ec) / Ec);                // :409-410
+                part += (double)(sig[k] * O * tl);
+            }
+        }
+        part = wave_sum_all(part);
+        // sharded: the term comes from job-wide tables, identical on every rank, and the objective block is summed over
+        // the ranks as a whole (it carries the failure count too): rank 0 contributes it
+        if (lane == 0 && (!multi || a.rank == 0)) atomicAdd(&a.obj[2 * HMX_OBJ_SLOTS], part);
+        return;
     }
+    if (wg != 0) return;
+
+    // ---- workgroup 0 closes the sweep: O, cluster mass, cross-entropy term (:405-411) -----------
+    if (wv == 0) wait_last();
     __syncthreads();
     for (int i = tid; i < GK; i += ROUND_THREADS) {
         double o = Ocur[i];
         if (!multi) {
-            const double* sn = a.S_new + (size_t)(a.nblk - 1) * HMX_ROUND_SLOTS * GK + i;
+            const double* sn = a.S_new + (size_t)(a.nblk - 1) * HMX_ROUND_SLOTS * GKs + i;
 #pragma unroll
-            for (int s = 0; s < HMX_ROUND_SLOTS; ++s) o += ld_agent(sn + (size_t)s * GK);
+            for (int s = 0; s < HMX_ROUND_SLOTS; ++s) o += ld_agent(sn + (size_t)s * GKs);
         } else {
-            const double* bx = a.my_box + box_data(a.n_ranks, GK, (a.nblk - 1) & 1, 0) + i;
-            for (int s = 0; s < a.n_ranks; ++s) o += ld_sys(bx + (size_t)s * GK);
+            const double* bx = a.my_box + box_data(a.n_ranks, GKs, (a.nblk - 1) & 1, 0) + i;
+            for (int s = 0; s < a.n_ranks; ++s) o += ld_sys(bx + (size_t)s * GKs);
         }
         Ocur[i] = o;
         a.O_out[i] = o;
@@ -3679,8 +3967,12 @@ __global__ __launch_bounds__(256) void k_order_runs(OrderArgs a) {
     const int padded = ((n + 15) / 16) * 16;
     if (tid == 0) {
         a.run_start[key] = start;
+        if (a.run_tiles) a.run_tiles[key] = start / 16;                       // (block, group) runs in tiles: k_round's group-affine map
         if (key % a.G == 0) a.blk_start[key / a.G] = start / 16;
-        if (key == nkeys - 1) a.blk_start[a.nblk] = (start + padded) / 16;
+        if (key == nkeys - 1) {
+            a.blk_start[a.nblk] = (start + padded) / 16;
+            if (a.run_tiles) a.run_tiles[nkeys] = (start + padded) / 16;
+        }
     }
     for (int i = n + tid; i < padded; i += 256) a.cells[start + i] = -1;
     for (int t = tid; t < padded / 16; t += 256) a.tile_grp[start / 16 + t] = key % a.G;
@@ -3975,12 +4267,13 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
     return 0;
 }
 
-size_t round_lds_bytes(int K16, int dp, int G, int B, int V, bool bf3) {
-    const size_t GK = (size_t)G * K16;
-    // sigma, -1/sigma, rp, lrp, rpc (V > 1) | O, S, T, objective scratch (fp64) | Pr_b, theta, group_cols (V <= 8), bgrp, block offsets | landing zones
+size_t round_lds_bytes(int K16, int dp, int G, int B, int V, bool bf3, bool ga, int nblk) {
+    const size_t GK = (size_t)(ga ? 1 : G) * K16;   // group-affine map: a workgroup keeps the tables of its own group only
+    // sigma, -1/sigma, rp, lrp, rpc (V > 1) | O, S, T, objective scratch (fp64) | Pr_b, theta, group_cols (V <= 8), bgrp, run offsets and
+    // lengths (2 x (nblk + 3)), one flag | landing zones
     const size_t ys = bf3 ? (size_t)3 * K16 * bf3_ldb(dp / 4) : (size_t)K16 * lds_ldy(dp);   // centroids: three bf16 planes, or fp32 rows
     return (ys + 2 * (size_t)K16 + 2 * GK + (V == 1 ? 0 : (size_t)K16 * B)) * 4 + (2 * GK + K16 + 2 * ROUND_WAVES) * 8 +
-           (3 * (size_t)B + (size_t)G * 8 + 64) * 4 + 16 + (size_t)ROUND_WAVES * ROUND_TPW * 16 * dp * 4
+           (3 * (size_t)B + (size_t)G * 8 + 2 * ((size_t)nblk + 3) + 2) * 4 + 16 + (size_t)ROUND_WAVES * ROUND_TPW * 16 * dp * 4
         ;
 }
 
@@ -4077,15 +4370,17 @@ static void launch_round_ks(const RoundArgs& a, int mt, int wgs, size_t sm, hipS
 // batch groups at that K), for blocks larger than the grid carries (`extra_tiles`: most tiles then go through the unpipelined
 // extra-tile loop, one tile per wave at a time, where the split is not hidden -- all 10 M cells of configs[3] on one GPU:
 // 3.22 ms per sweep against 3.03, profiles/r04_ab_k_round_bf16_pipe.txt) -- and for engines created under HMX_ROUND_F32=1 (`allow_bf16` false), the switch of the A/B runs and of the direct A/B test.
-bool round_uses_bf16_pipe(int K16, int dp, int G, int B, int V, bool extra_tiles, bool allow_bf16) {
-    return HMX_ROUND_BF3 && HMX_ROUND_EXP2 && allow_bf16 && !extra_tiles && round_lds_bytes(K16, dp, G, B, V, true) <= HMX_ROUND_LDS_LIMIT;
+bool round_uses_bf16_pipe(int K16, int dp, int G, int B, int V, bool extra_tiles, bool allow_bf16, bool ga, int nblk) {
+    return HMX_ROUND_BF3 && HMX_ROUND_EXP2 && allow_bf16 && !extra_tiles && round_lds_bytes(K16, dp, G, B, V, true, ga, nblk) <= HMX_ROUND_LDS_LIMIT;
 }
 
 int launch_round(const RoundArgs& a_in, int mt, int wgs, hipStream_t s, bool extra_tiles, bool allow_bf16) {
     RoundArgs a = a_in;
     a.ldy_lds = lds_ldy(a.dp);
-    const bool bf3 = round_uses_bf16_pipe(a.K16, a.dp, a.G, a.B, a.V, extra_tiles, allow_bf16);
-    const size_t sm = round_lds_bytes(a.K16, a.dp, a.G, a.B, a.V, bf3);
+    const bool ga = a.ga != 0;
+    if (ga && (a.V != 1 || !a.run_start || !a.wg_map)) return -1;
+    const bool bf3 = round_uses_bf16_pipe(a.K16, a.dp, a.G, a.B, a.V, extra_tiles, allow_bf16, ga, a.nblk);
+    const size_t sm = round_lds_bytes(a.K16, a.dp, a.G, a.B, a.V, bf3, ga, a.nblk);
     if (mt < 1 || mt > 7 || sm > HMX_ROUND_LDS_LIMIT) return -1;
     switch (a.dp) {
         case 32: if (bf3) launch_round_ks<8, true>(a, mt, wgs, sm, s); else launch_round_ks<8, false>(a, mt, wgs, sm, s); break;

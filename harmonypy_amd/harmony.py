@@ -435,6 +435,10 @@ class Harmony:
         if mode == "auto":
             mode = "torch" if self.N_global <= AUTO_DEVICE_ORDER_CELLS else "device"
         self.update_order = mode
+        # device order: the rounds of one cluster() call run inside the library (hmx_cluster).  HMX_CLUSTER_LOOP=python keeps
+        # them in the Python loop below, one hmx_cluster_round_seeded per round -- the same rounds, the same test; it exists
+        # so that tests can put the two drivers side by side (tests/test_parity_gpu.py)
+        self._cluster_in_library = os.environ.get("HMX_CLUSTER_LOOP", "library").lower() != "python"
         self._seed = int(random_state) if random_state is not None else 0
         if verbose and mode == "device":
             logger.info("  update order: keyed bijection on the device (a different random stream than the reference's "
@@ -737,7 +741,7 @@ class Harmony:
         """``_rounds`` (keyword only, not in the reference): run exactly that many rounds."""
         rounds = 0
         forced = _rounds if _rounds is not None else (self._schedule.pop(0) if self._schedule else None)
-        if self.update_order == "device":
+        if self.update_order == "device" and self._cluster_in_library:
             # device-side update order: all rounds of this call inside the library (hmx_cluster) -- the same rounds, the
             # same test on the same numbers (harmony.py:455-458, 517-523), no trip through Python between rounds
             terms = self._engine.cluster(self._seed, self._cells_per_block, self.max_iter_kmeans, forced,

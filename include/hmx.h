@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HMX_ABI_VERSION 7
+#define HMX_ABI_VERSION 8
 #define HMX_TILE 16 /* cells per tile */
 /* limits of this build, checked by hmx_create (the reference has none: harmony.py:123-124 caps only the default K) */
 #define HMX_MAX_CLUSTERS 208
@@ -266,8 +266,11 @@ int hmx_set_timing_stride(hmx_engine* e, int stride);
  * ranks when cells are sharded): out[4] waits, out[5] polls that found the hand-off incomplete (each followed by an
  * s_sleep of ~64 shader cycles), out[6] the most such polls any single wait took, out[7] streaming R^T.Z passes
  * (centroid numerators + removal sums, ridge statistics) that ran on the bf16 matrix pipe (k_rtz3c; engines created under
- * HMX_RTZ3_BF16=0 keep the f32-input kernel k_rtz3). */
-int hmx_counters(hmx_engine* e, int64_t out[8]);
+ * HMX_RTZ3_BF16=0 keep the f32-input kernel k_rtz3; wide shapes: k_rtzw2b), out[8] sweeps launched with the group-affine tile
+ * map (one batch variable: every workgroup of k_round owns one batch group; HMX_ROUND_GA=0 keeps the
+ * classic map), out[9] workgroups of the last such sweep; out[10..15] reserved (0). */
+#define HMX_N_COUNTERS 16
+int hmx_counters(hmx_engine* e, int64_t out[HMX_N_COUNTERS]);
 
 #ifdef __cplusplus
 }

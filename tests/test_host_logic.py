@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in hmx.h but not exported"
     assert sorted(_capi.EXPORTS) == declared
-    assert lib.hmx_abi_version() == _capi.HMX_ABI_VERSION == 7
+    assert lib.hmx_abi_version() == _capi.HMX_ABI_VERSION == 8
 
 
 def test_engine_fails_loudly_without_gpu():

@@ -342,6 +342,110 @@ def _bench_path_case(N, d, B, K, monkeypatch, ridge_dtype, rounds=(5, 5)):
     return ho
 
 
+def _decision_margins(objective_kmeans, rounds, window=3, eps=1e-5):
+    """Ratios (windowed relative change / eps) of every type-0 decision (harmony.py:455-458, 517-523) taken while the
+    LAST cluster() call, of `rounds` rounds, ran: the objective list holds one entry per round behind the initial one."""
+    obj = list(objective_kmeans)
+    out = []
+    first = len(obj) - rounds
+    for i in range(rounds):
+        if i > window:
+            hist = obj[:first + i + 1]
+            old, new = sum(hist[-window - 1:-1]), sum(hist[-window:])
+            out.append(abs(old - new) / abs(old) / eps)
+    return out
+
+
+def _free_running_case(Z, meta, vars_use, K, Y0, monkeypatch, iterations, ridge_dtype, label, **kw):
+    """The path bench.py's wall-clock-to-convergence figures come from -- hmx_cluster with NATURAL thresholds on the device
+    update order: deferred read-backs of rounds 0..3, windowed test and break inside the library -- against the oracle
+    thresholding its own objectives on the same update order (harmony.py:437-462).  Identical round counts, objectives 2e-5,
+    Z_corr 1e-4; a different count is accepted only where the oracle's own deciding ratio sat within 5 % of the threshold."""
+    from oracle.harmony_oracle import OracleHarmony, prepare_inputs
+    monkeypatch.setenv("HMX_UPDATE_ORDER", "device")
+    seed = 5
+    p = prepare_inputs(Z, meta, vars_use, nclust=K, **kw)
+    N = p["Z"].shape[1]
+    oo = OracleHarmony(p["Z"], p["phi"], p["Pr_b"], p["sigma"], p["theta"], p["lamb"], K=K, run=False,
+                       perm_source=_device_perm_source(N, seed), ridge_dtype=ridge_dtype)
+    oo.init_cluster(seed, Y0)
+    ho = _run_engine(Z, meta, vars_use, Y0=Y0, nclust=K, max_iter_harmony=0, random_state=seed, **kw)
+    assert ho.update_order == "device" and ho._cluster_in_library
+    for it in range(iterations):
+        oo.cluster()
+        ho.cluster()
+        r_o, r_e = oo.kmeans_rounds[-1], ho.kmeans_rounds[-1]
+        margins = _decision_margins(oo.objective_kmeans, r_o, eps=oo.epsilon_kmeans)
+        print(f"{label} iteration {it}: oracle {r_o} rounds, engine {r_e}; oracle's deciding ratios / eps: "
+              + " ".join(f"{m:.3f}" for m in margins))
+        if r_e != r_o:
+            n = min(r_e, r_o)                                  # the decision taken after round n (0-based n - 1) differed
+            deciding = margins[n - 5] if 0 <= n - 5 < len(margins) else None   # the test behind round n (decisions start behind round 5)
+            assert deciding is not None and abs(deciding - 1.0) < 0.05, (
+                f"{label} iteration {it}: engine stopped after {r_e} rounds, oracle after {r_o}, and the deciding ratio {deciding} was not marginal ({margins})")
+            n0 = len(oo.objective_kmeans) - r_o
+            np.testing.assert_allclose(ho.objective_kmeans[:n0 + n], oo.objective_kmeans[:n0 + n], rtol=2e-5)
+            print(f"{label}: schedules part at a marginal decision; everything before it agrees")
+            return ho
+        np.testing.assert_allclose(ho.objective_kmeans, oo.objective_kmeans, rtol=2e-5, err_msg=f"iteration {it}")
+        oo.moe_correct_ridge()
+        ho.moe_correct_ridge()
+        rel_f, max_rel = assert_z_close(ho.Z_corr, oo.result(), what=f"{label} Z_corr after iteration {it}")
+        print(f"{label} iteration {it}: Z_corr relF={rel_f:.2e} max={max_rel:.2e}")
+    assert ho.kmeans_rounds == oo.kmeans_rounds
+    return ho
+
+
+def test_free_running_library_loop_vs_oracle_c3_shape(monkeypatch):
+    """configs[2]'s shape (K = 100, 50 PCs, 8 batches) at 150k cells, free-running: hmx_cluster decides when to stop."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import quick_centroids, synthetic_dataset
+    Z, meta = synthetic_dataset(150_000, 50, 8, 100, seed=3)
+    Y0 = quick_centroids(Z, 100, seed=3, sample=20_000)
+    ho = _free_running_case(Z, meta, ["batch"], 100, Y0, monkeypatch, iterations=3, ridge_dtype=np.float64, label="free-running 150k")
+    assert ho._engine.counters()["seeded_rounds"] == sum(ho.kmeans_rounds)
+
+
+def test_free_running_library_loop_vs_oracle_pbmc(monkeypatch):
+    """The pbmc_3500 fixture on the device update order, free-running (the golden files hold the reference's torch.randperm
+    stream, so the oracle -- pinned to them in tests/test_oracle_golden.py -- is the checker here)."""
+    data, meta, vars_use, kw, g = load_case("pbmc_default")
+    K = int(np.asarray(g["Y0"]).shape[1])
+    _free_running_case(data, meta, vars_use, K, g["Y0"], monkeypatch, iterations=4, ridge_dtype=np.float32, label="free-running pbmc")
+
+
+@pytest.mark.parametrize("eps,N", [(1e-5, 150_000), (1e-2, 150_000), (1e-5, 20_000), (3e-4, 20_000)])
+def test_library_loop_and_python_loop_take_the_same_decisions(eps, N, monkeypatch):
+    """The same state driven twice: by hmx_cluster (rounds 0..3 read back late, the windowed test of harmony.py:517-523
+    restated in C) and by the Python loop (_round + check_convergence(0), one hmx_cluster_round_seeded per round, every
+    objective read back at once).  Same seeds, same update orders: identical round counts, the same objective lists.
+    eps = 1e-2 stops every call at round 5 -- the first decision, taken entirely on deferred read-backs."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import quick_centroids, synthetic_dataset
+    monkeypatch.setenv("HMX_UPDATE_ORDER", "device")
+    Z, meta = synthetic_dataset(N, 50, 8, 100, seed=4)
+    Y0 = quick_centroids(Z, 100, seed=4, sample=20_000)
+    runs = {}
+    for loop in ("library", "python"):
+        monkeypatch.setenv("HMX_CLUSTER_LOOP", loop)
+        ho = _run_engine(Z, meta, ["batch"], Y0=Y0, nclust=100, max_iter_harmony=0, random_state=9, epsilon_cluster=eps)
+        assert ho.update_order == "device" and ho._cluster_in_library == (loop == "library")
+        for it in range(3):
+            ho.cluster()
+            ho.moe_correct_ridge()
+        runs[loop] = (list(ho.kmeans_rounds), np.array(ho.objective_kmeans), ho.Z_corr)
+    (ra, oa, za), (rb, ob, zb) = runs["library"], runs["python"]
+    print(f"eps={eps:g} N={N}: library loop {ra}, Python loop {rb}")
+    assert ra == rb, f"round counts differ: library {ra}, Python {rb}"
+    if eps >= 1e-2:
+        assert ra == [5, 5, 5]
+    np.testing.assert_allclose(oa, ob, rtol=1e-6)   # (fp64 atomics in another order, rounded to fp32: an ulp at most)
+    rel_f, max_rel = assert_z_close(za, zb, tol=2e-6, what="Z_corr library vs Python loop")
+    print(f"  objectives agree to {np.abs(oa / ob - 1).max():.1e}, Z_corr relF={rel_f:.1e}")
+
+
 def test_bench_path_parity_c3_shape(monkeypatch):
     """BASELINE configs[2]'s shape (d=50, K=100, 8 batches -> the k_round<7,13> instantiation bench.py
     times) at 150k cells: seeded device-order rounds vs the oracle on the same per-round permutation

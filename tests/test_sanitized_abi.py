@@ -70,7 +70,7 @@ for bad in (dict(n_clusters=999), dict(n_pcs=0), dict(n_blocks=1000), dict(n_var
     assert lib.hmx_create(C.byref(c2), C.byref(h)) == -1
 assert lib.hmx_create(None, C.byref(h)) == -1
 import numpy as np
-out = np.zeros(8, np.int64)
+out = np.zeros(16, np.int64)
 assert lib.hmx_counters(None, out.ctypes.data_as(C.c_void_p)) == -1
 assert lib.hmx_sync(None) == -1 and lib.hmx_moe_correct_ridge(None) == -1
 lib.hmx_destroy(None)
