@@ -125,7 +125,7 @@ struct hmx_engine {
     int ga_nwg = 0;              // workgroups of that map (0: none planned)
     int64_t ga_key_block = -1;   // ... planned for this largest block size and this cap
     int ga_key_cap = -1;
-    bool ga_extra = false;       // ... some group's run may exceed 14 tiles per workgroup (the extra-tile loop will run)
+    bool ga_extra = false;       // ... some group's run may exceed 16 tiles per workgroup (the extra-tile loop will run)
     DevBuf<unsigned long long> wait_stats;   // {waits, incomplete polls, most polls of one wait} of the sweep kernels' grid-wide waits
     DevBuf<double> xch;
     double *Sold = nullptr, *Yacc64 = nullptr, *Snew = nullptr, *objacc = nullptr, *Sr = nullptr, *Oxr = nullptr;
@@ -1091,26 +1091,32 @@ static int replay_round(hmx_engine* e, int flags, const std::vector<int>& tiles_
     return read_objective(e, obj_out);
 }
 
-// The group-affine tile map of k_round (one batch variable, at most `cap` compute workgroups): workgroup w owns ONE batch
-// group; a group gets workgroups in proportion to the largest run of tiles it is expected to have in any block -- its share
-// of the rank's largest block (`max_tiles` tiles) + 5 sigma of that count, padded to whole tiles -- at HMX_ROUND_GA_WAVES x 2
-// = 14 tiles per workgroup and block.  When the grid cannot carry that (blocks larger than the grid), all `cap` workgroups
-// are dealt out so that the largest per-workgroup share is as small as possible and the kernel's extra-tile loop takes
-// the rest (*extra).  A run that exceeds the estimate is served by the same loop: the map decides speed, never results.
-// The map depends on the group sizes, the block size and the cap only, so it is planned once and kept on the device.
+// The group-affine tile map of k_round (one batch variable, one engine, at most `cap` compute workgroups): workgroup w owns
+// ONE batch group; a group gets workgroups in proportion to the largest run of tiles it is expected to have in any block --
+// its share of the largest block (`max_tiles` tiles) + 5 sigma of that count, padded to whole tiles -- at HMX_ROUND_GA_TILES =
+// 14 tiles per workgroup and block (the workgroup's last wave, which also runs the hand-off, then seldom carries tiles), at
+// all 16 slots when the grid cannot carry that.  When even that does not fit (blocks larger than the grid), all `cap`
+// workgroups are dealt out so that the largest per-workgroup share is as small as possible and the kernel's extra-tile
+// loop takes the rest (ga_extra).  A run that exceeds the estimate is served by the same loop: the map decides speed,
+// never results.  It depends on the group sizes, the block size and the cap only: planned once, kept on the device.
 static bool plan_ga(hmx_engine* e, int max_tiles, int cap) {
     if (!e->allow_round_ga || e->V != 1 || e->G > cap || (int)e->gsize.size() != e->G || e->N <= 0) return false;
+    if ((int64_t)max_tiles * HMX_TILE >= HMX_ROUND_GA_MAX_BLOCK_CELLS) return false;   // the fixed-point words of the hand-off
     if (e->ga_nwg > 0 && e->ga_key_block == max_tiles && e->ga_key_cap == cap) return true;
-    const int G = e->G, per_wg = 2 * HMX_ROUND_GA_WAVES;
-    const double block_cells = 16.0 * std::max(1, max_tiles - G);      // the rank's cells in its largest block (upper estimate)
+    const int G = e->G;
+    const double block_cells = 16.0 * std::max(1, max_tiles - G);      // the engine's cells in its largest block (upper estimate)
     std::vector<double> est(G);
     std::vector<int> ng(G);
     int total = 0;
-    for (int g = 0; g < G; ++g) {
-        const double mean = block_cells * (double)e->gsize[g] / (double)e->N;
-        est[g] = std::ceil((mean + 5.0 * std::sqrt(mean)) / 16.0) + (e->gsize[g] > 0 ? 1.0 : 0.0);
-        ng[g] = std::max(1, (int)std::ceil(est[g] / per_wg));
-        total += ng[g];
+    for (int per_wg : {HMX_ROUND_GA_TILES, 16}) {
+        total = 0;
+        for (int g = 0; g < G; ++g) {
+            const double mean = block_cells * (double)e->gsize[g] / (double)e->N;
+            est[g] = std::ceil((mean + 5.0 * std::sqrt(mean)) / 16.0) + (e->gsize[g] > 0 ? 1.0 : 0.0);
+            ng[g] = std::max(1, (int)std::ceil(est[g] / per_wg));
+            total += ng[g];
+        }
+        if (total <= cap) break;
     }
     e->ga_extra = total > cap;
     if (e->ga_extra) {                                                  // min-max: one more workgroup to the most loaded group
@@ -1141,14 +1147,14 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
     int rc;
     const size_t GK = (size_t)e->G * e->K16;
     const bool persistent = (flags & HMX_ROUND_UPDATE_R) && e->round_mode == 1 && (!sharded(e) || e->peers_enabled);
-    // the sweep's tile map: group-affine when the shape allows it and the lists carry their run offsets (decided from
-    // job-wide properties only -- every rank of a sharded job takes the same decision: the peer boxes carry different rows)
+    // the sweep's tile map: group-affine for a single engine when the shape allows it and the lists carry their run offsets
+    // (cells sharded over ranks: the classic map -- its exchange through the peer boxes is the one that has run on hardware)
     int max_upper = 0;
     for (int b = 0; b < e->nblk; ++b) max_upper = std::max(max_upper, tiles_upper[b]);
     const bool multi = e->peers_enabled && e->n_ranks > 1;
     int ga_cap = e->n_cus - (multi ? 1 : 0);
     if (e->round_wgs_cap > 0) ga_cap = std::min(ga_cap, e->round_wgs_cap);
-    const bool ga = persistent && e->mt <= 7 && round_row_floats(e->d) == e->dp && e->lists[e->cur].runs_ok && plan_ga(e, max_upper, ga_cap);
+    const bool ga = persistent && !sharded(e) && e->mt <= 7 && round_row_floats(e->d) == e->dp && e->lists[e->cur].runs_ok && plan_ga(e, max_upper, ga_cap);
     const bool mega = persistent && e->mt <= 7 && round_row_floats(e->d) == e->dp &&
                       round_lds_bytes(e->K16, e->dp, e->G, e->B, e->V, false, ga, e->nblk) <= HMX_ROUND_LDS_LIMIT;
     const bool r3 = streaming_rtz(e);
@@ -1228,7 +1234,7 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
             ra.K = e->K; ra.Kp = e->Kp; ra.K16 = e->K16; ra.dp = e->dp; ra.ldy = e->ldy; ra.G = e->G; ra.B = e->B; ra.V = e->V;
             ra.nblk = e->nblk; ra.spin_limit = e->spin_limit;
             ra.frozen = e->frozen();
-            if (ga) { ra.ga = 1; if (const char* go = getenv("HMX_ROUND_GA_OPTS")) ra.ga_opts = atoi(go); ra.run_start = e->lists[e->cur].run_tiles.p; ra.wg_map = e->ga_map.p; e->n_sweeps_ga++; }
+            if (ga) { ra.ga = 1; ra.run_start = e->lists[e->cur].run_tiles.p; ra.wg_map = e->ga_map.p; e->n_sweeps_ga++; }
             if (e->n_sweep_launches++ == e->test_fail_sweep) ra.spin_limit = 0;
             if (multi) {
                 ra.peer_box = e->peer_dev.p; ra.my_box = e->box; ra.n_ranks = e->n_ranks; ra.rank = e->rank;
@@ -1292,20 +1298,6 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
                         }
                     const double n = (double)wgs * (e->nblk - 1);
                     fprintf(stderr, "[k_round prof] pre(next) split: fragments %.0f, requests %.0f, split %.0f, k-step 0 %.0f, rest %.0f\n", s[0] / n, s[1] / n, s[2] / n, s[3] / n, s[4] / n);
-                }
-                if (ga) {   // the chain wave: publish, poll, table (block b's publish .. block b+1's table), and when it ends relative to wave 0's GEMM
-                    double s[4] = {0, 0, 0, 0};
-                    double n = 0;
-                    for (int w = 0; w < wgs; ++w)
-                        for (int b = 0; b + 1 < e->nblk; ++b) {
-                            const unsigned long long* r = &h[((size_t)w * e->nblk + b) * 32];
-                            if (!r[16] || !r[19]) continue;
-                            s[0] += (double)(r[17] - r[16]); s[1] += (double)(r[18] - r[17]); s[2] += (double)(r[19] - r[18]);
-                            s[3] += (double)r[19] - (double)r[5];   // > 0: the table came after wave 0's GEMM had ended
-                            n += 1;
-                        }
-                    fprintf(stderr, "[k_round prof] chain wave: publish %.0f, poll %.0f, table %.0f; table ready %.0f ticks after wave 0's GEMM ended\n",
-                            s[0] / n, s[1] / n, s[2] / n, s[3] / n);
                 }
                 fprintf(stderr, "[k_round prof] whole sweep mean %.0f ticks over %d workgroups\n", tot / wgs, wgs);
             }

@@ -63,10 +63,10 @@ struct RoundArgs {
     unsigned spin_limit;       // polls a wait may take before it gives up
     int n_ranks, rank;
     int K, Kp, K16, dp, ldy, ldy_lds, G, B, V, nblk;
-    // group-affine tile map (one batch variable): every compute workgroup owns ONE batch group and takes its tiles from that
-    // group's run inside each block; the hand-off then carries K16 entries of the group + K16 cluster masses instead of G x K16
+    // group-affine tile map (one batch variable, one engine): every compute workgroup owns ONE batch group and takes its tiles
+    // from that group's run inside each block; the hand-off then carries K16 entries of the group + K16 cluster masses instead
+    // of G x K16, as self-validating words (count << 55 | sum in 2^-32 fixed point: see k_round)
     int ga;                    // 1: group-affine map, 0: classic (tile pairs dealt round-robin over all workgroups)
-    int ga_opts;               // timing experiments (HMX_ROUND_GA_OPTS): 1 the chain starts behind the distance GEMM, 2 long sleeps between polls
     const int* run_start;      // ga: nblk * G + 1 tile offsets of the (block, group) runs of the list, key = block * G + group
     const int* wg_map;         // ga: per compute workgroup {group, rank among the group's workgroups, workgroups of the group}
 };
@@ -207,7 +207,8 @@ struct OrderArgs {
 
 size_t round_lds_bytes(int K16, int dp, int G, int B, int V, bool bf3, bool ga, int nblk);
 bool round_uses_bf16_pipe(int K16, int dp, int G, int B, int V, bool extra_tiles, bool allow_bf16, bool ga, int nblk);   // which k_round instance launch_round picks
-#define HMX_ROUND_GA_WAVES 7   /* tile-carrying waves of a workgroup under the group-affine map (the eighth runs the hand-off) */
+#define HMX_ROUND_GA_TILES 14  /* tiles per workgroup and block the group-affine map is planned for where the grid allows it (16 slots: the last wave, which runs the hand-off, then seldom carries tiles) */
+#define HMX_ROUND_GA_MAX_BLOCK_CELLS (1 << 22)   /* a block's sums must fit 23 + 32 bits of fixed point below the count field */
 // k_round has no static LDS and one workgroup per CU: everything the CU has (160 KB), less a small margin
 #define HMX_ROUND_LDS_LIMIT (size_t)(159 * 1024)
 int round_row_floats(int d);

@@ -542,18 +542,14 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES, 4) void k_assign_lds(AssignArgs 
 #ifdef HMX_ROUND_PROF   /* timing experiments only: per-workgroup phase stamps (s_memtime) */
 #define RSTAMP(slot) do { if (tid == 0 && a.prof) a.prof[((size_t)wg * a.nblk + b) * 32 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define TSTAMP(slot) do { if (tid == 0 && a.prof && prof_b >= 0) a.prof[((size_t)wg * a.nblk + prof_b) * 32 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
-/* the chain wave of the group-affine map (lane 0 of the last wave), slots 16.. of block `blk` */
-#define CSTAMP(blk, slot) do { if (lane == 0 && a.prof) a.prof[((size_t)wg * a.nblk + (blk)) * 32 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define RSTAMP(slot) do { } while (0)
 #define TSTAMP(slot) do { } while (0)
-#define CSTAMP(blk, slot) do { } while (0)
 #endif
 // s_waitcnt vmcnt(0) as the builtin (gfx9 encoding: vmcnt 0, expcnt 7, lgkmcnt 15), so that the compiler's own wait
 // insertion knows nothing is outstanding afterwards; as inline assembly it is invisible to it and every later
 // wait it computes assumes the older operations are still in flight
 #define WAIT_VMEM_ALL() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); } while (0)
-#define ROUND_FLAGS 8   /* group-affine map: replicas of the "block complete" flag, one 128-byte line each, behind the arrival counter */
 #define ROUND_WAVES 8   /* 2 waves per SIMD: 256 registers per lane, two tiles in flight per wave */
 #define ROUND_TPW 2     /* tiles a wave carries across the hand-off */
 #define ROUND_THREADS (64 * ROUND_WAVES)
@@ -953,10 +949,7 @@ __device__ __forceinline__ void block_sums_rs(const f32x4 (&sm)[NM], double* sd,
     if (i < 4 * NM) atomicAdd(sd + 16 * (i >> 2) + 4 * q + (i & 3), (double)tot);   // value i = cluster tile i / 4 of the group, register i % 4
 }
 
-// WHAT = 3: rows out and block sums (one pass); 1: block sums only, 2: rows only -- k_round's group-affine map runs the two
-// halves on either side of the workgroup barrier, so that the hand-off's atomics enter the CU's memory pipeline in FRONT of
-// the block's row stores instead of queueing behind them
-template <int MT, int WHAT = 3>
+template <int MT>
 __device__ __forceinline__ void round_post_pass2(float* R, int Kp, double* Sd, int c16, int q, const RoundTile<MT>& T0,
                                                  float scl0, bool has1, const RoundTile<MT>& T1, float scl1) {
     constexpr int K16 = 16 * MT;
@@ -978,11 +971,10 @@ __device__ __forceinline__ void round_post_pass2(float* R, int Kp, double* Sd, i
             rv0[m] = T0.arg[mt] * scl0;                    // :503
             rv1[m] = T1.arg[mt] * scl1;
 #if !(HMX_RABL & 2)
-            if ((WHAT & 2) && live0 && col < Kp) st4(row0 + col, rv0[m]);
-            if ((WHAT & 2) && live1 && col < Kp) st4(row1 + col, rv1[m]);
+            if (live0 && col < Kp) st4(row0 + col, rv0[m]);
+            if (live1 && col < Kp) st4(row1 + col, rv1[m]);
 #endif
         }
-        if (!(WHAT & 1)) return;
 #if !(HMX_RABL & 1)
         if (joint || !has1) {                              // one table row for both tiles (scl1 == 0 without a second tile)
 #pragma unroll
@@ -1421,19 +1413,21 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     constexpr int K16 = 16 * MT;
     constexpr int NF = KS / 4, NT = KS % 4;
     // Two ways of dealing a block's tiles out.  CLASSIC: tile pair p goes to workgroup p % nwg -- a workgroup's tiles are
-    // spread over the whole group-sorted block, so it keeps the diversity table of ALL groups (G x K16 entries) and publishes
-    // sums for all of them.  GROUP-AFFINE (a.ga; one batch variable): workgroup w owns ONE group g(w) (host table wg_map,
-    // workgroup counts in proportion to the groups' sizes) and takes its tiles from that group's run inside every block
-    // (run_start), so the per-block hand-off shrinks from G x K16 entries to K16 of its own group plus the K16 cluster masses
-    // T_k = sum_g O[g][k] (:491), which travel as row G of the slot tables: fold 4 x 2 K16 agent loads instead of 4 G K16,
-    // K16 powers instead of G K16, 2 K16 returning adds instead of G K16.  With the table that small the whole hand-off chain
-    // (publish, arrive, poll, fold, power table) is run by the workgroup's LAST wave alone (it carries no tiles) UNDER the
-    // other seven waves' distance GEMM of the next block.
+    // spread over the whole group-sorted block, so it keeps the diversity table of ALL groups (G x K16 entries), publishes
+    // sums for all of them with returning fp64 adds and arrives at a counter.  GROUP-AFFINE (a.ga; one batch variable, one
+    // engine): workgroup w owns ONE group g(w) (host table wg_map, workgroup counts in proportion to the groups' sizes) and
+    // takes its tiles from that group's run inside every block (run_start), so the per-block hand-off shrinks from G x K16
+    // entries to K16 of its own group plus the K16 cluster masses T_k = sum_g O[g][k] (:491), which travel as row G of the
+    // slot tables.  Its entries are SELF-VALIDATING: a workgroup adds  (1 << 55) + sum * 2^32  to every entry of its two rows
+    // with one 64-bit integer add, fire and forget; a reader that finds the count fields of an entry's four slots adding up
+    // to the number of contributors holds the complete sum -- no returning atomics, no vmcnt(0) in front of an arrival, no
+    // arrival counter, no poll of a line that carries read-modify-writes of 200 workgroups, and the poll that succeeds has
+    // brought the data along: one memory round trip where the classic hand-off has four (measured: profiles/r06_ab_k_round_ga_*).
     const bool ga = a.ga != 0;
     const int Gl = ga ? 1 : a.G;                       // rows of the workgroup's LDS tables
     const int GK = Gl * K16;                           // entries of the LDS tables
     const int GKg = a.G * K16;                         // entries of the global tables O_start, S_old, O_out
-    const int GKs = (a.G + 1) * K16;                   // stride of a slot table / of a rank's share of a peer box (row G: cluster mass, GA only)
+    const int GKs = (a.G + 1) * K16;                   // stride of a slot table / of a rank's share of a peer box (row G: cluster mass, group-affine map only)
     const int LDY = a.ldy_lds;
     constexpr bool LOG2 = HMX_ROUND_EXP2 != 0, A2TAB = HMX_ROUND_A2TAB != 0;
     constexpr bool BF3 = BF3T && LOG2;                                   // distance GEMM on the bf16 pipe (round_compute_bf3)
@@ -1461,7 +1455,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     int* bgrp = gcol + a.G * a.V;                                        // B: the group holding batch b (V == 1)
     int* bsS = bgrp + a.B;                                               // nblk + 3: first tile of the workgroup's run in block b (two sentinels)
     int* bsN = bsS + a.nblk + 3;                                         // nblk + 3: tiles of that run (classic: the whole block)
-    int* wgfail = bsN + a.nblk + 3;                                      // GA: a grid-wide wait of the chain wave gave up
+    int* wgfail = bsN + a.nblk + 3;                                      // group-affine map: the hand-off wave's wait gave up
 
     int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the wave's landing zones and roles are wave-uniform
@@ -1485,8 +1479,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                 }
             }
             __syncthreads();
-            const int nfw = ga ? GKs : GKg;   // group-affine: the cluster-mass row travels too
-            for (int i = tid; i < nfw; i += ROUND_THREADS) {
+            for (int i = tid; i < GKg; i += ROUND_THREADS) {
                 const double* sn = a.S_new + (size_t)b * HMX_ROUND_SLOTS * GKs + i;
                 double v = 0.0;
 #pragma unroll
@@ -1584,10 +1577,10 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         for (int bb = 0; bb < a.nblk; ++bb) max_ntl = max(max_ntl, bsN[bb]);
         pubwave = ROUND_TPW * (blockIdx.x + (multi ? (int)gridDim.x - 1 : (int)gridDim.x) * (ROUND_WAVES - 1)) >= max_ntl;
     }
-    // group-affine: the last wave carries no tile by construction (seven tile-carrying waves) and runs the hand-off chain
-    const bool nochain = ga && (a.ga_opts & 128);   // (experiment: eight tile-carrying waves, the hand-off by one wave between GEMM and finishing pass)
-    const bool service = (pubwave || (ga && !nochain)) && wv == ROUND_WAVES - 1;        // wave-uniform
-    const bool chain = ga && !nochain && wv == ROUND_WAVES - 1;
+    const bool service = pubwave && wv == ROUND_WAVES - 1;        // wave-uniform
+    // group-affine: the last wave runs the hand-off (table at the top of a block, publish behind its finishing pass); the host
+    // plans the map for 14 tiles per workgroup and block where the grid allows it, so that this wave seldom carries tiles
+    const bool hand = ga && wv == ROUND_WAVES - 1;
 
     RoundTile<MT> T[ROUND_TPW];
     float* zb[ROUND_TPW];
@@ -1598,12 +1591,11 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     bool valid2[ROUND_TPW] = {false, false};
     double km_acc = 0.0, ent_acc = 0.0;
     bool failed = false;
-    unsigned ws_n = 0, ws_sum = 0, ws_max = 0;   // this workgroup's grid-wide waits (wave 0; group-affine: the chain wave)
+    unsigned ws_n = 0, ws_sum = 0, ws_max = 0;   // this workgroup's grid-wide waits (wave 0; group-affine: the hand-off wave)
     // classic: tiles 2p, 2p+1 of a block go to workgroup p % nwg, wave (p / nwg) % WAVES (pass p / nwg / WAVES);
-    // group-affine: the same deal among the ng workgroups of the group over its run, seven waves per workgroup
-    const int cwaves = (ga && !nochain) ? ROUND_WAVES - 1 : ROUND_WAVES;
-    const int j_first = chain ? (1 << 28) : ROUND_TPW * (wl + ng * wv);
-    const int j_slot = ROUND_TPW * ng * cwaves;
+    // group-affine: the same deal among the ng workgroups of the group over its run
+    const int j_first = ROUND_TPW * (wl + ng * wv);
+    const int j_slot = ROUND_TPW * ng * ROUND_WAVES;
     auto load_ids = [&](int blk, int u, int& cell, int& grp) {   // blk may run past the last block: bsS / bsN have sentinels
         const int j = j_first + u;
         const bool valid = j < bsN[blk];
@@ -1732,18 +1724,10 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         unsigned spins = 0;
         if (a.spin_limit == 0) failed = true;   // test knob: give up without looking
         if (failed) {
-        } else if (!multi && ga && (a.ga_opts & 16)) {
-            // the workgroup that arrived LAST has raised the block's flag in every replica: the pollers read a line that carries
-            // no read-modify-writes, a few of them per line
-            const unsigned* fl = a.counter + 32 * (1 + (wg & (ROUND_FLAGS - 1)));
-            while (ld_agent(fl) < (unsigned)(bdone + 1)) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > a.spin_limit) { failed = true; break; }
-            }
         } else if (!multi) {
             const unsigned want = (unsigned)(bdone + 1) * (unsigned)nwg;
             while (ld_agent(a.counter) < want) {
-                if (a.ga_opts & 2) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(1);
                 if (++spins > a.spin_limit) { failed = true; break; }
             }
         } else {   // every rank's total of the block has landed in this rank's box
@@ -1761,86 +1745,61 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         if (lane == 0 && a.prof) a.prof[((size_t)wg * a.nblk + bdone + 1) * 32 + 10] = spins;
 #endif
     };
-    // ---- group-affine hand-off, run by the chain wave alone; a lane owns the table entries k = lane and lane + 64 ---------
-    // O of the own group and the cluster mass T without block b's old sums and with block b-1's new ones (:491-492,
-    // 506-507), then ratio ** theta and its log for block b (:495-499): one round trip of loads, one power chain.
-    // the sums all workgroups (all ranks) added for block bp, per own entry: own group's row ao[n][], cluster-mass row at[n][]
-    const bool fx = ga && !multi && (a.ga_opts & 32);
+    // ---- group-affine hand-off, run by the workgroup's last wave; a lane owns the table entries k = lane and lane + 64 -------
+    // The sums all workgroups added for block bp, per own entry: own group's row so[n], cluster-mass row st[n].  Polls until
+    // every entry's count fields (bits 55.. of the four slot words) add up to the number of contributors -- ng workgroups of
+    // the own group, all nwg for the cluster masses; the words that pass the test ARE the data (2^-32 fixed point).
     constexpr unsigned long long FX_MASK = (1ull << 55) - 1ull;
-    auto ga_fetch = [&](int bp, double (&ao)[2][8], double (&at)[2][8]) {
+    auto ga_fetch = [&](int bp, double (&so)[2], double (&st)[2]) {
+        so[0] = so[1] = st[0] = st[1] = 0.0;
+        if (bp < 0) return;
+        unsigned long long wo[2][HMX_ROUND_SLOTS], wt[2][HMX_ROUND_SLOTS];
+        unsigned spins = 0;
+        if (a.spin_limit == 0) failed = true;   // test knob: give up without looking
+        while (true) {
+            bool ok = true;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int k = min(lane + 64 * n, K16 - 1);                   // clamped, not predicated
+                const unsigned long long* sn = reinterpret_cast<const unsigned long long*>(a.S_new) + (size_t)bp * HMX_ROUND_SLOTS * GKs + k;
+#pragma unroll
+                for (int s = 0; s < HMX_ROUND_SLOTS; ++s) {                  // independent loads, all in flight together
+                    wo[n][s] = __hip_atomic_load(sn + (size_t)s * GKs + (size_t)g_own * K16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    wt[n][s] = __hip_atomic_load(sn + (size_t)s * GKs + (size_t)a.G * K16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                unsigned co = 0, ct = 0;
+#pragma unroll
+                for (int s = 0; s < HMX_ROUND_SLOTS; ++s) { co += (unsigned)(wo[n][s] >> 55); ct += (unsigned)(wt[n][s] >> 55); }
+                ok = ok && co == (unsigned)ng && ct == (unsigned)nwg;
+            }
+            if (__all(ok) || failed) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > a.spin_limit) { failed = true; break; }   // (a wait that gave up is not repeated block after block: the launch is lost)
+        }
+        ws_n += 1; ws_sum += spins; ws_max = max(ws_max, spins);
+#ifdef HMX_ROUND_PROF
+        if (lane == 0 && a.prof) a.prof[((size_t)wg * a.nblk + min(bp + 1, a.nblk - 1)) * 32 + 10] = spins;
+#endif
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int s = 0; s < 8; ++s) ao[n][s] = at[n][s] = 0.0;
-        if (bp < 0) return;
-        if (fx) {
-            // self-validating entries: every workgroup adds (1 << 55) + its sum in 2^-32 fixed point to every entry of its two
-            // rows, so an entry whose count field has reached the number of contributors IS complete -- no arrival counter, no
-            // flag, no ordering between addresses, and the poll that succeeds has brought the data along
-            unsigned long long wo[2][HMX_ROUND_SLOTS], wt[2][HMX_ROUND_SLOTS];
-            unsigned spins = 0;
-            if (a.spin_limit == 0) failed = true;
-            while (true) {
-                bool ok = true;
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    const int k = min(lane + 64 * n, K16 - 1);
-                    const unsigned long long* sn = reinterpret_cast<const unsigned long long*>(a.S_new) + (size_t)bp * HMX_ROUND_SLOTS * GKs + k;
-#pragma unroll
-                    for (int s = 0; s < HMX_ROUND_SLOTS; ++s) {
-                        wo[n][s] = __hip_atomic_load(sn + (size_t)s * GKs + (size_t)g_own * K16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        wt[n][s] = __hip_atomic_load(sn + (size_t)s * GKs + (size_t)a.G * K16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    unsigned co = 0, ct = 0;
-#pragma unroll
-                    for (int s = 0; s < HMX_ROUND_SLOTS; ++s) { co += (unsigned)(wo[n][s] >> 55); ct += (unsigned)(wt[n][s] >> 55); }
-                    ok = ok && co == (unsigned)ng && ct == (unsigned)nwg;
-                }
-                if (__all(ok) || failed) break;
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > a.spin_limit) { failed = true; break; }
+            for (int s = 0; s < HMX_ROUND_SLOTS; ++s) {
+                so[n] += (double)(long long)(wo[n][s] & FX_MASK) * 0x1p-32;
+                st[n] += (double)(long long)(wt[n][s] & FX_MASK) * 0x1p-32;
             }
-            ws_n += 1; ws_sum += spins; ws_max = max(ws_max, spins);
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int s = 0; s < HMX_ROUND_SLOTS; ++s) {
-                    ao[n][s] = (double)(long long)(wo[n][s] & FX_MASK) * 0x1p-32;
-                    at[n][s] = (double)(long long)(wt[n][s] & FX_MASK) * 0x1p-32;
-                }
-            return;
-        }
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int k = min(lane + 64 * n, K16 - 1);                   // clamped, not predicated
-            if (!multi) {
-                const double* sn = a.S_new + (size_t)bp * HMX_ROUND_SLOTS * GKs + k;
-#pragma unroll
-                for (int s = 0; s < HMX_ROUND_SLOTS; ++s) {      // independent loads, all in flight together
-                    ao[n][s] = ld_agent(sn + (size_t)s * GKs + (size_t)g_own * K16);
-                    at[n][s] = ld_agent(sn + (size_t)s * GKs + (size_t)a.G * K16);
-                }
-            } else {
-                const double* bx = a.my_box + box_data(a.n_ranks, GKs, bp & 1, 0) + k;
-#pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    ao[n][s] = ld_sys(bx + (size_t)min(s, a.n_ranks - 1) * GKs + (size_t)g_own * K16);
-                    at[n][s] = ld_sys(bx + (size_t)min(s, a.n_ranks - 1) * GKs + (size_t)a.G * K16);
-                }
-            }
-        }
     };
+    // O of the own group and the cluster mass T without block b's old sums and with block b-1's new ones (:491-492,
+    // 506-507), then ratio ** theta and its log for block b (:495-499): one round trip of loads, one power chain.
     auto ga_table = [&](int b) {
-        double so[2], st[2], ao[2][8], at[2][8];
-        ga_fetch(b - 1, ao, at);
+        double ro[2], rt[2], ao[2], at[2];
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            const int k = min(lane + 64 * n, K16 - 1);                   // clamped, not predicated
+            const int k = min(lane + 64 * n, K16 - 1);
             const double* sold = a.S_old + (size_t)b * GKg + k;         // constant during the launch: plain loads
-            so[n] = sold[(size_t)g_own * K16];
+            ro[n] = sold[(size_t)g_own * K16];
             double t = 0.0;
             for (int g0 = 0; g0 < a.G; g0 += 8) {                       // eight loads in flight at a time
                 double v[8];
@@ -1849,20 +1808,15 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) t += (g0 + j < a.G) ? v[j] : 0.0;
             }
-            st[n] = t;
+            rt[n] = t;
         }
+        ga_fetch(b - 1, ao, at);
         const int bo = gcol[g_own];                                      // the group's batch (one batch variable)
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const int k = lane + 64 * n;
             if (k < K16) {
-                double o = Ocur[k] - so[n], t = Tm[k] - st[n];
-#pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    const bool use = !multi ? s < HMX_ROUND_SLOTS : s < a.n_ranks;
-                    o += use ? ao[n][s] : 0.0;
-                    t += use ? at[n][s] : 0.0;
-                }
+                const double o = Ocur[k] - ro[n] + ao[n], t = Tm[k] - rt[n] + at[n];
                 Ocur[k] = o;
                 Tm[k] = t;
                 const float O = (float)o;
@@ -1875,11 +1829,11 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             }
         }
     };
-    // the workgroup's sums of block b into its group's row and into the cluster-mass row of one slot table, then arrive
+    // the workgroup's sums of block b into its group's row and into the cluster-mass row of one slot table: count and sum in
+    // one word, not returning, nothing to wait for (see ga_fetch).  EVERY entry is added to, zero sums too: the count is the arrival.
     auto ga_publish = [&](int b) {
-        double* dst = a.S_new + ((size_t)b * HMX_ROUND_SLOTS + (wg % HMX_ROUND_SLOTS)) * GKs;
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.S_new) + ((size_t)b * HMX_ROUND_SLOTS + (wg % HMX_ROUND_SLOTS)) * GKs;
         double a2s = 0.0;
-        double olds[4] = {0.0, 0.0, 0.0, 0.0};   // returning adds, all in flight together: behind the wave's vmcnt(0) they are PERFORMED
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const int k = lane + 64 * n;
@@ -1887,29 +1841,12 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                 const double v = Sd[k];
                 Sd[k] = 0.0;
                 if (A2TAB) a2s += v * (double)(lrpT[k] * sig[k]);       // (:402), see round_post_pass1
-                if (fx) {   // count + fixed-point sum in one word, fire and forget (see ga_fetch)
-                    const unsigned long long w = (1ull << 55) + (unsigned long long)__double2ll_rn(v * 4294967296.0);
-                    unsigned long long* du = reinterpret_cast<unsigned long long*>(dst);
-                    __hip_atomic_fetch_add(du + (size_t)g_own * K16 + k, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add(du + (size_t)a.G * K16 + k, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else if (v != 0.0) {
-                    olds[2 * n] = atomicAdd(dst + (size_t)g_own * K16 + k, v);
-                    olds[2 * n + 1] = atomicAdd(dst + (size_t)a.G * K16 + k, v);
-                }
+                const unsigned long long w = (1ull << 55) + (unsigned long long)__double2ll_rn(v * 4294967296.0);
+                __hip_atomic_fetch_add(dst + (size_t)g_own * K16 + k, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(dst + (size_t)a.G * K16 + k, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (A2TAB) ent_acc += a2s;
-        if (fx) return;
-        WAIT_VMEM_ALL();
-#pragma unroll
-        for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(olds[t]));
-        if (!multi && (a.ga_opts & 16)) {
-            unsigned old = 0;
-            if (lane == 0) old = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            old = __builtin_amdgcn_readfirstlane(old);
-            if (old + 1u == (unsigned)(b + 1) * (unsigned)nwg && lane < ROUND_FLAGS)   // the last arrival of the block raises the flags
-                __hip_atomic_store(a.counter + 32 * (1 + lane), (unsigned)(b + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (lane == 0) __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
     if (!service) {
@@ -1918,11 +1855,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         WAIT_VMEM_ALL();   // landed (nothing else orders an LDS read behind an LDS-DMA)
         tile_step(2);
     }
-    if (chain) ga_table(0);
-    if (nochain && wv == ROUND_WAVES - 1) ga_table(0);
 
-    const bool split_store = ga && !(a.ga_opts & 64);
-    float sclk0 = 0.f, sclk1 = 0.f;
     for (int b = 0; b < a.nblk; ++b) {
         const int tb = bsS[b], ntl = bsN[b];
         {   // the tables do not change, but re-reading them every block is cheaper than the ~150
@@ -1939,8 +1872,10 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         }
         RSTAMP(0);
         RSTAMP(8);
-        if (ga) { RSTAMP(9); RSTAMP(1); RSTAMP(6); RSTAMP(7); }
-        if (nochain && b > 0 && wv == ROUND_WAVES - 1) ga_table(b);
+        if (ga) {
+            RSTAMP(9); RSTAMP(1); RSTAMP(6); RSTAMP(7);
+            if (hand) ga_table(b);   // polls for block b-1's sums, folds them, builds block b's table; the other waves wait at the barrier
+        }
         if (!ga) {
         // ---- wait until every workgroup has added its sums of block b-1 ---------------------
         if (b > 0 && wv == 0) wait_block(b - 1);
@@ -2029,7 +1964,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             lrpT[i] = __builtin_amdgcn_logf(s) * 0.693147182464599609375f;   // v_log_f32 (log2, 1 ulp) * ln 2
         }
         }
-        }   // (!ga: the chain wave built block b's table behind the previous block's publish)
+        }   // (!ga)
         wg_barrier_lds();
         RSTAMP(2);
         // ---- finish this block's tiles --------------------------------------------------------
@@ -2040,8 +1975,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             if (has1) round_post_pass1<MT, true, LOG2, A2TAB>(sig, rpT, lrpT, q, T[1], scl1, km_acc, ent_acc);
             __builtin_amdgcn_sched_barrier(0);
-            if (split_store) { round_post_pass2<MT, 1>(a.R, a.Kp, Sd, c16, q, T[0], scl0, has1, T[1], scl1); sclk0 = scl0; sclk1 = scl1; }
-            else round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T[0], scl0, has1, T[1], scl1);
+            round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T[0], scl0, has1, T[1], scl1);
         }
         for (int j = j_first + j_slot; j < ntl; j += j_slot) {   // blocks larger than the grid carries
 #pragma unroll 1
@@ -2069,33 +2003,9 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         wg_barrier_lds();
         RSTAMP(3);
         // ---- publish the block's new sums, then arrive ---------------------------------------
-        if (nochain) {
-            if (split_store && j_first < ntl)
-                round_post_pass2<MT, 2>(a.R, a.Kp, Sd, c16, q, T[0], sclk0, j_first + 1 < ntl, T[1], sclk1);
-            if (wv == ROUND_WAVES - 1) ga_publish(b);
-            WAIT_VMEM_ALL();
-        } else if (ga) {
-            if (chain) {
-                CSTAMP(b, 16);
-                ga_publish(b);
-                CSTAMP(b, 17);
-                if (a.ga_opts & 1) wg_barrier_lds();   // (experiment: the chain waits for the other waves' distance GEMM)
-                if (a.ga_opts & 4) { for (int z = 0; z < (a.ga_opts >> 8); ++z) __builtin_amdgcn_s_sleep(16); }   // (experiment: sleep (opts >> 8) k cycles before the first poll)
-                if (a.ga_opts & 8) {   // (experiment: poll a word nobody writes for (opts >> 8) polls: a load in flight, no hot line)
-                    for (int z = 0; z < (a.ga_opts >> 8); ++z) { const unsigned v = ld_agent(a.counter + 64 + wg); asm volatile("" ::"v"(v)); __builtin_amdgcn_s_sleep(1); }
-                }
-                if (b + 1 < a.nblk) {   // straight on to the next block's table, under the other waves' distance GEMM
-                    if (!fx) wait_block(b);
-                    CSTAMP(b, 18);
-                    ga_table(b + 1);
-                    CSTAMP(b, 19);
-                }
-            } else {
-                // the rows go out BEHIND the barrier: the chain wave's adds are in the memory pipeline first
-                if (split_store && j_first < ntl)
-                    round_post_pass2<MT, 2>(a.R, a.Kp, Sd, c16, q, T[0], sclk0, j_first + 1 < ntl, T[1], sclk1);
-                WAIT_VMEM_ALL();   // this wave's row stores (and the next operands landed); nobody waits for it
-            }
+        if (ga) {
+            if (hand) ga_publish(b);   // behind the workgroup's barrier: the block sums in LDS are complete
+            WAIT_VMEM_ALL();           // this wave's row stores (and the next operands landed); nobody waits for the adds
         } else if (pubwave) {
             if (service) {
                 double* dst = a.S_new + ((size_t)b * HMX_ROUND_SLOTS + (wg % HMX_ROUND_SLOTS)) * GKs;
@@ -2156,7 +2066,6 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         prof_b = b;
         if (b + 1 < a.nblk && !service) tile_step(b + 3);   // rows landed: vmcnt(0) above
         RSTAMP(5);
-        if (ga && (a.ga_opts & 1) && !chain) wg_barrier_lds();
     }
 
     if (lane == 0 && wv == (ga ? ROUND_WAVES - 1 : 0) && a.wait_stats) {   // (the wave that waits)
@@ -2164,7 +2073,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         atomicAdd(a.wait_stats + 1, (unsigned long long)ws_sum);
         atomicMax(a.wait_stats + 2, (unsigned long long)ws_max);
     }
-    if (ga && wv == ROUND_WAVES - 1 && failed && lane == 0) *wgfail = 1;
+    if (hand && failed && lane == 0) *wgfail = 1;
     // ---- objective partial sums (:399, :402) ----------------------------------------------------
     km_acc = wave_sum_all(km_acc);
     ent_acc = wave_sum_all(ent_acc);
@@ -2208,24 +2117,17 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     if (ga) {
         // ---- group-affine: the first workgroup of every group closes its group's row of O, its share of the
         //      cross-entropy term (:405-411) and -- group 0's -- the cluster mass
-        if (wl != 0 || wv != ROUND_WAVES - 1) return;
-        if (!fx) wait_last();
+        if (wl != 0 || !hand) return;
         const int bo = gcol[g_own];
         double part = 0.0;
-        double ao[2][8], at[2][8];
+        double ao[2], at[2];
         const bool failed_before = failed;
         ga_fetch(a.nblk - 1, ao, at);
-        if (fx && failed && !failed_before) give_up();
+        if (failed && !failed_before) give_up();
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const int k = min(lane + 64 * n, K16 - 1);
-            double o = Ocur[k], t = Tm[k];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const bool use = !multi ? s < HMX_ROUND_SLOTS : s < a.n_ranks;
-                o += use ? ao[n][s] : 0.0;
-                t += use ? at[n][s] : 0.0;
-            }
+            const double o = Ocur[k] + ao[n], t = Tm[k] + at[n];
             if (lane + 64 * n < K16) {
                 a.O_out[(size_t)g_own * K16 + k] = o;
                 if (g_own == 0) a.T_out[k] = t;
@@ -4378,7 +4280,7 @@ int launch_round(const RoundArgs& a_in, int mt, int wgs, hipStream_t s, bool ext
     RoundArgs a = a_in;
     a.ldy_lds = lds_ldy(a.dp);
     const bool ga = a.ga != 0;
-    if (ga && (a.V != 1 || !a.run_start || !a.wg_map)) return -1;
+    if (ga && (a.V != 1 || a.n_ranks > 1 || !a.run_start || !a.wg_map)) return -1;
     const bool bf3 = round_uses_bf16_pipe(a.K16, a.dp, a.G, a.B, a.V, extra_tiles, allow_bf16, ga, a.nblk);
     const size_t sm = round_lds_bytes(a.K16, a.dp, a.G, a.B, a.V, bf3, ga, a.nblk);
     if (mt < 1 || mt > 7 || sm > HMX_ROUND_LDS_LIMIT) return -1;

@@ -481,16 +481,25 @@ def test_bench_path_parity_blocks_larger_than_the_grid(wgs, monkeypatch):
     cnt = ho._engine.counters()
     assert cnt["sweep_waits"] > 0 and cnt["sweep_fallbacks"] == 0, cnt
     assert cnt["sweeps_bf16_pipe"] == 0, cnt     # such blocks go to the f32-input instances (round_uses_bf16_pipe: the extra-tile loop does not hide the split)
+    # 23 workgroups: the group-affine map dealt out min-max over the 8 groups; 6 workgroups cannot give every group its own: classic map
+    assert (cnt["sweeps_group_affine"] > 0) == (wgs == 23), cnt
 
 
-def test_bench_path_parity_many_batches(monkeypatch):
-    """30 batch groups at K=100, d=50: the most the one-launch sweep serves (its LDS tables grow with the group
-    count: 161 KB of the CU's 160 KiB here); same checks as the C3 shape, and the persistent
-    kernel -- not the per-block fall-back -- must have run: its f32-input instance, the bf16 planes of the other one need
-    25 KB that 22 and more groups' tables take."""
+@pytest.mark.parametrize("ga", ["1", "0"])
+def test_bench_path_parity_many_batches(ga, monkeypatch):
+    """30 batch groups at K=100, d=50; same checks as the C3 shape, and the persistent kernel -- not the per-block
+    fall-back -- must have run.  Classic tile map (HMX_ROUND_GA=0): the most groups the one-launch sweep serves (its LDS tables
+    grow with the group count: 161 KB of the CU's 160 KiB here) and its f32-input instance, the bf16
+    planes of the other one need 25 KB that 22 and more groups' tables take.  Group-affine map (the default for one batch
+    variable): a workgroup keeps the tables of its own group only, so the bf16-pipe instance serves any number of groups."""
+    monkeypatch.setenv("HMX_ROUND_GA", ga)
     ho = _bench_path_case(40_000, 50, 30, 100, monkeypatch, ridge_dtype=np.float64, rounds=(3, 3))
     cnt = ho._engine.counters()
-    assert cnt["sweep_waits"] > 0 and cnt["sweeps_bf16_pipe"] == 0, cnt
+    assert cnt["sweep_waits"] > 0 and cnt["sweep_fallbacks"] == 0, cnt
+    if ga == "1":
+        assert cnt["sweeps_group_affine"] == 6 and cnt["sweeps_bf16_pipe"] == 6, cnt
+    else:
+        assert cnt["sweeps_group_affine"] == 0 and cnt["sweeps_bf16_pipe"] == 0, cnt
 
 
 def _ab_engines(N, d, B, K, monkeypatch, switch, value, **kw):
@@ -535,6 +544,70 @@ def test_bf16_pipe_distance_gemm_against_the_f32_input_instance(N, d, B, K, monk
         va, vb = getattr(a, name)[-1], getattr(b, name)[-1]
         assert abs(va - vb) <= 2e-6 * abs(vb), (name, va, vb)
     print(f"bf16x3 vs f32-input distance GEMM {N}x{d} K={K} B={B}: max|dR|={dR:.2e}")
+
+
+def _unbalanced_dataset(N, d, K, sizes, seed=8):
+    """synthetic_dataset's population with prescribed batch sizes (the last batch takes the rest): tiny groups -- fewer cells
+    than update blocks -- next to large ones."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import synthetic_dataset
+    Z, _ = synthetic_dataset(N, d, 2, K, seed=seed)
+    batch = np.full(N, len(sizes), np.int64)
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(N)
+    pos = 0
+    for b, n in enumerate(sizes):
+        batch[perm[pos:pos + n]] = b
+        pos += n
+    Z = Z + (batch[:, None] * 0.3).astype(np.float32) / np.sqrt(1.0 + np.arange(d, dtype=np.float32))
+    meta = pd.DataFrame({"batch": pd.Categorical.from_codes(batch, categories=[f"b{i}" for i in range(len(sizes) + 1)])})
+    return Z.astype(np.float32), meta
+
+
+GA_SHAPES = [(150_000, 50, 8, 100, None), (69_000, 50, 4, 30, None), (40_000, 50, 30, 100, None), (30_000, 17, 2, 7, None),
+             (50_000, 64, 5, 112, None), (60_000, 50, None, 100, (7, 19, 300, 5000, 20000)), (20_000, 32, None, 30, (1, 2, 3, 40))]
+
+
+@pytest.mark.parametrize("N,d,B,K,sizes", GA_SHAPES)
+def test_group_affine_map_against_the_classic_map(N, d, B, K, sizes, monkeypatch):
+    """Direct A/B of the sweep's two tile maps inside one build, on one state: the group-affine map (every workgroup of k_round
+    owns one batch group, the per-block sums travel as self-validating fixed-point words: count << 55 | sum * 2^32) against
+    the classic map (HMX_ROUND_GA=0: all groups' tables in every workgroup, returning fp64 adds + arrival counter) -- the C3
+    and configs[1] shapes, 30 groups, rows of 17 / 64 PCs, and two layouts with groups of 1 .. 40 cells (most of whose
+    (block, group) runs are EMPTY: their workgroups only arrive).  Two seeded rounds each -- the second starts from the O the
+    first one's closing wrote: the counters say which map ran, the new R rows differ by <= 2e-6 (6e-6 where the maps also pick different GEMM instances), O by 1e-6 relative to the
+    cluster masses, the objective terms by 2e-6 relative (harmony.py:464-513, 394-417)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import quick_centroids, synthetic_dataset
+    monkeypatch.setenv("HMX_UPDATE_ORDER", "device")
+    if sizes is None:
+        Z, meta = synthetic_dataset(N, d, B, K, seed=5)
+    else:
+        Z, meta = _unbalanced_dataset(N, d, K, sizes)
+    Y0 = quick_centroids(Z, K, seed=5, sample=20_000)
+    engines = {}
+    for ga in ("1", "0"):
+        monkeypatch.setenv("HMX_ROUND_GA", ga)
+        engines[ga] = _run_engine(Z, meta, ["batch"], Y0=Y0, nclust=K, max_iter_harmony=0, random_state=7)
+    a, b = engines["1"], engines["0"]
+    a.cluster(_rounds=2)
+    b.cluster(_rounds=2)
+    ca, cb = a._engine.counters(), b._engine.counters()
+    assert ca["sweeps_group_affine"] == 2 and cb["sweeps_group_affine"] == 0, (ca, cb)
+    assert ca["sweep_fallbacks"] == 0 and cb["sweep_fallbacks"] == 0 and ca["sweep_waits"] > 0
+    dR = float(np.abs(a.R - b.R).max())
+    # (30 groups: the classic map's tables leave no room for the bf16 planes, so the two engines also differ in the distance
+    # GEMM's instruction -- the bound of test_bf16_pipe_distance_gemm_against_the_f32_input_instance applies there)
+    bound = 2e-6 if ca["sweeps_bf16_pipe"] == cb["sweeps_bf16_pipe"] else 6e-6
+    assert dR <= bound, f"max |R(group-affine) - R(classic)| = {dR:.2e}"
+    assert np.abs(a.O - b.O).max() <= 1e-6 * max(1.0, float(np.abs(b.O).max()))
+    np.testing.assert_allclose(a.O.sum(axis=0), b.O.sum(axis=0), rtol=1e-6)
+    for name in ("objective_kmeans_dist", "objective_kmeans_entropy", "objective_kmeans_cross", "objective_kmeans"):
+        for va, vb in zip(getattr(a, name)[-2:], getattr(b, name)[-2:]):
+            assert abs(va - vb) <= 2e-6 * abs(vb), (name, va, vb)
+    print(f"group-affine vs classic map {N}x{d} K={K} groups={a.B}: max|dR|={dR:.2e}, {ca['sweep_group_affine_wgs']} workgroups")
 
 
 # (rows of 64 floats: k_rtz3c serves at most one extra one-hot tile = 16 update blocks there, and K <= 64 so that its four
