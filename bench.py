@@ -172,8 +172,8 @@ def cpu_baseline(d, B, K, rounds, sample_cells, seed=1):
     kind "reference": harmonypy itself (`run_harmony(..., device='cpu')`, harmony.py:49) when the environment variable
     HMX_REFERENCE_PATH names a checkout of it (the build container: /root/reference; a GPU box has none).
     kind "port": the NumPy oracle, a restatement of the same torch-CPU arithmetic, on min(32, cpus) BLAS threads; its
-    rate relative to the reference's on the same sample and cores is kept in profiles/r02_cpu_baseline_calibration.json
-    (measured where both run)."""
+    rate relative to the reference's on the same sample and cores is kept in profiles/r06_cpu_baseline_calibration.json
+    (scripts/cpu_calibration.py, measured in the build container, where both run: 200k and 1M cells)."""
     Z, meta = synthetic_dataset(sample_cells, d, B, K, seed=seed)
     Y0 = quick_centroids(Z, K, seed=seed)
     what = f"{sample_cells} cells x {d} PCs, {B} batches, K={K}: 1 iteration = {rounds} rounds + ridge"
@@ -195,7 +195,7 @@ def cpu_baseline(d, B, K, rounds, sample_cells, seed=1):
     from oracle.harmony_oracle import OracleHarmony, prepare_inputs
     cal = None
     try:
-        cal = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_baseline_calibration.json")))
+        cal = json.load(open(os.path.join(ROOT, "profiles", "r06_cpu_baseline_calibration.json")))
     except Exception:
         pass
     # the thread count the reference/port ratio was measured at (8), so that the ratio applies to this very run
@@ -224,13 +224,21 @@ def cpu_baseline(d, B, K, rounds, sample_cells, seed=1):
     if cal:
         out["reference_over_port"] = cal.get("reference_over_port")
         out["value_reference_equivalent"] = out["value"] * cal.get("reference_over_port", 1.0)
-        out["calibration"] = "profiles/r02_cpu_baseline_calibration.json (harmonypy itself vs this port, same sample, same 8 threads)"
+        out["value_reference_equivalent_is"] = ("a CROSS-HOST EXTRAPOLATION: this host's port rate x the reference/port ratio measured on the "
+                                                "build container (8 cpus), where harmonypy itself runs -- not a measurement of the reference on this box")
+        out["calibration"] = ("profiles/r06_cpu_baseline_calibration.json (scripts/cpu_calibration.py: harmonypy itself vs this port, same sample, "
+                              "same 8 threads, 200k and 1M cells, build container)")
+        big = cal.get("samples", {}).get("1000000")
+        if big:   # the reference itself at the HEADLINE size, measured this round where it runs
+            out["reference_at_1M_build_container"] = {"value": big["reference"]["value"], "unit": "cells/sec/Harmony-iteration",
+                                                      "cores": big["reference"]["cores"], "port_same_host": big["port"]["value"],
+                                                      "sample": big["reference"]["sample"]}
     return out
 
 
 def newest_pmc(engine_version):
     """HBM bytes per launch of the round kernels from the committed rocprofv3 --pmc passes (scripts/gpu_pmc.sh), only if they
-    were collected on the kernel set that is running: (kernels dict, file name) or (None, reason)."""
+    were collected on the kernel set that is running: (the file's document: "kernels", optional "trace", file name) or (None, reason)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c3_pmc_hbm.json")), reverse=True)
     for f in files:
@@ -239,7 +247,7 @@ def newest_pmc(engine_version):
         except Exception:
             continue
         if pm.get("engine_version") == engine_version:
-            return pm["kernels"], os.path.relpath(f, ROOT)
+            return pm, os.path.relpath(f, ROOT)
     return None, (f"no profiles/*_c3_pmc_hbm.json carries engine_version {engine_version}"
                   + (f" (newest: {os.path.basename(files[0])})" if files else ""))
 
@@ -274,13 +282,15 @@ def roofline_block(config, N, d, B, K, ktimes, steps, rounds, wide, ktimes_all=N
         t_round_kernels += sum(ktimes_all[k][0] for k in ("rtz_round", "rtz_reduce", "block_table") if k in ktimes_all) / max(rounds, 1)
     else:
         t_round_kernels += sum(ktimes[k][0] for k in ("rtz_round", "rtz_reduce", "block_table") if k in ktimes) / max(n_rounds, 1)
+    round_traffic = None
     if wide:
         flops = cells_per_launch * 2.0 * d * K
         achieved = flops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
         peak = BF16X3_PEAK_TF if bf16_sweep else F32_MFMA_PEAK_TF
         roof = {"bound": "mfma", "kernel": ("k_assign_wide3 (one launch per update block, centroids pre-split into bf16 fragments; K > 112 or d > 64)"
-                                            if bf16_sweep else "k_assign_wide2 (one launch per update block, f32-input MFMA; K > 112 or d > 64)"),
+                                            if bf16_sweep else "k_assign_wide (one launch per update block, f32-input MFMA; K > 112 or d > 64)"),
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "frac_of_f32_mfma_peak": achieved / F32_MFMA_PEAK_TF,   # (comparable with rounds 1-4, whose `frac` was against 157.3)
                 "peak_note": "fp32-exact ceiling of the instruction that ran: bf16x3 = 2.5 PFLOP/s / 6 products, f32-input MFMA = 157.3",
                 "traffic": None, "traffic_source": "not collected for this configuration",
                 "avg_launch_us": per_launch_ms * 1e3, "launches": cnt, "launches_timed": cnt_timed, "algorithmic_flops_per_launch": flops}
@@ -290,17 +300,27 @@ def roofline_block(config, N, d, B, K, ktimes, steps, rounds, wide, ktimes_all=N
         sweep_name = "k_round"
         kernel = (f"{sweep_name} (one persistent launch per update_R sweep: all 20 blocks)" if sweep
                   else "k_assign_lds (one launch per update block)")
-        traffic, traffic_src = None, None
+        traffic, traffic_src, round_traffic, trace = None, None, None, None
         if sweep and config == "c3":
             pm, src = newest_pmc(harmonypy_amd.engine_version())
             traffic_src = src
             if pm is not None:
-                for name, rec in pm.items():
+                round_traffic = 0.0
+                for name, rec in pm["kernels"].items():
                     if name.startswith("void " + sweep_name):
                         traffic = rec["hbm_bytes_corrected"]
+                    # the round's kernels: the sweep, the streaming R^T.Z pass over Z_cos (its one-hot block columns: <.., 1>), its finish kernel
+                    if name.startswith("void " + sweep_name) or (name.startswith("void k_rtz3") and name.rstrip(">(Rtz3Args)").endswith("1")) or name.startswith("k_rtz3_finish"):
+                        round_traffic += rec["hbm_bytes_corrected"]
+                trace = pm.get("trace")
         roof = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_us": per_launch_ms * 1e3, "launches": cnt, "launches_timed": cnt_timed, "algorithmic_bytes_per_launch": alg_bytes}
+        if trace and trace.get("k_round_avg_us"):
+            # the same kernel in the rocprofv3 kernel trace of the build that is running (stored next to its counters):
+            # a few per cent longer than between HIP events on the stream
+            roof["frac_trace"] = alg_bytes / (trace["k_round_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            roof["trace"] = trace
     round_bytes = N * (4 * d + 8 * K + 8)
     round_flops = N * 4 * d * K
     # Which roof: both GEMMs of a round (distance product in the sweep, R^T.Z in the streaming pass) keep fp32 operands and
@@ -312,6 +332,9 @@ def roofline_block(config, N, d, B, K, ktimes, steps, rounds, wide, ktimes_all=N
     t_mfma_us = round_flops / (ceiling * 1e12) * 1e6
     roof["round"] = {
         "algorithmic_bytes": round_bytes, "kernel_ms_per_round": t_round_kernels,
+        # HBM bytes of the round's kernels (sweep + streaming R^T.Z pass + its finish kernel) from the committed counter passes
+        # of the running build, and their ratio to the algorithmic bytes: re-reads show here
+        "traffic": (round_traffic if not wide else None), "traffic_over_algorithmic": (round_traffic / round_bytes if (not wide and round_traffic) else None),
         "frac_of_hbm_peak": (round_bytes / (t_round_kernels * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_round_kernels > 0 else 0.0,
         "mfma_flops": round_flops,
         "mfma_ceiling_fp32_exact_tf": {"f32_input_mfma": F32_MFMA_PEAK_TF, "bf16x3": BF16X3_PEAK_TF, "this_run": ceiling,

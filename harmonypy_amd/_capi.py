@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("HMX_LIB") or os.path.join(_HERE, "libhmx.so")   # HMX
 
 # mirrors include/hmx.h
 HMX_TILE = 16
-HMX_MAX_CLUSTERS, HMX_MAX_PCS, HMX_MAX_BLOCKS, HMX_MAX_VARS = 208, 208, 60, 8   # limits checked by hmx_create
+HMX_MAX_CLUSTERS, HMX_MAX_PCS, HMX_MAX_BLOCKS, HMX_MAX_VARS = 208, 208, 250, 8   # limits checked by hmx_create
 HMX_Z_ORIG, HMX_Z_COS, HMX_Z_CORR, HMX_R, HMX_Y, HMX_O_GROUP, HMX_T_MASS, HMX_W = range(8)
 HMX_ROUND_BLOCK_START, HMX_ROUND_CELLS, HMX_ROUND_TILE_GROUP = 8, 9, 10
 HMX_ROUND_CENTROIDS, HMX_ROUND_UPDATE_R, HMX_ROUND_OBJECTIVE = 1, 2, 4
@@ -346,7 +346,8 @@ class Engine:
         _check(self._lib.hmx_counters(self._h, _ptr(buf)))
         return {"collectives": int(buf[0]), "sweep_fallbacks": int(buf[1]), "seeded_rounds": int(buf[2]), "sweeps_bf16_pipe": int(buf[3]),
                 "sweep_waits": int(buf[4]), "sweep_wait_polls": int(buf[5]), "sweep_wait_polls_max": int(buf[6]), "rtz_bf16_pipe": int(buf[7]),
-                "sweeps_group_affine": int(buf[8]), "sweep_group_affine_wgs": int(buf[9])}
+                "sweeps_group_affine": int(buf[8]), "sweep_group_affine_wgs": int(buf[9]),
+                "peer_box": {0: "none", 1: "coarse", 2: "fine"}[int(buf[10])]}
 
     def kernel_times(self):
         """{family: (total_ms, launches)} since timing was enabled."""

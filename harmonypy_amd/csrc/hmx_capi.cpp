@@ -147,6 +147,7 @@ struct hmx_engine {
     // peer boxes: the in-kernel exchange of the per-block sums (k_round, cells sharded over ranks)
     double* box = nullptr;               // this rank's box (device memory, exported to the peers)
     size_t box_doubles = 0;
+    bool box_fine = false;               // the box is fine-grained device memory (hipExtMallocWithFlags)
     std::vector<void*> peer_ptrs;        // every rank's box as mapped here (own box included)
     DevBuf<double*> peer_dev;            // the same array on the device
     bool peers_attached = false, peers_enabled = false;
@@ -1239,7 +1240,7 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
             if (multi) {
                 ra.peer_box = e->peer_dev.p; ra.my_box = e->box; ra.n_ranks = e->n_ranks; ra.rank = e->rank;
                 ra.epoch = e->round_epoch;
-                e->round_epoch += 64;
+                e->round_epoch += 256;   // (> HMX_MAX_BLOCKS: the flag values of two launches never meet)
             }
 #ifdef HMX_ROUND_PROF
             static DevBuf<unsigned long long> prof;
@@ -1627,13 +1628,31 @@ int hmx_peer_export(hmx_engine* e, void* out_handle) {
     int rc;
     if ((rc = use_device(e))) return rc;
     peer_release(e);
-    const size_t GKs = (size_t)(e->G + 1) * e->K16;   // a rank's share: the G group rows + the cluster-mass row of k_round's slot tables
+    const size_t GKs = (size_t)(e->G + 1) * e->K16;   // a rank's share: the G group rows + one spare row (the slot tables' stride)
     e->box_doubles = peer_box_doubles(e->n_ranks, GKs);
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->box), e->box_doubles * sizeof(double)));
-    HIP_TRY(hipMemset(e->box, 0, e->box_doubles * sizeof(double)));
-    HIP_TRY(hipDeviceSynchronize());
+    // FINE-GRAINED device memory: the box is written by other GPUs over xGMI and polled by a kernel that is already running
+    // (k_round).  HIP specifies visibility of another device's writes during a kernel only for fine-grained allocations (a
+    // coarse-grained one may be cached, and is only promised coherent at kernel boundaries); HMX_PEER_BOX=coarse keeps the
+    // plain hipMalloc of rounds 3-5 (A/B), and an allocation or an export of the fine-grained box that fails falls back to it.
+    const char* kind = getenv("HMX_PEER_BOX");
+    bool fine = !(kind && std::string(kind) == "coarse");
     hipIpcMemHandle_t h;
-    HIP_TRY(hipIpcGetMemHandle(&h, e->box));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        hipError_t ae = fine ? hipExtMallocWithFlags(reinterpret_cast<void**>(&e->box), e->box_doubles * sizeof(double), hipDeviceMallocFinegrained)
+                             : hipMalloc(reinterpret_cast<void**>(&e->box), e->box_doubles * sizeof(double));
+        if (ae == hipSuccess) {
+            HIP_TRY(hipMemset(e->box, 0, e->box_doubles * sizeof(double)));
+            HIP_TRY(hipDeviceSynchronize());
+            ae = hipIpcGetMemHandle(&h, e->box);
+            if (ae == hipSuccess) break;
+            (void)hipFree(e->box);
+            e->box = nullptr;
+        }
+        (void)hipGetLastError();
+        if (!fine) return fail(HMX_ERR_HIP, "peer box: %s", hipGetErrorString(ae));
+        fine = false;                                   // second attempt: coarse-grained
+    }
+    e->box_fine = fine;
     std::memcpy(out_handle, &h, sizeof h);
     return HMX_OK;
 }
@@ -1644,6 +1663,17 @@ int hmx_peer_attach(hmx_engine* e, const void* handles) {
     int rc;
     if ((rc = use_device(e))) return rc;
     e->peer_ptrs.assign(e->n_ranks, nullptr);
+    {   // every GPU of the node must be reachable from this one (the usual layout: rank r drives device r): a missing link would
+        // only show as a failed hipIpcOpenMemHandle below, or as a self-test that times out
+        int n_dev = 0, mine = e->cfg.device_id;
+        if (hipGetDeviceCount(&n_dev) == hipSuccess && n_dev >= e->n_ranks)
+            for (int d = 0; d < n_dev; ++d) {
+                int can = 1;
+                if (d != mine && hipDeviceCanAccessPeer(&can, mine, d) == hipSuccess && !can)
+                    return fail(HMX_ERR_COMM, "device %d cannot access device %d: no peer exchange on this node", mine, d);
+            }
+        (void)hipGetLastError();
+    }
     for (int r = 0; r < e->n_ranks; ++r) {
         if (r == e->rank) { e->peer_ptrs[r] = e->box; continue; }
         hipIpcMemHandle_t h;
@@ -1669,7 +1699,9 @@ int hmx_peer_selftest(hmx_engine* e) {
     if ((rc = use_device(e))) return rc;
     HIP_TRY(hipMemsetAsync(e->sync_words.p, 0, 2 * sizeof(unsigned), e->stream));
     e->selftest_token += 1;
-    launch_peer_selftest(e->peer_dev.p, e->box, e->n_ranks, e->rank, (size_t)(e->G + 1) * e->K16, e->selftest_token, e->sync_words.p, e->stream);
+    int iters = 8;                                      // HMX_PEER_SELFTEST_ITERS: a soak (tests), at most 65535 cycles
+    if (const char* it = getenv("HMX_PEER_SELFTEST_ITERS")) iters = std::max(1, std::min(65535, atoi(it)));
+    launch_peer_selftest(e->peer_dev.p, e->box, e->n_ranks, e->rank, (size_t)(e->G + 1) * e->K16, e->selftest_token, iters, e->sync_words.p, e->stream);
     HIP_TRY(hipMemcpyAsync(e->sync_host, e->sync_words.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipGetLastError());
@@ -1885,7 +1917,8 @@ int hmx_counters(hmx_engine* e, int64_t out[HMX_N_COUNTERS]) {
     out[7] = e->n_rtz_bf16;
     out[8] = e->n_sweeps_ga;
     out[9] = e->n_sweeps_ga > 0 ? e->ga_nwg : 0;
-    for (int i = 10; i < HMX_N_COUNTERS; ++i) out[i] = 0;
+    out[10] = e->box ? (e->box_fine ? 2 : 1) : 0;
+    for (int i = 11; i < HMX_N_COUNTERS; ++i) out[i] = 0;
     return HMX_OK;
 }
 

@@ -214,7 +214,7 @@ bool round_uses_bf16_pipe(int K16, int dp, int G, int B, int V, bool extra_tiles
 int round_row_floats(int d);
 int launch_round(const RoundArgs& a, int mt, int wgs, hipStream_t s, bool extra_tiles, bool allow_bf16);   // extra_tiles: a block holds more tiles than the grid's 16 slots per workgroup
 size_t peer_box_doubles(int n_ranks, size_t GK);
-void launch_peer_selftest(double* const* peer_box, double* my_box, int n_ranks, int rank, size_t GK, unsigned long long token,
+void launch_peer_selftest(double* const* peer_box, double* my_box, int n_ranks, int rank, size_t GK, unsigned long long token, int iters,
                           unsigned* result, hipStream_t s);
 // LISI (hmx_lisi.hip)
 #define LISI_KNN_WAVES 4

@@ -2383,8 +2383,8 @@ __global__ __launch_bounds__(256, 2) void k_rtz2(RtzArgs a) {
     // per-tile bookkeeping (group, block) comes from LDS copies: a dependent global load per tile
     // would cost a full memory round trip on the critical path
     int* grp_l = reinterpret_cast<int*>(lds + 2 * tile_floats);      // window of 256 tiles: key = block * G + group
-    int* bs_l = grp_l + 256;                                          // nblk + 1 tile offsets
-    double* sd = reinterpret_cast<double*>(bs_l + 64);                // ONES: K16 running column sums (fp64), owned by the last wave
+    int* bs_l = grp_l + 256;                                          // nblk + 1 tile offsets (room for 256: HMX_MAX_BLOCKS = 250)
+    double* sd = reinterpret_cast<double*>(bs_l + 256);                // ONES: K16 running column sums (fp64), owned by the last wave
     if (ONES) for (int i = tid; i < a.K16; i += 256) sd[i] = 0.0;
     const int task_g = a.task_tile0 ? a.task_grp[wg] : -1;
     if (a.blk_start)
@@ -2618,7 +2618,7 @@ __global__ __launch_bounds__(512, 2) void k_rtz_wide(RtzArgs a) {
     // per-tile bookkeeping (group, block) comes from LDS copies: a dependent global load per tile
     // would cost a full memory round trip on the critical path
     int* grp_l = reinterpret_cast<int*>(lds + 2 * tile_floats);      // 256 tile groups
-    int* bs_l = grp_l + 256;                                          // nblk + 1 tile offsets
+    int* bs_l = grp_l + 256;                                          // nblk + 1 tile offsets (room for 256: HMX_MAX_BLOCKS = 250)
     const int task_g = a.task_tile0 ? a.task_grp[wg] : -1;
     if (a.blk_start)
         for (int i = tid; i <= a.nblk; i += 512) bs_l[i] = a.blk_start[i];
@@ -4181,7 +4181,7 @@ size_t round_lds_bytes(int K16, int dp, int G, int B, int V, bool bf3, bool ga, 
 
 size_t peer_box_doubles(int n_ranks, size_t GK) { return box_flags(n_ranks, GK) + 2 * (size_t)n_ranks + 2 * (size_t)n_ranks + 8; }
 
-// Self-test of the peer boxes, with time-outs: eight exchange cycles of exactly the pattern k_round
+// Self-test of the peer boxes, with time-outs: `iters` exchange cycles (8; HMX_PEER_SELFTEST_ITERS soaks) of exactly the pattern k_round
 // uses -- a payload of system-scope stores into every rank's box, s_waitcnt vmcnt(0), barrier, then
 // one flag word per peer -- and on the receiving side: poll the flag words, then read every rank's
 // payload with system-scope loads and compare.  A payload that is not complete when its flag is
@@ -4189,7 +4189,7 @@ size_t peer_box_doubles(int n_ranks, size_t GK) { return box_flags(n_ranks, GK) 
 // answers all give result 0.  Acknowledge words keep a fast rank from overwriting a payload that a
 // slow rank is still checking.
 __global__ __launch_bounds__(256) void k_peer_selftest(double* const* peer_box, double* my_box, int n_ranks, int rank, size_t GK,
-                                                      unsigned long long token, unsigned* result) {
+                                                      unsigned long long token, int iters, unsigned* result) {
     __shared__ int bad;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t tok0 = box_flags(n_ranks, GK) + 2 * (size_t)n_ranks;   // token words, then acknowledge words
@@ -4210,8 +4210,8 @@ __global__ __launch_bounds__(256) void k_peer_selftest(double* const* peer_box, 
         }
         __syncthreads();
     };
-    for (int it = 0; it < 8 && !bad; ++it) {
-        const unsigned long long tk = token * 16ull + (unsigned long long)it;
+    for (int it = 0; it < iters && !bad; ++it) {
+        const unsigned long long tk = token * 65536ull + (unsigned long long)it;
         const int par = it & 1;
         for (int r = 0; r < n_ranks; ++r)
 #if HMX_ROUND_RETURNING
@@ -4229,6 +4229,13 @@ __global__ __launch_bounds__(256) void k_peer_selftest(double* const* peer_box, 
             for (int i = tid; i < npay; i += 256)
                 wrong |= ld_sys(my_box + box_data(n_ranks, GK, par, r) + i) != (double)(tk % 1000003ull) + i;
         if (wrong) bad = 1;
+        // the stale-line case: touch the lines of the OTHER parity -- the ones every peer overwrites in the next cycle -- with the
+        // loads the sweep kernel uses, BEFORE the acknowledge that lets the peers go on.  Whatever copy of those lines this GPU
+        // keeps from now on is stale by construction; the next cycle's check must still see the peers' new payload.
+        double touch = 0.0;
+        for (int r = 0; r < n_ranks; ++r)
+            for (int i = tid; i < npay; i += 256) touch += ld_sys(my_box + box_data(n_ranks, GK, par ^ 1, r) + i);
+        asm volatile("" ::"v"(touch));
         __syncthreads();
         if (tid < n_ranks) st_sys(reinterpret_cast<unsigned long long*>(peer_box[tid]) + ack0 + rank, tk);
         wait_all(ack0, tk);
@@ -4237,9 +4244,9 @@ __global__ __launch_bounds__(256) void k_peer_selftest(double* const* peer_box, 
     if (tid == 0) *result = bad ? 0u : 1u;
 }
 
-void launch_peer_selftest(double* const* peer_box, double* my_box, int n_ranks, int rank, size_t GK, unsigned long long token,
+void launch_peer_selftest(double* const* peer_box, double* my_box, int n_ranks, int rank, size_t GK, unsigned long long token, int iters,
                           unsigned* result, hipStream_t s) {
-    hipLaunchKernelGGL(k_peer_selftest, dim3(1), dim3(256), 0, s, peer_box, my_box, n_ranks, rank, GK, token, result);
+    hipLaunchKernelGGL(k_peer_selftest, dim3(1), dim3(256), 0, s, peer_box, my_box, n_ranks, rank, GK, token, iters, result);
 }
 
 // k_round is compiled for Z_cos rows of 32, 52 and 64 floats (d <= 32, <= 52, <= 64: the engine pads
@@ -4328,7 +4335,7 @@ void launch_rtz2(const RtzArgs& a_in, int wgs, hipStream_t s) {
     const int ntd = a.dp == 32 ? 2 : 4;
     a.ldr = ((a.K16 + 31) / 32) * 32 + 16;          // row strides = 16 (mod 32) floats: conflict-free fragment reads
     a.ldz = ((16 * ntd + 31) / 32) * 32 + 16;
-    const size_t sm = (size_t)2 * 16 * (a.ldr + a.ldz) * sizeof(float) + (256 + 64) * sizeof(int) + (size_t)a.K16 * sizeof(double);
+    const size_t sm = (size_t)2 * 16 * (a.ldr + a.ldz) * sizeof(float) + (256 + 256) * sizeof(int) + (size_t)a.K16 * sizeof(double);
     if (ntd == 2) launch_rtz2_n<2, false>(a, a.mt, wgs, sm, s);
     else if (a.dp < 64) launch_rtz2_n<4, true>(a, a.mt, wgs, sm, s);     // a padding column carries the column sums of R
     else launch_rtz2_n<4, false>(a, a.mt, wgs, sm, s);
@@ -4386,7 +4393,7 @@ void launch_rtz_wide(const RtzArgs& a_in, int wgs, hipStream_t s) {
     a.ntd = ntd;
     a.ldr = ((a.K16 + 31) / 32) * 32 + 16;
     a.ldz = ((16 * ntd + 31) / 32) * 32 + 16;
-    const size_t sm = (size_t)2 * 16 * (a.ldr + a.ldz) * sizeof(float) + (256 + 64) * sizeof(int);
+    const size_t sm = (size_t)2 * 16 * (a.ldr + a.ldz) * sizeof(float) + (256 + 256) * sizeof(int);
     switch (a.mt) {
         case 1: hipLaunchKernelGGL((k_rtz_wide<1>), dim3(wgs), dim3(512), sm, s, a); break;
         case 2: hipLaunchKernelGGL((k_rtz_wide<2>), dim3(wgs), dim3(512), sm, s, a); break;

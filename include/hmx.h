@@ -34,7 +34,7 @@ extern "C" {
 /* limits of this build, checked by hmx_create (the reference has none: harmony.py:123-124 caps only the default K) */
 #define HMX_MAX_CLUSTERS 208
 #define HMX_MAX_PCS 208
-#define HMX_MAX_BLOCKS 60
+#define HMX_MAX_BLOCKS 250 /* block_size >= 0.004: a cell's block id of the round travels as one byte */
 #define HMX_MAX_VARS 8
 
 typedef enum hmx_status {
@@ -268,7 +268,8 @@ int hmx_set_timing_stride(hmx_engine* e, int stride);
  * (centroid numerators + removal sums, ridge statistics) that ran on the bf16 matrix pipe (k_rtz3c; engines created under
  * HMX_RTZ3_BF16=0 keep the f32-input kernel k_rtz3; wide shapes: k_rtzw2b), out[8] sweeps launched with the group-affine tile
  * map (one batch variable: every workgroup of k_round owns one batch group; HMX_ROUND_GA=0 keeps the
- * classic map), out[9] workgroups of the last such sweep; out[10..15] reserved (0). */
+ * classic map), out[9] workgroups of the last such sweep, out[10] the peer box of a sharded engine: 0 none, 1 coarse-grained
+ * device memory (HMX_PEER_BOX=coarse, or the fall-back), 2 fine-grained; out[11..15] reserved (0). */
 #define HMX_N_COUNTERS 16
 int hmx_counters(hmx_engine* e, int64_t out[HMX_N_COUNTERS]);
 

@@ -72,7 +72,7 @@ def main():
         out = dict(Z_corr=ho.Z_corr, objective_kmeans=ho.objective_kmeans, objective_harmony=ho.objective_harmony,
                    kmeans_rounds=ho.kmeans_rounds, K=ho.K, Pr_b=ho.Pr_b, theta=ho.theta, O=ho.O, E=ho.E, Y=ho.Y,
                    R_colsum_local=ho.R.sum(axis=0), transport=str(ho.transport),
-                   sweep_fallbacks=ho._engine.counters()["sweep_fallbacks"])
+                   sweep_fallbacks=ho._engine.counters()["sweep_fallbacks"], peer_box=ho._engine.counters()["peer_box"])
     else:
         raise SystemExit(f"unknown mode {mode}")
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), lo=lo, hi=hi, **out)

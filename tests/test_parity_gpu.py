@@ -245,10 +245,13 @@ def test_object_api_surface():
 
 @pytest.mark.parametrize("N,d,K,B,bs", [(37, 5, 3, 2, 0.05), (16, 4, 2, 1, 0.3), (1000, 33, 17, 5, 0.13),
                                         (2049, 64, 30, 4, 0.05), (900, 100, 150, 3, 0.05), (1500, 70, 20, 2, 0.1),
-                                        (640, 20, 120, 2, 0.05), (800, 40, 130, 2, 0.1)])   # last: K > 112 with 52-float rows: the generic kernels
+                                        (640, 20, 120, 2, 0.05), (800, 40, 130, 2, 0.1),    # K > 112 with 52-float rows: the generic kernels
+                                        (3456, 20, 10, 3, 0.01), (5000, 50, 30, 2, 0.004), (2500, 100, 130, 2, 0.0125)])   # 100 / 250 / 80 update blocks (harmony.py:474)
 def test_edge_shapes_against_oracle(N, d, K, B, bs):
-    """Ragged sizes: N below a block/tile, a single batch, K and d off the tile sizes, and shapes
-    beyond the LDS-resident kernels (K > 112 or d > 64: the generic kernels, BASELINE config 5's regime)."""
+    """Ragged sizes: N below a block/tile, a single batch, K and d off the tile sizes, shapes beyond the LDS-resident
+    kernels (K > 112 or d > 64: the generic kernels, BASELINE config 5's regime), and block_size down to 0.004: up to 250
+    update blocks per sweep (the reference takes any block_size, harmony.py:474-475; beyond 64 blocks the streaming R^T.Z
+    pass hands over to the list-order kernels)."""
     from oracle import oracle_run_harmony
     rng = np.random.default_rng(N)
     Z = rng.normal(size=(N, d)).astype(np.float32) * (1.0 / np.sqrt(1 + np.arange(d))).astype(np.float32)
@@ -617,7 +620,7 @@ def test_bf16_pipe_rtz_pass_against_the_f32_input_kernel(N, d, B, K, bs, monkeyp
     """Direct A/B of the streaming R^T.Z pass (harmony.py:443-444 centroid numerators, :491-492 removal sums, :550, :559-563
     ridge statistics): k_rtz3c (both operands split in registers, bf16 pipe) against k_rtz3 (f32-input MFMA, engines
     created under HMX_RTZ3_BF16=0), same shapes as above.  Two seeded rounds (the second round's pass reads the R the first
-    one wrote) + the ridge: Y atol 2e-6, O 2e-6 relative to the masses, R 4e-6, Z_corr 1e-6 relative Frobenius; the counter
+    one wrote) + the ridge: Y atol 2e-6, O 2e-6 relative to the masses, R 6e-6 (measured 3.6e-6), Z_corr 1e-6 relative Frobenius; the counter
     says which kernel ran."""
     a, b = _ab_engines(N, d, B, K, monkeypatch, "HMX_RTZ3_BF16", "0", block_size=bs)
     for h in (a, b):
@@ -644,7 +647,8 @@ def test_wide_bf16_pipe_kernels_against_the_f32_input_kernels(N, d, B, K, switch
     assignment (k_assign_wide3, harmony.py:447, 464-513) and its streaming R^T.Z pass (k_rtzw2b, :443-444, :491-492, :550,
     :559-563) run on the bf16 matrix pipe with every fp32 operand as three exact bf16 terms.  Direct A/B inside one build on
     one state against the f32-input kernels (engines created under HMX_ROUND_F32=1 / HMX_RTZ3_BF16=0): two seeded rounds +
-    the ridge; R 4e-6, Y 2e-6, O 2e-6 of the masses, objective terms 2e-6 relative, Z_corr 1e-6 relative Frobenius; the
+    the ridge; R max-abs 3e-5 and 6e-6 relative Frobenius (see the note at the assertion), Y 2e-6, O 2e-6 of the masses, objective terms 2e-6
+    relative, Z_corr 2e-6 relative Frobenius; the
     counters say which kernels ran (shapes outside k_rtzw2b's -- K <= 112, fewer than seven or more than fourteen column tiles -- keep k_rtzw)."""
     a, b = _ab_engines(N, d, B, K, monkeypatch, switch, value)
     assert a._wide_shape()

@@ -36,6 +36,26 @@ def test_two_shards_match_reference_golden(case, peer, tmp_path, monkeypatch):
     np.testing.assert_allclose(res[0]["R_colsum_local"] + res[1]["R_colsum_local"], g["R_colsum"], rtol=3e-4, atol=3e-4)
 
 
+@pytest.mark.parametrize("box", ["fine", "coarse"])
+def test_peer_boxes_fine_grained_and_selftest_soak(box, tmp_path, monkeypatch):
+    """The peer boxes are FINE-GRAINED device memory (hipExtMallocWithFlags: what HIP promises to keep coherent for another
+    device's writes while a kernel polls them; HMX_PEER_BOX=coarse keeps the plain hipMalloc of earlier rounds), exported through
+    IPC as before, and the self-test that gates the in-kernel exchange soaks: 3 000 exchange cycles instead of 8, every cycle
+    with the stale-line step (the reader touches the lines the peer overwrites next BEFORE it lets the peer go on).  Then the
+    job itself: two engines, block sums through the boxes, the reference's Z_corr within 1e-4."""
+    monkeypatch.setenv("HMX_PEER_EXCHANGE", "1")
+    monkeypatch.setenv("HMX_PEER_SELFTEST_ITERS", "3000")
+    monkeypatch.setenv("HMX_PEER_BOX", box)
+    case = "pbmc_short"
+    data, meta, vars_use, kw, g = load_case(case)
+    res = launch("engine", case, tmp_path, world=2, opts={"transport": "host", "order": "torch"})
+    for r in res:
+        assert str(r["transport"]) == "host+peer" and str(r["peer_box"]) == box and int(r["sweep_fallbacks"]) == 0
+    Z = np.concatenate([r["Z_corr"] for r in res], axis=0)
+    rel_f, max_rel = assert_z_close(Z, g["Z_corr"])
+    print(f"peer boxes {box}-grained, self-test soak of 3000 cycles: 2 shards vs reference relF={rel_f:.2e} max={max_rel:.2e}")
+
+
 def test_device_order_does_not_depend_on_sharding(tmp_path):
     """The device-side update order is a function of (seed, round, global cell id): one engine
     and two engines walk the same blocks, so their results agree to summation-order noise."""
@@ -154,4 +174,34 @@ def test_bench_four_ranks_on_one_gpu(tmp_path):
     print("4 ranks on one GPU:", round(line["value"] / 1e6, 1), "M cells/s/iteration; collectives per rank", total)
     # warm-up + timed steps (+ the one-off collectives of set-up and init_cluster): far below the 20 per round of the
     # one-collective-per-block path (rounds * 22 per step)
+    assert (steps + warmup) * per_step <= total <= (steps + warmup) * per_step + 40, total
+
+
+def test_bench_eight_ranks_on_one_gpu(tmp_path):
+    """`python bench.py --gpus 8`: the rank count of BASELINE configs[3] / [4] -- eight engines on the one GPU of the box over
+    gloo, 28 compute workgroups + a gateway each (232 of 256 CUs: all eight persistent sweeps resident together).  Executes
+    what a node of eight GPUs would index: eight peer boxes per rank, 8-way flags, eight gateway workgroups writing into every
+    box.  The in-kernel exchange must be on for every rank, nothing may time out, and the collective count per rank is the
+    small one (two per round + one per ridge step)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HMX_BENCH_BACKEND="gloo", HMX_ROUND_WGS="28", HMX_BENCH_CELLS="20000")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    steps, warmup, rounds = 1, 1, 10
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", str(steps), "--warmup", str(warmup),
+                        "--cpu-sample", "0", "--no-convergence"], capture_output=True, text=True, env=env, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["config"]["cells_total"] == 160000
+    ranks = line["ranks"]
+    assert len(ranks["per_rank"]) == 8 and ranks["transports"] == ["host+peer"] and ranks["peer_exchange_on_all"]
+    assert all(pr["fallback_rounds"] == 0 and pr["sweep_waits"] > 0 for pr in ranks["per_rank"]), ranks["per_rank"]
+    assert len(ranks["collectives_per_rank"]) == 1
+    per_step = (rounds * 2 + 1)
+    total = ranks["collectives_per_rank"][0]
+    print("8 ranks on one GPU:", round(line["value"] / 1e6, 1), "M cells/s/iteration; collectives per rank", total)
     assert (steps + warmup) * per_step <= total <= (steps + warmup) * per_step + 40, total
