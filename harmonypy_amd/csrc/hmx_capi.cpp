@@ -628,6 +628,10 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
             // k_rtz3 keeps two workgroups per CU resident, k_rtz3c (sixteen tile buffers) one: as many tasks as fit at once,
             // or a second round of workgroups pays the prologue, the slab reduction and the tail again (measured: 188 us per
             // pass with 505 tasks of 31 tiles per wave)
+            // The cut is decided from the ROUND pass (e->nblk block columns): ten of the eleven passes of a Harmony iteration.
+            // The ridge statistics and the device Lloyd iterations run the same tasks with ONE block column and may be served
+            // by the other kernel of the family there (wide shapes: rtzw2b_ok depends on the column tiles) -- results are the
+            // same on any cut, the cut is tuned for the majority pass (advisor finding, round 5).
             const bool one_per_cu = e->allow_rtz_bf16 && (rtz_wide_ok(e->mt, e->dp) ? rtzw2b_ok(e->mt, e->dp, e->d, e->nblk) : rtz3b_ok(e->mt, e->dp, e->nblk, e->Kp));
             const int target = std::max(1, (one_per_cu ? 1 : 2) * e->n_cus - e->G);
             const int CH3 = std::max(16, std::min(one_per_cu ? 2048 : 256, (n_static_tiles + target - 1) / target));

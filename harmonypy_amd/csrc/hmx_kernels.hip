@@ -906,6 +906,9 @@ __device__ __forceinline__ void round_post_pass1(const float* sig, const float* 
 #ifndef HMX_ROUND_RS
 #define HMX_ROUND_RS 1
 #endif
+#ifndef HMX_ROUND_R_NT
+#define HMX_ROUND_R_NT 0
+#endif
 #ifndef HMX_ROUND_PUBWAVE
 #define HMX_ROUND_PUBWAVE 1
 #endif
@@ -971,8 +974,13 @@ __device__ __forceinline__ void round_post_pass2(float* R, int Kp, double* Sd, i
             rv0[m] = T0.arg[mt] * scl0;                    // :503
             rv1[m] = T1.arg[mt] * scl1;
 #if !(HMX_RABL & 2)
+#if HMX_ROUND_R_NT   /* (experiment of round 6: the R rows are written once per round and read once by the next pass -- streaming stores) */
+            if (live0 && col < Kp) __builtin_nontemporal_store(rv0[m], reinterpret_cast<f32x4*>(row0 + col));
+            if (live1 && col < Kp) __builtin_nontemporal_store(rv1[m], reinterpret_cast<f32x4*>(row1 + col));
+#else
             if (live0 && col < Kp) st4(row0 + col, rv0[m]);
             if (live1 && col < Kp) st4(row1 + col, rv1[m]);
+#endif
 #endif
         }
 #if !(HMX_RABL & 1)
@@ -4527,9 +4535,10 @@ int launch_ridge_apply(const ApplyArgs& a_in, int max_wgs, hipStream_t s) {
         }                                                                                                             \
         hipLaunchKernelGGL((k_ridge_apply_wideb<M>), dim3(a.ntasks), dim3(64 * APPLYB_WAVES), sm, s, a);               \
     } break;
+        if (mtd < 1 || mtd > 13 || sm > (size_t)80 * 1024) return -1;   // (13 column tiles: 78 KB, the attribute's 80 KB)
         switch (mtd) {
             HMX_AWB(1) HMX_AWB(2) HMX_AWB(3) HMX_AWB(4) HMX_AWB(5) HMX_AWB(6) HMX_AWB(7) HMX_AWB(8) HMX_AWB(9) HMX_AWB(10) HMX_AWB(11) HMX_AWB(12)
-            default: hipLaunchKernelGGL((k_ridge_apply_wideb<13>), dim3(a.ntasks), dim3(64 * APPLYB_WAVES), sm, s, a); break;
+            HMX_AWB(13)   // (configs[4]: d = 200 -> 13 tiles, 78 KB of dynamic LDS: above the 64 KB default, so the attribute is set like everywhere else)
         }
 #undef HMX_AWB
         return 0;

@@ -34,6 +34,10 @@
 #include "hmx_internal.h"
 #include "hmx_device.h"
 
+#ifndef HMX_RTZ3_Z_NT
+#define HMX_RTZ3_Z_NT 1  /* k_rtz3c: Z rows requested non-temporal like the R rows (0: experiment of round 6 -- Z_cos, 200 MB at C3, read by both
+                            kernels of a round, left cacheable so that it might stay in the 256 MB memory-side cache: profiles/r06_ab_zcos_cacheable.txt) */
+#endif
 #ifndef HMX_RTZ3_NT
 #define HMX_RTZ3_NT 1    /* the rows are read once per pass: non-temporal requests (micro-benchmark of this very pattern: 6.2 -> 6.9 TB/s) */
 #endif
@@ -45,6 +49,7 @@ namespace {
 // `base` is wave-uniform and travels in scalar registers (the SADDR form of the instruction): the stream's addresses cost
 // no vector registers, however far ahead the compiler forms them.  Inline assembly on purpose: the
 // builtin makes the compiler drain vmcnt before any later LDS read.
+template <bool NT = true>
 __device__ __forceinline__ void dma16(const void* base_, unsigned voff, unsigned zone_) {
     const unsigned zone = __builtin_amdgcn_readfirstlane(zone_);   // (likewise: under pressure a uniform LDS address may sit in a vector register)
     // (under register pressure the compiler may park a wave-uniform pointer in vector registers: say it again that it is
@@ -54,10 +59,10 @@ __device__ __forceinline__ void dma16(const void* base_, unsigned voff, unsigned
     const void* base = (const void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(bits >> 32)) << 32) |
                                      (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)bits));
 #if HMX_RTZ3_NT
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(base), "s"(zone) : "memory", "m0");
-#else
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(zone) : "memory", "m0");
+    if (NT) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(base), "s"(zone) : "memory", "m0");
+    else
 #endif
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(zone) : "memory", "m0");
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) const void*)p);
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(64 * RTZ3C_WAVES, 1) void k_rtz3c(Rtz3Args a) {
             if (p + 1 < NR || 1024 * p + lane16 < 64 * Kp) dma16(r + 1024 * p, lane16, zb + 1024u * p);
 #pragma unroll
         for (int it = 0; it < NZ; ++it)
-            if (1024 * (it + 1) <= 64 * DP || 1024 * it + lane16 < 64 * DP) dma16(z + 1024 * it, lane16, zb + r_bytes + 1024u * it);
+            if (1024 * (it + 1) <= 64 * DP || 1024 * it + lane16 < 64 * DP) dma16<(HMX_RTZ3_Z_NT != 0)>(z + 1024 * it, lane16, zb + r_bytes + 1024u * it);
         if (lane == 0) dma16(id, lane16, zb + r_bytes + 64u * DP);
     };
     auto request_pair = [&](int i) {                                // (a missing second tile: the first one again, never read)
