@@ -123,6 +123,7 @@ struct hmx_engine {
     std::vector<int> gsize;      // cells of every batch group on this rank (host copy)
     DevBuf<int> ga_map;          // k_round's group-affine map: per compute workgroup {group, rank in group, workgroups of the group}
     int ga_nwg = 0;              // workgroups of that map (0: none planned)
+    int ga_per_wg = 0;           // ... planned for this many tiles per workgroup and block (14, or 16 when the grid cannot carry that)
     int64_t ga_key_block = -1;   // ... planned for this largest block size and this cap
     int ga_key_cap = -1;
     bool ga_extra = false;       // ... some group's run may exceed 16 tiles per workgroup (the extra-tile loop will run)
@@ -1115,6 +1116,7 @@ static bool plan_ga(hmx_engine* e, int max_tiles, int cap) {
     int total = 0;
     for (int per_wg : {HMX_ROUND_GA_TILES, 16}) {
         total = 0;
+        e->ga_per_wg = per_wg;
         for (int g = 0; g < G; ++g) {
             const double mean = block_cells * (double)e->gsize[g] / (double)e->N;
             est[g] = std::ceil((mean + 5.0 * std::sqrt(mean)) / 16.0) + (e->gsize[g] > 0 ? 1.0 : 0.0);
@@ -1239,6 +1241,11 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
             ra.K = e->K; ra.Kp = e->Kp; ra.K16 = e->K16; ra.dp = e->dp; ra.ldy = e->ldy; ra.G = e->G; ra.B = e->B; ra.V = e->V;
             ra.nblk = e->nblk; ra.spin_limit = e->spin_limit;
             ra.frozen = e->frozen();
+            if (ga) {
+                // row-request placement of the group-affine sweep (k_round, tile_step): measured per shape, HMX_ROUND_REQ overrides
+                ra.req_mode = e->ga_per_wg > HMX_ROUND_GA_TILES ? 1 : e->ga_nwg > 32 ? 2 : 0;
+                if (const char* rq = getenv("HMX_ROUND_REQ")) ra.req_mode = std::max(0, std::min(2, atoi(rq)));
+            }
             if (ga) { ra.ga = 1; ra.run_start = e->lists[e->cur].run_tiles.p; ra.wg_map = e->ga_map.p; e->n_sweeps_ga++; }
             if (e->n_sweep_launches++ == e->test_fail_sweep) ra.spin_limit = 0;
             if (multi) {

@@ -1705,18 +1705,26 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         };
         // the two waves of a SIMD stagger the request code: one issues it while the other's first tile keeps the pipe busy
         static_assert(ROUND_TPW == 2, "tile_step is written for two tiles per wave");
-        const bool second = wv >= ROUND_WAVES / 2;
+        // Where a wave issues its row requests.  Classic map (req_mode 0): half the waves in front of their GEMM, half between
+        // its k-steps -- never near the hand-off, whose poll and loads would wait behind them.  Under the group-affine map only
+        // the last wave polls, and the GEMM starts while the whole chip's row stores of the block are still draining (nobody
+        // waits for returning adds any more), so the best place depends on the shape (same-box A/B, profiles/r06_ab_k_round_requests.txt):
+        // 1: BEHIND the GEMM -- workgroups whose eight waves all carry tiles (configs[3] shard: 401-412 -> 326-332 us);
+        // 2: every wave between the k-steps -- large grids with the last wave free (C3: 247-255 -> 233-250 us); 0: small grids.
+        const bool late = a.req_mode == 1 && ga && !hand;
+        const bool second = (a.req_mode == 2 && ga) || wv >= ROUND_WAVES / 2;
         TSTAMP(11);
-        if (!second) request();
+        if (!second && !late) request();
         __builtin_amdgcn_sched_barrier(0);
         TSTAMP(12);
         if (!live) {
-            if (second) request();
+            if (second || late) request();
             return;
         }
         if (BF3) {
             // both tiles against one read of the centroid fragments; the `second` waves' requests ride between the k-steps
-            round_compute_bf3_pair<MT, KS>(Yb, nis, c16, q, raw[0], raw[1], T[0], T[1], [&]() { TSTAMP(14); if (second) request(); }, [&]() { TSTAMP(13); });
+            round_compute_bf3_pair<MT, KS>(Yb, nis, c16, q, raw[0], raw[1], T[0], T[1], [&]() { TSTAMP(14); if (second && !late) request(); }, [&]() { TSTAMP(13); });
+            if (late) request();
             return;
         }
         round_compute<MT, KS, LOG2>(Ys, nis, LDY, c16, q, Zf[0], T[0]);
