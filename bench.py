@@ -52,6 +52,8 @@ CONFIGS = {
     "c5": (1_250_000, 200, 32, 200),
     # all 10M cells of BASELINE configs[3] on ONE GPU (R = 4.5 GB of the 288 GB)
     "c4x1": (10_000_000, 50, 16, 100),
+    # ... and half of them: the per-GPU share of configs[3] on 2 GPUs (blocks of 250k cells: still larger than the sweep's grid)
+    "c4x2": (5_000_000, 50, 16, 100),
 }
 CUSTOM_SHAPES = set()
 if os.environ.get("BENCH_SHAPE"):   # experiments only: "name=N,d,B,K" replaces a configuration's shape (the line then says so: no BASELINE label)
@@ -65,7 +67,7 @@ def config_label(name):
     if name in CUSTOM_SHAPES:
         return f"EXPERIMENT SHAPE (BENCH_SHAPE, not a BASELINE configuration; slot {name.upper()})"
     return f"BASELINE configs[{CONFIG_INDEX[name]}] ({name.upper()})"
-CONFIG_INDEX = {"c2": 1, "c3": 2, "c4": 3, "c5": 4, "c4x1": 3}
+CONFIG_INDEX = {"c2": 1, "c3": 2, "c4": 3, "c5": 4, "c4x1": 3, "c4x2": 3}
 # cells of the whole job of the configurations BASELINE.json defines over several GPUs (sharded evenly: strong scaling)
 JOB_CELLS = {"c4": 10_000_000, "c5": 10_000_000}
 
@@ -680,6 +682,7 @@ def main():
         # measures) incl. the default run to convergence on them (north_star: "10M cells converged in < 10 s"), and the
         # per-GPU shard of configs[4] on 8 GPUs (wide-PC regime)
         out["configs_3_on_one_gpu"] = side_config("c4x1", args.rounds, steps=2, warmup=1, device=f"cuda:{local_rank}", converge=True)
+        out["configs_3_half_on_one_gpu"] = side_config("c4x2", args.rounds, steps=3, warmup=1, device=f"cuda:{local_rank}")
         out["configs_4_shard"] = side_config("c5", args.rounds, steps=2, warmup=1, device=f"cuda:{local_rank}")
     if args.cpu_sample > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(d, B, K, args.rounds, min(args.cpu_sample, N))

@@ -635,7 +635,12 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
             // same on any cut, the cut is tuned for the majority pass (advisor finding, round 5).
             const bool one_per_cu = e->allow_rtz_bf16 && (rtz_wide_ok(e->mt, e->dp) ? rtzw2b_ok(e->mt, e->dp, e->d, e->nblk) : rtz3b_ok(e->mt, e->dp, e->nblk, e->Kp));
             const int target = std::max(1, (one_per_cu ? 1 : 2) * e->n_cus - e->G);
-            const int CH3 = std::max(16, std::min(one_per_cu ? 2048 : 256, (n_static_tiles + target - 1) / target));
+            // (one workgroup per CU: tasks of up to 4096 tiles, so that 10 M cells still make ONE round of ~240 workgroups -- with the
+            // cap of 2048 of round 5 they made 305 tasks on 256 CUs: a second, mostly idle round of workgroups, k_rtz3c 1 647 us for
+            // 10 M cells against 124.5 us for 1 M.  A wave's fp32 accumulators then sum 512 tiles = 8 k cells before the fp64 fold.)
+            int cap3 = one_per_cu ? 4096 : 256;
+            if (const char* tc = getenv("HMX_RTZ3_TASK_CAP")) cap3 = std::max(16, atoi(tc));   // (A/B runs)
+            const int CH3 = std::max(16, std::min(cap3, (n_static_tiles + target - 1) / target));
             // HMX_RTZ3_TASKS=contig: a task is a contiguous run of a group's tiles; default: the m tasks of a group take
             // neighbouring quads of tiles (task j: tiles ts + 4j + w + 4m i) and sweep the group's rows together
             const char* tk = getenv("HMX_RTZ3_TASKS");
