@@ -166,6 +166,10 @@ struct hmx_engine {
     DevBuf<unsigned char> tile_blk[2], tile_blk_zero;
     DevBuf<unsigned> Yf;                 // wide shapes: the round's Y as bf16 fragments for k_assign_wide3 (launch_y_planes)
     DevBuf<unsigned> Wf;                 // wide shapes: W as bf16 fragments for k_ridge_apply_wideb (launch_w_planes)
+    DevBuf<unsigned> Zcf;                // wide shapes: Z_cos as bf16 planes in k_rtzw2b's B-fragment order (launch_zplanes), rebuilt when Z_cos changed
+    bool zcf_valid = false;              // Zcf holds the planes of the current Z_cos
+    bool allow_zcf = true;               // HMX_RTZW_ZF=0 at hmx_create: k_rtzw2b splits the fp32 rows of Z_cos in every pass (A/B runs and tests)
+    long n_rtz_zf = 0;                   // streaming passes that read the pre-split planes
     DevBuf<double> Osave;                // O at the start of the round in flight (exact replay after a time-out)
 
     struct Span { hipEvent_t a, b; int fam; };
@@ -403,6 +407,7 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
     if (const char* rf = getenv("HMX_ROUND_F32")) e->allow_round_bf16 = atoi(rf) == 0;
     if (const char* rg = getenv("HMX_ROUND_GA")) e->allow_round_ga = atoi(rg) != 0;
     if (const char* rb = getenv("HMX_RTZ3_BF16")) e->allow_rtz_bf16 = atoi(rb) != 0;
+    if (const char* zf = getenv("HMX_RTZW_ZF")) e->allow_zcf = atoi(zf) != 0;
     if (const char* rk = getenv("HMX_RTZ")) e->rtz_kernel = atoi(rk) == 2 ? 2 : 3;
     if (const char* fs = getenv("HMX_TEST_FAIL_SWEEP")) e->test_fail_sweep = atol(fs);
     if (const char* sl = getenv("HMX_SPIN_LIMIT")) e->spin_limit = (unsigned)std::max(0L, atol(sl));   // 0: every wait of the persistent kernels gives up at once (tests)
@@ -484,7 +489,7 @@ void hmx_destroy(hmx_engine* e) {
     if (e->pre_event) (void)hipEventDestroy(e->pre_event);
     e->task_t0.release(); e->task_t1.release();
     e->t3_t0.release(); e->t3_t1.release(); e->t3_stride.release(); e->t3_c0.release(); e->t3_cend.release(); e->t3_grp.release(); e->s_tile_start.release();
-    e->tile_blk[0].release(); e->tile_blk[1].release(); e->tile_blk_zero.release(); e->Osave.release(); e->Wf.release(); e->Yf.release();
+    e->tile_blk[0].release(); e->tile_blk[1].release(); e->tile_blk_zero.release(); e->Osave.release(); e->Wf.release(); e->Yf.release(); e->Zcf.release();
     e->task_grp.release(); e->gstart.release(); e->chunk_tab.release(); e->run_count.release(); e->run_start.release();
     e->Ogrp.release(); e->Tmass.release(); e->Ohist.release(); e->xch.release(); e->scratch.release();
     e->global_id.release(); e->wait_stats.release(); e->sync_words.p = nullptr; e->sync_words.n = 0; e->Sslots.release(); e->km_hn.release(); e->km_sums.release();
@@ -550,6 +555,7 @@ int hmx_upload(hmx_engine* e, const float* Z, const int32_t* static_cells, int64
         srow.release();
     }
     launch_normalize_rows(e->Zorig.p, e->Zcos.p, e->N, e->dp, e->stream);  // harmony.py:238
+    e->zcf_valid = false;
     std::vector<float> sg(e->K16, 0.f);
     std::memcpy(sg.data(), sigma, sizeof(float) * e->K);
     HIP_TRY(hipMemcpyAsync(e->sigma.p, sg.data(), sg.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
@@ -923,6 +929,16 @@ static int rtz3_pass(hmx_engine* e, int mode, const unsigned char* tile_blk, int
         r.task_t0 = e->t3_t0.p; r.task_t1 = e->t3_t1.p; r.task_stride = e->t3_stride.p; r.task_c0 = e->t3_c0.p; r.task_cend = e->t3_cend.p;
         r.slab = e->slab.p; r.ntasks = e->ntasks3; r.Kp = e->Kp;
         r.frozen = duties ? e->frozen() : nullptr;   // (the fused round of a single engine: the only path whose read-back is deferred)
+        if (wide && mode != 1 && e->allow_zcf && e->allow_rtz_bf16 && e->static_contig && rtzw2b_ok(e->mt, e->dp, e->d, nblk_cols) && rtzw2b_zf_ok(e->mt, e->dp)) {
+            // Z_cos is constant between two ridge steps: its three bf16 planes are split once, in k_rtzw2b's fragment order
+            if (!e->zcf_valid) {
+                if ((rc = e->Zcf.reserve((size_t)e->n_s_tiles * rtzw_zf_tile_words(e->dp)))) return rc;
+                launch_zplanes(e->Zcos.p, e->dp, e->n_s_tiles, e->s_tile_grp.p, e->gstart.p, e->s_tile_start.p, e->Zcf.p, e->stream);
+                e->zcf_valid = true;
+            }
+            r.Zf = e->Zcf.p;
+            e->n_rtz_zf++;
+        }
         const int lr = wide ? launch_rtzw(r, e->mt, e->dp, e->d, nblk_cols, e->stream, e->allow_rtz_bf16) : launch_rtz3(r, e->mt, e->dp, nblk_cols, e->stream, e->allow_rtz_bf16, e->rtz3_quad);
         if (lr > 0) e->n_rtz_bf16++;
         if (lr < 0)
@@ -1793,6 +1809,7 @@ int hmx_moe_correct_ridge(hmx_engine* e) {
         a.cells = e->s_cells.p; a.tile_grp = e->s_tile_grp.p; a.n_tiles = e->n_s_tiles;
         a.Kp = e->Kp; a.K16 = e->K16; a.dp = e->dp; a.ldw = e->ldy; a.mtd = e->ntd;
         if (rtz2 || rtzw) { a.task_tile0 = e->task_t0.p; a.task_tile1 = e->task_t1.p; a.task_grp = e->task_grp.p; a.ntasks = e->ntasks; }
+        e->zcf_valid = false;                                        // Z_cos is rewritten below
         if (rtzw && e->allow_round_bf16) {                           // the correction GEMM on the bf16 pipe: W split once into fragments
             if ((rc = e->Wf.reserve(w_planes_dwords(e->G, e->K16, e->dp)))) return rc;
             launch_w_planes(e->W.p, e->G, e->K16, e->ldy, e->dp, e->Wf.p, e->stream);
@@ -1882,6 +1899,7 @@ int hmx_set(hmx_engine* e, int which, const void* host_in, size_t bytes) {
     if (!e->uploaded) return fail(HMX_ERR_STATE, "hmx_upload must come first");
     if ((rc = use_device(e))) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
+    if (which == HMX_Z_COS) e->zcf_valid = false;
     HIP_TRY(hipMemset(p, 0, (size_t)rows * ld * elem));
     HIP_TRY(hipMemcpy2D(p, (size_t)ld * elem, host_in, (size_t)cols * elem, (size_t)cols * elem, rows, hipMemcpyHostToDevice));
     if (which == HMX_R) {  // keep O and T consistent with the new assignment (exact sums)
@@ -1912,6 +1930,7 @@ int hmx_device_ptr(hmx_engine* e, int which, void** d_ptr, size_t* bytes) {
     if (!e || !d_ptr || !bytes) return fail(HMX_ERR_ARG, "null argument");
     size_t need; int rows, cols, ld, elem, rc;
     if ((rc = locate(e, which, d_ptr, &need, &rows, &cols, &ld, &elem))) return rc;
+    if (which == HMX_Z_COS) e->allow_zcf = false;   // the caller may write Z_cos behind the engine's back: no cached planes of it any more
     *bytes = (size_t)rows * ld * elem;
     return HMX_OK;
 }
@@ -1934,7 +1953,8 @@ int hmx_counters(hmx_engine* e, int64_t out[HMX_N_COUNTERS]) {
     out[8] = e->n_sweeps_ga;
     out[9] = e->n_sweeps_ga > 0 ? e->ga_nwg : 0;
     out[10] = e->box ? (e->box_fine ? 2 : 1) : 0;
-    for (int i = 11; i < HMX_N_COUNTERS; ++i) out[i] = 0;
+    out[11] = e->n_rtz_zf;
+    for (int i = 12; i < HMX_N_COUNTERS; ++i) out[i] = 0;
     return HMX_OK;
 }
 

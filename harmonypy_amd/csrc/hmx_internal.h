@@ -101,6 +101,7 @@ struct Rtz3Args {
     float* slab;               // ntasks x MT x NT x 256 accumulators, [tile][lane][r]
     unsigned long long* prof;  // -DHMX_RTZ3_PROF builds: ntasks x waves x 8 time stamps (else null)
     const unsigned* frozen;    // non-zero: an earlier sweep of this cluster() call timed out -- do nothing (or null)
+    const unsigned* Zf;        // k_rtzw2b: Z as bf16 planes in its B-fragment order per static tile (launch_zplanes), or null: fp32 rows, split per pass
     int ntasks, Kp;
     int dp, d, nt;             // k_rtzw (wide shapes; set by its launcher): row floats of Z, PCs, output column tiles
 };
@@ -134,6 +135,9 @@ void launch_rtz3_finish(const Rtz3FinishArgs& a, hipStream_t s);
 bool rtzw_ok(int mt, int dp, int d, int nblk, int G);
 int rtzw_nt(int dp, int d, int nblk);
 int rtzw_slab_floats(int mt, int dp, int d, int nblk);
+size_t rtzw_zf_tile_words(int dp);
+bool rtzw2b_zf_ok(int mt, int dp);   // the pre-split Z planes fit k_rtzw2b's LDS
+void launch_zplanes(const float* Z, int dp, int n_tiles, const int* tile_grp, const int* gstart, const int* s_tile_start, unsigned* Zf, hipStream_t s);
 bool rtzw2b_ok(int mt, int dp, int d, int nblk);   // launch_rtzw takes the bf16-pipe kernel k_rtzw2b (one workgroup per CU)
 int launch_rtzw(const Rtz3Args& a, int mt, int dp, int d, int nblk, hipStream_t s, bool allow_bf16);   // 1: k_rtzw2b ran, 0: an f32-input kernel, -1 unsupported
 void launch_tile_blocks(const int* cells, const int* tile_grp, const int* blk_start, int nblk, int64_t n_pos_upper, const int* gstart,

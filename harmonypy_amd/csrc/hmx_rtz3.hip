@@ -793,17 +793,25 @@ __device__ __forceinline__ void static_for(F& f) {                    // f(integ
         static_for<I + 1, N>(f);
     }
 }
-template <int MT, int NTH>
+// ZF (round 6): Z_cos does not change during the rounds of a Harmony iteration, so its three bf16 planes are split ONCE per
+// iteration (k_zplanes) and stored per 16-cell static tile in the B-FRAGMENT order of this kernel -- [column tile][plane h, m, l]
+// [lane (q & 1, c16)][8 bf16 = cells 8 (q & 1) .. + 8] = 512 bytes per (tile, column tile, plane).  The pass then stages those
+// instead of fp32 rows (+50 % of the Z bytes: 1 248 instead of 832 per cell at 200 PCs, still far below the matrix floor), a
+// wave's B planes are three conflict-free 16-byte LDS reads per column tile, and the serial prologue of every pair -- 56
+// four-way conflicted 4-byte reads and 28 splits per wave with the matrix pipe idle -- is gone; only the one-hot block
+// columns (the last one or two column tiles) are still formed per pair.  The ridge statistics (Z_orig) keep ZF = false.
+template <int MT, int NTH, bool ZF>
 __global__ __launch_bounds__(64 * RTZWB_WAVES, 1) void k_rtzw2b(Rtz3Args a) {
     if (a.frozen && *a.frozen) return;
     constexpr int MTA = (MT + 1) / 2;
     constexpr int H = MT / 4, REM = MT % 4;
     constexpr int NRP = (64 * MT + 255) / 256;                       // 16-byte pieces of an R tile per thread (16 rows x Kp <= 16 MT floats)
-    constexpr int NZP = 4;                                           // ... of a Z tile (dp <= 208: 832 pieces)
+    constexpr int NZP = ZF ? 5 : 4;                                  // ... of a Z tile (dp <= 208: 832 pieces of fp32 rows, or 13 x 96 pieces of planes)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* lds = reinterpret_cast<float*>(smem);
     const int Kp = a.Kp, DP = a.dp, d = a.d, NT = a.nt, NTP = DP >> 4;
-    const int buf_floats = 256 * MT + 16 * DP + 4;                   // R tile (rows at stride Kp, padded to MT KB) | Z tile | 16 block-id bytes
+    const int zt_floats = ZF ? NTP * 3 * 128 : 16 * DP;              // a tile's Z part: fragments of three planes, or fp32 rows
+    const int buf_floats = 256 * MT + zt_floats + 4;                 // R tile (rows at stride Kp, padded to MT KB) | Z tile | 16 block-id bytes
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, c16 = lane & 15, q = lane >> 4;
@@ -824,7 +832,7 @@ __global__ __launch_bounds__(64 * RTZWB_WAVES, 1) void k_rtzw2b(Rtz3Args a) {
         const int tc = min(ti, n_tiles - 1);
         const size_t cell0 = (size_t)c_first + (size_t)16 * stride * tc;
         const float* rsrc = a.R + cell0 * Kp;
-        const float* zsrc = a.Z + cell0 * DP;
+        const float* zsrc = ZF ? reinterpret_cast<const float*>(a.Zf) + ((size_t)t0 + (size_t)stride * tc) * zt_floats : a.Z + cell0 * DP;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < NRP; ++j) {
@@ -834,7 +842,7 @@ __global__ __launch_bounds__(64 * RTZWB_WAVES, 1) void k_rtzw2b(Rtz3Args a) {
 #pragma unroll
         for (int j = 0; j < NZP; ++j) {
             const int p = tid + 256 * j;
-            sz[j] = (p < 4 * DP) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(zsrc) + p) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            sz[j] = (4 * p < zt_floats) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(zsrc) + p) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         sid = (tid == 0) ? *reinterpret_cast<const f32x4*>(a.tile_blk + (size_t)16 * (t0 + (size_t)stride * tc)) : (f32x4){0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_sched_barrier(0);
@@ -853,9 +861,10 @@ __global__ __launch_bounds__(64 * RTZWB_WAVES, 1) void k_rtzw2b(Rtz3Args a) {
 #pragma unroll
         for (int j = 0; j < NZP; ++j) {
             const int p = tid + 256 * j;
-            if (p < 4 * DP) st4(Zt + 4 * p, (4 * p < n_live * DP) ? sz[j] : (f32x4){0.f, 0.f, 0.f, 0.f});
+            // (planes: the rows past the group's end are zero in the stored fragments; a missing tile is written as zeros)
+            if (4 * p < zt_floats) st4(Zt + 4 * p, (ZF ? n_live > 0 : 4 * p < n_live * DP) ? sz[j] : (f32x4){0.f, 0.f, 0.f, 0.f});
         }
-        if (tid == 0) st4(Zt + 16 * DP, sid);
+        if (tid == 0) st4(Zt + zt_floats, sid);
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -881,7 +890,7 @@ __global__ __launch_bounds__(64 * RTZWB_WAVES, 1) void k_rtzw2b(Rtz3Args a) {
             // lane (c16, q): k slot j <-> cell 8 (q & 1) + j of tile q >> 1 of the pair
             const float* Rl = pb + (size_t)(q >> 1) * buf_floats + 8 * (q & 1) * Kp;
             const float* Zl = Rl + 256 * MT - 8 * (q & 1) * Kp + 8 * (q & 1) * DP;
-            const unsigned char* ids = reinterpret_cast<const unsigned char*>(pb + (size_t)(q >> 1) * buf_floats + 256 * MT + 16 * DP) + 8 * (q & 1);
+            const unsigned char* ids = reinterpret_cast<const unsigned char*>(pb + (size_t)(q >> 1) * buf_floats + 256 * MT + zt_floats) + 8 * (q & 1);
             int bid[8];
             {
                 const u32x2 w = *reinterpret_cast<const u32x2*>(ids);
@@ -890,6 +899,26 @@ __global__ __launch_bounds__(64 * RTZWB_WAVES, 1) void k_rtzw2b(Rtz3Args a) {
             }
             // ---- B planes of the column half: value = PC column (zero in the row padding) + one-hot of the block column ----
             u32x4 bh[NTH], bm[NTH], bl[NTH];
+            if constexpr (ZF) {
+                // the lane's fragment of tile q >> 1: 16 bytes per (column tile, plane), lanes of a quarter wave side by side
+                const unsigned* zf = reinterpret_cast<const unsigned*>(pb + (size_t)(q >> 1) * buf_floats + 256 * MT) + 4 * (16 * (q & 1) + c16);
+#pragma unroll
+                for (int u = 0; u < NTH; ++u) {
+                    const int nt = nt_lo + u;                         // wave-uniform
+                    u32x4 h = (u32x4){0u, 0u, 0u, 0u}, m = h, l = h;
+                    if (nt < NTP) {
+                        const unsigned* f = zf + (size_t)nt * 3 * 128;
+                        h = ld4u(f); m = ld4u(f + 128); l = ld4u(f + 256);
+                    }
+                    if (nt >= NTP - 1 && nt < NT) {                   // one-hot block columns: 1.0 = 0x3F80 in the h plane of a column whose PC planes are zero
+                        const int blk_col = nt < NTP ? 16 * nt + c16 - d : spare + 16 * (nt - NTP) + c16;
+#pragma unroll
+                        for (int p = 0; p < 4; ++p)
+                            h[p] |= (bid[2 * p] == blk_col ? 0x3F80u : 0u) | (bid[2 * p + 1] == blk_col ? 0x3F800000u : 0u);
+                    }
+                    bh[u] = h; bm[u] = m; bl[u] = l;
+                }
+            } else
 #pragma unroll
             for (int u = 0; u < NTH; ++u) {
                 const int nt = nt_lo + u;                             // wave-uniform
@@ -1315,20 +1344,62 @@ static void launch_rtzw_t(const Rtz3Args& a, size_t sm, hipStream_t s) {
     hipLaunchKernelGGL((k_rtzw<MT>), dim3(a.ntasks), dim3(64 * RTZW_WAVES), sm, s, a);
 }
 
+// ---- Z_cos as bf16 planes in k_rtzw2b's B-fragment order (see the kernel): one 512-byte piece per (static tile, column tile, plane)
+size_t rtzw_zf_tile_words(int dp) { return (size_t)(dp >> 4) * 3 * 128; }
+bool rtzw2b_zf_ok(int mt, int dp) { return (size_t)4 * (256 * mt + rtzw_zf_tile_words(dp) + 4) * sizeof(float) <= 160 * 1024; }
+__global__ __launch_bounds__(256) void k_zplanes(const float* __restrict__ Z, int DP, int n_tiles, const int* __restrict__ tile_grp,
+                                                 const int* __restrict__ gstart, const int* __restrict__ s_tile_start, unsigned* __restrict__ Zf) {
+    const int NTP = DP >> 4;
+    for (int T = blockIdx.x; T < n_tiles; T += gridDim.x) {
+        const int g = tile_grp[T];
+        const int cell0 = gstart[g] + 16 * (T - s_tile_start[g]);     // static tiles hold consecutive cells of one group
+        const int n_live = min(16, gstart[g + 1] - cell0);
+        unsigned* out = Zf + (size_t)T * NTP * 3 * 128;
+        for (int it = threadIdx.x; it < NTP * 32; it += 256) {
+            const int nt = it >> 5, l32 = it & 31, half = l32 >> 4, c16 = l32 & 15;
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = 8 * half + j;
+                x[j] = (r < n_live) ? Z[(size_t)(cell0 + r) * DP + 16 * nt + c16] : 0.f;   // rows past the group's end: zeros
+            }
+            u32x4 h, m, l;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                unsigned hh, mm, ll;
+                bf16_split3((f32x2){x[2 * p], x[2 * p + 1]}, hh, mm, ll);
+                h[p] = hh; m[p] = mm; l[p] = ll;
+            }
+            unsigned* o = out + ((size_t)nt * 3 * 32 + l32) * 4;
+            *reinterpret_cast<u32x4*>(o) = h;
+            *reinterpret_cast<u32x4*>(o + 128) = m;
+            *reinterpret_cast<u32x4*>(o + 256) = l;
+        }
+    }
+}
+void launch_zplanes(const float* Z, int dp, int n_tiles, const int* tile_grp, const int* gstart, const int* s_tile_start, unsigned* Zf, hipStream_t s) {
+    if (n_tiles <= 0) return;
+    hipLaunchKernelGGL(k_zplanes, dim3(std::min(n_tiles, 256 * 16)), dim3(256), 0, s, Z, dp, n_tiles, tile_grp, gstart, s_tile_start, Zf);
+}
+
 // ---- k_rtzw2b: K > 112, seven to fourteen column tiles; four tile buffers in one CU's LDS
 bool rtzw2b_ok(int mt, int dp, int d, int nblk) {
     if (!rtzw_ok(mt, dp, d, nblk, 1) || mt < 8 || mt > 13) return false;
     const int nth = (rtzw_nt(dp, d, nblk) + 1) / 2;
     return nth >= 4 && nth <= 7 && (size_t)4 * (256 * mt + 16 * dp + 4) * sizeof(float) <= 160 * 1024;
 }
-template <int MT, int NTH>
-static void launch_rtzw2b_t(const Rtz3Args& a, size_t sm, hipStream_t s) {
+template <int MT, int NTH, bool ZF>
+static void launch_rtzw2b_z(const Rtz3Args& a, size_t sm, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rtzw2b<MT, NTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rtzw2b<MT, NTH, ZF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_rtzw2b<MT, NTH>), dim3(a.ntasks), dim3(64 * RTZWB_WAVES), sm, s, a);
+    hipLaunchKernelGGL((k_rtzw2b<MT, NTH, ZF>), dim3(a.ntasks), dim3(64 * RTZWB_WAVES), sm, s, a);
+}
+template <int MT, int NTH>
+static void launch_rtzw2b_t(const Rtz3Args& a, size_t sm, hipStream_t s) {
+    if (a.Zf) launch_rtzw2b_z<MT, NTH, true>(a, sm, s); else launch_rtzw2b_z<MT, NTH, false>(a, sm, s);
 }
 template <int MT>
 static void launch_rtzw2b_m(const Rtz3Args& a, int nth, size_t sm, hipStream_t s) {
@@ -1341,7 +1412,7 @@ static void launch_rtzw2b_m(const Rtz3Args& a, int nth, size_t sm, hipStream_t s
 }
 static void launch_rtzw2b(const Rtz3Args& a, int mt, hipStream_t s) {
     const int nth = (a.nt + 1) / 2;
-    const size_t sm = (size_t)4 * (256 * mt + 16 * a.dp + 4) * sizeof(float);
+    const size_t sm = (size_t)4 * (256 * mt + (a.Zf ? rtzw_zf_tile_words(a.dp) : 16 * a.dp) + 4) * sizeof(float);
     switch (mt) {
         case 8: launch_rtzw2b_m<8>(a, nth, sm, s); break;
         case 9: launch_rtzw2b_m<9>(a, nth, sm, s); break;

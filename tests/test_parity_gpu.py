@@ -641,7 +641,7 @@ WIDE_AB_SHAPES = [(40_000, 200, 32, 200), (30_000, 100, 4, 130), (20_000, 208, 3
 
 
 @pytest.mark.parametrize("N,d,B,K", WIDE_AB_SHAPES)
-@pytest.mark.parametrize("switch,value", [("HMX_ROUND_F32", "1"), ("HMX_RTZ3_BF16", "0")])
+@pytest.mark.parametrize("switch,value", [("HMX_ROUND_F32", "1"), ("HMX_RTZ3_BF16", "0"), ("HMX_RTZW_ZF", "0")])
 def test_wide_bf16_pipe_kernels_against_the_f32_input_kernels(N, d, B, K, switch, value, monkeypatch):
     """The wide regime (K > 112 or d > 64: BASELINE configs[4] is K = d = 200) is bound by the f32-input MFMA; its block
     assignment (k_assign_wide3, harmony.py:447, 464-513) and its streaming R^T.Z pass (k_rtzw2b, :443-444, :491-492, :550,
@@ -663,7 +663,13 @@ def test_wide_bf16_pipe_kernels_against_the_f32_input_kernels(N, d, B, K, switch
     else:
         MT, NT = (K + 15) // 16, ((d + 15) // 16) + max(0, (20 - (((d + 15) & ~15) - d) + 15) // 16)
         served = 8 <= MT <= 13 and 4 <= (NT + 1) // 2 <= 7      # k_rtzw2b: the two round passes + the ridge pass (which has one block column: fewer tiles)
-        assert (ca["rtz_bf16_pipe"] >= 3 if served else ca["rtz_bf16_pipe"] <= 1) and cb["rtz_bf16_pipe"] == 0, (ca, cb, served)
+        if switch == "HMX_RTZ3_BF16":
+            assert (ca["rtz_bf16_pipe"] >= 3 if served else ca["rtz_bf16_pipe"] <= 1) and cb["rtz_bf16_pipe"] == 0, (ca, cb, served)
+        else:
+            # HMX_RTZW_ZF=0: the same bf16-pipe kernel splitting the fp32 rows of Z_cos in every pass, against the default, which reads
+            # the planes k_zplanes split once per Harmony iteration (the two round passes; the ridge statistics run on Z_orig)
+            assert ca["rtz_presplit_z"] == (2 if served else 0) and cb["rtz_presplit_z"] == 0, (ca, cb, served)
+            assert ca["rtz_bf16_pipe"] == cb["rtz_bf16_pipe"], (ca, cb)
     # (bounds: an R entry moves by c_k = 2 log2(e) / sigma = 28.9 times the rounding of its fp32 dot product of d terms; at
     # d = 200 two summation orders of the f32-input MFMA itself differ by that much -- measured here: 9.9e-6 / 3.5e-6 relative Frobenius)
     dR = float(np.abs(a.R - b.R).max())
