@@ -168,6 +168,7 @@ struct hmx_engine {
     DevBuf<unsigned> Wf;                 // wide shapes: W as bf16 fragments for k_ridge_apply_wideb (launch_w_planes)
     DevBuf<unsigned> Zcf;                // wide shapes: Z_cos as bf16 planes in k_rtzw2b's B-fragment order (launch_zplanes), rebuilt when Z_cos changed
     bool zcf_valid = false;              // Zcf holds the planes of the current Z_cos
+    bool fuse_block_table = true;        // HMX_FUSE_TABLE=0 at hmx_create: a k_block_table launch in front of every wide block assignment (A/B runs and tests)
     bool allow_zcf = true;               // HMX_RTZW_ZF=0 at hmx_create: k_rtzw2b splits the fp32 rows of Z_cos in every pass (A/B runs and tests)
     long n_rtz_zf = 0;                   // streaming passes that read the pre-split planes
     DevBuf<double> Osave;                // O at the start of the round in flight (exact replay after a time-out)
@@ -408,6 +409,7 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
     if (const char* rg = getenv("HMX_ROUND_GA")) e->allow_round_ga = atoi(rg) != 0;
     if (const char* rb = getenv("HMX_RTZ3_BF16")) e->allow_rtz_bf16 = atoi(rb) != 0;
     if (const char* zf = getenv("HMX_RTZW_ZF")) e->allow_zcf = atoi(zf) != 0;
+    if (const char* ft = getenv("HMX_FUSE_TABLE")) e->fuse_block_table = atoi(ft) != 0;
     if (const char* rk = getenv("HMX_RTZ")) e->rtz_kernel = atoi(rk) == 2 ? 2 : 3;
     if (const char* fs = getenv("HMX_TEST_FAIL_SWEEP")) e->test_fail_sweep = atol(fs);
     if (const char* sl = getenv("HMX_SPIN_LIMIT")) e->spin_limit = (unsigned)std::max(0L, atol(sl));   // 0: every wait of the persistent kernels gives up at once (tests)
@@ -1059,12 +1061,15 @@ static int blocks_loop(hmx_engine* e, int flags, const std::vector<int>& tiles_u
         if ((rc = e->Yf.reserve(y_planes_dwords(e->K16, e->dp)))) return rc;
         launch_y_planes(e->Y.p, e->K16, e->ldy, e->dp, e->Yf.p, e->stream);
     }
+    // the wide bf16-pipe assignment builds the block's table in its own prologue (one batch variable): 20 launches per sweep fewer
+    const bool fuse = y_frags && e->fuse_block_table && assign_wide3_fuses_table(e->mt, e->dp, e->V);
     for (int b = 0; b < e->nblk; ++b) {
-        {
+        const double* O_prev = (b == 0) ? e->Ogrp.p : e->Ohist.p + GK * (b - 1);
+        const double* S_add = (b == 0) ? nullptr : e->Snew + GK * (b - 1);
+        if (!fuse || tiles_upper[b] <= 0) {   // (a block without a tile on this rank: the chain of O still has to move on)
             Timed t(e, F_BLOCK_TABLE);
             TableArgs ta = table_args(e);
-            ta.O_prev = (b == 0) ? e->Ogrp.p : e->Ohist.p + GK * (b - 1);
-            ta.S_add = (b == 0) ? nullptr : e->Snew + GK * (b - 1);
+            ta.O_prev = O_prev; ta.S_add = S_add;
             ta.S_sub = e->Sold + GK * b;
             ta.O_out = e->Ohist.p + GK * b;
             ta.rp = e->rp.p; ta.lrp = e->lrp.p;
@@ -1076,6 +1081,10 @@ static int blocks_loop(hmx_engine* e, int flags, const std::vector<int>& tiles_u
             a.cells = e->lists[e->cur].cells.p; a.tile_grp = e->lists[e->cur].tile_grp.p; a.S_out = e->Snew + GK * b;
             a.blk_start = e->lists[e->cur].blk_start.p; a.blk = b;
             a.tile_begin = 0; a.tile_end = tiles_upper[b];
+            if (fuse) {
+                a.fuse_table = 1; a.O_prev = O_prev; a.S_add = S_add; a.S_sub = e->Sold + GK * b; a.O_out = e->Ohist.p + GK * b;
+                a.Pr_b = e->Pr_b.p; a.theta = e->theta.p;
+            }
             if (y_frags) a.Yf = e->Yf.p;
             const int la = launch_assign(a, true, e->max_wgs, e->stream);
             if (la < 0) return fail(HMX_ERR_ARG, "unsupported cluster count");

@@ -27,6 +27,14 @@ struct AssignArgs {
     int G, ldy_lds, tables_in_lds, tiles_per_wave, ablate;
     const unsigned* Yf;    // wide shapes, bf16 pipe: Y as the A fragments of k_assign_wide3 (launch_y_planes), or null (the f32-input kernel k_assign_wide)
     int bf16_pipe;         // wide shapes: the bf16-pipe instance k_assign_wide3 (0: engines created under HMX_ROUND_F32=1 keep k_assign_wide)
+    // k_assign_wide3 building the block's table itself (assign_wide3_fuses_table; one batch variable): O_b = O_prev + S_add - S_sub
+    int fuse_table;
+    const double* O_prev;  // G x K16: O behind the previous block
+    const double* S_add;   // G x K16: the previous block's new sums (null for the first block)
+    const double* S_sub;   // G x K16: this block's old sums
+    double* O_out;         // G x K16: O without this block (written by workgroup 0: the chain's next O_prev)
+    const float* Pr_b;
+    const float* theta;
     const float* hn;       // k_assign_wide without penalty only: half squared norms of the centres in Y (+inf for pads) -> HARD
                            // assignment of the device k-means (a one-hot row of R per cell) instead of the softmax; null otherwise
 };
@@ -285,6 +293,8 @@ size_t y_planes_dwords(int K16, int dp);
 void launch_y_planes(const float* Y, int K16, int ldy, int dp, unsigned* Yf, hipStream_t s);
 size_t w_planes_dwords(int G, int K16, int dp);
 void launch_w_planes(const float* W, int G, int K16, int ldw, int dp, unsigned* Wf, hipStream_t s);
+size_t assign_wide3_lds_bytes(int mt);
+bool assign_wide3_fuses_table(int mt, int dp, int V);
 int launch_assign(const AssignArgs& a, bool penalty, int max_wgs, hipStream_t s);   // 1: the bf16-pipe wide instance ran, 0: another kernel, -1 unsupported
 void rtz_geometry(int mt, int ntd, int* nsub, int* slab_per_wave);
 bool rtz2_ok(int mt, int dp);

@@ -1254,6 +1254,7 @@ __global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_assign_wide3(AssignArgs
     int* tg = reinterpret_cast<int*>(objw + 2 * WIDE3_WAVES);            // group of the workgroup's tile j (-1: no such tile)
     int* ts = tg + WIDE3_SLOTS;                                          // its slot: tiles of one group share table rows and sums
     int* sg = ts + WIDE3_SLOTS;                                          // group of a slot
+    double* Tp = reinterpret_cast<double*>(sg + WIDE3_SLOTS);            // 2 x K16 partial cluster masses (fused table only)
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, c16 = lane & 15, q = lane >> 4;
@@ -1324,6 +1325,50 @@ __global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_assign_wide3(AssignArgs
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_s_barrier();
     const int nslots = ts[WIDE3_SLOTS - 1] + 1;
+    if (a.fuse_table) {
+        // The block's diversity table (k_block_table's arithmetic, harmony.py:491-499; one batch variable: group g is batch g) built
+        // HERE, under the first fragment requests, instead of by a launch of its own in front of every block (200 launches of
+        // ~9.5 us per Harmony iteration at configs[4]): O of every group without this block's old sums and with the previous
+        // block's new ones -- complete since the previous launch ended -- summed to the cluster masses by 2 x K16 threads, the
+        // rows of the workgroup's own groups turned into ratio ** theta and its log.  Workgroup 0 also writes the O chain.
+        if (tid < 2 * K16) {
+            const int h = tid / K16, k = tid - h * K16;
+            double t = 0.0;
+            for (int g0 = h; g0 < a.G; g0 += 16) {                       // eight groups per trip: 24 loads in flight
+                double op[8], sa[8], ss[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const size_t i = (size_t)min(g0 + 2 * j, a.G - 1) * K16 + k;
+                    op[j] = a.O_prev[i];
+                    sa[j] = a.S_add ? a.S_add[i] : 0.0;
+                    ss[j] = a.S_sub[i];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (g0 + 2 * j < a.G) {
+                        const double o = op[j] + sa[j] - ss[j];
+                        t += o;
+                        if (blockIdx.x == 0 && a.O_out) a.O_out[(size_t)(g0 + 2 * j) * K16 + k] = o;
+                    }
+                }
+            }
+            Tp[tid] = t;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        for (int i = tid; i < nslots * K16; i += 64 * WIDE3_WAVES) {
+            const int sl = i / K16, k = i - sl * K16, g = sg[sl];
+            const size_t src = (size_t)g * K16 + k;
+            const double o = a.O_prev[src] + (a.S_add ? a.S_add[src] : 0.0) - a.S_sub[src];
+            const float O = (float)o;
+            const float E = (float)(Tp[k] + Tp[K16 + k]) * a.Pr_b[g];
+            const float oe = fmaxf(O + E, 1e-8f);                       // :495-496
+            const float ratio = fminf(fmaxf(E / oe, 1e-8f), 1.0f);      // :497-498
+            const float rp = pow_unit(ratio, a.theta[g]);               // :499 (v_log_f32 / v_exp_f32 with split products, as k_round's table)
+            rpL[i] = rp;
+            lrpL[i] = __builtin_amdgcn_logf(rp) * 0.693147182464599609375f;
+        }
+    } else
     for (int i = tid; i < nslots * K16; i += 64 * WIDE3_WAVES) {
         const int sl = i / K16, k = i - sl * K16;
         const size_t src = (size_t)sg[sl] * K16 + k;
@@ -4100,6 +4145,14 @@ static void launch_assign_lds(const AssignArgs& a, bool penalty, int wgs, size_t
     else hipLaunchKernelGGL((k_assign_lds<MT, false>), dim3(wgs), dim3(64 * ASSIGN_WAVES), sm, s, a);
 }
 
+size_t assign_wide3_lds_bytes(int mt) {
+    const size_t K16 = 16 * (size_t)mt;
+    return (size_t)2 * 3 * mt * 1024 + (2 * K16 + 2 * WIDE3_SLOTS * K16) * sizeof(float) + (WIDE3_SLOTS * K16 + 2 * WIDE3_WAVES + 2 * K16) * sizeof(double) +
+           3 * WIDE3_SLOTS * sizeof(int);
+}
+// the wide block assignment can build its own diversity table (one batch variable, the bf16-pipe instance)
+bool assign_wide3_fuses_table(int mt, int dp, int V) { return V == 1 && dp % 16 == 0 && mt >= 1 && mt <= 13 && (mt > 7 || dp > 64) && assign_wide3_lds_bytes(mt) <= 160 * 1024; }
+
 int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t s) {
     AssignArgs a = a_in;
     const int ntiles = a.tile_end - a.tile_begin;
@@ -4134,9 +4187,9 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
         // the penalised block assignment of the round loop on the bf16 matrix pipe, centroids pre-split into fragments
         // (k_assign_wide3: eight waves, two tiles each, one workgroup per CU); engines created under HMX_ROUND_F32=1 and the
         // assignments without a penalty (init_cluster, the device Lloyd) take the f32-input kernel k_assign_wide below
+        if (a.fuse_table && !(penalty && !a.hn && a.bf16_pipe && a.Yf && assign_wide3_lds_bytes(a.mt) <= 160 * 1024)) return -1;   // only k_assign_wide3 builds its own table
         if (penalty && !a.hn && a.bf16_pipe && a.Yf) {
-            const size_t sm3 = (size_t)2 * 3 * a.mt * 1024 + ((size_t)2 * a.K16 + 2 * WIDE3_SLOTS * a.K16) * sizeof(float) +
-                               ((size_t)WIDE3_SLOTS * a.K16 + 2 * WIDE3_WAVES) * sizeof(double) + 3 * WIDE3_SLOTS * sizeof(int);
+            const size_t sm3 = assign_wide3_lds_bytes(a.mt);
             const int wgs3 = cdiv(ntiles, WIDE3_SLOTS);
 #define HMX_WIDE3_CASE(M)                                                                                               \
     case M: {                                                                                                         \

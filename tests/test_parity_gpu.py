@@ -641,7 +641,7 @@ WIDE_AB_SHAPES = [(40_000, 200, 32, 200), (30_000, 100, 4, 130), (20_000, 208, 3
 
 
 @pytest.mark.parametrize("N,d,B,K", WIDE_AB_SHAPES)
-@pytest.mark.parametrize("switch,value", [("HMX_ROUND_F32", "1"), ("HMX_RTZ3_BF16", "0"), ("HMX_RTZW_ZF", "0")])
+@pytest.mark.parametrize("switch,value", [("HMX_ROUND_F32", "1"), ("HMX_RTZ3_BF16", "0"), ("HMX_RTZW_ZF", "0"), ("HMX_FUSE_TABLE", "0")])
 def test_wide_bf16_pipe_kernels_against_the_f32_input_kernels(N, d, B, K, switch, value, monkeypatch):
     """The wide regime (K > 112 or d > 64: BASELINE configs[4] is K = d = 200) is bound by the f32-input MFMA; its block
     assignment (k_assign_wide3, harmony.py:447, 464-513) and its streaming R^T.Z pass (k_rtzw2b, :443-444, :491-492, :550,
@@ -656,7 +656,11 @@ def test_wide_bf16_pipe_kernels_against_the_f32_input_kernels(N, d, B, K, switch
         h.cluster(_rounds=2)
         h.moe_correct_ridge()
     ca, cb = a._engine.counters(), b._engine.counters()
-    if switch == "HMX_ROUND_F32":
+    if switch == "HMX_FUSE_TABLE":
+        # the block's diversity table built in k_assign_wide3's prologue (default) against a k_block_table launch per block: the same
+        # arithmetic on the same inputs, the same kernels otherwise
+        assert ca["sweeps_bf16_pipe"] == cb["sweeps_bf16_pipe"] and ca["rtz_bf16_pipe"] == cb["rtz_bf16_pipe"], (ca, cb)
+    elif switch == "HMX_ROUND_F32":
         dp = 32 if d <= 32 else 52 if d <= 52 else 64 if d <= 64 else (d + 15) & ~15
         served = dp % 16 == 0                                # (rows of 52 floats with K > 112: the generic kernels, f32-input only)
         assert ca["sweeps_bf16_pipe"] == (2 if served else 0) and cb["sweeps_bf16_pipe"] == 0, (ca, cb)
