@@ -39,7 +39,9 @@ struct AssignArgs {
                            // assignment of the device k-means (a one-hot row of R per cell) instead of the softmax; null otherwise
 };
 
-#define HMX_ROUND_SLOTS 4 /* k_round: a block's new sums are spread over this many fp64 tables */
+#ifndef HMX_ROUND_SLOTS
+#define HMX_ROUND_SLOTS 4 /* k_round: a block's new sums are spread over this many fp64 tables (2 and 8 measured in round 6: profiles/r06_ab_k_round_slots_poll.txt) */
+#endif
 
 // One whole update_R sweep (all blocks) in one persistent launch (k_round).
 struct RoundArgs {

@@ -1774,10 +1774,11 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
         }
         round_compute<MT, KS, LOG2>(Ys, nis, LDY, c16, q, Zf[0], T[0]);
         __builtin_amdgcn_sched_barrier(0);
-        if (second) request();
+        if (second && !late) request();
         __builtin_amdgcn_sched_barrier(0);
         round_compute<MT, KS, LOG2>(Ys, nis, LDY, c16, q, Zf[1], T[1]);
         __builtin_amdgcn_sched_barrier(0);
+        if (late) request();
     };
     // ---- grid-wide wait: every workgroup has added its sums of block `bdone` (one wave; its lanes are all active) --------
     auto wait_block = [&](int bdone) {
@@ -1810,11 +1811,16 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     // The sums all workgroups added for block bp, per own entry: own group's row so[n], cluster-mass row st[n].  Polls until
     // every entry's count fields (bits 55.. of the four slot words) add up to the number of contributors -- ng workgroups of
     // the own group, all nwg for the cluster masses; the words that pass the test ARE the data (2^-32 fixed point).
+#ifndef HMX_GA_SLOTS
+#define HMX_GA_SLOTS 2   /* slot tables the group-affine map spreads a block's adds over (of the HMX_ROUND_SLOTS allocated): every slot is two more loads per
+                            entry of the poll; 8 / 4 / 2 measured (profiles/r06_ab_k_round_slots_poll.txt): contention on the words is not what costs */
+#endif
+    static_assert(HMX_GA_SLOTS <= HMX_ROUND_SLOTS, "the slot tables are allocated for HMX_ROUND_SLOTS");
     constexpr unsigned long long FX_MASK = (1ull << 55) - 1ull;
     auto ga_fetch = [&](int bp, double (&so)[2], double (&st)[2]) {
         so[0] = so[1] = st[0] = st[1] = 0.0;
         if (bp < 0) return;
-        unsigned long long wo[2][HMX_ROUND_SLOTS], wt[2][HMX_ROUND_SLOTS];
+        unsigned long long wo[2][HMX_GA_SLOTS], wt[2][HMX_GA_SLOTS];
         unsigned spins = 0;
         if (a.spin_limit == 0) failed = true;   // test knob: give up without looking
         while (true) {
@@ -1824,7 +1830,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                 const int k = min(lane + 64 * n, K16 - 1);                   // clamped, not predicated
                 const unsigned long long* sn = reinterpret_cast<const unsigned long long*>(a.S_new) + (size_t)bp * HMX_ROUND_SLOTS * GKs + k;
 #pragma unroll
-                for (int s = 0; s < HMX_ROUND_SLOTS; ++s) {                  // independent loads, all in flight together
+                for (int s = 0; s < HMX_GA_SLOTS; ++s) {                  // independent loads, all in flight together
                     wo[n][s] = __hip_atomic_load(sn + (size_t)s * GKs + (size_t)g_own * K16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     wt[n][s] = __hip_atomic_load(sn + (size_t)s * GKs + (size_t)a.G * K16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -1833,11 +1839,14 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             for (int n = 0; n < 2; ++n) {
                 unsigned co = 0, ct = 0;
 #pragma unroll
-                for (int s = 0; s < HMX_ROUND_SLOTS; ++s) { co += (unsigned)(wo[n][s] >> 55); ct += (unsigned)(wt[n][s] >> 55); }
+                for (int s = 0; s < HMX_GA_SLOTS; ++s) { co += (unsigned)(wo[n][s] >> 55); ct += (unsigned)(wt[n][s] >> 55); }
                 ok = ok && co == (unsigned)ng && ct == (unsigned)nwg;
             }
             if (__all(ok) || failed) break;
-            __builtin_amdgcn_s_sleep(2);
+#ifndef HMX_GA_POLL_SLEEP
+#define HMX_GA_POLL_SLEEP 2
+#endif
+            __builtin_amdgcn_s_sleep(HMX_GA_POLL_SLEEP);
             if (++spins > a.spin_limit) { failed = true; break; }   // (a wait that gave up is not repeated block after block: the launch is lost)
         }
         ws_n += 1; ws_sum += spins; ws_max = max(ws_max, spins);
@@ -1847,7 +1856,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int s = 0; s < HMX_ROUND_SLOTS; ++s) {
+            for (int s = 0; s < HMX_GA_SLOTS; ++s) {
                 so[n] += (double)(long long)(wo[n][s] & FX_MASK) * 0x1p-32;
                 st[n] += (double)(long long)(wt[n][s] & FX_MASK) * 0x1p-32;
             }
@@ -1893,7 +1902,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     // the workgroup's sums of block b into its group's row and into the cluster-mass row of one slot table: count and sum in
     // one word, not returning, nothing to wait for (see ga_fetch).  EVERY entry is added to, zero sums too: the count is the arrival.
     auto ga_publish = [&](int b) {
-        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.S_new) + ((size_t)b * HMX_ROUND_SLOTS + (wg % HMX_ROUND_SLOTS)) * GKs;
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.S_new) + ((size_t)b * HMX_ROUND_SLOTS + (wg % HMX_GA_SLOTS)) * GKs;
         double a2s = 0.0;
 #pragma unroll
         for (int n = 0; n < 2; ++n) {

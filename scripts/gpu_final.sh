@@ -25,7 +25,9 @@ with open("gpurun_out/kernel_stats_by_grid.txt", "w") as out:
     for (k, wg), v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:40]:
         out.write(f"{k:56s} {wg:10d} {len(v):6d} {sum(v)/1e3:10.2f} {sum(v)/len(v):10.1f}\n")
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("void k_round<7, 13") and int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]) == 224]
+c3 = [r for r in rows if r["Kernel_Name"].startswith("void k_round<7, 13, true>")]
+wgs_c3 = collections.Counter(int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]) for r in c3).most_common(1)[0][0] if c3 else -1   # (the C3 loop's grid: 224 with the classic tile map, ~243 with the group-affine one)
+idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("void k_round<7, 13, true>") and int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]) == wgs_c3]
 if idx:
     mid = idx[len(idx) // 3]
     t0 = int(rows[mid]["Start_Timestamp"])

@@ -36,6 +36,21 @@ out = {"engine_version": harmonypy_amd.engine_version(),
        "config": "C3: 1M cells x 50 PCs, 8 batches, K=100, 1 MI355X (timed loop only)",
        "units": "FETCH_SIZE / WRITE_SIZE are KiB per dispatch (mean over dispatches); hbm_bytes_corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE counts half the bytes of 16-byte-per-lane reads (MI355X_MICROARCH.md, HBM section)",
        "kernels": dict(sorted(kern.items(), key=lambda kv: -kv[1]["hbm_bytes_corrected"] * kv[1]["dispatches"])[:12])}
+# the same kernel's average duration in the rocprofv3 kernel trace of THIS build (scripts/gpu_final.sh, run before this script on the same
+# box): bench.py quotes roofline.frac_trace from it
+try:
+    best = None
+    for line in open("gpurun_out/kernel_stats_by_grid.txt"):
+        if line.startswith("void k_round<7, 13, true>(RoundArgs)"):
+            f = line.split()
+            wgs, calls, avg = int(f[-4]), int(f[-3]), float(f[-1])
+            if best is None or calls > best[1]:
+                best = (wgs, calls, avg)
+    if best:
+        out["trace"] = {"k_round_avg_us": best[2], "workgroups": best[0], "calls": best[1],
+                        "source": "rocprofv3 --kernel-trace --stats of `python bench.py --cpu-sample 0 --no-roofline` on the same box and build (kernel_stats_by_grid)"}
+except OSError:
+    pass
 json.dump(out, open("gpurun_out/pmc_hbm.json", "w"), indent=1)
 for k, r in list(out["kernels"].items())[:8]:
     print(f"{k:60s} n={r['dispatches']:4d} corrected MB = {r['hbm_bytes_corrected'] / 1e6:9.1f}")
