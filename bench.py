@@ -628,6 +628,10 @@ def main():
             "distance_gemm": ("bf16x3: every fp32 operand as the exact sum of three bf16 terms, six bf16 MFMAs per 32 k with fp32 "
                               "accumulation (as close to float64 as the f32-input MFMA)" if counters.get("sweeps_bf16_pipe", 0) > 0
                               else "f32-input MFMA"),
+            # how the sweep kernel deals a block's tiles out and hands the block sums on
+            "sweep_tile_map": (f"group-affine: one batch group per workgroup ({counters.get('sweep_group_affine_wgs', 0)} workgroups), block sums as "
+                               "self-validating fixed-point words (count << 55 | sum * 2^32)" if counters.get("sweeps_group_affine", 0) > 0
+                               else "classic: tile pairs round-robin over all workgroups, returning fp64 adds + arrival counter"),
             "init": "k-means++ on a 50k-cell subsample, untimed",
             "parallelism": (f"cells sharded over {world} ranks (1 per GPU), transport {transport}: "
                             + ("block sums exchanged inside the sweep kernel through peer boxes (xGMI), 1 all-reduce per "
