@@ -101,39 +101,58 @@ class Shard:
         return name + ("+peer" if self.peer_exchange else "")
 
     def _attach_peers(self, engine):
+        """Peer boxes for the in-kernel exchange of the per-block sums.  First attempt: FINE-GRAINED device memory (what HIP keeps
+        coherent for another device's writes while a kernel polls; the engine's default).  If any rank cannot export, map or
+        pass the self-test with those -- e.g. a stack whose IPC does not open fine-grained allocations across devices -- all
+        ranks together try once more with plain (coarse-grained) boxes, the allocation of rounds 3-5; if that fails too, one
+        collective per update block.  ``HMX_PEER_BOX`` pins the kind (no second attempt)."""
         import logging
         import os
         from . import _capi
         if os.environ.get("HMX_PEER_EXCHANGE", "1") == "0" or self.world > 8:
             return False
-        ok, err, handle = 1, "", b""
+        pinned = os.environ.get("HMX_PEER_BOX")
+        err = ""
         try:
             engine.set_ranks(self.world, self.rank)
-            handle = engine.peer_export()
+            ranks_ok = 1
         except _capi.HmxError as exc:
-            ok, err = 0, str(exc)
-        handles = self.allgather_object(handle)
-        if ok and all(len(h) == _capi.HMX_PEER_HANDLE_BYTES for h in handles):
+            ranks_ok, err = 0, str(exc)
+        for kind in ([pinned] if pinned else ["fine", "coarse"]):
+            ok, handle = ranks_ok, b""
+            os.environ["HMX_PEER_BOX"] = kind                      # read by hmx_peer_export
             try:
-                engine.peer_attach(b"".join(handles))
+                if ok:
+                    handle = engine.peer_export()
             except _capi.HmxError as exc:
                 ok, err = 0, str(exc)
-        else:
-            ok = 0
-        flag = np.array([ok], dtype=np.int64)
-        self.allreduce_(flag)                          # also a barrier: every box is mapped everywhere
-        if int(flag[0]) == self.world:
-            try:
-                ok = 1 if engine.peer_selftest() else 0
-            except _capi.HmxError as exc:
-                ok, err = 0, str(exc)
+            finally:
+                if pinned is None:
+                    os.environ.pop("HMX_PEER_BOX", None)
+            handles = self.allgather_object(handle)
+            if ok and all(len(h) == _capi.HMX_PEER_HANDLE_BYTES for h in handles):
+                try:
+                    engine.peer_attach(b"".join(handles))
+                except _capi.HmxError as exc:
+                    ok, err = 0, str(exc)
+            else:
+                ok = 0
             flag = np.array([ok], dtype=np.int64)
-            self.allreduce_(flag)
-        if int(flag[0]) == self.world:
-            engine.peer_enable(True)
-            return True
+            self.allreduce_(flag)                          # also a barrier: every box is mapped everywhere
+            if int(flag[0]) == self.world:
+                try:
+                    ok = 1 if engine.peer_selftest() else 0
+                except _capi.HmxError as exc:
+                    ok, err = 0, str(exc)
+                flag = np.array([ok], dtype=np.int64)
+                self.allreduce_(flag)
+            if int(flag[0]) == self.world:
+                engine.peer_enable(True)
+                return True
+            logging.getLogger("harmonypy_amd").warning(
+                f"rank {self.rank}: in-kernel peer exchange unavailable with {kind}-grained boxes {err}")
         logging.getLogger("harmonypy_amd").warning(
-            f"rank {self.rank}: in-kernel peer exchange unavailable {err}; one collective per update block instead")
+            f"rank {self.rank}: in-kernel peer exchange unavailable; one collective per update block instead")
         return False
 
     def _attach_transport(self, engine):

@@ -269,3 +269,65 @@ def test_device_order_restatement_is_a_permutation(n):
         blk = cells[bs[b] * 16: bs[b + 1] * 16]
         want = (n - cpb * (nb - 1)) if b == nb - 1 else cpb
         assert (blk >= 0).sum() == want
+
+
+def test_peer_attach_retries_with_coarse_boxes(monkeypatch):
+    """harmonypy_amd.dist.Shard._attach_peers: fine-grained peer boxes first; if any rank cannot export / map / pass the self-test
+    with them, all ranks together try once more with coarse-grained boxes, then give the in-kernel exchange up.  Driven here
+    with a fake engine and a one-rank "world" (no GPU, no process group): the order of the calls and of HMX_PEER_BOX is the logic."""
+    import os
+    from harmonypy_amd import _capi
+    from harmonypy_amd.dist import Shard
+
+    class FakeEngine:
+        def __init__(self, fail):
+            self.fail, self.calls, self.kinds = fail, [], []
+
+        def set_ranks(self, world, rank):
+            self.calls.append("set_ranks")
+
+        def peer_export(self):
+            kind = os.environ.get("HMX_PEER_BOX")
+            self.kinds.append(kind)
+            self.calls.append(f"export:{kind}")
+            if ("export", kind) in self.fail:
+                raise _capi.HmxError("export failed", -2)
+            return b"\0" * _capi.HMX_PEER_HANDLE_BYTES
+
+        def peer_attach(self, handles):
+            self.calls.append(f"attach:{self.kinds[-1]}")
+            if ("attach", self.kinds[-1]) in self.fail:
+                raise _capi.HmxError("hipIpcOpenMemHandle failed", -4)
+
+        def peer_selftest(self):
+            self.calls.append(f"selftest:{self.kinds[-1]}")
+            return ("selftest", self.kinds[-1]) not in self.fail
+
+        def peer_enable(self, on):
+            self.calls.append(f"enable:{self.kinds[-1]}")
+
+    def shard():
+        s = Shard.__new__(Shard)
+        s.rank, s.world = 0, 1
+        s.allgather_object = lambda obj: [obj]
+        s.allreduce_ = lambda arr: None
+        return s
+
+    monkeypatch.delenv("HMX_PEER_BOX", raising=False)
+    monkeypatch.delenv("HMX_PEER_EXCHANGE", raising=False)
+    e = FakeEngine(fail=set())
+    assert shard()._attach_peers(e) is True
+    assert e.calls == ["set_ranks", "export:fine", "attach:fine", "selftest:fine", "enable:fine"] and "HMX_PEER_BOX" not in os.environ
+    e = FakeEngine(fail={("attach", "fine")})                      # e.g. IPC does not open fine-grained memory across devices
+    assert shard()._attach_peers(e) is True
+    assert e.calls == ["set_ranks", "export:fine", "attach:fine", "export:coarse", "attach:coarse", "selftest:coarse", "enable:coarse"]
+    e = FakeEngine(fail={("selftest", "fine"), ("selftest", "coarse")})
+    assert shard()._attach_peers(e) is False
+    assert e.calls[-1] == "selftest:coarse" and not any(c.startswith("enable") for c in e.calls)
+    monkeypatch.setenv("HMX_PEER_BOX", "coarse")                   # pinned: one attempt only, the variable stays
+    e = FakeEngine(fail={("export", "coarse")})
+    assert shard()._attach_peers(e) is False
+    assert e.kinds == ["coarse"] and os.environ["HMX_PEER_BOX"] == "coarse"
+    monkeypatch.setenv("HMX_PEER_EXCHANGE", "0")
+    e = FakeEngine(fail=set())
+    assert shard()._attach_peers(e) is False and e.calls == []
