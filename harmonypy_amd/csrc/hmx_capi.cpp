@@ -1180,7 +1180,7 @@ static bool plan_ga(hmx_engine* e, int max_tiles, int cap) {
 // block ids in static tile order (tile_blk) are already in device memory.  tiles_upper[b] bounds the tile count of block b
 // (grid sizing only).
 static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::vector<int>& tiles_upper, double obj_out[4],
-                      const std::function<int()>& before_sweep = nullptr, double* defer_slot = nullptr, bool no_replay = false) {
+                      const std::function<int(int)>& before_sweep = nullptr, double* defer_slot = nullptr, bool no_replay = false) {
     int rc;
     const size_t GK = (size_t)e->G * e->K16;
     const bool persistent = (flags & HMX_ROUND_UPDATE_R) && e->round_mode == 1 && (!sharded(e) || e->peers_enabled);
@@ -1246,7 +1246,10 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
             launch_y_normalize_d(e->Yacc64, e->Y.p, e->K, e->K16, e->d, e->ldy, e->stream);  // :444
         }
     }
-    if (before_sweep && (rc = before_sweep())) return rc;   // side-stream work that should run beside the sweep, not beside the R^T.Z pass
+    // side-stream work that should run beside the sweep, not beside the R^T.Z pass: its start is MARKED in the main stream here (phase 0),
+    // its launches are enqueued behind the sweep's own (phase 1) -- four launches of host time that the sweep does not wait for
+    if (before_sweep && (rc = before_sweep(0))) return rc;
+    if (before_sweep && !mega && (rc = before_sweep(1))) return rc;
     if (mega) {
         // the whole sweep in one persistent launch (k_round); closes O, T and the objective itself
         if (!fused) {
@@ -1274,6 +1277,7 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
             if (ga) {
                 // row-request placement of the group-affine sweep (k_round, tile_step): measured per shape, HMX_ROUND_REQ overrides
                 ra.req_mode = e->ga_per_wg > HMX_ROUND_GA_TILES ? 1 : e->ga_nwg > 32 ? 2 : 0;
+                ra.ga_slots = e->ga_nwg > 32 ? 2 : 1;
                 if (const char* rq = getenv("HMX_ROUND_REQ")) ra.req_mode = std::max(0, std::min(2, atoi(rq)));
             }
             if (ga) { ra.ga = 1; ra.run_start = e->lists[e->cur].run_tiles.p; ra.wg_map = e->ga_map.p; e->n_sweeps_ga++; }
@@ -1292,6 +1296,7 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
 #endif
             const bool extra_tiles = ga ? e->ga_extra : max_upper > 16 * wgs;   // (ROUND_TPW x ROUND_WAVES slots per workgroup; group-affine: 14 per workgroup of the run's group)
             if (launch_round(ra, e->mt, multi ? wgs + 1 : wgs, e->stream, extra_tiles, e->allow_round_bf16)) return fail(HMX_ERR_ARG, "unsupported shape for k_round");
+            if (before_sweep && (rc = before_sweep(1))) return rc;
             if (round_uses_bf16_pipe(ra.K16, ra.dp, ra.G, ra.B, ra.V, extra_tiles, e->allow_round_bf16, ga, e->nblk)) e->n_sweeps_bf16++;
 #ifdef HMX_ROUND_PROF
             if (++prof_rounds == 25) {   // one round in steady state: phase durations over workgroups and blocks
@@ -1484,9 +1489,13 @@ static int seeded_round(hmx_engine* e, int flags, uint64_t seed, int64_t cells_p
     e->pre_outstanding = false;   // either the main stream now waits for it, or stream2 was drained
     // next round's lists depend on (seed, counter) only: they are built on the second stream beside the sweep
     // kernel, which leaves a few CUs idle.  The scratch tables (chunk_tab, run_*) are free by then.
-    auto prefetch = [&]() -> int {
+    // (enqueueing the four list launches in front of the sweep's launch instead made no measurable difference: the host is ahead of the device)
+    auto prefetch = [&](int phase) -> int {
         if (!e->prefetch_lists || !e->stream2 || replay_only) return 0;
-        HIP_TRY(hipEventRecord(e->pre_event, e->stream));
+        if (phase == 0) {
+            HIP_TRY(hipEventRecord(e->pre_event, e->stream));
+            return 0;
+        }
         HIP_TRY(hipStreamWaitEvent(e->stream2, e->pre_event, 0));
         build(counter + 1, e->cur ^ 1, e->stream2);
         HIP_TRY(hipEventRecord(e->pre_event, e->stream2));

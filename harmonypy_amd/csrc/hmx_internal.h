@@ -79,6 +79,7 @@ struct RoundArgs {
     int ga;                    // 1: group-affine map, 0: classic (tile pairs dealt round-robin over all workgroups)
     const int* run_start;      // ga: nblk * G + 1 tile offsets of the (block, group) runs of the list, key = block * G + group
     const int* wg_map;         // ga: per compute workgroup {group, rank among the group's workgroups, workgroups of the group}
+    int ga_slots;              // ga: slot tables a block's adds are spread over (1 on small grids, else 2)
     int req_mode;              // ga: where the waves issue the next block's row requests (0 classic stagger, 1 behind the GEMM, 2 between its k-steps)
 };
 

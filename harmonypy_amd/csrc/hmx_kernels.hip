@@ -515,7 +515,8 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES, 4) void k_assign_lds(AssignArgs 
 // cell needs (its Z_cos row, the distance GEMM against Y, exp and the first normalisation,
 // harmony.py:447, 466-468) does not depend on that table.  So:
 //   * one workgroup of 8 waves per CU stays resident for the whole sweep; Y, sigma live in LDS;
-//   * block b's tiles are dealt round-robin over the workgroups, two tiles per wave; the
+//   * block b's tiles are dealt out two per wave -- round-robin over all workgroups (classic map), or every workgroup from
+//     the run of its OWN batch group (group-affine map, round 6: see the comment at the top of the kernel body); the
 //     table-independent half of a tile ("pre": distance MFMAs; the exponent arguments stay in
 //     4*MT registers per tile) runs BEFORE the wave waits for block b-1 to complete, i.e. it
 //     overlaps the grid-wide hand-off;
@@ -525,7 +526,8 @@ __global__ __launch_bounds__(64 * ASSIGN_WAVES, 4) void k_assign_lds(AssignArgs 
 //     rows held in registers across "post" put the kernel into scratch;
 //   * a wave's own coordinates (lane, c16, q, tid) are refreshed through an empty asm at the top
 //     of every block, so nothing derived from them is hoisted out of the sweep and spilled;
-//   * hand-off: every workgroup adds its block sums to one of HMX_ROUND_SLOTS fp64 tables with
+//   * hand-off (classic map; the group-affine map exchanges self-validating fixed-point words instead: no returning
+//     atomics, no counter): every workgroup adds its block sums to one of HMX_ROUND_SLOTS fp64 tables with
 //     agent-scope atomics, drains them (s_waitcnt vmcnt(0)), and one lane bumps an arrival
 //     counter; consumers poll the counter with relaxed agent-scope loads and read the tables
 //     with agent-scope atomic loads -- 8-byte agent atomics on both sides, so no cache
@@ -952,7 +954,20 @@ __device__ __forceinline__ void block_sums_rs(const f32x4 (&sm)[NM], double* sd,
     if (i < 4 * NM) atomicAdd(sd + 16 * (i >> 2) + 4 * q + (i & 3), (double)tot);   // value i = cluster tile i / 4 of the group, register i % 4
 }
 
+// the R rows of one tile (:503)
 template <int MT>
+__device__ __forceinline__ void round_store_rows(float* R, int Kp, int q, const RoundTile<MT>& T, float scl) {
+    if (T.cell < 0) return;
+    float* row = R + (size_t)T.cell * Kp;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int col = 16 * mt + 4 * q;
+        if (col < Kp) st4(row + col, T.arg[mt] * scl);
+    }
+}
+// STORE0 = false: the first tile's rows are out already (k_round stores them in front of the second tile's exp pass: a longer,
+// flatter burst of row stores -- 0-2 % on every configuration, profiles/r06_ab_k_round_early_store.txt)
+template <int MT, bool STORE0 = true>
 __device__ __forceinline__ void round_post_pass2(float* R, int Kp, double* Sd, int c16, int q, const RoundTile<MT>& T0,
                                                  float scl0, bool has1, const RoundTile<MT>& T1, float scl1) {
     constexpr int K16 = 16 * MT;
@@ -978,7 +993,7 @@ __device__ __forceinline__ void round_post_pass2(float* R, int Kp, double* Sd, i
             if (live0 && col < Kp) __builtin_nontemporal_store(rv0[m], reinterpret_cast<f32x4*>(row0 + col));
             if (live1 && col < Kp) __builtin_nontemporal_store(rv1[m], reinterpret_cast<f32x4*>(row1 + col));
 #else
-            if (live0 && col < Kp) st4(row0 + col, rv0[m]);
+            if (STORE0 && live0 && col < Kp) st4(row0 + col, rv0[m]);
             if (live1 && col < Kp) st4(row1 + col, rv1[m]);
 #endif
 #endif
@@ -1812,8 +1827,9 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     // every entry's count fields (bits 55.. of the four slot words) add up to the number of contributors -- ng workgroups of
     // the own group, all nwg for the cluster masses; the words that pass the test ARE the data (2^-32 fixed point).
 #ifndef HMX_GA_SLOTS
-#define HMX_GA_SLOTS 2   /* slot tables the group-affine map spreads a block's adds over (of the HMX_ROUND_SLOTS allocated): every slot is two more loads per
-                            entry of the poll; 8 / 4 / 2 measured (profiles/r06_ab_k_round_slots_poll.txt): contention on the words is not what costs */
+#define HMX_GA_SLOTS 2   /* slot tables the group-affine map spreads a block's adds over AT MOST (of the HMX_ROUND_SLOTS allocated; a.ga_slots of them are
+                            used): every slot is two more loads per entry of the poll; 8 / 4 / 2 / 1 measured (profiles/r06_ab_k_round_slots_poll.txt):
+                            contention on the words only costs on large grids (one slot: C3 294 vs 242 us, configs[1] 110.5 vs 112 us) */
 #endif
     static_assert(HMX_GA_SLOTS <= HMX_ROUND_SLOTS, "the slot tables are allocated for HMX_ROUND_SLOTS");
     constexpr unsigned long long FX_MASK = (1ull << 55) - 1ull;
@@ -1831,8 +1847,11 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
                 const unsigned long long* sn = reinterpret_cast<const unsigned long long*>(a.S_new) + (size_t)bp * HMX_ROUND_SLOTS * GKs + k;
 #pragma unroll
                 for (int s = 0; s < HMX_GA_SLOTS; ++s) {                  // independent loads, all in flight together
-                    wo[n][s] = __hip_atomic_load(sn + (size_t)s * GKs + (size_t)g_own * K16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    wt[n][s] = __hip_atomic_load(sn + (size_t)s * GKs + (size_t)a.G * K16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    wo[n][s] = wt[n][s] = 0ull;
+                    if (s < a.ga_slots) {                                    // (uniform: small grids use one slot table)
+                        wo[n][s] = __hip_atomic_load(sn + (size_t)s * GKs + (size_t)g_own * K16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        wt[n][s] = __hip_atomic_load(sn + (size_t)s * GKs + (size_t)a.G * K16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
 #pragma unroll
@@ -1902,7 +1921,7 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
     // the workgroup's sums of block b into its group's row and into the cluster-mass row of one slot table: count and sum in
     // one word, not returning, nothing to wait for (see ga_fetch).  EVERY entry is added to, zero sums too: the count is the arrival.
     auto ga_publish = [&](int b) {
-        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.S_new) + ((size_t)b * HMX_ROUND_SLOTS + (wg % HMX_GA_SLOTS)) * GKs;
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.S_new) + ((size_t)b * HMX_ROUND_SLOTS + (wg % a.ga_slots)) * GKs;
         double a2s = 0.0;
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
@@ -2043,9 +2062,11 @@ __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
             const bool has1 = j_first + 1 < ntl;
             round_post_pass1<MT, true, LOG2, A2TAB>(sig, rpT, lrpT, q, T[0], scl0, km_acc, ent_acc);
             __builtin_amdgcn_sched_barrier(0);
+            round_store_rows<MT>(a.R, a.Kp, q, T[0], scl0);
+            __builtin_amdgcn_sched_barrier(0);
             if (has1) round_post_pass1<MT, true, LOG2, A2TAB>(sig, rpT, lrpT, q, T[1], scl1, km_acc, ent_acc);
             __builtin_amdgcn_sched_barrier(0);
-            round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T[0], scl0, has1, T[1], scl1);
+            round_post_pass2<MT, false>(a.R, a.Kp, Sd, c16, q, T[0], scl0, has1, T[1], scl1);
         }
         for (int j = j_first + j_slot; j < ntl; j += j_slot) {   // blocks larger than the grid carries
 #pragma unroll 1
@@ -4365,7 +4386,7 @@ int launch_round(const RoundArgs& a_in, int mt, int wgs, hipStream_t s, bool ext
     RoundArgs a = a_in;
     a.ldy_lds = lds_ldy(a.dp);
     const bool ga = a.ga != 0;
-    if (ga && (a.V != 1 || a.n_ranks > 1 || !a.run_start || !a.wg_map)) return -1;
+    if (ga && (a.V != 1 || a.n_ranks > 1 || !a.run_start || !a.wg_map || a.ga_slots < 1 || a.ga_slots > HMX_GA_SLOTS)) return -1;
     const bool bf3 = round_uses_bf16_pipe(a.K16, a.dp, a.G, a.B, a.V, extra_tiles, allow_bf16, ga, a.nblk);
     const size_t sm = round_lds_bytes(a.K16, a.dp, a.G, a.B, a.V, bf3, ga, a.nblk);
     if (mt < 1 || mt > 7 || sm > HMX_ROUND_LDS_LIMIT) return -1;
