@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("HMX_LIB") or os.path.join(_HERE, "libhmx.so")   # HMX
 
 # mirrors include/hmx.h
 HMX_TILE = 16
-HMX_MAX_CLUSTERS, HMX_MAX_PCS, HMX_MAX_BLOCKS, HMX_MAX_VARS = 208, 208, 250, 8   # limits checked by hmx_create
+HMX_MAX_CLUSTERS, HMX_MAX_PCS, HMX_MAX_BLOCKS, HMX_MAX_VARS = 320, 320, 250, 32   # limits checked by hmx_create
 HMX_Z_ORIG, HMX_Z_COS, HMX_Z_CORR, HMX_R, HMX_Y, HMX_O_GROUP, HMX_T_MASS, HMX_W = range(8)
 HMX_ROUND_BLOCK_START, HMX_ROUND_CELLS, HMX_ROUND_TILE_GROUP = 8, 9, 10
 HMX_ROUND_CENTROIDS, HMX_ROUND_UPDATE_R, HMX_ROUND_OBJECTIVE = 1, 2, 4

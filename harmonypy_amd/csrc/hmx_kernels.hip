@@ -4209,8 +4209,8 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
             return 0;
         }
     }
-    if (a.dp % 16 == 0 && a.mt >= 1 && a.mt <= 13 && (a.mt > 7 || a.dp > 64)) {
-        // wide shapes: k-step staged centroid columns, 8 tiles per workgroup pass
+    if (a.dp % 16 == 0 && a.dp <= 208 && a.mt >= 1 && a.mt <= 13 && (a.mt > 7 || a.dp > 64)) {
+        // wide shapes: k-step staged centroid columns, 8 tiles per workgroup pass (K, d <= 208; beyond: the generic kernel below)
         const size_t gk_bytes = (size_t)a.G * a.K16 * sizeof(double);
         a.tables_in_lds = gk_bytes <= 64 * 1024 ? 1 : 0;
         const size_t sm = ((size_t)2 * a.K16 * 20 + 2 * a.K16) * sizeof(float) + (a.tables_in_lds ? gk_bytes : 0) + 2 * WIDE_WAVES * sizeof(double);
@@ -4262,6 +4262,11 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
         const int wgs = assign_grid(ntiles, NT, max_wgs);
         if (penalty) hipLaunchKernelGGL((k_assign<13, NT, true>), dim3(wgs), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_assign<13, NT, false>), dim3(wgs), dim3(256), 0, s, a);
+    } else if (a.mt <= 20) {   // up to 320 clusters: the generic kernel's widest instance (51 KB of staged centroid columns)
+        constexpr int NT = 1;
+        const int wgs = assign_grid(ntiles, NT, max_wgs);
+        if (penalty) hipLaunchKernelGGL((k_assign<20, NT, true>), dim3(wgs), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_assign<20, NT, false>), dim3(wgs), dim3(256), 0, s, a);
     } else {
         return -1;
     }
@@ -4270,11 +4275,11 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
 
 size_t round_lds_bytes(int K16, int dp, int G, int B, int V, bool bf3, bool ga, int nblk) {
     const size_t GK = (size_t)(ga ? 1 : G) * K16;   // group-affine map: a workgroup keeps the tables of its own group only
-    // sigma, -1/sigma, rp, lrp, rpc (V > 1) | O, S, T, objective scratch (fp64) | Pr_b, theta, group_cols (V <= 8), bgrp, run offsets and
+    // sigma, -1/sigma, rp, lrp, rpc (V > 1) | O, S, T, objective scratch (fp64) | Pr_b, theta, group_cols (G x V), bgrp, run offsets and
     // lengths (2 x (nblk + 3)), one flag | landing zones
     const size_t ys = bf3 ? (size_t)3 * K16 * bf3_ldb(dp / 4) : (size_t)K16 * lds_ldy(dp);   // centroids: three bf16 planes, or fp32 rows
     return (ys + 2 * (size_t)K16 + 2 * GK + (V == 1 ? 0 : (size_t)K16 * B)) * 4 + (2 * GK + K16 + 2 * ROUND_WAVES) * 8 +
-           (3 * (size_t)B + (size_t)G * 8 + 2 * ((size_t)nblk + 3) + 2) * 4 + 16 + (size_t)ROUND_WAVES * ROUND_TPW * 16 * dp * 4
+           (3 * (size_t)B + (size_t)G * (size_t)(V > 8 ? V : 8) + 2 * ((size_t)nblk + 3) + 2) * 4 + 16 + (size_t)ROUND_WAVES * ROUND_TPW * 16 * dp * 4
         ;
 }
 
@@ -4658,6 +4663,7 @@ int launch_ridge_apply(const ApplyArgs& a_in, int max_wgs, hipStream_t s) {
     const int wgs = assign_grid(a.n_tiles, NT, max_wgs);
     if (a.mtd <= 4) hipLaunchKernelGGL((k_ridge_apply<4, NT>), dim3(wgs), dim3(256), 0, s, a);
     else if (a.mtd <= 13) hipLaunchKernelGGL((k_ridge_apply<13, NT>), dim3(wgs), dim3(256), 0, s, a);
+    else if (a.mtd <= 20) hipLaunchKernelGGL((k_ridge_apply<20, 1>), dim3(assign_grid(a.n_tiles, 1, max_wgs)), dim3(256), 0, s, a);   // up to 320 PCs
     else return -1;
     return 0;
 }

@@ -32,10 +32,10 @@ extern "C" {
 #define HMX_ABI_VERSION 8
 #define HMX_TILE 16 /* cells per tile */
 /* limits of this build, checked by hmx_create (the reference has none: harmony.py:123-124 caps only the default K) */
-#define HMX_MAX_CLUSTERS 208
-#define HMX_MAX_PCS 208
+#define HMX_MAX_CLUSTERS 320 /* beyond 208 clusters or PCs: the generic kernels (no MFMA-tiled fast path) */
+#define HMX_MAX_PCS 320
 #define HMX_MAX_BLOCKS 250 /* block_size >= 0.004: a cell's block id of the round travels as one byte */
-#define HMX_MAX_VARS 8
+#define HMX_MAX_VARS 32
 
 typedef enum hmx_status {
     HMX_OK = 0,

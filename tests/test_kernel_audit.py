@@ -39,6 +39,10 @@ KNOWN_SPILLS = {
     "_Z5k_rtzILi7ELi4EEv7RtzArgs": 4,
     "_ZN12_GLOBAL__N_110k_lisi_knnILi4ELi4ELi256EEEv11LisiKnnArgs": 3,      # the 50-PC LISI search
     "_Z6k_rtz3ILi7ELi8ELi1EEv8Rtz3Args": 20,                           # K > 96 with d <= 32 and 33..48 update blocks
+    # 209..320 clusters (round 6: shapes the reference accepts and earlier builds refused): the generic kernel's widest instance keeps
+    # 3 x 80 per-cluster values per lane and spills -- a correct, slow last resort, not a hot kernel
+    "_Z8k_assignILi20ELi1ELb0EEv10AssignArgs": 330,
+    "_Z8k_assignILi20ELi1ELb1EEv10AssignArgs": 523,
 }
 
 

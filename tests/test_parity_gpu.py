@@ -246,7 +246,8 @@ def test_object_api_surface():
 @pytest.mark.parametrize("N,d,K,B,bs", [(37, 5, 3, 2, 0.05), (16, 4, 2, 1, 0.3), (1000, 33, 17, 5, 0.13),
                                         (2049, 64, 30, 4, 0.05), (900, 100, 150, 3, 0.05), (1500, 70, 20, 2, 0.1),
                                         (640, 20, 120, 2, 0.05), (800, 40, 130, 2, 0.1),    # K > 112 with 52-float rows: the generic kernels
-                                        (3456, 20, 10, 3, 0.01), (5000, 50, 30, 2, 0.004), (2500, 100, 130, 2, 0.0125)])   # 100 / 250 / 80 update blocks (harmony.py:474)
+                                        (3456, 20, 10, 3, 0.01), (5000, 50, 30, 2, 0.004), (2500, 100, 130, 2, 0.0125),   # 100 / 250 / 80 update blocks (harmony.py:474)
+                                        (1500, 30, 260, 2, 0.05), (1200, 250, 40, 3, 0.05), (1400, 224, 230, 2, 0.1), (900, 320, 320, 2, 0.05)])   # K or d beyond 208: the generic kernels' widest instances
 def test_edge_shapes_against_oracle(N, d, K, B, bs):
     """Ragged sizes: N below a block/tile, a single batch, K and d off the tile sizes, shapes beyond the LDS-resident
     kernels (K > 112 or d > 64: the generic kernels, BASELINE config 5's regime), and block_size down to 0.004: up to 250
@@ -266,6 +267,35 @@ def test_edge_shapes_against_oracle(N, d, K, B, bs):
     assert ho.kmeans_rounds == oo.kmeans_rounds
     assert_z_close(ho.Z_corr, oo.result())
     np.testing.assert_allclose(ho.objective_kmeans, oo.objective_kmeans, rtol=2e-5)
+
+
+@pytest.mark.parametrize("n_vars,N,K", [(10, 3000, 12), (3, 20000, 30), (12, 1500, 8)])
+def test_many_batch_variables_against_oracle(n_vars, N, K):
+    """More batch variables than the 8 earlier builds accepted (harmony.py:133-166 takes any number): ten and twelve binary /
+    ternary variables -- hundreds of distinct multi-hot groups, far more than the persistent sweep keeps tables for, so the
+    per-block kernels run -- and three variables at 20k cells; two Harmony iterations against the oracle on the same schedule."""
+    from oracle import oracle_run_harmony
+    rng = np.random.default_rng(100 + n_vars)
+    d = 24
+    Z = rng.normal(size=(N, d)).astype(np.float32) * (1.0 / np.sqrt(1 + np.arange(d))).astype(np.float32)
+    meta = {}
+    for v in range(n_vars):
+        levels = 2 + (v % 2)
+        codes = rng.integers(0, levels, size=N)
+        codes[:levels] = np.arange(levels)
+        Z += (codes[:, None] * (0.15 + 0.05 * v)).astype(np.float32) * rng.normal(size=(1, d)).astype(np.float32) * 0.3
+        meta[f"v{v}"] = [f"l{c}" for c in codes]
+    meta = pd.DataFrame(meta)
+    vars_use = list(meta.columns)
+    kw = dict(nclust=K, max_iter_harmony=2, max_iter_kmeans=3, random_state=2, epsilon_cluster=0.0, epsilon_harmony=-1e30)
+    # (the ridge system has 1 + sum of levels unknowns per cluster here: the oracle evaluates it in float64 -- the variant pinned to the
+    # reference's own moe_correct_ridge on float64 copies, tests/test_large_golden.py; its fp32 form is 1e-4-noisy at this conditioning)
+    oo = oracle_run_harmony(Z, meta, vars_use, ridge_dtype=np.float64, **kw)
+    ho = _run_engine(Z, meta, vars_use, Y0=oo.Y0, **kw)
+    assert ho.kmeans_rounds == oo.kmeans_rounds
+    rel_f, max_rel = assert_z_close(ho.Z_corr, oo.result())
+    np.testing.assert_allclose(ho.objective_kmeans, oo.objective_kmeans, rtol=2e-5)
+    print(f"{n_vars} batch variables, {N} cells: {ho._G} groups, Z_corr relF={rel_f:.2e} max={max_rel:.2e}")
 
 
 def test_config2_shape_properties_and_oracle():

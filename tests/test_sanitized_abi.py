@@ -64,7 +64,7 @@ cfg = _capi.HmxConfig(n_cells=64, n_cells_global=0, n_pcs=5, n_clusters=3, n_bat
 h = C.c_void_p()
 rc = lib.hmx_create(C.byref(cfg), C.byref(h))
 assert rc != 0 and h.value is None and lib.hmx_last_error()
-for bad in (dict(n_clusters=999), dict(n_pcs=0), dict(n_blocks=1000), dict(n_vars=9), dict(n_cells=-1)):
+for bad in (dict(n_clusters=999), dict(n_pcs=0), dict(n_blocks=1000), dict(n_vars=33), dict(n_cells=-1)):
     c2 = _capi.HmxConfig(n_cells=64, n_cells_global=0, n_pcs=5, n_clusters=3, n_batches=2, n_groups=2, n_vars=1, n_blocks=20, device_id=0)
     for k, v in bad.items(): setattr(c2, k, v)
     assert lib.hmx_create(C.byref(c2), C.byref(h)) == -1
