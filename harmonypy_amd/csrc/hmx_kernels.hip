@@ -1254,6 +1254,18 @@ __global__ __launch_bounds__(64) void k_y_planes(const float* __restrict__ Y, in
 
 #define WIDE3_WAVES 8
 #define WIDE3_SLOTS (2 * WIDE3_WAVES)
+#define WIDE3_TSUB 4  /* the fused table's cluster masses: partial sums over the groups g = th (mod 4) */
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+#ifdef HMX_WIDE3_PROF   /* timing experiments only: s_memtime stamps per wave (workgroups x waves x 16) */
+__device__ unsigned long long g_w3prof[512 * WIDE3_WAVES * 32];
+#define W3STAMP(k) do { if (lane == 0 && blockIdx.x < 512) g_w3prof[((size_t)blockIdx.x * WIDE3_WAVES + wv) * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define W3ACC(k, v) do { if (lane == 0 && blockIdx.x < 512) g_w3prof[((size_t)blockIdx.x * WIDE3_WAVES + wv) * 32 + (k)] += (v); } while (0)
+#define W3ZERO(k) do { if (lane == 0 && blockIdx.x < 512) g_w3prof[((size_t)blockIdx.x * WIDE3_WAVES + wv) * 32 + (k)] = 0; } while (0)
+#else
+#define W3STAMP(k) do { } while (0)
+#define W3ACC(k, v) do { } while (0)
+#define W3ZERO(k) do { } while (0)
+#endif
 template <int MT>
 __global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_assign_wide3(AssignArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1269,24 +1281,21 @@ __global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_assign_wide3(AssignArgs
     int* tg = reinterpret_cast<int*>(objw + 2 * WIDE3_WAVES);            // group of the workgroup's tile j (-1: no such tile)
     int* ts = tg + WIDE3_SLOTS;                                          // its slot: tiles of one group share table rows and sums
     int* sg = ts + WIDE3_SLOTS;                                          // group of a slot
-    double* Tp = reinterpret_cast<double*>(sg + WIDE3_SLOTS);            // 2 x K16 partial cluster masses (fused table only)
+    double* Tp = reinterpret_cast<double*>(sg + WIDE3_SLOTS);            // WIDE3_TSUB x K16 partial cluster masses (fused table only)
+    float* spr = reinterpret_cast<float*>(Tp + WIDE3_TSUB * K16);        // Pr_b of a slot's group
+    float* sth = spr + WIDE3_SLOTS;                                      // theta of a slot's group
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, c16 = lane & 15, q = lane >> 4;
     const int ns = (a.dp + 31) >> 5;                                     // k-steps of 32 PCs
-    const int tile_begin = a.blk_start ? a.blk_start[a.blk] : a.tile_begin;
-    const int tile_end = a.blk_start ? a.blk_start[a.blk + 1] : a.tile_end;
-    const int ntiles = tile_end - tile_begin;
-    const int base = blockIdx.x * WIDE3_SLOTS;
-    if (base >= ntiles) return;                                          // (the grid is sized for an upper bound of the block)
-
-    RoundTile<MT> T0, T1;
-    const int j0 = base + 2 * wv;
-    const bool has0 = j0 < ntiles, has1 = j0 + 1 < ntiles;              // wave-uniform
-    T0.cell = has0 ? a.cells[(size_t)(tile_begin + j0) * 16 + c16] : -1;
-    T1.cell = has1 ? a.cells[(size_t)(tile_begin + j0 + 1) * 16 + c16] : -1;
-    const float* zr0 = a.Zcos + (size_t)(T0.cell >= 0 ? T0.cell : 0) * a.dp + 8 * q;
-    const float* zr1 = a.Zcos + (size_t)(T1.cell >= 0 ? T1.cell : 0) * a.dp + 8 * q;
+    W3STAMP(0); W3ZERO(9);
+#ifdef HMX_WIDE3_PROF
+    if (lane == 0 && blockIdx.x < 512) g_w3prof[((size_t)blockIdx.x * WIDE3_WAVES + wv) * 32 + 16] = wall_clock64();
+#endif
+    // The prologue is a chain of memory round trips (2-3 k cycles each at the start of a launch, nothing of the block is in a
+    // cache): what does not depend on the block -- the first centroid fragments, sigma, the O / S tables of the fused table --
+    // is requested FIRST, then the block's cells and groups, then the Z rows; the table is folded out of registers once the
+    // slots are known (profiles/r06_ab_wide3_prologue.txt: 22 k of 92 k cycles per wave with one round trip after the other).
     auto u64 = [](unsigned long long v) {
         return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v);
@@ -1307,6 +1316,44 @@ __global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_assign_wide3(AssignArgs
             }
         }
     };
+    request(0);
+    // the fused table's inputs: thread (th, pair of clusters tk) takes groups th, th + 4, ... -- eight per trip, 24 sixteen-byte loads
+    constexpr int KP = K16 / 2;
+    const bool tsum = a.fuse_table && tid < WIDE3_TSUB * KP;
+    const int th = tid / KP, tk = 2 * (tid - th * KP);
+    f64x2 op[8], sa[8], ss[8];
+    auto table_load = [&](int g0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const size_t i = (size_t)min(g0 + WIDE3_TSUB * j, a.G - 1) * K16 + tk;
+            op[j] = *reinterpret_cast<const f64x2*>(a.O_prev + i);
+            sa[j] = a.S_add ? *reinterpret_cast<const f64x2*>(a.S_add + i) : (f64x2){0.0, 0.0};
+            ss[j] = *reinterpret_cast<const f64x2*>(a.S_sub + i);
+        }
+    };
+    if (tsum) table_load(th);
+    const float sgm = (tid < a.K) ? a.sigma[tid] : 0.f;                  // (K16 <= 208 < threads of the workgroup)
+    __builtin_amdgcn_sched_barrier(0);
+    W3STAMP(10);
+    const int tile_begin = a.blk_start ? a.blk_start[a.blk] : a.tile_begin;
+    const int tile_end = a.blk_start ? a.blk_start[a.blk + 1] : a.tile_end;
+    const int ntiles = tile_end - tile_begin;
+    const int base = blockIdx.x * WIDE3_SLOTS;
+    if (base >= ntiles) {                                                // (the grid is sized for an upper bound of the block)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the fragment requests write LDS: not past the end of the workgroup
+        return;
+    }
+
+    W3STAMP(11);
+    RoundTile<MT> T0, T1;
+    const int j0 = base + 2 * wv;
+    const bool has0 = j0 < ntiles, has1 = j0 + 1 < ntiles;              // wave-uniform
+    T0.cell = has0 ? a.cells[(size_t)(tile_begin + j0) * 16 + c16] : -1;
+    T1.cell = has1 ? a.cells[(size_t)(tile_begin + j0 + 1) * 16 + c16] : -1;
+    const int tgv = (tid < WIDE3_SLOTS && base + tid < ntiles) ? a.tile_grp[tile_begin + base + tid] : -1;
+    __builtin_amdgcn_sched_barrier(0);
+    const float* zr0 = a.Zcos + (size_t)(T0.cell >= 0 ? T0.cell : 0) * a.dp + 8 * q;
+    const float* zr1 = a.Zcos + (size_t)(T1.cell >= 0 ? T1.cell : 0) * a.dp + 8 * q;
     f32x4 z[4];                                                          // raw Z_cos values of the coming step (dead once the step has split them)
     auto load_z = [&](int s) {                                           // ordinary loads, pinned where they are written; PCs past the row are zeros
         __builtin_amdgcn_sched_barrier(0);
@@ -1318,68 +1365,71 @@ __global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_assign_wide3(AssignArgs
         z[3] = in_row ? ld4(zr1 + 32 * s + 4) : zero;
         __builtin_amdgcn_sched_barrier(0);
     };
-    request(0);
     load_z(0);
+    W3STAMP(12);
+    const float prv = (a.fuse_table && tgv >= 0) ? a.Pr_b[tgv] : 0.f;    // (one batch variable: group g is batch g)
+    const float thv = (a.fuse_table && tgv >= 0) ? a.theta[tgv] : 0.f;
 
     // ---- set-up: sigma, the groups of the workgroup's tiles, their table rows, zeroed sums ----
-    for (int i = tid; i < K16; i += 64 * WIDE3_WAVES) {
-        const float sgm = (i < a.K) ? a.sigma[i] : 0.f;
-        sig[i] = sgm;
-        nis[i] = (i < a.K) ? -(2.885390081777926814f / sgm) : -200.f;   // -c_k = -2 log2(e) / sigma_k; pads: Y row 0 -> 2^-200 == 0
+    if (tid < K16) {
+        sig[tid] = sgm;
+        nis[tid] = (tid < a.K) ? -(2.885390081777926814f / sgm) : -200.f;   // -c_k = -2 log2(e) / sigma_k; pads: Y row 0 -> 2^-200 == 0
     }
-    if (tid < WIDE3_SLOTS) tg[tid] = base + tid < ntiles ? a.tile_grp[tile_begin + base + tid] : -1;
+    if (tid < WIDE3_SLOTS) tg[tid] = tgv;
     for (int i = tid; i < WIDE3_SLOTS * K16; i += 64 * WIDE3_WAVES) Sd[i] = 0.0;
+    W3STAMP(13);
     __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0) only: the requests above stay in flight
     __builtin_amdgcn_s_barrier();
+    W3STAMP(14);
     if (tid < WIDE3_SLOTS) {
         int slot = 0;
         for (int u = 1; u <= tid; ++u) slot += (tg[u] != tg[u - 1] && tg[u] >= 0) ? 1 : 0;
         ts[tid] = slot;
-        if (tg[tid] >= 0 && (tid == 0 || tg[tid] != tg[tid - 1])) sg[slot] = tg[tid];
+        if (tg[tid] >= 0 && (tid == 0 || tg[tid] != tg[tid - 1])) { sg[slot] = tg[tid]; spr[slot] = prv; sth[slot] = thv; }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_s_barrier();
     const int nslots = ts[WIDE3_SLOTS - 1] + 1;
+    W3STAMP(1);
     if (a.fuse_table) {
         // The block's diversity table (k_block_table's arithmetic, harmony.py:491-499; one batch variable: group g is batch g) built
-        // HERE, under the first fragment requests, instead of by a launch of its own in front of every block (200 launches of
-        // ~9.5 us per Harmony iteration at configs[4]): O of every group without this block's old sums and with the previous
-        // block's new ones -- complete since the previous launch ended -- summed to the cluster masses by 2 x K16 threads, the
-        // rows of the workgroup's own groups turned into ratio ** theta and its log.  Workgroup 0 also writes the O chain.
-        if (tid < 2 * K16) {
-            const int h = tid / K16, k = tid - h * K16;
-            double t = 0.0;
-            for (int g0 = h; g0 < a.G; g0 += 16) {                       // eight groups per trip: 24 loads in flight
-                double op[8], sa[8], ss[8];
+        // HERE instead of by a launch of its own in front of every block (200 launches of ~9.5 us per Harmony iteration at
+        // configs[4]): O of every group without this block's old sums and with the previous block's new ones -- complete since
+        // the previous launch ended -- summed to the cluster masses by WIDE3_TSUB x K16 / 2 threads out of the registers filled at
+        // the top; the O values of the workgroup's own groups are parked in rpL and turned into ratio ** theta and its log below.
+        // Workgroup 0 also writes the O chain.
+        if (tsum) {
+            f64x2 t = {0.0, 0.0};
+            for (int g0 = th; g0 < a.G; g0 += 8 * WIDE3_TSUB) {
+                if (g0 != th) table_load(g0);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const size_t i = (size_t)min(g0 + 2 * j, a.G - 1) * K16 + k;
-                    op[j] = a.O_prev[i];
-                    sa[j] = a.S_add ? a.S_add[i] : 0.0;
-                    ss[j] = a.S_sub[i];
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (g0 + 2 * j < a.G) {
-                        const double o = op[j] + sa[j] - ss[j];
+                    const int g = g0 + WIDE3_TSUB * j;
+                    if (g < a.G) {
+                        const f64x2 o = op[j] + sa[j] - ss[j];
                         t += o;
-                        if (blockIdx.x == 0 && a.O_out) a.O_out[(size_t)(g0 + 2 * j) * K16 + k] = o;
+                        if (blockIdx.x == 0 && a.O_out) *reinterpret_cast<f64x2*>(a.O_out + (size_t)g * K16 + tk) = o;
+                        for (int sl = 0; sl < nslots; ++sl)
+                            if (sg[sl] == g) { rpL[sl * K16 + tk] = (float)o[0]; rpL[sl * K16 + tk + 1] = (float)o[1]; }
                     }
                 }
             }
-            Tp[tid] = t;
+            Tp[th * K16 + tk] = t[0];
+            Tp[th * K16 + tk + 1] = t[1];
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();
+        W3STAMP(2);
         for (int i = tid; i < nslots * K16; i += 64 * WIDE3_WAVES) {
-            const int sl = i / K16, k = i - sl * K16, g = sg[sl];
-            const size_t src = (size_t)g * K16 + k;
-            const double o = a.O_prev[src] + (a.S_add ? a.S_add[src] : 0.0) - a.S_sub[src];
-            const float O = (float)o;
-            const float E = (float)(Tp[k] + Tp[K16 + k]) * a.Pr_b[g];
+            const int sl = i / K16, k = i - sl * K16;
+            const float O = rpL[i];
+            double T = Tp[k];
+#pragma unroll
+            for (int u = 1; u < WIDE3_TSUB; ++u) T += Tp[u * K16 + k];   // (all WIDE3_TSUB partials exist: 4 x K16 / 2 <= 416 threads)
+            const float E = (float)T * spr[sl];
             const float oe = fmaxf(O + E, 1e-8f);                       // :495-496
             const float ratio = fminf(fmaxf(E / oe, 1e-8f), 1.0f);      // :497-498
-            const float rp = pow_unit(ratio, a.theta[g]);               // :499 (v_log_f32 / v_exp_f32 with split products, as k_round's table)
+            const float rp = pow_unit(ratio, sth[sl]);                  // :499 (v_log_f32 / v_exp_f32 with split products, as k_round's table)
             rpL[i] = rp;
             lrpL[i] = __builtin_amdgcn_logf(rp) * 0.693147182464599609375f;
         }
@@ -1397,6 +1447,7 @@ __global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_assign_wide3(AssignArgs
         T0.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         T1.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    W3STAMP(3);
 
     // ---- the k-steps ---------------------------------------------------------------------------------------------------
     auto split4 = [&](const f32x4& lo, const f32x4& hi, u32x4 (&pl)[3]) {   // 8 values -> three bf16 planes (k slot j <-> value j)
@@ -1409,8 +1460,17 @@ __global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_assign_wide3(AssignArgs
 #pragma unroll 1
     for (int s = 0; s < ns; ++s) {
         __builtin_amdgcn_sched_barrier(0);
+#ifdef HMX_WIDE3_PROF
+        const unsigned long long w3t0 = __builtin_amdgcn_s_memtime();
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's fragments and Z values of step s (requested a whole step ago)
+#ifdef HMX_WIDE3_PROF
+        const unsigned long long w3t1 = __builtin_amdgcn_s_memtime();
+#endif
         wg_barrier_lds();                                            // everybody's fragments of step s are in; nobody reads step s-1 any more
+#ifdef HMX_WIDE3_PROF
+        W3ACC(9, (__builtin_amdgcn_s_memtime() - w3t1) << 32 | (w3t1 - w3t0));
+#endif
         const unsigned* slot = ring + (size_t)(s & 1) * SLOT + 4 * lane;
         u32x4 zp0[3], zp1[3];                                        // the two tiles' B planes of this step
         split4(z[0], z[1], zp0);
@@ -1442,6 +1502,7 @@ __global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_assign_wide3(AssignArgs
     }
 
     // ---- finish: exp, penalty, renormalisation, R rows, block sums, objective terms (k_round's passes) ---------------
+    W3STAMP(4);
     double km_acc = 0.0, ent_acc = 0.0;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -1453,8 +1514,12 @@ __global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_assign_wide3(AssignArgs
         float scl0, scl1 = 0.f;
         round_post_pass1<MT, true, true, false, (HMX_ROUND_PK != 0 && MT <= 8)>(sig, rpL, lrpL, q, T0, scl0, km_acc, ent_acc);
         if (has1) round_post_pass1<MT, true, true, false, (HMX_ROUND_PK != 0 && MT <= 8)>(sig, rpL, lrpL, q, T1, scl1, km_acc, ent_acc);
+        W3STAMP(5);
         round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T0, scl0, has1, T1, scl1);
+    } else {
+        W3STAMP(5);
     }
+    W3STAMP(6);
     km_acc = wave_sum_all(km_acc);
     ent_acc = wave_sum_all(ent_acc);
     if (lane == 0) {
@@ -1472,7 +1537,67 @@ __global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_assign_wide3(AssignArgs
         const int sl = i / K16;
         if (v != 0.0) atomicAdd(&a.S_out[(size_t)sg[sl] * K16 + (i - sl * K16)], v);
     }
+    W3STAMP(7);
+#ifdef HMX_WIDE3_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (stamp 8: the wave's stores and atomics have been acknowledged)
+    W3STAMP(8);
+    if (lane == 0 && blockIdx.x < 512) g_w3prof[((size_t)blockIdx.x * WIDE3_WAVES + wv) * 32 + 17] = wall_clock64();
+#endif
 }
+
+#ifdef HMX_WIDE3_PROF
+#include <vector>
+static void wide3_prof_dump(int wgs, hipStream_t s) {
+    static int calls = 0;
+    ++calls;
+    if (calls != 450 && calls != 451 && calls != 1250) return;
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned long long> h((size_t)512 * WIDE3_WAVES * 32);
+    (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_w3prof), h.size() * 8);
+    const int n = std::min(wgs, 512);
+    // (the counters of the eight XCDs are not aligned with each other: spans and skews per XCD = workgroup index mod 8; workgroups
+    // past the block's tiles leave old stamps: a wave counts when its stamps lie within 1M ticks of its XCD's latest)
+    double seg[9] = {0}, segmax[9] = {0}, wv_ = 0, wb = 0, start = 0, startmax = 0, nw = 0, span = 0, fine[6] = {0};
+    for (int x = 0; x < 8; ++x) {
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int g = x; g < n; g += 8) for (int v = 0; v < WIDE3_WAVES; ++v) t1 = std::max(t1, h[((size_t)g * WIDE3_WAVES + v) * 32 + 8]);
+        auto live = [&](const unsigned long long* r) { return r[8] + 1000000ull > t1 && r[0] < r[8] && r[0] + 1000000ull > t1; };
+        for (int g = x; g < n; g += 8) for (int v = 0; v < WIDE3_WAVES; ++v) { const unsigned long long* r = &h[((size_t)g * WIDE3_WAVES + v) * 32]; if (live(r)) t0 = std::min(t0, r[0]); }
+        span += (double)(t1 - t0) / 8;
+        for (int g = x; g < n; g += 8) for (int v = 0; v < WIDE3_WAVES; ++v) {
+            const unsigned long long* r = &h[((size_t)g * WIDE3_WAVES + v) * 32];
+            if (!live(r)) continue;
+            nw += 1;
+            for (int k = 1; k <= 8; ++k) { const double d = (double)(r[k] - r[k - 1]); seg[k] += d; segmax[k] = std::max(segmax[k], d); }
+            wv_ += (double)(r[9] & 0xffffffffull); wb += (double)(r[9] >> 32);
+            fine[0] += (double)(r[10] - r[0]); fine[1] += (double)(r[11] - r[10]); fine[2] += (double)(r[12] - r[11]); fine[3] += (double)(r[13] - r[12]);
+            fine[4] += (double)(r[14] - r[13]); fine[5] += (double)(r[1] - r[14]);
+            start += (double)(r[0] - t0); startmax = std::max(startmax, (double)(r[0] - t0));
+        }
+    }
+    const unsigned long long t0 = 0, t1 = (unsigned long long)span;
+    {   // the constant-rate counter (100 MHz, one for the chip): the kernel's active span and the core clock it implies
+        unsigned long long w1 = 0, w0 = ~0ull; double life_c = 0, life_w = 0, cnt = 0;
+        for (int w = 0; w < n * WIDE3_WAVES; ++w) w1 = std::max(w1, h[(size_t)w * 32 + 17]);
+        for (int w = 0; w < n * WIDE3_WAVES; ++w) {
+            const unsigned long long* r = &h[(size_t)w * 32];
+            if (r[17] + 100000ull < w1 || r[16] > r[17]) continue;
+            w0 = std::min(w0, r[16]); life_c += (double)(r[8] - r[0]); life_w += (double)(r[17] - r[16]); cnt += 1;
+        }
+        fprintf(stderr, "[k_assign_wide3 prof]   constant-rate counter: first wave start to last wave end %.2f us; wave lifetime %.2f us mean = %.0f core ticks (%.0f ticks per us); %.0f waves\n",
+                (double)(w1 - w0) / 100.0, life_w / cnt / 100.0, life_c / cnt, life_c / life_w * 100.0, cnt);
+    }
+    fprintf(stderr, "[k_assign_wide3 prof] call %d, %d wgs, span %.0f ticks (%.1f us at 100 MHz); per wave mean (max): start after first %.0f (%.0f); "
+            "setup %.0f (%.0f), table sums %.0f (%.0f), table rows %.0f (%.0f), k-steps %.0f (%.0f) [vmcnt wait %.0f, barrier wait %.0f], pass1 %.0f (%.0f), "
+            "pass2 %.0f (%.0f), tail+atomics %.0f (%.0f), drain %.0f (%.0f); %.0f live waves\n", calls, wgs, (double)(t1 - t0), (double)(t1 - t0) / 100.0, start / nw, startmax,
+            seg[1] / nw, segmax[1], seg[2] / nw, segmax[2], seg[3] / nw, segmax[3], seg[4] / nw, segmax[4], wv_ / nw, wb / nw, seg[5] / nw, segmax[5],
+            seg[6] / nw, segmax[6], seg[7] / nw, segmax[7], seg[8] / nw, segmax[8], nw);
+    fprintf(stderr, "[k_assign_wide3 prof]   setup in detail: first requests issued %.0f, block bounds (scalar loads) %.0f, cells in + Z requested %.0f, "
+            "sigma/groups in + LDS filled %.0f, barrier %.0f, slots + barrier %.0f\n", fine[0] / nw, fine[1] / nw, fine[2] / nw, fine[3] / nw, fine[4] / nw, fine[5] / nw);
+}
+#else
+static inline void wide3_prof_dump(int, hipStream_t) {}
+#endif
 
 template <int MT, int KS, bool BF3T>
 __global__ __launch_bounds__(ROUND_THREADS) void k_round(RoundArgs a) {
@@ -4177,8 +4302,8 @@ static void launch_assign_lds(const AssignArgs& a, bool penalty, int wgs, size_t
 
 size_t assign_wide3_lds_bytes(int mt) {
     const size_t K16 = 16 * (size_t)mt;
-    return (size_t)2 * 3 * mt * 1024 + (2 * K16 + 2 * WIDE3_SLOTS * K16) * sizeof(float) + (WIDE3_SLOTS * K16 + 2 * WIDE3_WAVES + 2 * K16) * sizeof(double) +
-           3 * WIDE3_SLOTS * sizeof(int);
+    return (size_t)2 * 3 * mt * 1024 + (2 * K16 + 2 * WIDE3_SLOTS * K16) * sizeof(float) + (WIDE3_SLOTS * K16 + 2 * WIDE3_WAVES + WIDE3_TSUB * K16) * sizeof(double) +
+           5 * WIDE3_SLOTS * sizeof(int);
 }
 // the wide block assignment can build its own diversity table (one batch variable, the bf16-pipe instance)
 bool assign_wide3_fuses_table(int mt, int dp, int V) { return V == 1 && dp % 16 == 0 && mt >= 1 && mt <= 13 && (mt > 7 || dp > 64) && assign_wide3_lds_bytes(mt) <= 160 * 1024; }
@@ -4229,6 +4354,7 @@ int launch_assign(const AssignArgs& a_in, bool penalty, int max_wgs, hipStream_t
             attr_done = true;                                                                                         \
         }                                                                                                             \
         hipLaunchKernelGGL((k_assign_wide3<M>), dim3(wgs3), dim3(64 * WIDE3_WAVES), sm3, s, a);                        \
+        wide3_prof_dump(wgs3, s);                                                                                     \
     } break;
             if (sm3 <= 160 * 1024) {
                 switch (a.mt) {
