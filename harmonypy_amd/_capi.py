@@ -347,7 +347,8 @@ class Engine:
         return {"collectives": int(buf[0]), "sweep_fallbacks": int(buf[1]), "seeded_rounds": int(buf[2]), "sweeps_bf16_pipe": int(buf[3]),
                 "sweep_waits": int(buf[4]), "sweep_wait_polls": int(buf[5]), "sweep_wait_polls_max": int(buf[6]), "rtz_bf16_pipe": int(buf[7]),
                 "sweeps_group_affine": int(buf[8]), "sweep_group_affine_wgs": int(buf[9]),
-                "peer_box": {0: "none", 1: "coarse", 2: "fine"}[int(buf[10])], "rtz_presplit_z": int(buf[11])}
+                "peer_box": {0: "none", 1: "coarse", 2: "fine"}[int(buf[10])], "rtz_presplit_z": int(buf[11]),
+                "sweeps_wide_persistent": int(buf[12])}
 
     def kernel_times(self):
         """{family: (total_ms, launches)} since timing was enabled."""

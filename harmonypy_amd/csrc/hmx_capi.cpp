@@ -113,6 +113,9 @@ struct hmx_engine {
     int round_mode = 1;          // 1: persistent sweep kernel when the shape allows it, 0: one launch per block (HMX_ROUND_MODE=blocks)
     unsigned spin_limit = 1u << 24;  // polls a grid-wide wait may take (HMX_SPIN_LIMIT; tests shrink it to force the fall-back)
     long n_sweep_fallbacks = 0;  // rounds repeated through the per-block path after a wait timed out
+    bool wide_sweep = true;      // wide shapes on a single engine: the whole sweep in one persistent launch (k_sweep_wide3; HMX_WIDE_SWEEP=0: one launch per block)
+    bool wide_sweep_launched = false;   // ... by the last blocks_loop
+    long n_sweeps_wide = 0;
     long n_rtz_bf16 = 0;         // R^T.Z passes launched on the bf16-pipe instance k_rtz3c
     bool allow_round_bf16 = true;   // HMX_ROUND_F32=1 at hmx_create: the f32-input instances of k_round (A/B runs and tests)
     int rtz3_quad = 4;              // tiles a workgroup of the narrow streaming pass takes side by side (8: the tasks are cut for k_rtz3c)
@@ -171,6 +174,7 @@ struct hmx_engine {
     bool fuse_block_table = true;        // HMX_FUSE_TABLE=0 at hmx_create: a k_block_table launch in front of every wide block assignment (A/B runs and tests)
     bool allow_zcf = true;               // HMX_RTZW_ZF=0 at hmx_create: k_rtzw2b splits the fp32 rows of Z_cos in every pass (A/B runs and tests)
     long n_rtz_zf = 0;                   // streaming passes that read the pre-split planes
+    DevBuf<double> Opriv;                // k_sweep_wide3: every workgroup's own copy of O (grid x G x K16)
     DevBuf<double> Osave;                // O at the start of the round in flight (exact replay after a time-out)
 
     struct Span { hipEvent_t a, b; int fam; };
@@ -412,6 +416,7 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
     if (const char* ft = getenv("HMX_FUSE_TABLE")) e->fuse_block_table = atoi(ft) != 0;
     if (const char* rk = getenv("HMX_RTZ")) e->rtz_kernel = atoi(rk) == 2 ? 2 : 3;
     if (const char* fs = getenv("HMX_TEST_FAIL_SWEEP")) e->test_fail_sweep = atol(fs);
+    if (const char* ws = getenv("HMX_WIDE_SWEEP")) e->wide_sweep = atoi(ws) != 0;
     if (const char* sl = getenv("HMX_SPIN_LIMIT")) e->spin_limit = (unsigned)std::max(0L, atol(sl));   // 0: every wait of the persistent kernels gives up at once (tests)
     int rc = 0;
     do {
@@ -491,7 +496,7 @@ void hmx_destroy(hmx_engine* e) {
     if (e->pre_event) (void)hipEventDestroy(e->pre_event);
     e->task_t0.release(); e->task_t1.release();
     e->t3_t0.release(); e->t3_t1.release(); e->t3_stride.release(); e->t3_c0.release(); e->t3_cend.release(); e->t3_grp.release(); e->s_tile_start.release();
-    e->tile_blk[0].release(); e->tile_blk[1].release(); e->tile_blk_zero.release(); e->Osave.release(); e->Wf.release(); e->Yf.release(); e->Zcf.release();
+    e->tile_blk[0].release(); e->tile_blk[1].release(); e->tile_blk_zero.release(); e->Osave.release(); e->Opriv.release(); e->Wf.release(); e->Yf.release(); e->Zcf.release();
     e->task_grp.release(); e->gstart.release(); e->chunk_tab.release(); e->run_count.release(); e->run_start.release();
     e->Ogrp.release(); e->Tmass.release(); e->Ohist.release(); e->xch.release(); e->scratch.release();
     e->global_id.release(); e->wait_stats.release(); e->sync_words.p = nullptr; e->sync_words.n = 0; e->Sslots.release(); e->km_hn.release(); e->km_sums.release();
@@ -1052,9 +1057,10 @@ static void note_sweep_timeout(hmx_engine* e) {
 // update_R block by block (harmony.py:476-507): per block the diversity table (k_block_table), the assignment of the
 // block's tiles (bounded launch) and the block's new sums over all ranks; closes O, T and the cross-entropy term.
 // Needs Sold (removal sums) and Y of this round; Snew and objacc zeroed by the caller.
-static int blocks_loop(hmx_engine* e, int flags, const std::vector<int>& tiles_upper) {
+static int blocks_loop(hmx_engine* e, int flags, const std::vector<int>& tiles_upper, bool allow_sweep = true) {
     int rc;
     const size_t GK = (size_t)e->G * e->K16;
+    e->wide_sweep_launched = false;
     int bf16_blocks = 0;                                            // blocks assigned by the bf16-pipe instance of the wide kernel
     const bool y_frags = e->allow_round_bf16 && rtz_wide_ok(e->mt, e->dp);
     if (y_frags) {                                                  // Y of this round, split once into the fragments k_assign_wide3 multiplies with
@@ -1063,6 +1069,42 @@ static int blocks_loop(hmx_engine* e, int flags, const std::vector<int>& tiles_u
     }
     // the wide bf16-pipe assignment builds the block's table in its own prologue (one batch variable): 20 launches per sweep fewer
     const bool fuse = y_frags && e->fuse_block_table && assign_wide3_fuses_table(e->mt, e->dp, e->V);
+    // ... and on a single engine the whole sweep is ONE persistent launch (k_sweep_wide3): every block has tiles, the lists carry
+    // their (block, group) run offsets, a (block, group) pair is held by at most 511 chunks of sixteen tiles (the count field of the
+    // hand-off words).  A launch whose waits gave up is replayed block by block (round_body), the second one retires the path.
+    int min_upper = tiles_upper.empty() ? 0 : tiles_upper[0], max_upper = 0;
+    for (int b = 0; b < e->nblk; ++b) { min_upper = std::min(min_upper, tiles_upper[b]); max_upper = std::max(max_upper, tiles_upper[b]); }
+    if (allow_sweep && fuse && e->wide_sweep && !sharded(e) && e->lists[e->cur].runs_ok && min_upper > 0 && max_upper <= 511 * 16 &&
+        sweep_wide3_ok(e->mt, e->dp, e->V, e->G, e->nblk)) {
+        HIP_TRY(hipMemcpyAsync(e->Osave.p, e->Ogrp.p, GK * sizeof(double), hipMemcpyDeviceToDevice, e->stream));   // for an exact replay
+        {
+            Timed t(e, F_ASSIGN_BLOCK);
+            AssignArgs a = assign_args(e);
+            a.cells = e->lists[e->cur].cells.p; a.tile_grp = e->lists[e->cur].tile_grp.p; a.blk_start = e->lists[e->cur].blk_start.p;
+            a.run_tiles = e->lists[e->cur].run_tiles.p; a.nblk = e->nblk;
+            a.S_out = e->Snew; a.S_sub = e->Sold; a.O_prev = e->Ogrp.p; a.O_out = e->Ohist.p; a.Pr_b = e->Pr_b.p; a.theta = e->theta.p;
+            a.fuse_table = 1; a.Yf = e->Yf.p;
+            a.spin_limit = e->spin_limit;
+            a.fail = e->objacc + 2 * HMX_OBJ_SLOTS + 1;
+            if (e->n_sweep_launches++ == e->test_fail_sweep) a.spin_limit = 0;
+            int wgs = std::min(std::max(1, e->n_cus - 8), (max_upper + 15) / 16);   // (a few CUs stay free for the second stream's launches)
+            if (e->round_wgs_cap > 0) wgs = std::min(wgs, e->round_wgs_cap);
+            if ((rc = e->Opriv.reserve((size_t)wgs * GK))) return rc;
+            a.O_priv = e->Opriv.p;
+            if (launch_sweep_wide3(a, wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported shape for k_sweep_wide3");
+            e->wide_sweep_launched = true;
+            e->n_sweeps_wide++;
+        }
+        e->n_sweeps_bf16++;
+        Timed t(e, F_BLOCK_TABLE);
+        TableArgs ta = table_args(e);  // close the round: O, T state and the cross-entropy term
+        ta.O_prev = e->Ohist.p + GK * (e->nblk - 1);
+        ta.S_add = e->Snew + GK * (e->nblk - 1);
+        ta.O_out = e->Ogrp.p; ta.T_out = e->Tmass.p;
+        if (flags & HMX_ROUND_OBJECTIVE) ta.obj_cross = e->objacc + 2 * HMX_OBJ_SLOTS;
+        launch_block_table(ta, e->K16, e->stream);
+        return 0;
+    }
     for (int b = 0; b < e->nblk; ++b) {
         const double* O_prev = (b == 0) ? e->Ogrp.p : e->Ohist.p + GK * (b - 1);
         const double* S_add = (b == 0) ? nullptr : e->Snew + GK * (b - 1);
@@ -1123,7 +1165,7 @@ static int replay_round(hmx_engine* e, int flags, const std::vector<int>& tiles_
     HIP_TRY(hipMemsetAsync(e->frozen(), 0, sizeof(unsigned long long), e->stream));
     HIP_TRY(hipMemcpyAsync(e->Ogrp.p, e->Osave.p, GK * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
     HIP_TRY(hipMemsetAsync(e->Snew, 0, (size_t)((e->objacc + 2 * HMX_OBJ_SLOTS + 2) - e->Snew) * sizeof(double), e->stream));
-    if ((rc = blocks_loop(e, flags, tiles_upper))) return rc;
+    if ((rc = blocks_loop(e, flags, tiles_upper, false))) return rc;
     return read_objective(e, obj_out);
 }
 
@@ -1369,6 +1411,14 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
     }
     if (flags & HMX_ROUND_UPDATE_R) {
         if ((rc = blocks_loop(e, flags, tiles_upper))) return rc;
+        if (e->wide_sweep_launched) {                                // the persistent wide sweep: a wait that gave up shows in the objective block
+            if ((rc = read_objective(e, obj_out))) return rc;
+            if (e->obj_host[2 * HMX_OBJ_SLOTS + 1] != 0.0) {
+                if (e->n_sweep_fallbacks >= 1) e->wide_sweep = false;   // (the second time-out: this engine stays on the per-block path)
+                return replay_round(e, flags, tiles_upper, obj_out);
+            }
+            return 0;
+        }
     }
     return read_objective(e, obj_out);
 }
@@ -1972,7 +2022,8 @@ int hmx_counters(hmx_engine* e, int64_t out[HMX_N_COUNTERS]) {
     out[9] = e->n_sweeps_ga > 0 ? e->ga_nwg : 0;
     out[10] = e->box ? (e->box_fine ? 2 : 1) : 0;
     out[11] = e->n_rtz_zf;
-    for (int i = 12; i < HMX_N_COUNTERS; ++i) out[i] = 0;
+    out[12] = e->n_sweeps_wide;
+    for (int i = 13; i < HMX_N_COUNTERS; ++i) out[i] = 0;
     return HMX_OK;
 }
 

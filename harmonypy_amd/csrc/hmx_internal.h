@@ -35,6 +35,13 @@ struct AssignArgs {
     double* O_out;         // G x K16: O without this block (written by workgroup 0: the chain's next O_prev)
     const float* Pr_b;
     const float* theta;
+    // k_sweep_wide3 (all blocks in one persistent launch): S_out / S_sub / O_out are the bases of the per-block tables, O_prev is O at the
+    // start of the round; S_out of every block but the last is read as 64-bit fixed-point words (zeroed by the caller)
+    int nblk;
+    const int* run_tiles;  // nblk*G + 1: first tile of every (block, group) run
+    unsigned spin_limit;   // polls a wait for a block's sums may take
+    double* O_priv;        // grid x G x K16: every workgroup's own copy of O (each entry read and written by one thread only)
+    double* fail;          // += 1 per workgroup whose wait gave up (the launch ends, the host replays the round block by block)
     const float* hn;       // k_assign_wide without penalty only: half squared norms of the centres in Y (+inf for pads) -> HARD
                            // assignment of the device k-means (a one-hot row of R per cell) instead of the softmax; null otherwise
 };
@@ -298,6 +305,8 @@ size_t w_planes_dwords(int G, int K16, int dp);
 void launch_w_planes(const float* W, int G, int K16, int ldw, int dp, unsigned* Wf, hipStream_t s);
 size_t assign_wide3_lds_bytes(int mt);
 bool assign_wide3_fuses_table(int mt, int dp, int V);
+bool sweep_wide3_ok(int mt, int dp, int V, int G, int nblk);
+int launch_sweep_wide3(const AssignArgs& a, int wgs, hipStream_t s);   // k_sweep_wide3: all blocks of a wide sweep in one persistent launch
 int launch_assign(const AssignArgs& a, bool penalty, int max_wgs, hipStream_t s);   // 1: the bf16-pipe wide instance ran, 0: another kernel, -1 unsupported
 void rtz_geometry(int mt, int ntd, int* nsub, int* slab_per_wave);
 bool rtz2_ok(int mt, int dp);

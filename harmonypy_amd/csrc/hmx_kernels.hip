@@ -1545,8 +1545,424 @@ __global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_assign_wide3(AssignArgs
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// k_sweep_wide3: ALL blocks of a wide update_R sweep (harmony.py:476-507) in ONE persistent launch -- k_assign_wide3's chunk
+// of sixteen tiles as the unit of work, chunk c of every block on workgroup c mod grid, one workgroup per CU, all resident.
+// What a launch per block pays twenty times per round -- 9 us between the last wave of a launch and the first of the next,
+// the chain of cold round trips kernel arguments -> block bounds -> cells -> Z rows, the O / S tables read by every
+// workgroup (profiles/r06_ab_wide3_prologue.txt) -- is paid once or hidden behind the block before:
+//   * O of all groups lives in REGISTERS of the workgroup (thread (th, pair of clusters): groups th, th + 4, ...; G <= 32),
+//     updated per block with the block's removal sums (plain loads, requested early) and the previous block's new sums;
+//   * the new sums travel as k_round's SELF-VALIDATING fixed-point words (group-affine map): a chunk adds
+//     (1 << 55) + sum * 2^32  to the word of every (group it holds, cluster) of the block's table with one non-returning 64-bit
+//     add; a reader that finds the count field equal to the number of chunks holding the group (from the (block, group) run
+//     offsets of the lists) holds the complete sum.  No counter, no flag, no returning atomic; the successful poll IS the data;
+//   * cells, groups, first centroid fragments and first Z rows of a workgroup's next chunk are requested behind the
+//     finishing pass of the current one.
+// The last block's sums go out as fp64 adds (the closing table launch reads them), workgroup 0 writes the O chain as before.
+// A wait that exceeds the spin limit counts the workgroup in *fail and ends the launch; the host replays the round with one
+// launch per block.  Table and sums per (block, group, cluster): ONE word -- at most 511 chunks per block and group, sums
+// below 2^23 (the host checks the block size).
+// ------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_sweep_wide3(AssignArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int K16 = 16 * MT;
+    constexpr int SLOT = 3 * MT * 256;                                   // dwords of a ring slot (one step, three planes)
+    constexpr int KP = K16 / 2;
+    constexpr unsigned long long FXM = (1ull << 55) - 1;
+    unsigned* ring = reinterpret_cast<unsigned*>(smem);                  // 2 x SLOT
+    float* sig = reinterpret_cast<float*>(ring + 2 * SLOT);              // K16
+    float* nis = sig + K16;                                              // K16: -2 log2(e) / sigma (-200 for pads)
+    float* rpL = nis + K16;                                              // slots x K16
+    float* lrpL = rpL + WIDE3_SLOTS * K16;
+    double* Sd = reinterpret_cast<double*>(lrpL + WIDE3_SLOTS * K16);    // slots x K16 block sums
+    double* objw = Sd + WIDE3_SLOTS * K16;                               // waves x 2
+    int* tsA = reinterpret_cast<int*>(objw + 2 * WIDE3_WAVES);           // 2 x slots: slot of the chunk's tile j (tiles of one group share table rows and sums)
+    int* sgA = tsA + 2 * WIDE3_SLOTS;                                    // 2 x slots: group of a slot (both by chunk parity: the sums of a chunk go out
+                                                                         //            while the first wave already deals with the next chunk)
+    double* Tp = reinterpret_cast<double*>(sgA + 2 * WIDE3_SLOTS);       // WIDE3_TSUB x K16 partial cluster masses
+    float* prG = reinterpret_cast<float*>(Tp + WIDE3_TSUB * K16);        // 32: Pr_b of a group (one batch variable: group g is batch g)
+    float* thG = prG + 32;                                               // 32: theta of a group
+    int* bst = reinterpret_cast<int*>(thG + 32);                         // nblk + 1 block starts (tiles)
+    int* wfail = bst + a.nblk + 1;                                       // a wave's wait gave up
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, c16 = lane & 15, q = lane >> 4;
+    const int ns = (a.dp + 31) >> 5;                                     // k-steps of 32 PCs
+    const int nwg = gridDim.x, wg = blockIdx.x;
+#ifdef HMX_WIDE3_PROF
+    for (int i_ = 0; i_ < 16; ++i_) W3ZERO(i_);
+    unsigned long long pt_ = __builtin_amdgcn_s_memtime();
+#define SWSEG(k_) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); W3ACC(k_, n_ - pt_); pt_ = n_; } while (0)
+#else
+#define SWSEG(k_) do { } while (0)
+#endif
+    const size_t GK = (size_t)a.G * K16;
+    auto u64 = [](unsigned long long v) {
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
+               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v);
+    };
+    const unsigned long long ysrc = u64((unsigned long long)a.Yf);
+    const unsigned ring0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)ring);
+    const unsigned voff = 16u * (unsigned)lane;
+    auto request = [&](int s) {                                          // this wave's fragments of step s: pieces wv, wv + 8, ... of 3 MT
+        const unsigned long long src0 = ysrc + (unsigned long long)s * (SLOT * 4);
+        const unsigned zone0 = ring0 + (unsigned)(s & 1) * (SLOT * 4);
+#pragma unroll
+        for (int j = 0; j < (3 * MT + WIDE3_WAVES - 1) / WIDE3_WAVES; ++j) {
+            const int p = wv + WIDE3_WAVES * j;                          // wave-uniform
+            if (p < 3 * MT) {
+                const unsigned long long src = src0 + 1024ull * p;
+                const unsigned zone = zone0 + 1024u * p;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(zone) : "memory", "m0");
+            }
+        }
+    };
+    request(0);                                                          // (every chunk starts with the same fragments)
+    // O of all groups is kept per workgroup in a private global table (a.O_priv: grid x G x K16 doubles, touched only by the
+    // threads that own its entries): thread (th, clusters tk, tk + 1) owns groups th, th + 4, ..., th + 28
+    const bool tsum = tid < WIDE3_TSUB * KP;
+    const int th = tid / KP, tk = 2 * (tid - th * KP);
+    double* Opriv = a.O_priv + (size_t)wg * GK;
+    const int goff = th * K16 + tk;                                      // (group th, cluster tk) in a G x K16 table
+    if (tid < K16) {
+        const float sgm = (tid < a.K) ? a.sigma[tid] : 0.f;
+        sig[tid] = sgm;
+        nis[tid] = (tid < a.K) ? -(2.885390081777926814f / sgm) : -200.f;   // -c_k = -2 log2(e) / sigma_k; pads: Y row 0 -> 2^-200 == 0
+    }
+    for (int i = tid; i <= a.nblk; i += 64 * WIDE3_WAVES) bst[i] = a.blk_start[i];
+    for (int i = tid; i < WIDE3_SLOTS * K16; i += 64 * WIDE3_WAVES) Sd[i] = 0.0;
+    if (tid == 0) *wfail = 0;
+    if (tid < 32) { prG[tid] = tid < a.G ? a.Pr_b[tid] : 0.f; thG[tid] = tid < a.G ? a.theta[tid] : 0.f; }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+
+    // what is requested ahead for a chunk: its cells and (in every wave's lanes 0 .. 15) the groups of its sixteen tiles
+    int pf_b = -1, pf_c = -1, pf_cell0 = -1, pf_cell1 = -1, pf_tg = -1;
+    auto prefetch = [&](int b, int c) {
+        const int t0 = bst[b], nt = bst[b + 1] - t0, j0 = 16 * c + 2 * wv;
+        pf_cell0 = j0 < nt ? a.cells[(size_t)(t0 + j0) * 16 + c16] : -1;
+        pf_cell1 = j0 + 1 < nt ? a.cells[(size_t)(t0 + j0 + 1) * 16 + c16] : -1;
+        pf_tg = (lane < WIDE3_SLOTS && 16 * c + lane < nt) ? a.tile_grp[t0 + 16 * c + lane] : -1;
+        pf_b = b; pf_c = c;
+    };
+    {
+        const int nt0 = bst[1] - bst[0];
+        if (16 * wg < nt0) prefetch(0, wg);
+    }
+    double km_acc = 0.0, ent_acc = 0.0;
+    bool ring_requested = true;                                          // request(0) of the coming chunk is out
+    int parity = 0;
+
+#pragma unroll 1
+    for (int b = 0; b < a.nblk; ++b) {
+        const int tile_begin = bst[b], ntiles = bst[b + 1] - tile_begin;
+        const int nch = (ntiles + WIDE3_SLOTS - 1) / WIDE3_SLOTS;
+        bool first_chunk = true;
+        int c = wg;
+#pragma unroll 1
+        do {                                                             // (at least once per block: the table is kept by every workgroup)
+            const bool work = c < nch;
+            SWSEG(0);                                                    // 0: between chunks (the sums' adds, loop overhead)
+            // ---- slots of the chunk's groups: every wave works them out for itself (no barrier; sg goes to LDS for indexed reads) ----
+            int* sg = sgA + parity * WIDE3_SLOTS;
+            parity ^= 1;
+            int myslot = 0, nslots = 0;
+            if (work) {
+                if (!(pf_b == b && pf_c == c)) prefetch(b, c);           // (cold: the first chunk of a workgroup that sat out a block)
+                if (!ring_requested) request(0);
+                const int tgv = pf_tg;
+                const int prev = __shfl_up(tgv, 1);
+                const bool first = lane < WIDE3_SLOTS && tgv >= 0 && (lane == 0 || tgv != prev);
+                const bool later = lane < WIDE3_SLOTS && lane > 0 && tgv >= 0 && tgv != prev;   // (the serial count of k_assign_wide3: changes of group behind tile 0)
+                const unsigned long long changes = __ballot(later);
+                myslot = __popcll(changes & ((2ull << lane) - 1ull));
+                nslots = __shfl(myslot, WIDE3_SLOTS - 1) + 1;
+                if (first) sg[myslot] = tgv;                             // (every wave writes the same values)
+            }
+            SWSEG(1);                                                    // 1: the chunk's groups in
+            const int base = c * WIDE3_SLOTS;
+            RoundTile<MT> T0, T1;
+            const int j0 = base + 2 * wv;
+            const bool has0 = j0 < ntiles, has1 = j0 + 1 < ntiles;      // wave-uniform
+            T0.cell = pf_cell0; T1.cell = pf_cell1;
+            const float* zr0 = a.Zcos + (size_t)(T0.cell >= 0 ? T0.cell : 0) * a.dp + 8 * q;
+            const float* zr1 = a.Zcos + (size_t)(T1.cell >= 0 ? T1.cell : 0) * a.dp + 8 * q;
+            f32x4 z[4];
+            auto load_z = [&](int s) {                                   // ordinary loads, pinned where they are written; PCs past the row are zeros
+                __builtin_amdgcn_sched_barrier(0);
+                const bool in_row = 32 * s + 8 * q < a.dp;
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                z[0] = in_row ? ld4(zr0 + 32 * s) : zero;
+                z[1] = in_row ? ld4(zr0 + 32 * s + 4) : zero;
+                z[2] = in_row ? ld4(zr1 + 32 * s) : zero;
+                z[3] = in_row ? ld4(zr1 + 32 * s + 4) : zero;
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if (work) {
+                // the distance GEMM needs nothing of the previous block: it runs AHEAD of the hand-off, whose wait then finds the sums in
+                load_z(0);
+                T0.grp = __shfl(myslot, 2 * wv);
+                T1.grp = has1 ? __shfl(myslot, 2 * wv + 1) : T0.grp;
+    #pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    T0.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    T1.arg[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+
+                // ---- the k-steps (k_assign_wide3's) ----------------------------------------------------------------------------
+                auto split4 = [&](const f32x4& lo, const f32x4& hi, u32x4 (&pl)[3]) {
+                    unsigned h, m, l;
+                    bf16_split3((f32x2){lo[0], lo[1]}, h, m, l); pl[0][0] = h; pl[1][0] = m; pl[2][0] = l;
+                    bf16_split3((f32x2){lo[2], lo[3]}, h, m, l); pl[0][1] = h; pl[1][1] = m; pl[2][1] = l;
+                    bf16_split3((f32x2){hi[0], hi[1]}, h, m, l); pl[0][2] = h; pl[1][2] = m; pl[2][2] = l;
+                    bf16_split3((f32x2){hi[2], hi[3]}, h, m, l); pl[0][3] = h; pl[1][3] = m; pl[2][3] = l;
+                };
+    #pragma unroll 1
+                for (int s = 0; s < ns; ++s) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    wg_barrier_lds();
+                    const unsigned* slot = ring + (size_t)(s & 1) * SLOT + 4 * lane;
+                    u32x4 zp0[3], zp1[3];
+                    split4(z[0], z[1], zp0);
+                    split4(z[2], z[3], zp1);
+                    u32x4 yp[2][3];
+                    auto fetch = [&](int mt, u32x4 (&pl)[3]) {
+    #pragma unroll
+                        for (int pn = 0; pn < 3; ++pn) pl[pn] = ld4u(slot + (pn * MT + mt) * 256);
+                    };
+                    auto products = [&](int mt, const u32x4 (&pl)[3]) {
+                        T0.arg[mt] = MFMA_BF16(pl[2], zp0[0], T0.arg[mt]);  T1.arg[mt] = MFMA_BF16(pl[2], zp1[0], T1.arg[mt]);
+                        T0.arg[mt] = MFMA_BF16(pl[0], zp0[2], T0.arg[mt]);  T1.arg[mt] = MFMA_BF16(pl[0], zp1[2], T1.arg[mt]);
+                        T0.arg[mt] = MFMA_BF16(pl[1], zp0[1], T0.arg[mt]);  T1.arg[mt] = MFMA_BF16(pl[1], zp1[1], T1.arg[mt]);
+                        T0.arg[mt] = MFMA_BF16(pl[1], zp0[0], T0.arg[mt]);  T1.arg[mt] = MFMA_BF16(pl[1], zp1[0], T1.arg[mt]);
+                        T0.arg[mt] = MFMA_BF16(pl[0], zp0[1], T0.arg[mt]);  T1.arg[mt] = MFMA_BF16(pl[0], zp1[1], T1.arg[mt]);
+                        T0.arg[mt] = MFMA_BF16(pl[0], zp0[0], T0.arg[mt]);  T1.arg[mt] = MFMA_BF16(pl[0], zp1[0], T1.arg[mt]);
+                    };
+                    fetch(0, yp[0]);
+    #pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        if (mt + 1 < MT) fetch(mt + 1, yp[(mt + 1) & 1]);
+                        products(mt, yp[mt & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (mt == 0 && s + 1 < ns) {
+                            request(s + 1);
+                            load_z(s + 1);
+                        }
+                    }
+                }
+
+            }
+            SWSEG(7);                                                    // 7: the k-steps (first wait behind the R rows' stores)
+            // ---- the block's O: without its old sums, with the previous block's new ones (:491-492, :506-507); the chunk's rows parked
+            bool failed = false;
+            if (tsum) {
+                // (addresses: a wave-uniform base per group trip + ONE per-thread offset; groups past G are predicated off, not clamped.
+                //  Two passes of four groups each: the whole table at once does not fit the registers beside the loop's state.)
+                f64x2 t = {0.0, 0.0};
+#pragma unroll 1
+                for (int half = 0; half < 2; ++half) {
+                    const size_t hoff = (size_t)(4 * half) * (WIDE3_TSUB * K16) + goff;
+                    const int g0 = th + WIDE3_TSUB * 4 * half;           // groups g0, g0 + 4, g0 + 8, g0 + 12
+                    f64x2 o[4];
+                    const double* osrc = ((first_chunk && b == 0) ? a.O_prev : Opriv) + hoff;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        o[j] = (g0 + WIDE3_TSUB * j < a.G) ? *reinterpret_cast<const f64x2*>(osrc + (size_t)j * (WIDE3_TSUB * K16)) : (f64x2){0.0, 0.0};
+                    if (first_chunk) {
+                        {
+                            const double* ssub = a.S_sub + (size_t)b * GK + hoff;
+                            f64x2 ss[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                ss[j] = (g0 + WIDE3_TSUB * j < a.G) ? *reinterpret_cast<const f64x2*>(ssub + (size_t)j * (WIDE3_TSUB * K16)) : (f64x2){0.0, 0.0};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[j] -= ss[j];  // without the block's old sums (:491-492)
+                        }
+                        if (b > 0) {
+                            int need[4];
+                            const int t0 = bst[b - 1];
+                            const int* runs = a.run_tiles + (size_t)(b - 1) * a.G + g0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {                // chunks of block b-1 holding tiles of group g
+                                need[j] = 0;
+                                if (g0 + WIDE3_TSUB * j < a.G) {
+                                    const int rs = runs[WIDE3_TSUB * j] - t0, re = runs[WIDE3_TSUB * j + 1] - t0;
+                                    need[j] = re > rs ? (re - 1) / WIDE3_SLOTS - rs / WIDE3_SLOTS + 1 : 0;
+                                }
+                            }
+                            const unsigned long long* W = reinterpret_cast<const unsigned long long*>(a.S_out + (size_t)(b - 1) * GK) + hoff;
+                            unsigned long long w[4][2];
+                            unsigned spins = 0;
+                            if (a.spin_limit == 0) failed = true;        // test knob: give up without looking
+                            while (true) {
+                                bool ok = true;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {            // eight independent loads in flight
+                                    w[j][0] = w[j][1] = 0ull;
+                                    if (g0 + WIDE3_TSUB * j < a.G) {
+                                        const unsigned long long* wp = W + (size_t)j * (WIDE3_TSUB * K16);
+                                        w[j][0] = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        w[j][1] = __hip_atomic_load(wp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    }
+                                }
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) ok = ok && (int)(w[j][0] >> 55) == need[j] && (int)(w[j][1] >> 55) == need[j];
+                                if (__all(ok) || failed) break;
+                                __builtin_amdgcn_s_sleep(2);
+                                if (++spins > a.spin_limit || (spins % 64 == 0 && __hip_atomic_load(reinterpret_cast<const unsigned long long*>(a.fail), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) { failed = true; break; }
+                            }
+                            W3ACC(10, spins);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)                  // with the previous block's new sums (:506-507)
+                                o[j] += (f64x2){(double)(long long)(w[j][0] & FXM) * 0x1p-32, (double)(long long)(w[j][1] & FXM) * 0x1p-32};
+                        }
+                        double* odst = Opriv + hoff;
+                        double* hdst = a.O_out + (size_t)b * GK + hoff;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (g0 + WIDE3_TSUB * j < a.G) {
+                                t += o[j];
+                                *reinterpret_cast<f64x2*>(odst + (size_t)j * (WIDE3_TSUB * K16)) = o[j];
+                                if (wg == 0) *reinterpret_cast<f64x2*>(hdst + (size_t)j * (WIDE3_TSUB * K16)) = o[j];
+                            }
+                        }
+                    }
+                    if (work) {                                          // O of the chunk's groups, parked where its table rows go
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int g = g0 + WIDE3_TSUB * j;
+                            if (g < a.G)
+                                for (int sl = 0; sl < nslots; ++sl)
+                                    if (sg[sl] == g) { rpL[sl * K16 + tk] = (float)o[j][0]; rpL[sl * K16 + tk + 1] = (float)o[j][1]; }
+                        }
+                    }
+                }
+                SWSEG(2);                                                // 2: loads, polls, O update, parked rows
+                if (first_chunk) {
+                    Tp[th * K16 + tk] = t[0];
+                    Tp[th * K16 + tk + 1] = t[1];
+                    if (failed && lane == 0) *wfail = 1;
+                }
+            }
+            SWSEG(3);                                                    // 3: O update, partial masses, parked rows
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();                                // Tp, parked rows, wfail
+            SWSEG(4);                                                    // 4: barrier behind the table (waves without table duty wait here for the poll)
+            if (*wfail) {
+                if (tid == 0) atomicAdd(a.fail, 1.0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (fragment requests write LDS: not past the end of the workgroup)
+                return;
+            }
+            first_chunk = false;
+            if (!work) break;
+            for (int i = tid; i < nslots * K16; i += 64 * WIDE3_WAVES) {
+                const int sl = i / K16, k = i - sl * K16;
+                const float O = rpL[i];
+                double T = Tp[k];
+#pragma unroll
+                for (int u = 1; u < WIDE3_TSUB; ++u) T += Tp[u * K16 + k];
+                const float E = (float)T * prG[sg[sl]];
+                const float oe = fmaxf(O + E, 1e-8f);                   // :495-496
+                const float ratio = fminf(fmaxf(E / oe, 1e-8f), 1.0f);  // :497-498
+                const float rp = pow_unit(ratio, thG[sg[sl]]);          // :499
+                rpL[i] = rp;
+                lrpL[i] = __builtin_amdgcn_logf(rp) * 0.693147182464599609375f;
+            }
+            SWSEG(6);                                                    // 6: table rows
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();                                // the chunk's table rows
+            SWSEG(5);                                                    // 5: barrier behind them
+            // ---- finish: exp, penalty, renormalisation, R rows, block sums, objective terms ----------------------------------
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f32x4 ni = ld4(nis + 16 * mt + 4 * q);
+                T0.arg[mt] = __builtin_elementwise_fma(T0.arg[mt], -ni, ni);
+                T1.arg[mt] = __builtin_elementwise_fma(T1.arg[mt], -ni, ni);
+            }
+            if (has0) {
+                float scl0, scl1 = 0.f;
+                round_post_pass1<MT, true, true, false, (HMX_ROUND_PK != 0 && MT <= 8)>(sig, rpL, lrpL, q, T0, scl0, km_acc, ent_acc);
+                if (has1) round_post_pass1<MT, true, true, false, (HMX_ROUND_PK != 0 && MT <= 8)>(sig, rpL, lrpL, q, T1, scl1, km_acc, ent_acc);
+                round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T0, scl0, has1, T1, scl1);
+            }
+            SWSEG(8);                                                    // 8: finishing passes
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();                                // Sd complete; the ring is free
+            SWSEG(9);                                                    // 9: barrier behind them
+            // the workgroup's next chunk: its fragments, cells and groups are requested before the sums go out
+            {
+                int nb = b, nc = c + nwg;
+                if (nc >= nch) { nb = b + 1; nc = wg; }
+                ring_requested = false;
+                if (nb < a.nblk && 16 * nc < bst[nb + 1] - bst[nb]) {
+                    request(0);
+                    ring_requested = true;
+                    prefetch(nb, nc);
+                }
+            }
+            if (b + 1 < a.nblk) {
+                unsigned long long* W = reinterpret_cast<unsigned long long*>(a.S_out + (size_t)b * GK);
+                for (int i = tid; i < nslots * K16; i += 64 * WIDE3_WAVES) {
+                    const double v = Sd[i];
+                    Sd[i] = 0.0;
+                    const int sl = i / K16;
+                    const unsigned long long word = (1ull << 55) + (unsigned long long)__double2ll_rn(v * 0x1p32);
+                    __hip_atomic_fetch_add(W + (size_t)sg[sl] * K16 + (i - sl * K16), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                double* So = a.S_out + (size_t)b * GK;
+                for (int i = tid; i < nslots * K16; i += 64 * WIDE3_WAVES) {
+                    const double v = Sd[i];
+                    Sd[i] = 0.0;
+                    const int sl = i / K16;
+                    if (v != 0.0) atomicAdd(&So[(size_t)sg[sl] * K16 + (i - sl * K16)], v);
+                }
+            }
+            SWSEG(11);                                                   // 11: next chunk's requests + the sums' adds issued
+            // (sg of this chunk is read here while a faster wave may fill the other parity's; Sd entries are zeroed by their reader)
+            c += nwg;
+        } while (c < nch);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    km_acc = wave_sum_all(km_acc);
+    ent_acc = wave_sum_all(ent_acc);
+    if (lane == 0) {
+        objw[2 * wv] = km_acc;
+        objw[2 * wv + 1] = ent_acc;
+    }
+    __syncthreads();
+    if (tid < 2) {
+        double v = 0.0;
+        for (int w = 0; w < WIDE3_WAVES; ++w) v += objw[2 * w + tid];
+        if (v != 0.0) atomicAdd(&a.obj[2 * (blockIdx.x & (HMX_OBJ_SLOTS - 1)) + tid], v);
+    }
+}
+
 #ifdef HMX_WIDE3_PROF
 #include <vector>
+static void sweep3_prof_dump(int wgs, int nblk, hipStream_t s) {
+    static int calls = 0;
+    ++calls;
+    if (calls != 25 && calls != 26) return;
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned long long> h((size_t)512 * WIDE3_WAVES * 32);
+    (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_w3prof), h.size() * 8);
+    const char* names[12] = {"between chunks", "groups in (store drain)", "loads + poll + O + park", "Tp", "barrier behind table", "barrier behind rows", "table rows", "k-steps",
+                             "finishing passes", "barrier behind passes", "(polls)", "requests+adds"};
+    const int n = std::min(wgs, 512);
+    fprintf(stderr, "[k_sweep_wide3 prof] call %d, %d wgs, %d blocks: per wave and block, mean over waves (max over waves):\n", calls, wgs, nblk);
+    double tot = 0;
+    for (int k = 0; k < 12; ++k) {
+        double sum = 0, mx = 0;
+        for (int w = 0; w < n * WIDE3_WAVES; ++w) { const double v = (double)h[(size_t)w * 32 + k] / nblk; sum += v; mx = std::max(mx, v); }
+        fprintf(stderr, "[k_sweep_wide3 prof]   %-24s %9.0f (%9.0f)\n", names[k], sum / (n * WIDE3_WAVES), mx);
+        if (k != 10) tot += sum / (n * WIDE3_WAVES);
+    }
+    fprintf(stderr, "[k_sweep_wide3 prof]   %-24s %9.0f\n", "sum", tot);
+}
 static void wide3_prof_dump(int wgs, hipStream_t s) {
     static int calls = 0;
     ++calls;
@@ -1597,6 +2013,7 @@ static void wide3_prof_dump(int wgs, hipStream_t s) {
 }
 #else
 static inline void wide3_prof_dump(int, hipStream_t) {}
+static inline void sweep3_prof_dump(int, int, hipStream_t) {}
 #endif
 
 template <int MT, int KS, bool BF3T>
@@ -4304,6 +4721,36 @@ size_t assign_wide3_lds_bytes(int mt) {
     const size_t K16 = 16 * (size_t)mt;
     return (size_t)2 * 3 * mt * 1024 + (2 * K16 + 2 * WIDE3_SLOTS * K16) * sizeof(float) + (WIDE3_SLOTS * K16 + 2 * WIDE3_WAVES + WIDE3_TSUB * K16) * sizeof(double) +
            5 * WIDE3_SLOTS * sizeof(int);
+}
+// the whole wide sweep in one persistent launch (k_sweep_wide3): one batch variable, at most 32 groups, lists with run offsets
+size_t sweep_wide3_lds_bytes(int mt, int nblk) {
+    const size_t K16 = 16 * (size_t)mt;
+    return (size_t)2 * 3 * mt * 1024 + (2 * K16 + 2 * WIDE3_SLOTS * K16) * sizeof(float) + (WIDE3_SLOTS * K16 + 2 * WIDE3_WAVES + WIDE3_TSUB * K16) * sizeof(double) +
+           (4 * WIDE3_SLOTS + 64 + nblk + 2) * sizeof(int);
+}
+bool sweep_wide3_ok(int mt, int dp, int V, int G, int nblk) {
+    return V == 1 && G <= 32 && dp % 16 == 0 && mt >= 1 && mt <= 13 && (mt > 7 || dp > 64) && sweep_wide3_lds_bytes(mt, nblk) <= 160 * 1024;
+}
+int launch_sweep_wide3(const AssignArgs& a, int wgs, hipStream_t s) {
+    if (!sweep_wide3_ok(a.mt, a.dp, 1, a.G, a.nblk) || !a.Yf || !a.run_tiles || !a.fail || !a.O_priv || !a.O_out || wgs < 1) return -1;
+    const size_t sm = sweep_wide3_lds_bytes(a.mt, a.nblk);
+#define HMX_SWEEP3_CASE(M)                                                                                              \
+    case M: {                                                                                                         \
+        static bool attr_done = false;                                                                                \
+        if (!attr_done) {                                                                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_wide3<M>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_done = true;                                                                                         \
+        }                                                                                                             \
+        hipLaunchKernelGGL((k_sweep_wide3<M>), dim3(wgs), dim3(64 * WIDE3_WAVES), sm, s, a);                           \
+        sweep3_prof_dump(wgs, a.nblk, s);                                                                             \
+    } break;
+    switch (a.mt) {
+        HMX_SWEEP3_CASE(1) HMX_SWEEP3_CASE(2) HMX_SWEEP3_CASE(3) HMX_SWEEP3_CASE(4) HMX_SWEEP3_CASE(5) HMX_SWEEP3_CASE(6) HMX_SWEEP3_CASE(7)
+        HMX_SWEEP3_CASE(8) HMX_SWEEP3_CASE(9) HMX_SWEEP3_CASE(10) HMX_SWEEP3_CASE(11) HMX_SWEEP3_CASE(12) HMX_SWEEP3_CASE(13)
+        default: return -1;
+    }
+#undef HMX_SWEEP3_CASE
+    return 0;
 }
 // the wide block assignment can build its own diversity table (one batch variable, the bf16-pipe instance)
 bool assign_wide3_fuses_table(int mt, int dp, int V) { return V == 1 && dp % 16 == 0 && mt >= 1 && mt <= 13 && (mt > 7 || dp > 64) && assign_wide3_lds_bytes(mt) <= 160 * 1024; }

@@ -270,7 +270,9 @@ int hmx_set_timing_stride(hmx_engine* e, int stride);
  * map (one batch variable: every workgroup of k_round owns one batch group; HMX_ROUND_GA=0 keeps the
  * classic map), out[9] workgroups of the last such sweep, out[10] the peer box of a sharded engine: 0 none, 1 coarse-grained
  * device memory (HMX_PEER_BOX=coarse, or the fall-back), 2 fine-grained; out[11] wide streaming R^T.Z passes that read Z_cos as
- * pre-split bf16 planes (k_rtzw2b<.., true>; HMX_RTZW_ZF=0: fp32 rows split in every pass); out[12..15] reserved (0). */
+ * pre-split bf16 planes (k_rtzw2b<.., true>; HMX_RTZW_ZF=0: fp32 rows split in every pass); out[12] wide sweeps (clusters or PCs beyond 112 / 64) that ran as ONE persistent
+ * launch (k_sweep_wide3: single engine, one batch variable, at most 32 groups; HMX_WIDE_SWEEP=0 keeps one launch per block);
+ * out[13..15] reserved (0). */
 #define HMX_N_COUNTERS 16
 int hmx_counters(hmx_engine* e, int64_t out[HMX_N_COUNTERS]);
 
