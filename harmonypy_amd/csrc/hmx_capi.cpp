@@ -174,7 +174,7 @@ struct hmx_engine {
     bool fuse_block_table = true;        // HMX_FUSE_TABLE=0 at hmx_create: a k_block_table launch in front of every wide block assignment (A/B runs and tests)
     bool allow_zcf = true;               // HMX_RTZW_ZF=0 at hmx_create: k_rtzw2b splits the fp32 rows of Z_cos in every pass (A/B runs and tests)
     long n_rtz_zf = 0;                   // streaming passes that read the pre-split planes
-    DevBuf<double> Opriv;                // k_sweep_wide3: every workgroup's own copy of O (grid x G x K16)
+    DevBuf<double> Opriv;                // k_sweep_wide3: every workgroup's own copies of O (2 x grid x G x K16)
     DevBuf<double> Osave;                // O at the start of the round in flight (exact replay after a time-out)
 
     struct Span { hipEvent_t a, b; int fam; };
@@ -1089,7 +1089,7 @@ static int blocks_loop(hmx_engine* e, int flags, const std::vector<int>& tiles_u
             if (e->n_sweep_launches++ == e->test_fail_sweep) a.spin_limit = 0;
             int wgs = std::min(std::max(1, e->n_cus - 8), (max_upper + 15) / 16);   // (a few CUs stay free for the second stream's launches)
             if (e->round_wgs_cap > 0) wgs = std::min(wgs, e->round_wgs_cap);
-            if ((rc = e->Opriv.reserve((size_t)wgs * GK))) return rc;
+            if ((rc = e->Opriv.reserve((size_t)2 * wgs * GK))) return rc;
             a.O_priv = e->Opriv.p;
             if (launch_sweep_wide3(a, wgs, e->stream)) return fail(HMX_ERR_ARG, "unsupported shape for k_sweep_wide3");
             e->wide_sweep_launched = true;

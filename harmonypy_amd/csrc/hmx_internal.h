@@ -40,7 +40,7 @@ struct AssignArgs {
     int nblk;
     const int* run_tiles;  // nblk*G + 1: first tile of every (block, group) run
     unsigned spin_limit;   // polls a wait for a block's sums may take
-    double* O_priv;        // grid x G x K16: every workgroup's own copy of O (each entry read and written by one thread only)
+    double* O_priv;        // 2 x grid x G x K16: every workgroup's own copies of O (each entry read and written by one thread only)
     double* fail;          // += 1 per workgroup whose wait gave up (the launch ends, the host replays the round block by block)
     const float* hn;       // k_assign_wide without penalty only: half squared norms of the centres in Y (+inf for pads) -> HARD
                            // assignment of the device k-means (a one-hot row of R per cell) instead of the softmax; null otherwise

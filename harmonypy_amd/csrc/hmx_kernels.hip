@@ -1624,7 +1624,7 @@ __global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_sweep_wide3(AssignArgs 
     // threads that own its entries): thread (th, clusters tk, tk + 1) owns groups th, th + 4, ..., th + 28
     const bool tsum = tid < WIDE3_TSUB * KP;
     const int th = tid / KP, tk = 2 * (tid - th * KP);
-    double* Opriv = a.O_priv + (size_t)wg * GK;
+    double* Opriv = a.O_priv + (size_t)wg * GK;                          // (a second table of the same shape follows at + grid x G x K16)
     const int goff = th * K16 + tk;                                      // (group th, cluster tk) in a G x K16 table
     if (tid < K16) {
         const float sgm = (tid < a.K) ? a.sigma[tid] : 0.f;
@@ -1760,47 +1760,57 @@ __global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_sweep_wide3(AssignArgs 
             bool failed = false;
             if (tsum) {
                 // (addresses: a wave-uniform base per group trip + ONE per-thread offset; groups past G are predicated off, not clamped.
-                //  Two passes of four groups each: the whole table at once does not fit the registers beside the loop's state.)
+                //  Two passes of four groups each: the whole table at once does not fit the registers beside the loop's state -- nor do the
+                //  words of both passes requested ahead (tried: 48 spilled registers at K16 = 208).
+                //  ONE round trip per pass: the private table holds O with the removal sums of the block ALREADY taken off -- done
+                //  a block ahead, with the next block's sums loaded beside the words of the hand-off.)
                 f64x2 t = {0.0, 0.0};
 #pragma unroll 1
                 for (int half = 0; half < 2; ++half) {
                     const size_t hoff = (size_t)(4 * half) * (WIDE3_TSUB * K16) + goff;
                     const int g0 = th + WIDE3_TSUB * 4 * half;           // groups g0, g0 + 4, g0 + 8, g0 + 12
                     f64x2 o[4];
-                    const double* osrc = ((first_chunk && b == 0) ? a.O_prev : Opriv) + hoff;
+                    // (a later chunk of the block: O of the block as the first chunk left it, in the second private table)
+                    const double* osrc = (first_chunk ? (b == 0 ? a.O_prev : Opriv) : Opriv + (size_t)nwg * GK) + hoff;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         o[j] = (g0 + WIDE3_TSUB * j < a.G) ? *reinterpret_cast<const f64x2*>(osrc + (size_t)j * (WIDE3_TSUB * K16)) : (f64x2){0.0, 0.0};
                     if (first_chunk) {
-                        {
-                            const double* ssub = a.S_sub + (size_t)b * GK + hoff;
-                            f64x2 ss[4];
+                        f64x2 ss[4];                                     // the NEXT block's old sums (block 0: its own first)
+                        const bool pre = b + 1 < a.nblk;
+                        if (b == 0) {
+                            const double* ssub = a.S_sub + hoff;
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
                                 ss[j] = (g0 + WIDE3_TSUB * j < a.G) ? *reinterpret_cast<const f64x2*>(ssub + (size_t)j * (WIDE3_TSUB * K16)) : (f64x2){0.0, 0.0};
 #pragma unroll
                             for (int j = 0; j < 4; ++j) o[j] -= ss[j];  // without the block's old sums (:491-492)
                         }
+                        {
+                            const double* ssub = a.S_sub + (size_t)(pre ? b + 1 : b) * GK + hoff;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                ss[j] = (pre && g0 + WIDE3_TSUB * j < a.G) ? *reinterpret_cast<const f64x2*>(ssub + (size_t)j * (WIDE3_TSUB * K16)) : (f64x2){0.0, 0.0};
+                        }
                         if (b > 0) {
-                            int need[4];
                             const int t0 = bst[b - 1];
                             const int* runs = a.run_tiles + (size_t)(b - 1) * a.G + g0;
+                            int rs[4], re[4];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {                // chunks of block b-1 holding tiles of group g
-                                need[j] = 0;
-                                if (g0 + WIDE3_TSUB * j < a.G) {
-                                    const int rs = runs[WIDE3_TSUB * j] - t0, re = runs[WIDE3_TSUB * j + 1] - t0;
-                                    need[j] = re > rs ? (re - 1) / WIDE3_SLOTS - rs / WIDE3_SLOTS + 1 : 0;
-                                }
+                            for (int j = 0; j < 4; ++j) {
+                                const bool v = g0 + WIDE3_TSUB * j < a.G;
+                                rs[j] = v ? runs[WIDE3_TSUB * j] : 0;
+                                re[j] = v ? runs[WIDE3_TSUB * j + 1] : 0;
                             }
                             const unsigned long long* W = reinterpret_cast<const unsigned long long*>(a.S_out + (size_t)(b - 1) * GK) + hoff;
                             unsigned long long w[4][2];
+                            int need[4];
                             unsigned spins = 0;
                             if (a.spin_limit == 0) failed = true;        // test knob: give up without looking
                             while (true) {
                                 bool ok = true;
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) {            // eight independent loads in flight
+                                for (int j = 0; j < 4; ++j) {            // eight independent loads in flight (beside the ones above on the first trip)
                                     w[j][0] = w[j][1] = 0ull;
                                     if (g0 + WIDE3_TSUB * j < a.G) {
                                         const unsigned long long* wp = W + (size_t)j * (WIDE3_TSUB * K16);
@@ -1809,7 +1819,11 @@ __global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_sweep_wide3(AssignArgs 
                                     }
                                 }
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) ok = ok && (int)(w[j][0] >> 55) == need[j] && (int)(w[j][1] >> 55) == need[j];
+                                for (int j = 0; j < 4; ++j) {            // chunks of block b-1 holding tiles of group g
+                                    const int r0 = rs[j] - t0, r1 = re[j] - t0;
+                                    need[j] = r1 > r0 ? (r1 - 1) / WIDE3_SLOTS - r0 / WIDE3_SLOTS + 1 : 0;
+                                    ok = ok && (int)(w[j][0] >> 55) == need[j] && (int)(w[j][1] >> 55) == need[j];
+                                }
                                 if (__all(ok) || failed) break;
                                 __builtin_amdgcn_s_sleep(2);
                                 if (++spins > a.spin_limit || (spins % 64 == 0 && __hip_atomic_load(reinterpret_cast<const unsigned long long*>(a.fail), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) { failed = true; break; }
@@ -1821,11 +1835,13 @@ __global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_sweep_wide3(AssignArgs 
                         }
                         double* odst = Opriv + hoff;
                         double* hdst = a.O_out + (size_t)b * GK + hoff;
+                        const bool more = c + nwg < nch;                 // (uniform) later chunks of this block will want O of the block itself
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             if (g0 + WIDE3_TSUB * j < a.G) {
                                 t += o[j];
-                                *reinterpret_cast<f64x2*>(odst + (size_t)j * (WIDE3_TSUB * K16)) = o[j];
+                                *reinterpret_cast<f64x2*>(odst + (size_t)j * (WIDE3_TSUB * K16)) = o[j] - ss[j];   // (the next block's old sums taken off ahead)
+                                if (more) *reinterpret_cast<f64x2*>(odst + (size_t)nwg * GK + (size_t)j * (WIDE3_TSUB * K16)) = o[j];
                                 if (wg == 0) *reinterpret_cast<f64x2*>(hdst + (size_t)j * (WIDE3_TSUB * K16)) = o[j];
                             }
                         }
@@ -1884,8 +1900,8 @@ __global__ __launch_bounds__(64 * WIDE3_WAVES, 1) void k_sweep_wide3(AssignArgs 
             }
             if (has0) {
                 float scl0, scl1 = 0.f;
-                round_post_pass1<MT, true, true, false, (HMX_ROUND_PK != 0 && MT <= 8)>(sig, rpL, lrpL, q, T0, scl0, km_acc, ent_acc);
-                if (has1) round_post_pass1<MT, true, true, false, (HMX_ROUND_PK != 0 && MT <= 8)>(sig, rpL, lrpL, q, T1, scl1, km_acc, ent_acc);
+                round_post_pass1<MT, true, true, false, (HMX_ROUND_PK != 0 && MT <= 6)>(sig, rpL, lrpL, q, T0, scl0, km_acc, ent_acc);
+                if (has1) round_post_pass1<MT, true, true, false, (HMX_ROUND_PK != 0 && MT <= 6)>(sig, rpL, lrpL, q, T1, scl1, km_acc, ent_acc);
                 round_post_pass2<MT>(a.R, a.Kp, Sd, c16, q, T0, scl0, has1, T1, scl1);
             }
             SWSEG(8);                                                    // 8: finishing passes

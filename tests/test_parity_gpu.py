@@ -673,7 +673,7 @@ WIDE_AB_SHAPES = [(40_000, 200, 32, 200), (30_000, 100, 4, 130), (20_000, 208, 3
 
 
 @pytest.mark.parametrize("N,d,B,K", WIDE_AB_SHAPES)
-@pytest.mark.parametrize("switch,value", [("HMX_ROUND_F32", "1"), ("HMX_RTZ3_BF16", "0"), ("HMX_RTZW_ZF", "0"), ("HMX_FUSE_TABLE", "0")])
+@pytest.mark.parametrize("switch,value", [("HMX_ROUND_F32", "1"), ("HMX_RTZ3_BF16", "0"), ("HMX_RTZW_ZF", "0"), ("HMX_FUSE_TABLE", "0"), ("HMX_WIDE_SWEEP", "0")])
 def test_wide_bf16_pipe_kernels_against_the_f32_input_kernels(N, d, B, K, switch, value, monkeypatch):
     """The wide regime (K > 112 or d > 64: BASELINE configs[4] is K = d = 200) is bound by the f32-input MFMA; its block
     assignment (k_assign_wide3, harmony.py:447, 464-513) and its streaming R^T.Z pass (k_rtzw2b, :443-444, :491-492, :550,
@@ -688,7 +688,14 @@ def test_wide_bf16_pipe_kernels_against_the_f32_input_kernels(N, d, B, K, switch
         h.cluster(_rounds=2)
         h.moe_correct_ridge()
     ca, cb = a._engine.counters(), b._engine.counters()
-    if switch == "HMX_FUSE_TABLE":
+    if switch == "HMX_WIDE_SWEEP":
+        # all blocks of the sweep in ONE persistent launch (k_sweep_wide3: the block sums handed on as fixed-point words) against one
+        # launch of k_assign_wide3 per block: the same GEMM, table arithmetic and finishing passes
+        dp = 32 if d <= 32 else 52 if d <= 52 else 64 if d <= 64 else (d + 15) & ~15
+        served = dp % 16 == 0
+        assert ca["sweeps_wide_persistent"] == (2 if served else 0) and cb["sweeps_wide_persistent"] == 0, (ca, cb)
+        assert ca["sweeps_bf16_pipe"] == cb["sweeps_bf16_pipe"] and ca["sweep_fallbacks"] == 0, (ca, cb)
+    elif switch == "HMX_FUSE_TABLE":
         # the block's diversity table built in k_assign_wide3's prologue (default) against a k_block_table launch per block: the same
         # arithmetic on the same inputs, the same kernels otherwise
         assert ca["sweeps_bf16_pipe"] == cb["sweeps_bf16_pipe"] and ca["rtz_bf16_pipe"] == cb["rtz_bf16_pipe"], (ca, cb)
@@ -719,6 +726,54 @@ def test_wide_bf16_pipe_kernels_against_the_f32_input_kernels(N, d, B, K, switch
     rel = float(np.linalg.norm(a.Z_corr - b.Z_corr) / np.linalg.norm(b.Z_corr))
     assert rel <= 2e-6, f"Z_corr relF {rel:.2e}"
     print(f"wide bf16 pipe vs f32 input ({switch}) {N}x{d} K={K} B={B}: max|dR|={dR:.2e} relF {relR:.2e}  Z_corr relF {rel:.2e}")
+
+
+@pytest.mark.parametrize("wgs", [3, 7, 40])
+def test_wide_sweep_on_a_small_grid(wgs, monkeypatch):
+    """k_sweep_wide3 with fewer workgroups than a block has chunks of sixteen tiles (HMX_ROUND_WGS): every workgroup then carries
+    several chunks per block (the later ones read O of the block from its second private table), some sit a block out at the
+    ragged end.  Against one launch per block on the same state: two seeded rounds + the ridge."""
+    monkeypatch.setenv("HMX_ROUND_WGS", str(wgs))
+    a, b = _ab_engines(30_000, 100, 4, 130, monkeypatch, "HMX_WIDE_SWEEP", "0")
+    for h in (a, b):
+        h.cluster(_rounds=2)
+        h.moe_correct_ridge()
+    ca, cb = a._engine.counters(), b._engine.counters()
+    assert ca["sweeps_wide_persistent"] == 2 and cb["sweeps_wide_persistent"] == 0 and ca["sweep_fallbacks"] == 0, (ca, cb)
+    dR = float(np.abs(a.R - b.R).max())
+    assert dR <= 3e-5, dR
+    assert np.abs(a.O - b.O).max() <= 2e-6 * max(1.0, float(np.abs(b.O).max()))
+    for name in ("objective_kmeans_dist", "objective_kmeans_entropy", "objective_kmeans_cross"):
+        for va, vb in zip(getattr(a, name), getattr(b, name)):
+            assert abs(va - vb) <= 2e-6 * abs(vb), (name, va, vb)
+    rel = float(np.linalg.norm(a.Z_corr - b.Z_corr) / np.linalg.norm(b.Z_corr))
+    assert rel <= 2e-6, f"Z_corr relF {rel:.2e}"
+    print(f"k_sweep_wide3 on {wgs} workgroups vs one launch per block: max|dR|={dR:.2e}  Z_corr relF {rel:.2e}")
+
+
+@pytest.mark.parametrize("fail_at", [0, 2])
+def test_wide_sweep_timeout_is_replayed_block_by_block(fail_at, monkeypatch, capfd):
+    """A wait of k_sweep_wide3 that gives up (HMX_TEST_FAIL_SWEEP: the k-th persistent launch runs with spin limit 0) ends the
+    launch; the host sees the count in the objective block and replays the round with one launch per block from the round's
+    own start (O saved, removal sums and lists untouched): same results as the engine that never used the persistent launch."""
+    a, b = _ab_engines(30_000, 100, 4, 130, monkeypatch, "HMX_WIDE_SWEEP", "0")
+    monkeypatch.setenv("HMX_TEST_FAIL_SWEEP", str(fail_at))
+    c, _ = _ab_engines(30_000, 100, 4, 130, monkeypatch, "HMX_WIDE_SWEEP", "0")
+    monkeypatch.delenv("HMX_TEST_FAIL_SWEEP")
+    for h in (b, c):
+        h.cluster(_rounds=4)
+        h.moe_correct_ridge()
+    cc = c._engine.counters()
+    assert cc["sweep_fallbacks"] == 1 and cc["sweeps_wide_persistent"] == 4, cc
+    assert "timed out" in capfd.readouterr().err
+    dR = float(np.abs(c.R - b.R).max())
+    assert dR <= 3e-5, dR
+    for name in ("objective_kmeans_dist", "objective_kmeans_entropy", "objective_kmeans_cross"):
+        for va, vb in zip(getattr(c, name), getattr(b, name)):
+            assert abs(va - vb) <= 2e-6 * abs(vb), (name, va, vb)
+    rel = float(np.linalg.norm(c.Z_corr - b.Z_corr) / np.linalg.norm(b.Z_corr))
+    assert rel <= 2e-6, f"Z_corr relF {rel:.2e}"
+    print(f"k_sweep_wide3 timed out in launch {fail_at}, replayed: max|dR|={dR:.2e}  Z_corr relF {rel:.2e}")
 
 
 def test_bench_path_parity_c5_shape(monkeypatch):
