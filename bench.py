@@ -395,6 +395,9 @@ def side_config(name, rounds, steps, warmup, device, repeats=1, converge=False):
                        f"{B} batches, K={K}; step = {rounds} k-means rounds + 1 ridge correction",
            "value": N * steps / dt, "unit": "cells/sec/Harmony-iteration", "ms_per_step": 1e3 * dt / steps, "steps": steps,
            "roofline": roof}
+    if wide:   # how the wide sweep ran (hmx_counters out[12]): all 20 blocks in one persistent launch, or one launch per block
+        out["sweep"] = ("one persistent launch per round (k_sweep_wide3: block sums as self-validating fixed-point words)"
+                        if counters.get("sweeps_wide_persistent", 0) > 0 else "one launch per block (k_assign_wide3)")
     if len(dts) > 1:
         out["repeats_ms_per_step"] = [round(1e3 * x / steps, 4) for x in dts]
         out["value_is"] = f"median of {len(dts)} timed regions of {steps} steps"
