@@ -113,6 +113,7 @@ struct hmx_engine {
     int round_mode = 1;          // 1: persistent sweep kernel when the shape allows it, 0: one launch per block (HMX_ROUND_MODE=blocks)
     unsigned spin_limit = 1u << 24;  // polls a grid-wide wait may take (HMX_SPIN_LIMIT; tests shrink it to force the fall-back)
     long n_sweep_fallbacks = 0;  // rounds repeated through the per-block path after a wait timed out
+    bool lists_beside_rtz = true;   // wide shapes: the next round's list build starts beside the R^T.Z pass (HMX_LISTS_BESIDE_RTZ=0: beside the sweep)
     bool wide_sweep = true;      // wide shapes on a single engine: the whole sweep in one persistent launch (k_sweep_wide3; HMX_WIDE_SWEEP=0: one launch per block)
     bool wide_sweep_launched = false;   // ... by the last blocks_loop
     long n_sweeps_wide = 0;
@@ -417,6 +418,7 @@ int hmx_create(const hmx_config* cfg, hmx_engine** out) {
     if (const char* rk = getenv("HMX_RTZ")) e->rtz_kernel = atoi(rk) == 2 ? 2 : 3;
     if (const char* fs = getenv("HMX_TEST_FAIL_SWEEP")) e->test_fail_sweep = atol(fs);
     if (const char* ws = getenv("HMX_WIDE_SWEEP")) e->wide_sweep = atoi(ws) != 0;
+    if (const char* lb = getenv("HMX_LISTS_BESIDE_RTZ")) e->lists_beside_rtz = atoi(lb) != 0;
     if (const char* sl = getenv("HMX_SPIN_LIMIT")) e->spin_limit = (unsigned)std::max(0L, atol(sl));   // 0: every wait of the persistent kernels gives up at once (tests)
     int rc = 0;
     do {
@@ -1057,6 +1059,17 @@ static void note_sweep_timeout(hmx_engine* e) {
 // update_R block by block (harmony.py:476-507): per block the diversity table (k_block_table), the assignment of the
 // block's tiles (bounded launch) and the block's new sums over all ranks; closes O, T and the cross-entropy term.
 // Needs Sold (removal sums) and Y of this round; Snew and objacc zeroed by the caller.
+// Will blocks_loop run the wide sweep as one persistent launch (k_sweep_wide3)?  Single engine, the fused-table instance of the wide
+// bf16-pipe assignment, every block with tiles, lists with their (block, group) run offsets, at most 511 chunks of sixteen tiles
+// per block (the count field of the hand-off words).
+static bool wide_sweep_planned(hmx_engine* e, const std::vector<int>& tiles_upper) {
+    if (!e->wide_sweep || sharded(e) || !e->lists[e->cur].runs_ok || (int)tiles_upper.size() < e->nblk) return false;
+    if (!(e->allow_round_bf16 && rtz_wide_ok(e->mt, e->dp) && e->fuse_block_table && assign_wide3_fuses_table(e->mt, e->dp, e->V))) return false;
+    for (int b = 0; b < e->nblk; ++b)
+        if (tiles_upper[b] <= 0 || tiles_upper[b] > 511 * 16) return false;
+    return sweep_wide3_ok(e->mt, e->dp, e->V, e->G, e->nblk);
+}
+
 static int blocks_loop(hmx_engine* e, int flags, const std::vector<int>& tiles_upper, bool allow_sweep = true) {
     int rc;
     const size_t GK = (size_t)e->G * e->K16;
@@ -1072,10 +1085,9 @@ static int blocks_loop(hmx_engine* e, int flags, const std::vector<int>& tiles_u
     // ... and on a single engine the whole sweep is ONE persistent launch (k_sweep_wide3): every block has tiles, the lists carry
     // their (block, group) run offsets, a (block, group) pair is held by at most 511 chunks of sixteen tiles (the count field of the
     // hand-off words).  A launch whose waits gave up is replayed block by block (round_body), the second one retires the path.
-    int min_upper = tiles_upper.empty() ? 0 : tiles_upper[0], max_upper = 0;
-    for (int b = 0; b < e->nblk; ++b) { min_upper = std::min(min_upper, tiles_upper[b]); max_upper = std::max(max_upper, tiles_upper[b]); }
-    if (allow_sweep && fuse && e->wide_sweep && !sharded(e) && e->lists[e->cur].runs_ok && min_upper > 0 && max_upper <= 511 * 16 &&
-        sweep_wide3_ok(e->mt, e->dp, e->V, e->G, e->nblk)) {
+    int max_upper = 0;
+    for (int b = 0; b < e->nblk; ++b) max_upper = std::max(max_upper, tiles_upper[b]);
+    if (allow_sweep && wide_sweep_planned(e, tiles_upper)) {
         HIP_TRY(hipMemcpyAsync(e->Osave.p, e->Ogrp.p, GK * sizeof(double), hipMemcpyDeviceToDevice, e->stream));   // for an exact replay
         {
             Timed t(e, F_ASSIGN_BLOCK);
@@ -1240,6 +1252,13 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
     // a single engine on the persistent sweep: k_rtz3_finish normalises the centroids itself (no collective is due in
     // between) and does the sweep kernel's fills -- three launches per round
     const bool fused = r3 && mega && !sharded(e);
+    // Wide shapes: the next round's list build runs beside the R^T.Z PASS, whose workgroups leave registers free on every CU (k_rtzw2b:
+    // 4 waves x 408), not beside the sweep: k_sweep_wide3 fills every register of its CUs (2 x 254 per SIMD lane) -- the scan kernel of
+    // the build sat out the whole sweep and pushed the next pass back by 110 us -- and the per-block launches paid 1.2 ms per iteration
+    // for their neighbour (profiles/r06_c5_timeline.txt).  Marked HERE, in front of the pass; the launches are enqueued behind the
+    // pass's own -- host time the main stream does not wait for.
+    const bool wsweep = (flags & HMX_ROUND_UPDATE_R) && !mega && r3 && rtz_wide_ok(e->mt, e->dp) && e->lists_beside_rtz;
+    if (wsweep && before_sweep && (rc = before_sweep(0))) return rc;
     if (!fused)   // Sold | Yacc64 | Snew | objacc are neighbours in xch: one fill instead of four
         HIP_TRY(hipMemsetAsync(e->Sold, 0, (size_t)((e->objacc + 2 * HMX_OBJ_SLOTS + 2) - e->Sold) * sizeof(double), e->stream));
 
@@ -1290,7 +1309,7 @@ static int round_body(hmx_engine* e, int flags, int n_tiles_upper, const std::ve
     }
     // side-stream work that should run beside the sweep, not beside the R^T.Z pass: its start is MARKED in the main stream here (phase 0),
     // its launches are enqueued behind the sweep's own (phase 1) -- four launches of host time that the sweep does not wait for
-    if (before_sweep && (rc = before_sweep(0))) return rc;
+    if (before_sweep && !wsweep && (rc = before_sweep(0))) return rc;
     if (before_sweep && !mega && (rc = before_sweep(1))) return rc;
     if (mega) {
         // the whole sweep in one persistent launch (k_round); closes O, T and the objective itself
